@@ -1,0 +1,88 @@
+/*
+ * spmv_hip.h -- extensions of the MI355X build.  NOT part of the reference API: a program that
+ * only uses spmv.h never needs this header.  Everything here is optional control around the four
+ * drop-in functions; no extension changes what spmv() computes.
+ *
+ * Why they exist (SURVEY 8b "Errors", "Host-pointer cost", 5 "Config / flags"):
+ *   - the reference API is all-void with no error channel      -> spmv_hip_last_error*()
+ *   - the reference has no notion of a device or a stream      -> spmv_hip_set_stream / _set_async / _synchronize
+ *   - SELL's C and sigma and CSR5's sigma are hard-wired in the reference (common.c:139-140,
+ *     csr5_spmv.cpp:30)                                         -> spmv_hip_set_option (also env SPMV_HIP_<KEY>)
+ *   - measurement (hipEvent per launch on the launch stream)    -> spmv_hip_time_launches
+ */
+#include "spmv_Defines.h"
+#if defined(__cplusplus)
+extern "C" {
+#endif
+#ifndef SPMV_HIP_EXT_H
+#define SPMV_HIP_EXT_H
+
+/* ---- error channel ------------------------------------------------------------------------ */
+enum {
+    SPMV_HIP_OK = 0,
+    SPMV_HIP_E_NODEVICE = 1,   /* no usable gfx950 device / HIP runtime failure at init */
+    SPMV_HIP_E_ALLOC = 2,      /* hipMalloc failed */
+    SPMV_HIP_E_ARG = 3,        /* NULL / negative / inconsistent argument */
+    SPMV_HIP_E_RUNTIME = 4,    /* a HIP call or kernel launch failed */
+    SPMV_HIP_E_NOSTATE = 5,    /* handle has no device state (create failed or handle was cleared) */
+    SPMV_HIP_E_RANGE = 6       /* nnz or padded size does not fit the index type */
+};
+/* Code of the most recent failure on the calling thread (0 if none since the last clear). */
+int spmv_hip_last_error(void);
+/* Human-readable text for it ("" if none).  Valid until the next failing call on this thread. */
+const char *spmv_hip_last_error_string(void);
+void spmv_hip_clear_error(void);
+
+/* ---- device / stream ---------------------------------------------------------------------- */
+/* Number of visible HIP devices (0 if none or the runtime cannot initialise). */
+int spmv_hip_device_count(void);
+/* Launch this handle's kernels on `hip_stream` (a hipStream_t; NULL = the default stream). */
+int spmv_hip_set_stream(spmv_Handle_t handle, void *hip_stream);
+/* async != 0: spmv() with DEVICE x and y returns after enqueueing (stream-ordered); the caller
+ * synchronises.  Default 0: spmv() returns when Y is complete, like the reference.
+ * Host x or y always synchronise. */
+int spmv_hip_set_async(spmv_Handle_t handle, int async);
+int spmv_hip_synchronize(spmv_Handle_t handle);
+
+/* ---- options (process-wide; read at create) ---------------------------------------------- */
+/* keys: "lanes_per_row" (CSR-vector, 0 = auto, else 2..64 power of two)
+ *       "sell_c" (64)  "sell_sigma" (1024)  "sell_lds_x" (0/1: stage narrow x windows in LDS)
+ *       "csr5_sigma" (0 = auto)  "rowblock_nnz" (nnz capacity of a Balanced row block, 0 = auto)
+ *       "variant" (kernel variant selector used by the tuning harness, 0 = default)
+ * Each key can also be preset with the environment variable SPMV_HIP_<KEY IN CAPS>.
+ * Returns 0, or SPMV_HIP_E_ARG for an unknown key / illegal value. */
+int spmv_hip_set_option(const char *key, long value);
+long spmv_hip_get_option(const char *key);
+
+/* ---- introspection ------------------------------------------------------------------------ */
+typedef struct spmv_hip_info {
+    int device;                 /* HIP device ordinal the handle lives on */
+    int schedule;               /* 0 csr-scalar 1 csr-vector 2 row-block 3 nnz-split 4 sell-c-sigma 5 csr5 */
+    int lanes_per_row;          /* csr-vector */
+    int sell_c, sell_sigma;     /* sell */
+    int tile_nnz;               /* nnz-split / csr5 tile size */
+    int m, n;
+    long long nnz;
+    long long stored_nnz;       /* incl. SELL padding */
+    int max_row_len, min_row_len, empty_rows;
+    double mean_row_len;
+    long long device_bytes;     /* HBM held by the handle */
+    long long alg_bytes;        /* B_alg = 4(m+1) + nnz(4+s) + s*n + s*m    */
+    double inspect_ms;          /* wall time of the inspector inside create */
+    const char *schedule_name;
+    const char *kernel_name;    /* symbol of the dominant kernel (as rocprofv3 shows it) */
+} spmv_hip_info;
+int spmv_hip_get_info(spmv_Handle_t handle, spmv_hip_info *out);
+
+/* ---- measurement -------------------------------------------------------------------------- */
+/* `warmup` untimed + `iters` timed spmv() launches back to back on the handle's stream, each
+ * timed launch bracketed by hipEvents recorded on that stream; ms_out[i] (may be NULL) receives
+ * launch i's duration.  x and y must be DEVICE pointers.  Returns the mean in ms, < 0 on error. */
+double spmv_hip_time_launches(spmv_Handle_t handle, const void *x, void *y,
+                              int warmup, int iters, float *ms_out);
+
+#endif /* SPMV_HIP_EXT_H */
+
+#if defined(__cplusplus)
+}
+#endif

@@ -1,0 +1,86 @@
+"""Build libspmv_hip.so in-tree (spmv_amd/lib/) for gfx950.
+
+    python -m spmv_amd.build            # rebuild what is out of date
+    python -m spmv_amd.build --force
+
+Host C (spmv_api.c, spmv_plan.c) is compiled by gcc as C11; the HIP shim by hipcc for gfx950
+only (no other offload arch, no CUDA path).  The shared object carries no torch dependency: its
+entry points are the plain C ABI of include/*.h.
+"""
+from __future__ import annotations
+
+import os
+import shutil
+import subprocess
+import sys
+
+PKG = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(PKG)
+CSRC = os.path.join(PKG, "csrc")
+INC = os.path.join(ROOT, "include")
+LIBDIR = os.path.join(PKG, "lib")
+OBJDIR = os.path.join(PKG, "build")
+LIB = os.path.join(LIBDIR, "libspmv_hip.so")
+
+HIPCC = os.environ.get("HIPCC") or shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
+CC = os.environ.get("CC") or "gcc"
+ARCH = "gfx950"
+
+C_SOURCES = ["spmv_api.c", "spmv_plan.c"]
+HIP_SOURCES = ["spmv_shim.hip"]
+HIP_FLAGS = ["-O3", "-std=c++17", "-fPIC", f"--offload-arch={ARCH}", "-Wall", "-Wno-unused-function",
+             "-ffp-contract=fast"]
+C_FLAGS = ["-O2", "-std=c11", "-fPIC", "-Wall", "-Wextra", "-D_POSIX_C_SOURCE=200809L"]
+
+
+def _newest(paths):
+    return max(os.path.getmtime(p) for p in paths)
+
+
+def _deps():
+    out = []
+    for base, _, files in os.walk(CSRC):
+        out += [os.path.join(base, f) for f in files]
+    out += [os.path.join(INC, f) for f in os.listdir(INC)]
+    return out
+
+
+def _run(cmd):
+    r = subprocess.run(cmd, capture_output=True, text=True)
+    if r.returncode != 0:
+        raise RuntimeError("build failed: " + " ".join(cmd) + "\n" + r.stdout + r.stderr)
+    if r.stderr.strip():
+        sys.stderr.write(r.stderr)
+
+
+def build(force=False, verbose=False):
+    os.makedirs(LIBDIR, exist_ok=True)
+    os.makedirs(OBJDIR, exist_ok=True)
+    if not force and os.path.exists(LIB) and os.path.getmtime(LIB) >= _newest(_deps()):
+        return LIB
+    if not os.path.exists(HIPCC):
+        raise RuntimeError(f"hipcc not found ({HIPCC}); libspmv_hip.so cannot be built")
+    objs = []
+    for src in C_SOURCES:
+        obj = os.path.join(OBJDIR, src + ".o")
+        cmd = [CC, *C_FLAGS, f"-I{INC}", f"-I{CSRC}", "-c", os.path.join(CSRC, src), "-o", obj]
+        if verbose:
+            print(" ".join(cmd))
+        _run(cmd)
+        objs.append(obj)
+    for src in HIP_SOURCES:
+        obj = os.path.join(OBJDIR, src + ".o")
+        cmd = [HIPCC, *HIP_FLAGS, f"-I{INC}", f"-I{CSRC}", "-c", os.path.join(CSRC, src), "-o", obj]
+        if verbose:
+            print(" ".join(cmd))
+        _run(cmd)
+        objs.append(obj)
+    cmd = [HIPCC, "-shared", "-fPIC", f"--offload-arch={ARCH}", "-o", LIB, *objs]
+    if verbose:
+        print(" ".join(cmd))
+    _run(cmd)
+    return LIB
+
+
+if __name__ == "__main__":
+    print(build(force="--force" in sys.argv, verbose=True))

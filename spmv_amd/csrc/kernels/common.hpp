@@ -1,0 +1,97 @@
+// common.hpp -- device helpers shared by every gfx950 kernel of this library.
+// Written for CDNA4 only: 64-lane wavefronts, no other target is considered.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace spmv {
+
+constexpr int kWave = 64;   // wavefront width (cdna_hip_programming.md 1: hard-code 64)
+constexpr int kBlock = 256; // 4 waves per workgroup: one per SIMD
+
+typedef int i32x2 __attribute__((ext_vector_type(2)));
+typedef int i32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef double f64x2 __attribute__((ext_vector_type(2)));
+
+// Matrix streams (RowPtr/ColIdx/Val) are read exactly once per SpMV: load them non-temporal so
+// they do not push x out of L2 / Infinity Cache (MI355X_MICROARCH.md "nt-weights": once-read
+// streams; x is the re-read operand).
+template <typename T>
+__device__ __forceinline__ T ld_stream(const T *p) { return __builtin_nontemporal_load(p); }
+
+// 16-byte streaming loads of 4 consecutive elements starting at a 16-byte aligned element index.
+__device__ __forceinline__ void ld_stream4(const int *p, int (&o)[4])
+{
+    const i32x4 v = __builtin_nontemporal_load(reinterpret_cast<const i32x4 *>(p));
+    o[0] = v.x; o[1] = v.y; o[2] = v.z; o[3] = v.w;
+}
+__device__ __forceinline__ void ld_stream4(const float *p, float (&o)[4])
+{
+    const f32x4 v = __builtin_nontemporal_load(reinterpret_cast<const f32x4 *>(p));
+    o[0] = v.x; o[1] = v.y; o[2] = v.z; o[3] = v.w;
+}
+__device__ __forceinline__ void ld_stream4(const double *p, double (&o)[4])
+{
+    const f64x2 a = __builtin_nontemporal_load(reinterpret_cast<const f64x2 *>(p));
+    const f64x2 b = __builtin_nontemporal_load(reinterpret_cast<const f64x2 *>(p) + 1);
+    o[0] = a.x; o[1] = a.y; o[2] = b.x; o[3] = b.y;
+}
+
+__device__ __forceinline__ float fmadd(float a, float b, float c) { return __builtin_fmaf(a, b, c); }
+__device__ __forceinline__ double fmadd(double a, double b, double c) { return __builtin_fma(a, b, c); }
+
+// Sum over groups of W consecutive lanes (W = power of two <= 64); every lane of the group gets
+// the total (xor butterfly), so any lane may store it.
+template <int W, typename T>
+__device__ __forceinline__ T group_sum(T v)
+{
+#pragma unroll
+    for (int o = W / 2; o > 0; o >>= 1) v += __shfl_xor(v, o, kWave);
+    return v;
+}
+
+// Same with a run-time width (row-block kernel).
+template <typename T>
+__device__ __forceinline__ T group_sum_rt(T v, int w)
+{
+    for (int o = w >> 1; o > 0; o >>= 1) v += __shfl_xor(v, o, kWave);
+    return v;
+}
+
+// LDS hand-off between lanes of ONE wave (no s_barrier: the waves of a workgroup run different
+// trip counts).  DS operations of a wave execute in issue order; the fences keep the compiler
+// from moving LDS accesses across the point and make it wait for outstanding DS results.
+__device__ __forceinline__ void wave_lds_sync()
+{
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
+// First index in [0, n) with a[idx] >= key (n if none).  std::lower_bound; the reference's
+// lower_bound shim is csr5_spmv.cpp:54-56.
+__device__ __forceinline__ int lower_bound_dev(const int *a, int n, long long key)
+{
+    int lo = 0, hi = n;
+    while (lo < hi) {
+        const int mid = lo + ((hi - lo) >> 1);
+        if ((long long) a[mid] < key) lo = mid + 1; else hi = mid;
+    }
+    return lo;
+}
+
+// First index in [0, n) with a[idx] > key (n if none).  The reference's
+// binary_search_right_boundary_kernel (parallel_balanced_spmv.c:17-37) computes the same thing.
+__device__ __forceinline__ int upper_bound_dev(const int *a, int n, long long key)
+{
+    int lo = 0, hi = n;
+    while (lo < hi) {
+        const int mid = lo + ((hi - lo) >> 1);
+        if ((long long) a[mid] <= key) lo = mid + 1; else hi = mid;
+    }
+    return lo;
+}
+
+} // namespace spmv

@@ -1,0 +1,161 @@
+// nnz_split.hpp -- equal-nnz tiles with a segmented wavefront reduction and a carry fix-up.
+//
+// GPU schedule of Method_Balanced2 / Method_Balanced_Yid.  The reference's clean formulation is
+// Balanced_Yid (parallel_balanced_Yid_spmv.c:16-53 inspector, :97-160 executor): worker i owns
+// the nnz range [stride*i, stride*(i+1)); l = lower_bound(RowPtr, begin) is its first whole row,
+// the piece in front of it belongs to row l-1 ("begin_val"), the last row may be cut
+// ("end_val"), and a serial pass adds the pieces into y.  Here:
+//
+//   worker        = one 64-lane wavefront, tile = 64 lanes x 4 consecutive elements = 256 nnz,
+//                   so every load of the matrix stream is a full 16 B/lane coalesced line;
+//   inspector     = tile_first[t] = lower_bound(RowPtr, 256 t)   (4 B per tile, on the device);
+//                   tile t OWNS the rows whose first nnz position lies in the tile: it zeroes
+//                   the empty ones and starts a segment for the others;
+//   executor      = per lane a 4-element running sum cut at row starts, then a backward
+//                   segmented scan over the 64 lanes (ballot mask + 6 shuffles) joins the pieces
+//                   of rows that span lanes; every row start writes y[row] exactly once;
+//   carries       = the piece in front of the tile's first row start (the reference's
+//                   begin_val) goes to carry[t]; nnz_fixup_kernel adds the carries of a row's
+//                   continuation tiles in tile order -- deterministic, no float atomics.
+//
+// The reference's defects are not reproduced: row 0 receives its carries, leading /
+// interior / trailing empty rows are written, T > nnz is fine.
+//
+// Extra HBM traffic on top of B_alg: 4 B (tile_first) + s B (carry) per 256 nnz  (< 0.5 %).
+#pragma once
+#include "common.hpp"
+
+namespace spmv {
+
+constexpr int kSplitK = 4;                    // consecutive elements per lane
+constexpr int kSplitTile = kWave * kSplitK;   // 256 nnz per wavefront tile
+
+// tile_first[t] = first row r with RowPtr[r] >= t*TILE, t = 0..ntiles-1; tile_first[ntiles] = m
+// (the last tile also owns trailing empty rows).  *any_head is set when some row crosses a tile
+// boundary, i.e. the fix-up pass has work.
+__global__ __launch_bounds__(kBlock) void nnz_tile_first_kernel(int m, int ntiles, const int *__restrict__ rowptr,
+                                                                int *__restrict__ tile_first,
+                                                                int *__restrict__ any_head)
+{
+    const int t = blockIdx.x * kBlock + threadIdx.x;
+    if (t > ntiles) return;
+    if (t == ntiles) { tile_first[t] = m; return; }
+    const long long base = (long long) t * kSplitTile;
+    const int r = lower_bound_dev(rowptr, m + 1, base);
+    tile_first[t] = r;
+    if (t > 0 && (long long) rowptr[r] > base) *any_head = 1; // row r-1 runs into this tile
+}
+
+template <typename T>
+__global__ __launch_bounds__(kBlock) void nnz_split_kernel(int m, int nnz, int ntiles,
+                                                           const int *__restrict__ rowptr,
+                                                           const int *__restrict__ colidx,
+                                                           const T *__restrict__ val,
+                                                           const T *__restrict__ x, T *__restrict__ y,
+                                                           const int *__restrict__ tile_first,
+                                                           T *__restrict__ carry)
+{
+    __shared__ int seg_lds[kBlock / kWave][kSplitTile]; // row-start marks of the wave's tile
+    const int lane = threadIdx.x & (kWave - 1);
+    const int wave = threadIdx.x / kWave;
+    int *seg = seg_lds[wave];
+    const int waves_total = gridDim.x * (kBlock / kWave);
+
+    for (int t = blockIdx.x * (kBlock / kWave) + wave; t < ntiles; t += waves_total) {
+        const long long base = (long long) t * kSplitTile;
+        const long long p = base + lane * kSplitK;
+
+        // 1. matrix stream: 4 consecutive elements per lane (16 B of ColIdx, 16/32 B of Val)
+        int c[kSplitK];
+        T v[kSplitK];
+        if (base + kSplitTile <= nnz) {
+            ld_stream4(colidx + p, c);
+            ld_stream4(val + p, v);
+        } else { // last, partial tile
+#pragma unroll
+            for (int k = 0; k < kSplitK; ++k) {
+                const bool in = p + k < nnz;
+                c[k] = in ? colidx[p + k] : 0;
+                v[k] = in ? val[p + k] : T(0);
+            }
+        }
+        // 2. gather x (n > 0 whenever nnz > 0; padded slots read x[0] and multiply by 0... they are
+        //    masked below instead, so a NaN/Inf in x[0] cannot leak)
+        T xv[kSplitK];
+#pragma unroll
+        for (int k = 0; k < kSplitK; ++k) xv[k] = x[c[k]];
+
+        // 3. rows owned by this tile: zero the empty ones, mark the start of the others
+        const int rf = tile_first[t];
+        const int rl = tile_first[t + 1];
+        {
+            i32x4 minus1 = {-1, -1, -1, -1};
+            *reinterpret_cast<i32x4 *>(seg + lane * kSplitK) = minus1;
+        }
+        wave_lds_sync();
+        for (int i = lane; i < rl - rf; i += kWave) {
+            const int r = rf + i;
+            const int s = rowptr[r], e = rowptr[r + 1];
+            if (e == s) y[r] = T(0);
+            else seg[s - (int) base] = i;
+        }
+        wave_lds_sync();
+        const i32x4 mk4 = *reinterpret_cast<const i32x4 *>(seg + lane * kSplitK);
+        const int mk[kSplitK] = {mk4.x, mk4.y, mk4.z, mk4.w};
+        wave_lds_sync(); // marks are in registers before the next tile clears the array
+
+        // 4. per-lane running sum, cut at row starts
+        T head = 0, acc = 0;
+        int cur = -1; // row offset (from rf) of the segment open in this lane, -1: none started here
+#pragma unroll
+        for (int k = 0; k < kSplitK; ++k) {
+            if (mk[k] >= 0) {
+                if (cur >= 0) y[rf + cur] = acc; // segment began and ended inside this lane
+                else head = acc;                 // piece of a segment begun in an earlier lane/tile
+                cur = mk[k];
+                acc = 0;
+            }
+            if (p + k < nnz) acc = fmadd(v[k], xv[k], acc);
+        }
+        if (cur < 0) { head = acc; acc = 0; }
+
+        // 5. backward segmented scan of the heads: B[i] = head[i] + ... + head[j], j = first lane
+        //    >= i that holds a row start (or 63)
+        const unsigned long long starts = __ballot(cur >= 0);
+        T B = head;
+#pragma unroll
+        for (int d = 1; d < kWave; d <<= 1) {
+            const T nb = __shfl_down(B, d, kWave);
+            const bool cut = ((starts >> lane) & ((1ull << d) - 1ull)) != 0ull;
+            if (!cut && lane + d < kWave) B += nb;
+        }
+        T next = __shfl_down(B, 1, kWave);
+        if (lane == kWave - 1) next = 0;
+        // 6. each lane's last row start owns everything up to the next start (or the tile end:
+        //    then the following tiles' carries complete the row in the fix-up pass)
+        if (cur >= 0) y[rf + cur] = acc + next;
+        if (lane == 0) carry[t] = B; // piece in front of the tile's first row start (0 if none)
+    }
+}
+
+// One lane per tile t >= 1.  If row hr = tile_first[t]-1 started in tile t-1 and runs into tile t,
+// this lane adds carry[t..te] (te = last tile the row reaches) into y[hr], in tile order.
+template <typename T>
+__global__ __launch_bounds__(kBlock) void nnz_fixup_kernel(int ntiles, const int *__restrict__ rowptr,
+                                                           const int *__restrict__ tile_first,
+                                                           const T *__restrict__ carry, T *__restrict__ y)
+{
+    const int t = blockIdx.x * kBlock + threadIdx.x + 1;
+    if (t >= ntiles) return;
+    const long long base = (long long) t * kSplitTile;
+    const int hr = tile_first[t] - 1;             // >= 0: RowPtr[0] = 0 < base
+    const long long hend = rowptr[hr + 1];
+    if (hend <= base) return;                     // nothing in front of the first row start
+    if ((long long) rowptr[hr] < base - kSplitTile) return; // row began earlier: not the run's first tile
+    const int te = (int) ((hend - 1) / kSplitTile);
+    T sum = 0;
+    for (int u = t; u <= te; ++u) sum += carry[u];
+    y[hr] += sum;
+}
+
+} // namespace spmv

@@ -1,0 +1,190 @@
+// sell.hpp -- SELL-C-sigma with C = 64 (one wavefront per chunk, lane = row).
+//
+// GPU schedule of Method_SellCSigma.  Reference: sell_C_Sigma_spmv.c -- inspector :61-130 and
+// :141-247 (sigma-window sort by row length with qsort, per-chunk column-major ValT/ColIndex with
+// -1 padding, ld[] prefix of chunk widths, RowIndex permutation), executor :249-352 and the chunk
+// kernel basic_d_lineProductGather_avx2 (inner_spmv.h:448-477).  The reference is called with
+// C = 4 and sigma ~ m/nthreads (common.c:139-140); here C = 64 so that element j of all rows of a
+// chunk is ONE contiguous 256 B (fp32) / 512 B (fp64) line, and sigma = 1024 (16 chunks).
+//
+// HBM layout (global arrays instead of the reference's per-window mallocs):
+//   perm      int32[nchunks*64]   original row of each sorted slot, -1 = no row (padding slot,
+//                                 or a LONG row handled by sell_long_rows_kernel)
+//   chunk_ptr int64[nchunks+1]    prefix sum of chunk widths (in columns; element offset = *64)
+//   col / val [chunk_ptr[nchunks]*64]  column-major inside a chunk: (row slot l, j) at
+//                                 (chunk_ptr[c] + j)*64 + l;  padding: col = -1, val = 0
+//   long_rows int32[nlong]        rows longer than `long_thr`: excluded from the slabs (they would
+//                                 pad their whole chunk to their length) and computed one
+//                                 wavefront per row straight from CSR -- the analogue of the
+//                                 reference's CSR remainder loop (sell_C_Sigma_spmv.c:289-298).
+// Rows are sorted DESCENDING by length inside a window (the reference sorts ascending; either is
+// fine) so a chunk's width is the length of its first slot.
+#pragma once
+#include "common.hpp"
+
+namespace spmv {
+
+constexpr int kSellC = kWave;
+
+// One workgroup per sigma window: bitonic sort of (length, slot) keys in LDS.
+__global__ __launch_bounds__(kBlock) void sell_sort_kernel(int m, int sigma, int long_thr,
+                                                           const int *__restrict__ rowptr,
+                                                           int *__restrict__ perm,
+                                                           int *__restrict__ chunk_width,
+                                                           int *__restrict__ long_rows,
+                                                           int *__restrict__ long_count)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char sell_lds[];
+    unsigned long long *keys = reinterpret_cast<unsigned long long *>(sell_lds);
+    const long long w0 = (long long) blockIdx.x * sigma;
+    for (int i = threadIdx.x; i < sigma; i += kBlock) {
+        const long long row = w0 + i;
+        unsigned len = 0, valid = 0;
+        if (row < m) {
+            len = (unsigned) (rowptr[row + 1] - rowptr[row]);
+            valid = 1;
+            if ((int) len > long_thr) {
+                long_rows[atomicAdd(long_count, 1)] = (int) row;
+                len = 0;
+                valid = 0;
+            }
+        }
+        keys[i] = ((unsigned long long) len << 32) | ((unsigned long long) (sigma - 1 - i) << 1) | valid;
+    }
+    __syncthreads();
+    for (int k = 2; k <= sigma; k <<= 1) {
+        for (int j = k >> 1; j > 0; j >>= 1) {
+            for (int i = threadIdx.x; i < sigma; i += kBlock) {
+                const int o = i ^ j;
+                if (o > i) {
+                    const unsigned long long a = keys[i], b = keys[o];
+                    const bool desc = (i & k) == 0;
+                    if (desc ? (a < b) : (a > b)) { keys[i] = b; keys[o] = a; }
+                }
+            }
+            __syncthreads();
+        }
+    }
+    for (int i = threadIdx.x; i < sigma; i += kBlock) {
+        const unsigned long long key = keys[i];
+        const int slot = sigma - 1 - (int) ((key & 0xFFFFFFFFull) >> 1);
+        perm[w0 + i] = (key & 1ull) ? (int) (w0 + slot) : -1;
+        if ((i & (kSellC - 1)) == 0) chunk_width[(w0 + i) / kSellC] = (int) (key >> 32);
+    }
+}
+
+// Exclusive prefix sum int32 -> int64 over n values (+ the total at out[n]); one workgroup walks
+// the array in 256-element steps.  n is the chunk count (1.6e5 for 1e7 rows): inspector only.
+__global__ __launch_bounds__(kBlock) void scan_i32_to_i64_kernel(int n, const int *__restrict__ in,
+                                                                 long long *__restrict__ out)
+{
+    __shared__ long long wave_tot[kBlock / kWave];
+    __shared__ long long carry_s;
+    const int lane = threadIdx.x & (kWave - 1), wave = threadIdx.x / kWave;
+    if (threadIdx.x == 0) carry_s = 0;
+    __syncthreads();
+    for (int base = 0; base < n; base += kBlock) {
+        const int i = base + threadIdx.x;
+        const long long v = i < n ? (long long) in[i] : 0;
+        long long inc = v;
+#pragma unroll
+        for (int d = 1; d < kWave; d <<= 1) {
+            const long long o = __shfl_up(inc, d, kWave);
+            if (lane >= d) inc += o;
+        }
+        if (lane == kWave - 1) wave_tot[wave] = inc;
+        __syncthreads();
+        long long off = carry_s;
+        for (int w = 0; w < wave; ++w) off += wave_tot[w];
+        if (i < n) out[i] = off + inc - v;
+        __syncthreads();
+        if (threadIdx.x == kBlock - 1) carry_s = off + inc;
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) out[n] = carry_s;
+}
+
+// One wavefront per chunk: copy each slot's CSR row into the column-major slab.
+template <typename T>
+__global__ __launch_bounds__(kBlock) void sell_fill_kernel(int nchunks, const int *__restrict__ rowptr,
+                                                           const int *__restrict__ colidx,
+                                                           const T *__restrict__ val,
+                                                           const int *__restrict__ perm,
+                                                           const long long *__restrict__ chunk_ptr,
+                                                           int *__restrict__ scol, T *__restrict__ sval)
+{
+    const int lane = threadIdx.x & (kWave - 1);
+    const int c = blockIdx.x * (kBlock / kWave) + threadIdx.x / kWave;
+    if (c >= nchunks) return;
+    const long long c0 = chunk_ptr[c];
+    const int width = (int) (chunk_ptr[c + 1] - c0);
+    const int row = perm[(long long) c * kSellC + lane];
+    int p0 = 0, len = 0;
+    if (row >= 0) { p0 = rowptr[row]; len = rowptr[row + 1] - p0; }
+    for (int j = 0; j < width; ++j) {
+        const size_t o = (size_t) (c0 + j) * kSellC + lane;
+        const bool in = j < len;
+        scol[o] = in ? colidx[p0 + j] : -1;
+        sval[o] = in ? val[p0 + j] : T(0);
+    }
+}
+
+// Executor: one wavefront per chunk, lane = row slot; every load of the slab is a full line.
+template <typename T>
+__global__ __launch_bounds__(kBlock) void sell_kernel(int nchunks, const long long *__restrict__ chunk_ptr,
+                                                      const int *__restrict__ scol,
+                                                      const T *__restrict__ sval,
+                                                      const int *__restrict__ perm,
+                                                      const T *__restrict__ x, T *__restrict__ y)
+{
+    const int lane = threadIdx.x & (kWave - 1);
+    const int waves_total = gridDim.x * (kBlock / kWave);
+    for (int c = blockIdx.x * (kBlock / kWave) + threadIdx.x / kWave; c < nchunks; c += waves_total) {
+        const long long c0 = chunk_ptr[c];
+        const int width = (int) (chunk_ptr[c + 1] - c0);
+        const int *pc = scol + (size_t) c0 * kSellC + lane;
+        const T *pv = sval + (size_t) c0 * kSellC + lane;
+        T sum = 0;
+        int j = 0;
+        for (; j + 4 <= width; j += 4) { // 4 lines of each stream in flight per wave
+            int cc[4];
+            T vv[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                cc[u] = ld_stream(pc + (size_t) (j + u) * kSellC);
+                vv[u] = ld_stream(pv + (size_t) (j + u) * kSellC);
+            }
+#pragma unroll
+            for (int u = 0; u < 4; ++u)
+                if (cc[u] >= 0) sum = fmadd(vv[u], x[cc[u]], sum); // padding never touches x
+        }
+        for (; j < width; ++j) {
+            const int cc = ld_stream(pc + (size_t) j * kSellC);
+            const T vv = ld_stream(pv + (size_t) j * kSellC);
+            if (cc >= 0) sum = fmadd(vv, x[cc], sum);
+        }
+        const int row = perm[(long long) c * kSellC + lane];
+        if (row >= 0) y[row] = sum;
+    }
+}
+
+// One wavefront per long row, straight from CSR.
+template <typename T>
+__global__ __launch_bounds__(kBlock) void sell_long_rows_kernel(int nlong, const int *__restrict__ long_rows,
+                                                                const int *__restrict__ rowptr,
+                                                                const int *__restrict__ colidx,
+                                                                const T *__restrict__ val,
+                                                                const T *__restrict__ x, T *__restrict__ y)
+{
+    const int lane = threadIdx.x & (kWave - 1);
+    const int i = blockIdx.x * (kBlock / kWave) + threadIdx.x / kWave;
+    if (i >= nlong) return;
+    const int row = long_rows[i];
+    const int p0 = rowptr[row], p1 = rowptr[row + 1];
+    T sum = 0;
+    for (int p = p0 + lane; p < p1; p += kWave) sum = fmadd(ld_stream(val + p), x[ld_stream(colidx + p)], sum);
+    sum = group_sum<kWave>(sum);
+    if (lane == 0) y[row] = sum;
+}
+
+} // namespace spmv

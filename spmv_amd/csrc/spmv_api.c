@@ -1,0 +1,241 @@
+/*
+ * spmv_api.c -- host side of the drop-in API, plain C11 (north_star: "host code stays C").
+ *
+ * Replaces the reference's handle + dispatch layer, src/src_spmv/common.c:
+ *   gemv_Handle_init / gemv_create_handle / handle_init_common_parameters   common.c:18-29, 63-83
+ *   spmv_create_handle_all_in_one                                           common.c:123-190
+ *   spmv (indirect call through spmv_functions[])                           common.c:278-304, 85-94
+ *   spmv_clear_handle / spmv_destory_handle                                 common.c:31-71
+ *   Methods_names / Vectorized_names / funcNames                            common.c:306-339
+ *
+ * What is different by design: the per-method "get_handle" inspectors and "_Selected" executors
+ * of the reference (serial_spmv.c ... csr5_spmv.cpp) are CPU code; here create() asks the
+ * planner (spmv_plan.c) for a GPU schedule and hands it to the HIP shim (spmv_shim.hip), and
+ * spmv() forwards to the shim.  There is no CPU arithmetic in this library: without a working
+ * HIP device every call reports SPMV_HIP_E_NODEVICE and computes nothing.
+ */
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+
+#include "spmv.h"
+#include "spmv_hip.h"
+#include "spmv_internal.h"
+#include "spmv_shim.h"
+
+/* ---------------------------------------------------------------- name tables (ABI data symbols) */
+const char *Methods_names[] = {
+    "Method_Serial", "Method_Parallel", "Method_Balanced", "Method_Balanced2",
+    "Method_BalancedYid", "Method_SellCSigma", "Method_Csr5Spmv",
+};
+const char *Vectorized_names[] = {
+    "VECTOR_NONE", "VECTOR_AVX2", "VECTOR_AVX512", "VECTOR_HIP",
+};
+#define FN4(m) m "_VECTOR_NONE", m "_VECTOR_AVX2", m "_VECTOR_AVX512", m "_VECTOR_HIP"
+const char *funcNames[] = {
+    FN4("Method_Serial"), FN4("Method_Parallel"), FN4("Method_Balanced"), FN4("Method_Balanced2"),
+    FN4("Method_BalancedYid"), FN4("Method_SellCSigma"), FN4("Method_Csr5Spmv"),
+};
+
+/* ---------------------------------------------------------------- error channel (thread-local) */
+static _Thread_local int g_err_code = 0;
+static _Thread_local char g_err_text[512] = "";
+
+void spmv_set_error(int code, const char *where, const char *what)
+{
+    g_err_code = code;
+    snprintf(g_err_text, sizeof g_err_text, "%s: %s", where, what ? what : "");
+    if (!getenv("SPMV_HIP_QUIET")) fprintf(stderr, "[spmv_hip] error %d in %s\n", code, g_err_text);
+}
+int spmv_hip_last_error(void) { return g_err_code; }
+const char *spmv_hip_last_error_string(void) { return g_err_text; }
+void spmv_hip_clear_error(void) { g_err_code = 0; g_err_text[0] = 0; }
+int spmv_hip_device_count(void) { return spmv_shim_device_count(); }
+
+/* ---------------------------------------------------------------- handle life-cycle */
+static void handle_reset(spmv_Handle_t h) /* common.c:18-29 */
+{
+    h->spmvMethod = Method_Serial;
+    h->data_size = 0;
+    h->nthreads = 0;
+    h->vectorizedWay = VECTOR_NONE;
+    h->Level_3_opt_used = 0;
+    h->RowPtr = NULL;
+    h->ColIdx = NULL;
+    h->index = NULL;
+    h->Matrix_Val = NULL;
+    h->Y_temp = NULL;
+    h->extraHandle = NULL;
+}
+
+static void state_free(spmv_Handle_t h)
+{
+    spmv_hip_state *st = (spmv_hip_state *) h->extraHandle;
+    if (st) {
+        if (st->dev) spmv_shim_matrix_destroy(st->dev);
+        free(st);
+        h->extraHandle = NULL;
+    }
+}
+
+void spmv_clear_handle(spmv_Handle_t h) /* common.c:31-52, 69-71 */
+{
+    if (!h) return;
+    state_free(h);
+    handle_reset(h);
+}
+
+void spmv_destory_handle(spmv_Handle_t h) /* common.c:54-61 */
+{
+    if (!h) return;
+    state_free(h);
+    free(h);
+}
+
+/* Upload + plan + inspect.  Used by create and by spmv() when it is handed another matrix. */
+static int state_build(spmv_Handle_t h, spmv_hip_state *st, int m, int n, const int *RowPtr,
+                       const int *ColIdx, const void *Val)
+{
+    spmv_stats stats;
+    SPMV_METHODS actual = st->requested;
+    int rc;
+    if (st->dev) { spmv_shim_matrix_destroy(st->dev); st->dev = NULL; }
+    if (m < 0 || n < 0 || (m > 0 && !RowPtr)) {
+        spmv_set_error(SPMV_HIP_E_ARG, "create", "negative size or NULL RowPtr");
+        return SPMV_HIP_E_ARG;
+    }
+    rc = spmv_shim_matrix_create(&st->dev, m, n, RowPtr, ColIdx, Val, (size_t) h->data_size);
+    if (rc) { spmv_set_error(rc, "create/upload", spmv_shim_error_text()); return rc; }
+    rc = spmv_shim_matrix_stats(st->dev, &stats);
+    if (rc) { spmv_set_error(rc, "create/stats", spmv_shim_error_text()); return rc; }
+    spmv_plan_choose(st->requested, &stats, (size_t) h->data_size, &st->plan, &actual);
+    rc = spmv_shim_build(st->dev, &st->plan);
+    if (rc) {
+        spmv_set_error(rc, "create/inspect", spmv_shim_error_text());
+        spmv_shim_matrix_destroy(st->dev);
+        st->dev = NULL;
+        return rc;
+    }
+    if (st->stream_set) spmv_shim_set_stream(st->dev, st->stream);
+    spmv_shim_set_async(st->dev, st->async);
+    st->m = m;
+    st->n = n;
+    h->spmvMethod = actual;
+    h->RowPtr = (BASIC_INT_TYPE *) RowPtr;
+    h->ColIdx = (BASIC_INT_TYPE *) ColIdx;
+    h->Matrix_Val = (void *) Val;
+    return SPMV_HIP_OK;
+}
+
+void spmv_create_handle_all_in_one(spmv_Handle_t *Handle, BASIC_INT_TYPE m, BASIC_INT_TYPE n,
+                                   BASIC_INT_TYPE *RowPtr, BASIC_INT_TYPE *ColIdx, void *Matrix_Val,
+                                   BASIC_SIZE_TYPE nthreads, SPMV_METHODS Function, BASIC_SIZE_TYPE size,
+                                   VECTORIZED_WAY vectorizedWay, const char *MtxToken)
+{
+    spmv_Handle_t h;
+    spmv_hip_state *st;
+    (void) MtxToken; /* the reference uses it for METIS cache file names only (common.c:152-154) */
+    if (!Handle) { spmv_set_error(SPMV_HIP_E_ARG, "create", "Handle is NULL"); return; }
+    h = (spmv_Handle_t) malloc(sizeof(spmv_Handle)); /* common.c:63-67 */
+    *Handle = h;
+    if (!h) { spmv_set_error(SPMV_HIP_E_ALLOC, "create", "malloc(handle)"); return; }
+    handle_reset(h);
+    if ((int) Function < (int) Method_Serial || (int) Function >= (int) Method_Total_Size)
+        Function = Method_Serial; /* common.c:136 */
+    /* common.c:74-83 */
+    h->nthreads = nthreads;
+    h->vectorizedWay = vectorizedWay;
+    h->data_size = size;
+    h->spmvMethod = Function;
+
+    st = (spmv_hip_state *) calloc(1, sizeof *st);
+    if (!st) { spmv_set_error(SPMV_HIP_E_ALLOC, "create", "malloc(state)"); return; }
+    st->requested = Function;
+    h->extraHandle = st;
+    if (state_build(h, st, m, n, RowPtr, ColIdx, Matrix_Val) != SPMV_HIP_OK) {
+        /* keep a valid handle whose spmv() is a reported no-op */
+        free(st);
+        h->extraHandle = NULL;
+    }
+}
+
+void spmv(const spmv_Handle_t handle, BASIC_INT_TYPE m, const BASIC_INT_TYPE *RowPtr,
+          const BASIC_INT_TYPE *ColIdx, const void *Matrix_Val, const void *X, void *Y)
+{
+    spmv_hip_state *st;
+    int rc;
+    if (handle == NULL) return; /* common.c:285 */
+    st = (spmv_hip_state *) handle->extraHandle;
+    if (!st || !st->dev) {
+        spmv_set_error(SPMV_HIP_E_NOSTATE, "spmv", "handle has no device state (create failed?)");
+        return;
+    }
+    /* The reference re-reads the CSR arguments on every call (common.c:286-298).  Same pointers
+     * and m as at create -> the HBM-resident matrix; anything else -> re-inspect that matrix. */
+    if (m != st->m || RowPtr != handle->RowPtr || ColIdx != handle->ColIdx ||
+        Matrix_Val != handle->Matrix_Val) {
+        if (!st->warned_rebuild && !getenv("SPMV_HIP_QUIET")) {
+            fprintf(stderr, "[spmv_hip] spmv(): CSR arguments differ from create(); re-inspecting "
+                            "(slow path, DESIGN.md \"CSR arguments\")\n");
+            st->warned_rebuild = 1;
+        }
+        if (state_build(handle, st, m, st->n, RowPtr, ColIdx, Matrix_Val) != SPMV_HIP_OK) return;
+    }
+    rc = spmv_shim_run(st->dev, X, Y);
+    if (rc) spmv_set_error(rc, "spmv", spmv_shim_error_text());
+}
+
+/* ---------------------------------------------------------------- extensions */
+static spmv_hip_state *state_of(spmv_Handle_t h, const char *where)
+{
+    spmv_hip_state *st = h ? (spmv_hip_state *) h->extraHandle : NULL;
+    if (!st || !st->dev) {
+        spmv_set_error(SPMV_HIP_E_NOSTATE, where, "handle has no device state");
+        return NULL;
+    }
+    return st;
+}
+
+int spmv_hip_set_stream(spmv_Handle_t h, void *stream)
+{
+    spmv_hip_state *st = state_of(h, "set_stream");
+    if (!st) return SPMV_HIP_E_NOSTATE;
+    st->stream = stream;
+    st->stream_set = 1;
+    return spmv_shim_set_stream(st->dev, stream);
+}
+
+int spmv_hip_set_async(spmv_Handle_t h, int async)
+{
+    spmv_hip_state *st = state_of(h, "set_async");
+    if (!st) return SPMV_HIP_E_NOSTATE;
+    st->async = async != 0;
+    return spmv_shim_set_async(st->dev, st->async);
+}
+
+int spmv_hip_synchronize(spmv_Handle_t h)
+{
+    spmv_hip_state *st = state_of(h, "synchronize");
+    int rc;
+    if (!st) return SPMV_HIP_E_NOSTATE;
+    rc = spmv_shim_sync(st->dev);
+    if (rc) spmv_set_error(rc, "synchronize", spmv_shim_error_text());
+    return rc;
+}
+
+int spmv_hip_get_info(spmv_Handle_t h, spmv_hip_info *out)
+{
+    spmv_hip_state *st = state_of(h, "get_info");
+    if (!st || !out) return SPMV_HIP_E_NOSTATE;
+    return spmv_shim_info(st->dev, out);
+}
+
+double spmv_hip_time_launches(spmv_Handle_t h, const void *x, void *y, int warmup, int iters, float *ms_out)
+{
+    spmv_hip_state *st = state_of(h, "time_launches");
+    double r;
+    if (!st) return -1.0;
+    r = spmv_shim_time(st->dev, x, y, warmup, iters, ms_out);
+    if (r < 0) spmv_set_error(SPMV_HIP_E_RUNTIME, "time_launches", spmv_shim_error_text());
+    return r;
+}

@@ -1,0 +1,142 @@
+/*
+ * spmv_plan.c -- SPMV_METHODS -> GPU schedule policy, plain C (north_star: "SPMV_METHODS mapping
+ * to GPU schedules").  The reference hard-wires its tuning constants at create
+ * (C = 4, Times = m/nthreads/C: common.c:139-140; CSR5 sigma = 16: csr5_spmv.cpp:30); here they
+ * are options with defaults chosen for a 64-lane wavefront.
+ *
+ * Method map (VECTOR_HIP column):
+ *   Method_Serial        -> CSR-scalar
+ *   Method_Parallel      -> CSR-vector, L lanes per row from the mean row length
+ *   Method_Balanced(2)   -> same rule as the reference's parallel_balanced2_get_handle
+ *                           (parallel_balanced2_spmv.c:72-92): if some row is longer than one
+ *                           equal-nnz share ("stride") the handle becomes Method_Balanced2 =
+ *                           nnz-split with carries, otherwise Method_Balanced = equal-nnz row
+ *                           blocks.  On the GPU the share is the nnz capacity of one workgroup.
+ *   Method_Balanced_Yid  -> nnz-split with carries (parallel_balanced_Yid_spmv.c:16-53 semantics)
+ *   Method_SellCSigma    -> SELL-C-sigma, C = 64, sigma = 1024
+ *   Method_CSR5SPMV      -> CSR5, omega = 64 (fp32 too: the reference falls back to SELL for
+ *                           fp32, common.c:174-181; this build has a native fp32 CSR5)
+ */
+#include <ctype.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+
+#include "spmv_hip.h"
+#include "spmv_internal.h"
+
+/* ---------------------------------------------------------------- options */
+typedef struct { const char *key; long value; long lo, hi; int pow2; int env_read; } opt_t;
+static opt_t g_opts[] = {
+    {"lanes_per_row", 0, 0, 64, 1, 0},
+    {"sell_c", 64, 64, 64, 1, 0},          /* one wavefront per chunk: C is the wave width */
+    {"sell_sigma", 1024, 64, 1 << 20, 1, 0},
+    {"sell_lds_x", 0, 0, 1, 0, 0},
+    {"csr5_sigma", 0, 0, 32, 0, 0},
+    {"rowblock_nnz", 0, 0, 4096, 0, 0},   /* 2*4096 fp64 products = 64 KiB of LDS */
+    {"variant", 0, 0, 1 << 20, 0, 0},
+};
+#define N_OPTS ((int) (sizeof g_opts / sizeof g_opts[0]))
+
+static int is_pow2_or_zero(long v) { return v == 0 || (v & (v - 1)) == 0; }
+
+static opt_t *opt_find(const char *key)
+{
+    int i;
+    if (!key) return NULL;
+    for (i = 0; i < N_OPTS; ++i) {
+        if (strcmp(g_opts[i].key, key) == 0) {
+            opt_t *o = &g_opts[i];
+            if (!o->env_read) { /* SPMV_HIP_<KEY> presets the option once */
+                char name[64] = "SPMV_HIP_";
+                size_t k, off = strlen(name);
+                const char *e;
+                for (k = 0; key[k] && off + k + 1 < sizeof name; ++k) name[off + k] = (char) toupper((unsigned char) key[k]);
+                name[off + k] = 0;
+                e = getenv(name);
+                if (e && *e) {
+                    long v = strtol(e, NULL, 10);
+                    if (v >= o->lo && v <= o->hi && (!o->pow2 || is_pow2_or_zero(v))) o->value = v;
+                }
+                o->env_read = 1;
+            }
+            return o;
+        }
+    }
+    return NULL;
+}
+
+int spmv_hip_set_option(const char *key, long value)
+{
+    opt_t *o = opt_find(key);
+    if (!o || value < o->lo || value > o->hi || (o->pow2 && !is_pow2_or_zero(value))) {
+        spmv_set_error(SPMV_HIP_E_ARG, "set_option", key ? key : "(null)");
+        return SPMV_HIP_E_ARG;
+    }
+    o->value = value;
+    return SPMV_HIP_OK;
+}
+
+long spmv_hip_get_option(const char *key)
+{
+    opt_t *o = opt_find(key);
+    return o ? o->value : -1;
+}
+
+/* ---------------------------------------------------------------- policy */
+static int pow2_at_least(double v, int lo, int hi)
+{
+    int p = lo;
+    while (p < hi && (double) p < v) p <<= 1;
+    return p;
+}
+
+void spmv_plan_choose(SPMV_METHODS requested, const spmv_stats *st, size_t value_size,
+                      spmv_plan *plan, SPMV_METHODS *actual)
+{
+    long lanes = spmv_hip_get_option("lanes_per_row");
+    long rb = spmv_hip_get_option("rowblock_nnz");
+    memset(plan, 0, sizeof *plan);
+    plan->variant = (int) spmv_hip_get_option("variant");
+    plan->sell_c = (int) spmv_hip_get_option("sell_c");
+    plan->sell_sigma = (int) spmv_hip_get_option("sell_sigma");
+    plan->sell_lds_x = (int) spmv_hip_get_option("sell_lds_x");
+    plan->csr5_sigma = (int) spmv_hip_get_option("csr5_sigma");
+    /* one workgroup's equal-nnz share: 2048 products = 16 KiB of fp64 (8 KiB fp32) in LDS */
+    plan->rowblock_nnz = rb > 0 ? (int) rb : 2048;
+    /* CSR-vector: lanes per row = power of two >= mean row length / 2 (each lane then takes
+     * about two elements, i.e. 16 B of fp64 values), within [2, 64] */
+    plan->lanes_per_row = lanes > 0 ? (int) lanes : pow2_at_least(st->mean_row_len / 2.0, 2, 64);
+    if (plan->lanes_per_row < 2) plan->lanes_per_row = 2;
+    (void) value_size;
+    *actual = requested;
+    switch (requested) {
+    case Method_Parallel:
+        plan->sched = SPMV_SCHED_CSR_VECTOR;
+        break;
+    case Method_Balanced:
+    case Method_Balanced2:
+        if (st->max_row_len > plan->rowblock_nnz) {
+            *actual = Method_Balanced2;
+            plan->sched = SPMV_SCHED_NNZ_SPLIT;
+        } else {
+            *actual = Method_Balanced;
+            plan->sched = SPMV_SCHED_ROWBLOCK;
+        }
+        break;
+    case Method_Balanced_Yid:
+        plan->sched = SPMV_SCHED_NNZ_SPLIT;
+        break;
+    case Method_SellCSigma:
+        plan->sched = SPMV_SCHED_SELL;
+        break;
+    case Method_CSR5SPMV:
+        plan->sched = SPMV_SCHED_CSR5;
+        break;
+    case Method_Serial:
+    default:
+        *actual = Method_Serial;
+        plan->sched = SPMV_SCHED_CSR_SCALAR;
+        break;
+    }
+}

@@ -1,0 +1,68 @@
+/*
+ * spmv_shim.h -- the ONE place host C meets HIP ("thin shim = the only place
+ * host C meets HIP").  spmv_api.c / spmv_plan.c (plain C11, gcc) sit above this interface and
+ * hold the reference-shaped logic (handle life-cycle, method -> schedule policy, argument
+ * rules); spmv_shim.hip (hipcc, gfx950) sits below it and holds device memory, inspectors and
+ * kernels.  Plain pointers and sizes only.
+ */
+#ifndef SPMV_SHIM_H
+#define SPMV_SHIM_H
+#include <stddef.h>
+#include "spmv_hip.h"
+
+#if defined(__cplusplus)
+extern "C" {
+#endif
+
+typedef struct spmv_dev spmv_dev; /* opaque: device-resident matrix + inspector products */
+
+enum spmv_sched {
+    SPMV_SCHED_CSR_SCALAR = 0,
+    SPMV_SCHED_CSR_VECTOR = 1,
+    SPMV_SCHED_ROWBLOCK = 2,
+    SPMV_SCHED_NNZ_SPLIT = 3,
+    SPMV_SCHED_SELL = 4,
+    SPMV_SCHED_CSR5 = 5,
+    SPMV_SCHED_COUNT
+};
+
+typedef struct spmv_stats {
+    int m, n;
+    long long nnz;
+    int max_row_len, min_row_len, empty_rows;
+    double mean_row_len;
+} spmv_stats;
+
+typedef struct spmv_plan {
+    int sched;          /* enum spmv_sched */
+    int lanes_per_row;  /* csr-vector */
+    int sell_c, sell_sigma, sell_lds_x;
+    int csr5_sigma;
+    int rowblock_nnz;
+    int variant;
+} spmv_plan;
+
+/* All functions return SPMV_HIP_OK or an SPMV_HIP_E_* code and record a message retrievable
+ * with spmv_shim_error_text() (thread-local). */
+int spmv_shim_device_count(void);
+const char *spmv_shim_error_text(void);
+
+/* Classify + copy the CSR arrays into HBM (host or device sources), compute row statistics. */
+int spmv_shim_matrix_create(spmv_dev **out, int m, int n, const int *rowptr, const int *colidx,
+                            const void *val, size_t value_size);
+int spmv_shim_matrix_stats(const spmv_dev *d, spmv_stats *out);
+/* Run the inspector of plan->sched (device side); may be called again with another plan. */
+int spmv_shim_build(spmv_dev *d, const spmv_plan *plan);
+/* y = A x.  x, y: host or device pointers. */
+int spmv_shim_run(spmv_dev *d, const void *x, void *y);
+int spmv_shim_set_stream(spmv_dev *d, void *stream);
+int spmv_shim_set_async(spmv_dev *d, int async);
+int spmv_shim_sync(spmv_dev *d);
+int spmv_shim_info(const spmv_dev *d, spmv_hip_info *out);
+double spmv_shim_time(spmv_dev *d, const void *x, void *y, int warmup, int iters, float *ms_out);
+void spmv_shim_matrix_destroy(spmv_dev *d);
+
+#if defined(__cplusplus)
+}
+#endif
+#endif

@@ -1,0 +1,551 @@
+// spmv_shim.hip -- the HIP side of the C-ABI shim (see spmv_shim.h): device memory, the
+// device-side inspectors and the kernel launches.  gfx950 only.
+//
+// Division of labour with the reference (all CPU there):
+//   matrix storage     the reference BORROWS the caller's CSR arrays (common.c:157-159); here they
+//                      are copied into HBM once at create and stay resident (288 GB per GPU).
+//   inspectors         parallel_balanced2_get_handle / parallel_balanced_Yid_get_handle /
+//                      sell_C_Sigma_get_handle_Selected / csr5 asCSR5 run on the host in the
+//                      reference; here every inspector is a device kernel over the resident CSR,
+//                      so create() never walks the matrix on the CPU.
+//   executors          one launch (two for nnz-split: tiles + carry fix-up; SELL: slabs + long rows).
+#include <hip/hip_runtime.h>
+
+#include <chrono>
+#include <climits>
+#include <cstdarg>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <vector>
+
+#include "spmv_shim.h"
+#include "kernels/common.hpp"
+#include "kernels/csr_rows.hpp"
+#include "kernels/nnz_split.hpp"
+#include "kernels/rowblock.hpp"
+#include "kernels/sell.hpp"
+
+using namespace spmv;
+
+// ------------------------------------------------------------------------------------ errors
+static thread_local char t_err[400] = "";
+
+static int fail(int code, const char *fmt, ...)
+{
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(t_err, sizeof t_err, fmt, ap);
+    va_end(ap);
+    return code;
+}
+
+extern "C" const char *spmv_shim_error_text(void) { return t_err; }
+
+#define HIP_TRY(expr)                                                                              \
+    do {                                                                                           \
+        hipError_t e__ = (expr);                                                                   \
+        if (e__ != hipSuccess) {                                                                   \
+            (void) hipGetLastError();                                                              \
+            return fail(e__ == hipErrorOutOfMemory ? SPMV_HIP_E_ALLOC : SPMV_HIP_E_RUNTIME,        \
+                        "%s -> %s", #expr, hipGetErrorString(e__));                                \
+        }                                                                                          \
+    } while (0)
+
+// ------------------------------------------------------------------------------------ state
+struct DevStats {
+    int max_len, min_len, empty, bad, first, last;
+};
+
+struct spmv_dev {
+    int device = 0;
+    int cus = 256;
+    hipStream_t stream = nullptr;
+    int async = 0;
+    int m = 0, n = 0;
+    long long nnz = 0;
+    size_t vsize = 8;
+    // resident CSR
+    int *rowptr = nullptr, *colidx = nullptr;
+    void *val = nullptr;
+    spmv_stats stats{};
+    spmv_plan plan{};
+    bool built = false;
+    // nnz-split
+    int ntiles = 0, need_fixup = 0;
+    int *tile_first = nullptr;
+    void *carry = nullptr;
+    // row blocks
+    int nblocks = 0, rb_stride = 0;
+    int *rb_split = nullptr;
+    // sell
+    int nchunks = 0, nlong = 0, long_thr = 0;
+    long long sell_cols = 0; // sum of chunk widths
+    int *perm = nullptr, *scol = nullptr, *long_rows = nullptr;
+    long long *chunk_ptr = nullptr;
+    void *sval = nullptr;
+    // staging for host x / y
+    void *x_stage = nullptr, *y_stage = nullptr;
+    long long device_bytes = 0;
+    double inspect_ms = 0;
+    std::vector<void *> sched_allocs; // freed when the schedule is rebuilt
+};
+
+static int dev_alloc(spmv_dev *d, void **p, size_t bytes, bool sched)
+{
+    *p = nullptr;
+    if (bytes == 0) bytes = 16;
+    HIP_TRY(hipMalloc(p, bytes));
+    d->device_bytes += (long long) bytes;
+    if (sched) d->sched_allocs.push_back(*p);
+    return SPMV_HIP_OK;
+}
+#define ALLOC_TRY(d, p, bytes, sched)                                        \
+    do {                                                                     \
+        int rc__ = dev_alloc((d), (void **) (p), (bytes), (sched));          \
+        if (rc__) return rc__;                                               \
+    } while (0)
+
+static void free_schedule(spmv_dev *d)
+{
+    for (void *p : d->sched_allocs) (void) hipFree(p);
+    d->sched_allocs.clear();
+    d->tile_first = nullptr; d->carry = nullptr; d->rb_split = nullptr;
+    d->perm = d->scol = d->long_rows = nullptr; d->chunk_ptr = nullptr; d->sval = nullptr;
+    d->ntiles = d->nblocks = d->nchunks = d->nlong = 0;
+    d->built = false;
+}
+
+// true if the pointer is usable by a kernel as is (device or managed memory)
+static bool is_device_ptr(const void *p)
+{
+    if (!p) return false;
+    hipPointerAttribute_t a;
+    memset(&a, 0, sizeof a);
+    if (hipPointerGetAttributes(&a, p) != hipSuccess) {
+        (void) hipGetLastError(); // plain malloc memory: "invalid value", not an error for us
+        return false;
+    }
+    return a.type == hipMemoryTypeDevice || a.type == hipMemoryTypeManaged;
+}
+
+extern "C" int spmv_shim_device_count(void)
+{
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) { (void) hipGetLastError(); return 0; }
+    return n;
+}
+
+// ------------------------------------------------------------------------------------ stats
+__global__ __launch_bounds__(kBlock) void stats_kernel(int m, const int *__restrict__ rowptr, DevStats *s)
+{
+    int mx = 0, mn = INT_MAX, em = 0, bad = 0;
+    const long long stride = (long long) gridDim.x * kBlock;
+    for (long long r = (long long) blockIdx.x * kBlock + threadIdx.x; r < m; r += stride) {
+        const int len = rowptr[r + 1] - rowptr[r];
+        mx = max(mx, len);
+        mn = min(mn, len);
+        em += len == 0;
+        bad |= len < 0;
+    }
+#pragma unroll
+    for (int o = kWave / 2; o > 0; o >>= 1) {
+        mx = max(mx, __shfl_xor(mx, o, kWave));
+        mn = min(mn, __shfl_xor(mn, o, kWave));
+        em += __shfl_xor(em, o, kWave);
+        bad |= __shfl_xor(bad, o, kWave);
+    }
+    if ((threadIdx.x & (kWave - 1)) == 0) {
+        atomicMax(&s->max_len, mx);
+        atomicMin(&s->min_len, mn);
+        atomicAdd(&s->empty, em);
+        if (bad) atomicOr(&s->bad, 1);
+    }
+    if (blockIdx.x == 0 && threadIdx.x == 0) { s->first = rowptr[0]; s->last = rowptr[m]; }
+}
+
+__global__ __launch_bounds__(kBlock) void count_longer_kernel(int m, int thr, const int *__restrict__ rowptr, int *count)
+{
+    int c = 0;
+    const long long stride = (long long) gridDim.x * kBlock;
+    for (long long r = (long long) blockIdx.x * kBlock + threadIdx.x; r < m; r += stride)
+        c += (rowptr[r + 1] - rowptr[r]) > thr;
+#pragma unroll
+    for (int o = kWave / 2; o > 0; o >>= 1) c += __shfl_xor(c, o, kWave);
+    if ((threadIdx.x & (kWave - 1)) == 0 && c) atomicAdd(count, c);
+}
+
+template <typename T>
+__global__ __launch_bounds__(kBlock) void fill_zero_kernel(long long n, T *y)
+{
+    const long long stride = (long long) gridDim.x * kBlock;
+    for (long long i = (long long) blockIdx.x * kBlock + threadIdx.x; i < n; i += stride) y[i] = T(0);
+}
+
+static int grid_for(long long work_items, int per_block, int cap)
+{
+    long long g = (work_items + per_block - 1) / per_block;
+    if (g < 1) g = 1;
+    if (g > cap) g = cap;
+    return (int) g;
+}
+
+// ------------------------------------------------------------------------------------ create
+extern "C" int spmv_shim_matrix_create(spmv_dev **out, int m, int n, const int *rowptr, const int *colidx,
+                                       const void *val, size_t value_size)
+{
+    *out = nullptr;
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) {
+        (void) hipGetLastError();
+        return fail(SPMV_HIP_E_NODEVICE, "no HIP device visible (this library has no CPU path)");
+    }
+    spmv_dev *d = new spmv_dev();
+    HIP_TRY(hipGetDevice(&d->device));
+    hipDeviceProp_t prop;
+    HIP_TRY(hipGetDeviceProperties(&prop, d->device));
+    d->cus = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
+    d->m = m;
+    d->n = n;
+    d->vsize = value_size == sizeof(double) ? sizeof(double) : sizeof(float); // serial_spmv.c:48-54
+    int rc = SPMV_HIP_OK;
+    auto bail = [&](int code) { spmv_shim_matrix_destroy(d); return code; };
+
+    if ((rc = dev_alloc(d, (void **) &d->rowptr, sizeof(int) * ((size_t) m + 1), false))) return bail(rc);
+    if (m > 0) {
+        if (hipMemcpy(d->rowptr, rowptr, sizeof(int) * ((size_t) m + 1), hipMemcpyDefault) != hipSuccess)
+            return bail(fail(SPMV_HIP_E_RUNTIME, "copy RowPtr to HBM: %s", hipGetErrorString(hipGetLastError())));
+    } else {
+        (void) hipMemset(d->rowptr, 0, sizeof(int));
+    }
+    // row statistics (also validates RowPtr)
+    DevStats hs{0, INT_MAX, 0, 0, 0, 0};
+    DevStats *ds = nullptr;
+    if (hipMalloc((void **) &ds, sizeof(DevStats)) != hipSuccess) return bail(fail(SPMV_HIP_E_ALLOC, "hipMalloc(stats)"));
+    (void) hipMemcpy(ds, &hs, sizeof hs, hipMemcpyHostToDevice);
+    if (m > 0) {
+        stats_kernel<<<grid_for(m, kBlock, d->cus * 8), kBlock>>>(m, d->rowptr, ds);
+        if (hipGetLastError() != hipSuccess) { (void) hipFree(ds); return bail(fail(SPMV_HIP_E_RUNTIME, "stats kernel launch failed")); }
+    }
+    hipError_t e = hipMemcpy(&hs, ds, sizeof hs, hipMemcpyDeviceToHost);
+    (void) hipFree(ds);
+    if (e != hipSuccess) return bail(fail(SPMV_HIP_E_RUNTIME, "stats kernel: %s", hipGetErrorString(e)));
+    if (m > 0 && (hs.bad || hs.first != 0 || hs.last < 0))
+        return bail(fail(SPMV_HIP_E_ARG, "RowPtr must start at 0 and be non-decreasing (RowPtr[0]=%d)", hs.first));
+    d->nnz = m > 0 ? hs.last : 0;
+    if (d->nnz > 0 && (!colidx || !val)) return bail(fail(SPMV_HIP_E_ARG, "ColIdx / Matrix_Val is NULL"));
+    d->stats.m = m;
+    d->stats.n = n;
+    d->stats.nnz = d->nnz;
+    d->stats.max_row_len = m > 0 ? hs.max_len : 0;
+    d->stats.min_row_len = m > 0 ? hs.min_len : 0;
+    d->stats.empty_rows = hs.empty;
+    d->stats.mean_row_len = m > 0 ? (double) d->nnz / m : 0.0;
+
+    if ((rc = dev_alloc(d, (void **) &d->colidx, sizeof(int) * (size_t) d->nnz, false))) return bail(rc);
+    if ((rc = dev_alloc(d, &d->val, d->vsize * (size_t) d->nnz, false))) return bail(rc);
+    if (d->nnz > 0) {
+        if (hipMemcpy(d->colidx, colidx, sizeof(int) * (size_t) d->nnz, hipMemcpyDefault) != hipSuccess ||
+            hipMemcpy(d->val, val, d->vsize * (size_t) d->nnz, hipMemcpyDefault) != hipSuccess)
+            return bail(fail(SPMV_HIP_E_RUNTIME, "copy ColIdx/Val to HBM: %s", hipGetErrorString(hipGetLastError())));
+    }
+    *out = d;
+    return SPMV_HIP_OK;
+}
+
+extern "C" int spmv_shim_matrix_stats(const spmv_dev *d, spmv_stats *out)
+{
+    if (!d || !out) return fail(SPMV_HIP_E_ARG, "stats: NULL");
+    *out = d->stats;
+    return SPMV_HIP_OK;
+}
+
+extern "C" void spmv_shim_matrix_destroy(spmv_dev *d)
+{
+    if (!d) return;
+    free_schedule(d);
+    if (d->rowptr) (void) hipFree(d->rowptr);
+    if (d->colidx) (void) hipFree(d->colidx);
+    if (d->val) (void) hipFree(d->val);
+    if (d->x_stage) (void) hipFree(d->x_stage);
+    if (d->y_stage) (void) hipFree(d->y_stage);
+    delete d;
+}
+
+// ------------------------------------------------------------------------------------ inspectors
+template <typename T>
+static int build_nnz_split(spmv_dev *d)
+{
+    d->ntiles = (int) ((d->nnz + kSplitTile - 1) / kSplitTile);
+    if (d->ntiles == 0) return SPMV_HIP_OK;
+    ALLOC_TRY(d, &d->tile_first, sizeof(int) * ((size_t) d->ntiles + 1), true);
+    ALLOC_TRY(d, &d->carry, sizeof(T) * (size_t) d->ntiles, true);
+    int *flag = nullptr;
+    ALLOC_TRY(d, &flag, sizeof(int), true);
+    HIP_TRY(hipMemsetAsync(flag, 0, sizeof(int), d->stream));
+    nnz_tile_first_kernel<<<grid_for((long long) d->ntiles + 1, kBlock, INT_MAX), kBlock, 0, d->stream>>>(
+        d->m, d->ntiles, d->rowptr, d->tile_first, flag);
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipMemcpyAsync(&d->need_fixup, flag, sizeof(int), hipMemcpyDeviceToHost, d->stream));
+    HIP_TRY(hipStreamSynchronize(d->stream));
+    return SPMV_HIP_OK;
+}
+
+static int build_rowblock(spmv_dev *d)
+{
+    d->rb_stride = d->plan.rowblock_nnz;
+    d->nblocks = (int) ((d->nnz + d->rb_stride - 1) / d->rb_stride);
+    if (d->nblocks < 1) d->nblocks = 1;
+    ALLOC_TRY(d, &d->rb_split, sizeof(int) * ((size_t) d->nblocks + 1), true);
+    rowblock_split_kernel<<<grid_for((long long) d->nblocks + 1, kBlock, INT_MAX), kBlock, 0, d->stream>>>(
+        d->m, (int) d->nnz, d->nblocks, d->rb_stride, d->rowptr, d->rb_split);
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipStreamSynchronize(d->stream));
+    return SPMV_HIP_OK;
+}
+
+template <typename T>
+static int build_sell(spmv_dev *d)
+{
+    const int sigma = d->plan.sell_sigma;
+    if (d->plan.sell_c != kSellC) return fail(SPMV_HIP_E_ARG, "sell_c must be 64 (one wavefront per chunk)");
+    if (sigma < kSellC || sigma > 4096 || (sigma & (sigma - 1)))
+        return fail(SPMV_HIP_E_ARG, "sell_sigma must be a power of two in [64, 4096], got %d", sigma);
+    if (d->m == 0) return SPMV_HIP_OK;
+    const int nwin = (int) (((long long) d->m + sigma - 1) / sigma);
+    d->nchunks = nwin * (sigma / kSellC);
+    // rows that would pad a whole chunk to their length are kept in CSR (see sell.hpp)
+    double thr = 8.0 * d->stats.mean_row_len;
+    if (thr < 64.0) thr = 64.0;
+    d->long_thr = thr > (double) INT_MAX ? INT_MAX : (int) thr;
+    int *cnt = nullptr, *width = nullptr;
+    ALLOC_TRY(d, &cnt, sizeof(int), true);
+    HIP_TRY(hipMemsetAsync(cnt, 0, sizeof(int), d->stream));
+    count_longer_kernel<<<grid_for(d->m, kBlock, d->cus * 8), kBlock, 0, d->stream>>>(d->m, d->long_thr, d->rowptr, cnt);
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipMemcpyAsync(&d->nlong, cnt, sizeof(int), hipMemcpyDeviceToHost, d->stream));
+    HIP_TRY(hipStreamSynchronize(d->stream));
+    ALLOC_TRY(d, &d->long_rows, sizeof(int) * (size_t) (d->nlong > 0 ? d->nlong : 1), true);
+    ALLOC_TRY(d, &d->perm, sizeof(int) * (size_t) nwin * sigma, true);
+    ALLOC_TRY(d, &width, sizeof(int) * (size_t) d->nchunks, true);
+    ALLOC_TRY(d, &d->chunk_ptr, sizeof(long long) * ((size_t) d->nchunks + 1), true);
+    HIP_TRY(hipMemsetAsync(cnt, 0, sizeof(int), d->stream));
+    sell_sort_kernel<<<nwin, kBlock, sizeof(unsigned long long) * (size_t) sigma, d->stream>>>(
+        d->m, sigma, d->long_thr, d->rowptr, d->perm, width, d->long_rows, cnt);
+    HIP_TRY(hipGetLastError());
+    scan_i32_to_i64_kernel<<<1, kBlock, 0, d->stream>>>(d->nchunks, width, d->chunk_ptr);
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipMemcpyAsync(&d->sell_cols, d->chunk_ptr + d->nchunks, sizeof(long long), hipMemcpyDeviceToHost, d->stream));
+    HIP_TRY(hipStreamSynchronize(d->stream));
+    const size_t slots = (size_t) d->sell_cols * kSellC;
+    ALLOC_TRY(d, &d->scol, sizeof(int) * slots, true);
+    ALLOC_TRY(d, &d->sval, sizeof(T) * slots, true);
+    sell_fill_kernel<T><<<grid_for(d->nchunks, kBlock / kWave, INT_MAX), kBlock, 0, d->stream>>>(
+        d->nchunks, d->rowptr, d->colidx, (const T *) d->val, d->perm, d->chunk_ptr, d->scol, (T *) d->sval);
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipStreamSynchronize(d->stream));
+    return SPMV_HIP_OK;
+}
+
+extern "C" int spmv_shim_build(spmv_dev *d, const spmv_plan *plan)
+{
+    if (!d || !plan) return fail(SPMV_HIP_E_ARG, "build: NULL");
+    if (plan->sched < 0 || plan->sched >= SPMV_SCHED_COUNT) return fail(SPMV_HIP_E_ARG, "unknown schedule %d", plan->sched);
+    free_schedule(d);
+    d->plan = *plan;
+    const auto t0 = std::chrono::steady_clock::now();
+    int rc = SPMV_HIP_OK;
+    const bool f64 = d->vsize == sizeof(double);
+    switch (plan->sched) {
+    case SPMV_SCHED_CSR_SCALAR: break;
+    case SPMV_SCHED_CSR_VECTOR: {
+        const int L = plan->lanes_per_row;
+        if (L < 2 || L > 64 || (L & (L - 1))) return fail(SPMV_HIP_E_ARG, "lanes_per_row must be a power of two in [2, 64], got %d", L);
+        break;
+    }
+    case SPMV_SCHED_NNZ_SPLIT: rc = f64 ? build_nnz_split<double>(d) : build_nnz_split<float>(d); break;
+    case SPMV_SCHED_ROWBLOCK:
+        if (plan->rowblock_nnz < 64 || plan->rowblock_nnz > 4096) return fail(SPMV_HIP_E_ARG, "rowblock_nnz must be in [64, 4096]");
+        if (d->stats.max_row_len > plan->rowblock_nnz) return fail(SPMV_HIP_E_ARG, "row-block schedule needs max_row_len <= rowblock_nnz");
+        rc = build_rowblock(d);
+        break;
+    case SPMV_SCHED_SELL: rc = f64 ? build_sell<double>(d) : build_sell<float>(d); break;
+    case SPMV_SCHED_CSR5: return fail(SPMV_HIP_E_ARG, "CSR5 schedule: not built in this round yet");
+    }
+    if (rc) { free_schedule(d); return rc; }
+    d->inspect_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+    d->built = true;
+    return SPMV_HIP_OK;
+}
+
+// ------------------------------------------------------------------------------------ executors
+template <typename T, int L>
+static void launch_vector(spmv_dev *d, const T *x, T *y)
+{
+    constexpr int rows = kBlock / L;
+    const int grid = grid_for(d->m, rows, d->cus * 8 * 4);
+    csr_vector_kernel<T, L><<<grid, kBlock, 0, d->stream>>>(d->m, d->rowptr, d->colidx, (const T *) d->val, x, y);
+}
+
+template <typename T>
+static int launch(spmv_dev *d, const T *x, T *y)
+{
+    if (d->m == 0) return SPMV_HIP_OK;
+    if (d->nnz == 0) { // nothing to multiply: y = 0
+        fill_zero_kernel<T><<<grid_for(d->m, kBlock, d->cus * 8), kBlock, 0, d->stream>>>(d->m, y);
+        HIP_TRY(hipGetLastError());
+        return SPMV_HIP_OK;
+    }
+    const T *val = (const T *) d->val;
+    switch (d->plan.sched) {
+    case SPMV_SCHED_CSR_SCALAR:
+        csr_scalar_kernel<T><<<grid_for(d->m, kBlock, d->cus * 8), kBlock, 0, d->stream>>>(d->m, d->rowptr, d->colidx, val, x, y);
+        break;
+    case SPMV_SCHED_CSR_VECTOR:
+        switch (d->plan.lanes_per_row) {
+        case 2: launch_vector<T, 2>(d, x, y); break;
+        case 4: launch_vector<T, 4>(d, x, y); break;
+        case 8: launch_vector<T, 8>(d, x, y); break;
+        case 16: launch_vector<T, 16>(d, x, y); break;
+        case 32: launch_vector<T, 32>(d, x, y); break;
+        default: launch_vector<T, 64>(d, x, y); break;
+        }
+        break;
+    case SPMV_SCHED_NNZ_SPLIT: {
+        const int grid = grid_for(d->ntiles, kBlock / kWave, d->cus * 8);
+        nnz_split_kernel<T><<<grid, kBlock, 0, d->stream>>>(d->m, (int) d->nnz, d->ntiles, d->rowptr, d->colidx, val, x, y,
+                                                             d->tile_first, (T *) d->carry);
+        if (d->need_fixup && d->ntiles > 1)
+            nnz_fixup_kernel<T><<<grid_for(d->ntiles - 1, kBlock, INT_MAX), kBlock, 0, d->stream>>>(
+                d->ntiles, d->rowptr, d->tile_first, (const T *) d->carry, y);
+        break;
+    }
+    case SPMV_SCHED_ROWBLOCK:
+        rowblock_kernel<T><<<d->nblocks, kBlock, 2 * (size_t) d->rb_stride * sizeof(T), d->stream>>>(
+            d->rb_split, d->rowptr, d->colidx, val, x, y);
+        break;
+    case SPMV_SCHED_SELL:
+        sell_kernel<T><<<grid_for(d->nchunks, kBlock / kWave, d->cus * 8), kBlock, 0, d->stream>>>(
+            d->nchunks, d->chunk_ptr, d->scol, (const T *) d->sval, d->perm, x, y);
+        if (d->nlong > 0)
+            sell_long_rows_kernel<T><<<grid_for(d->nlong, kBlock / kWave, INT_MAX), kBlock, 0, d->stream>>>(
+                d->nlong, d->long_rows, d->rowptr, d->colidx, val, x, y);
+        break;
+    default: return fail(SPMV_HIP_E_ARG, "schedule %d has no executor", d->plan.sched);
+    }
+    HIP_TRY(hipGetLastError());
+    return SPMV_HIP_OK;
+}
+
+extern "C" int spmv_shim_run(spmv_dev *d, const void *x, void *y)
+{
+    if (!d || !d->built) return fail(SPMV_HIP_E_NOSTATE, "run: schedule not built");
+    if ((d->n > 0 && d->nnz > 0 && !x) || (d->m > 0 && !y)) return fail(SPMV_HIP_E_ARG, "run: X or Y is NULL");
+    int cur = -1;
+    if (hipGetDevice(&cur) == hipSuccess && cur != d->device) HIP_TRY(hipSetDevice(d->device));
+    const bool xdev = is_device_ptr(x), ydev = is_device_ptr(y);
+    const void *xd = x;
+    void *yd = y;
+    if (!xdev && d->n > 0 && x) { // host x: stage through HBM (correct, PCIe-bound)
+        if (!d->x_stage) ALLOC_TRY(d, &d->x_stage, d->vsize * (size_t) d->n, false);
+        HIP_TRY(hipMemcpyAsync(d->x_stage, x, d->vsize * (size_t) d->n, hipMemcpyHostToDevice, d->stream));
+        xd = d->x_stage;
+    }
+    if (!ydev && d->m > 0) {
+        if (!d->y_stage) ALLOC_TRY(d, &d->y_stage, d->vsize * (size_t) d->m, false);
+        yd = d->y_stage;
+    }
+    int rc = d->vsize == sizeof(double) ? launch<double>(d, (const double *) xd, (double *) yd)
+                                        : launch<float>(d, (const float *) xd, (float *) yd);
+    if (rc) return rc;
+    if (!ydev && d->m > 0) HIP_TRY(hipMemcpyAsync(y, d->y_stage, d->vsize * (size_t) d->m, hipMemcpyDeviceToHost, d->stream));
+    if (!d->async || !xdev || !ydev) HIP_TRY(hipStreamSynchronize(d->stream));
+    return SPMV_HIP_OK;
+}
+
+extern "C" int spmv_shim_set_stream(spmv_dev *d, void *stream)
+{
+    if (!d) return fail(SPMV_HIP_E_ARG, "set_stream: NULL");
+    d->stream = (hipStream_t) stream;
+    return SPMV_HIP_OK;
+}
+
+extern "C" int spmv_shim_set_async(spmv_dev *d, int async)
+{
+    if (!d) return fail(SPMV_HIP_E_ARG, "set_async: NULL");
+    d->async = async;
+    return SPMV_HIP_OK;
+}
+
+extern "C" int spmv_shim_sync(spmv_dev *d)
+{
+    if (!d) return fail(SPMV_HIP_E_ARG, "sync: NULL");
+    HIP_TRY(hipStreamSynchronize(d->stream));
+    return SPMV_HIP_OK;
+}
+
+extern "C" double spmv_shim_time(spmv_dev *d, const void *x, void *y, int warmup, int iters, float *ms_out)
+{
+    if (!d || !d->built || iters <= 0) { fail(SPMV_HIP_E_ARG, "time: bad arguments"); return -1.0; }
+    if (!is_device_ptr(x) || !is_device_ptr(y)) { fail(SPMV_HIP_E_ARG, "time: x and y must be device pointers"); return -1.0; }
+    const int keep_async = d->async;
+    d->async = 1;
+    std::vector<hipEvent_t> ev((size_t) iters + 1);
+    for (auto &e : ev) if (hipEventCreate(&e) != hipSuccess) { d->async = keep_async; fail(SPMV_HIP_E_RUNTIME, "hipEventCreate"); return -1.0; }
+    int rc = SPMV_HIP_OK;
+    for (int i = 0; i < warmup && !rc; ++i) rc = spmv_shim_run(d, x, y);
+    for (int i = 0; i < iters && !rc; ++i) {
+        (void) hipEventRecord(ev[i], d->stream);
+        rc = spmv_shim_run(d, x, y);
+    }
+    (void) hipEventRecord(ev[iters], d->stream);
+    hipError_t e = hipStreamSynchronize(d->stream);
+    d->async = keep_async;
+    double mean = -1.0;
+    if (!rc && e == hipSuccess) {
+        double tot = 0;
+        for (int i = 0; i < iters; ++i) {
+            float ms = 0;
+            (void) hipEventElapsedTime(&ms, ev[i], ev[i + 1]);
+            if (ms_out) ms_out[i] = ms;
+            tot += ms;
+        }
+        mean = tot / iters;
+    } else if (e != hipSuccess) {
+        fail(SPMV_HIP_E_RUNTIME, "time: %s", hipGetErrorString(e));
+    }
+    for (auto &v : ev) (void) hipEventDestroy(v);
+    return mean;
+}
+
+// ------------------------------------------------------------------------------------ info
+static const char *kSchedNames[] = {"csr-scalar", "csr-vector", "row-block", "nnz-split", "sell-c-sigma", "csr5"};
+static const char *kKernelNames[] = {"csr_scalar_kernel", "csr_vector_kernel", "rowblock_kernel",
+                                     "nnz_split_kernel", "sell_kernel", "csr5_kernel"};
+
+extern "C" int spmv_shim_info(const spmv_dev *d, spmv_hip_info *o)
+{
+    if (!d || !o) return fail(SPMV_HIP_E_ARG, "info: NULL");
+    memset(o, 0, sizeof *o);
+    o->device = d->device;
+    o->schedule = d->plan.sched;
+    o->lanes_per_row = d->plan.sched == SPMV_SCHED_CSR_VECTOR ? d->plan.lanes_per_row : 0;
+    o->sell_c = d->plan.sched == SPMV_SCHED_SELL ? kSellC : 0;
+    o->sell_sigma = d->plan.sched == SPMV_SCHED_SELL ? d->plan.sell_sigma : 0;
+    o->tile_nnz = d->plan.sched == SPMV_SCHED_NNZ_SPLIT ? kSplitTile : (d->plan.sched == SPMV_SCHED_ROWBLOCK ? d->rb_stride : 0);
+    o->m = d->m;
+    o->n = d->n;
+    o->nnz = d->nnz;
+    o->stored_nnz = d->plan.sched == SPMV_SCHED_SELL ? d->sell_cols * kSellC + (long long) 0 : d->nnz;
+    o->max_row_len = d->stats.max_row_len;
+    o->min_row_len = d->stats.min_row_len;
+    o->empty_rows = d->stats.empty_rows;
+    o->mean_row_len = d->stats.mean_row_len;
+    o->device_bytes = d->device_bytes;
+    const long long s = (long long) d->vsize;
+    o->alg_bytes = 4ll * ((long long) d->m + 1) + d->nnz * (4 + s) + s * d->n + s * d->m;
+    o->inspect_ms = d->inspect_ms;
+    o->schedule_name = kSchedNames[d->plan.sched];
+    o->kernel_name = kKernelNames[d->plan.sched];
+    return SPMV_HIP_OK;
+}

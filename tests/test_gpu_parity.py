@@ -1,0 +1,179 @@
+"""GPU parity: every HIP schedule against the golden vectors captured from the reference's
+Method_Serial and against the oracle, through the C ABI (spmv_amd.api is a ctypes mirror of it).
+
+Bars (north_star): exact-arithmetic ("eighths") inputs -> BIT-EXACT for every schedule;
+random inputs -> |y - y_exact| <= tol * sum_j |a_ij x_j| per row with tol = 1e-6 (fp64) /
+1e-3 (fp32); additionally a sharper sanity bound of 64 ulp-units of the row magnitude."""
+import json
+import os
+
+import numpy as np
+import pytest
+
+import oracle
+from conftest import GOLDEN, load_golden
+from spmv_amd import api, build, synth
+
+pytestmark = pytest.mark.gpu
+
+M = api.SPMV_METHODS
+with open(os.path.join(GOLDEN, "manifest.json")) as _f:
+    NAMES = sorted(json.load(_f)["cases"].keys())
+
+ALL_METHODS = [M.Method_Serial, M.Method_Parallel, M.Method_Balanced, M.Method_Balanced2,
+               M.Method_Balanced_Yid, M.Method_SellCSigma, M.Method_CSR5SPMV]
+TOL = {np.dtype(np.float64): 1e-6, np.dtype(np.float32): 1e-3}          # north_star
+SHARP = {np.dtype(np.float64): 64 * 2.3e-16, np.dtype(np.float32): 64 * 1.2e-7}
+
+
+@pytest.fixture(scope="module", autouse=True)
+def _lib():
+    build.build()
+    lib = api.load()
+    assert lib.spmv_hip_device_count() > 0, "GPU tests need a device"
+    return lib
+
+
+def run_host(csr, x, method, way=api.VECTORIZED_WAY.VECTOR_HIP, nthreads=1):
+    """Reference-harness call sequence with HOST arrays (test_spmv.c:88-104)."""
+    y = np.full(csr.m, np.nan, dtype=csr.val.dtype)
+    h = api.spmv_create_handle_all_in_one(csr.m, csr.n, csr.rowptr, csr.colidx, csr.val, nthreads, method,
+                                          csr.val.dtype.itemsize, way, "golden")
+    actual = h.contents.spmvMethod
+    api.spmv(h, csr.m, csr.rowptr, csr.colidx, csr.val, x, y)
+    api.spmv_destory_handle(h)
+    return y, actual
+
+
+def check(y, csr, x, y_ref, exact):
+    assert not np.isnan(y).any(), f"{int(np.isnan(y).sum())} rows left unwritten"
+    if exact:
+        assert np.array_equal(y.view(np.uint8), y_ref.view(np.uint8))
+        return
+    ye = oracle.spmv_exact(csr, x)
+    s = oracle.row_abs_sum(csr, x)
+    err = np.abs(y.astype(np.float64) - ye)
+    assert (err <= TOL[y.dtype] * s + 1e-300).all(), float((err / np.maximum(s, 1e-300)).max())
+    assert (err <= SHARP[y.dtype] * np.maximum(1, np.diff(csr.rowptr)) * s + 1e-300).all()
+
+
+@pytest.mark.parametrize("method", ALL_METHODS, ids=lambda m: m.name)
+@pytest.mark.parametrize("name", NAMES)
+def test_golden_host_pointers(name, method):
+    csr, x, y_ref = load_golden(name)
+    y, _ = run_host(csr, x, method)
+    check(y, csr, x, y_ref, exact=name.endswith("eighths"))
+
+
+@pytest.mark.parametrize("method", ALL_METHODS, ids=lambda m: m.name)
+@pytest.mark.parametrize("name", ["banded_f64_eighths", "powerlaw_f32_eighths", "empty_mix_f64_uniform",
+                                  "dense_row0_f32_uniform", "skewed_f32_eighths", "nnz0_f64_uniform"])
+def test_golden_device_pointers(name, method):
+    import torch
+    csr, x, y_ref = load_golden(name)
+    dev = torch.device("cuda:0")
+    rp, ci = torch.from_numpy(csr.rowptr).to(dev), torch.from_numpy(csr.colidx).to(dev)
+    va, xd = torch.from_numpy(csr.val).to(dev), torch.from_numpy(x).to(dev)
+    yd = torch.full((csr.m,), float("nan"), dtype=va.dtype, device=dev)
+    with api.Handle(csr.m, csr.n, rp, ci, va, method) as h:
+        h.spmv(xd, yd)
+        h.spmv(xd, yd)  # idempotent
+    torch.cuda.synchronize()
+    check(yd.cpu().numpy(), csr, x, y_ref, exact=name.endswith("eighths"))
+
+
+@pytest.mark.parametrize("way", list(api.VECTORIZED_WAY)[:4], ids=lambda w: w.name)
+def test_every_vectorized_way_runs_the_hip_backend(way):
+    """The reference stores vectorizedWay and never reads it (common.c:80); here all four values
+    select the HIP schedules and the handle records what was asked."""
+    csr, x, y_ref = load_golden("banded_f64_eighths")
+    y = np.full(csr.m, np.nan)
+    h = api.spmv_create_handle_all_in_one(csr.m, csr.n, csr.rowptr, csr.colidx, csr.val, 4, M.Method_Parallel, 8, way)
+    assert h.contents.vectorizedWay == int(way) and h.contents.nthreads == 4
+    assert h.contents.index is None or not h.contents.index
+    api.spmv(h, csr.m, csr.rowptr, csr.colidx, csr.val, x, y)
+    api.spmv_destory_handle(h)
+    assert np.array_equal(y, y_ref)
+
+
+def test_out_of_range_method_is_serial():
+    csr, x, y_ref = load_golden("tiny_f64_eighths")
+    for bad in (-3, 7, 8, 99):
+        y, actual = run_host(csr, x, bad)
+        assert actual == M.Method_Serial and np.array_equal(y, y_ref)   # common.c:136
+
+
+def test_balanced_request_is_rewritten_like_the_reference():
+    """parallel_balanced2_spmv.c:72-92: Balanced/Balanced2 become Balanced2 when some row is longer
+    than one equal-nnz share, Balanced otherwise."""
+    short, x1, _ = load_golden("banded_f64_eighths")
+    long_, x2, _ = load_golden("single_long_f64_eighths")
+    for req in (M.Method_Balanced, M.Method_Balanced2):
+        assert run_host(short, x1, req)[1] == M.Method_Balanced
+        assert run_host(long_, x2, req)[1] == M.Method_Balanced2
+
+
+@pytest.mark.parametrize("method", ALL_METHODS, ids=lambda m: m.name)
+@pytest.mark.parametrize("dtype", [np.float64, np.float32])
+def test_lifecycle_create_spmv_clear_reuse_destroy(method, dtype):
+    csr = synth.powerlaw(2000, 2000, 6.0, 700, 1.5, "eighths", dtype, seed=5)
+    x = synth.fill_x(csr.n, "eighths", dtype, 9)
+    want = oracle.spmv_serial(csr, x)
+    h = api.spmv_create_handle_all_in_one(csr.m, csr.n, csr.rowptr, csr.colidx, csr.val, 8, method, csr.val.dtype.itemsize)
+    for _ in range(3):
+        y = np.full(csr.m, np.nan, dtype=dtype)
+        api.spmv(h, csr.m, csr.rowptr, csr.colidx, csr.val, x, y)
+        assert np.array_equal(y, want)
+    api.spmv_clear_handle(h)                                    # common.c:69-71
+    assert h.contents.spmvMethod == M.Method_Serial and not h.contents.extraHandle
+    api.spmv(h, csr.m, csr.rowptr, csr.colidx, csr.val, x, y, check=False)   # cleared handle: reported no-op
+    assert api.last_error()[0] == 5
+    api.load().spmv_hip_clear_error()
+    api.spmv_destory_handle(h)
+
+
+def test_spmv_with_other_csr_arrays_reinspects(monkeypatch):
+    """The reference computes with the arrays passed to spmv() (common.c:286-298)."""
+    monkeypatch.setenv("SPMV_HIP_QUIET", "1")
+    a = synth.banded(500, 500, 8, 7, "eighths", np.float64, seed=1)
+    b = synth.powerlaw(700, 500, 5.0, 300, 1.5, "eighths", np.float64, seed=2)
+    x = synth.fill_x(500, "eighths", np.float64, 3)
+    h = api.spmv_create_handle_all_in_one(a.m, a.n, a.rowptr, a.colidx, a.val, 1, M.Method_Balanced_Yid, 8)
+    y = np.full(b.m, np.nan)
+    api.spmv(h, b.m, b.rowptr, b.colidx, b.val, x, y)
+    assert np.array_equal(y, oracle.spmv_serial(b, x))
+    y = np.full(a.m, np.nan)
+    api.spmv(h, a.m, a.rowptr, a.colidx, a.val, x, y)
+    assert np.array_equal(y, oracle.spmv_serial(a, x))
+    api.spmv_destory_handle(h)
+
+
+@pytest.mark.parametrize("lanes", [2, 4, 8, 16, 32, 64])
+def test_csr_vector_every_lane_width(lanes):
+    csr, x, y_ref = load_golden("rowlen_sweep_f64_eighths")
+    api.set_option("lanes_per_row", lanes)
+    try:
+        y, _ = run_host(csr, x, M.Method_Parallel)
+    finally:
+        api.set_option("lanes_per_row", 0)
+    assert np.array_equal(y, y_ref)
+
+
+def test_nan_in_x_stays_in_its_rows():
+    """Padding (SELL) and masked tile slots never multiply x: a NaN in x reaches only rows that
+    reference its column (the reference guards padded slots too, inner_spmv.h:466-474)."""
+    csr = synth.skewed_rows(1500, 4096, "uniform", np.float64, seed=6)
+    x = synth.fill_x(csr.n, "uniform", np.float64, 1)
+    x[0] = np.nan
+    want = oracle.spmv_serial(csr, x)
+    for method in ALL_METHODS:
+        y, _ = run_host(csr, x, method)
+        assert np.array_equal(np.isnan(y), np.isnan(want)), method
+
+
+def test_handle_info_and_alg_bytes():
+    csr, x, _ = load_golden("banded_f64_uniform")
+    with api.Handle(csr.m, csr.n, csr.rowptr, csr.colidx, csr.val, M.Method_Parallel) as h:
+        info = h.info()
+    assert info["schedule_name"] == "csr-vector" and info["nnz"] == csr.nnz
+    assert info["alg_bytes"] == 4 * (csr.m + 1) + csr.nnz * 12 + 8 * csr.n + 8 * csr.m

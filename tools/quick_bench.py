@@ -1,0 +1,57 @@
+#!/usr/bin/env python3
+"""Developer tool: time every schedule on a config-2-shaped matrix (not the judged bench)."""
+import argparse, json, sys, os, time
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+from spmv_amd import api, synth, build
+
+ap = argparse.ArgumentParser()
+ap.add_argument("--m", type=int, default=10_000_000)
+ap.add_argument("--k", type=int, default=32)
+ap.add_argument("--dtype", default="f64")
+ap.add_argument("--kind", default="banded")
+ap.add_argument("--methods", default="1,2,3,4,5,0")
+ap.add_argument("--lanes", default="0")
+ap.add_argument("--variants", default="0")
+ap.add_argument("--iters", type=int, default=30)
+a = ap.parse_args()
+build.build()
+dt = torch.float64 if a.dtype == "f64" else torch.float32
+dev = "cuda:0"
+t0 = time.time()
+if a.kind == "banded":
+    m, n, rp, ci, va = synth.banded_device(a.m, a.m, a.k, "uniform", dt, dev, 1)
+elif a.kind == "random":
+    m, n, rp, ci, va = synth.uniform_k_device(a.m, a.m, a.k, "uniform", dt, dev, 1)
+elif a.kind == "skewed":
+    m, n, rp, ci, va = synth.from_row_lengths_device(synth.skewed_lengths_device(a.m, dev, 1), a.m, "uniform", dt, dev, 1, local=4096)
+elif a.kind == "powerlaw":
+    m, n, rp, ci, va = synth.from_row_lengths_device(synth.powerlaw_lengths_device(a.m, a.k, 100000, 1.6, dev, 1), a.m, "uniform", dt, dev, 1)
+torch.cuda.synchronize()
+x = torch.rand(n, dtype=dt, device=dev) * 2 - 1
+y = torch.empty(m, dtype=dt, device=dev)
+nnz = int(rp[-1].item())
+print(f"# {a.kind} m={m} nnz={nnz} gen {time.time()-t0:.1f}s", flush=True)
+yref = None
+for meth in [int(s) for s in a.methods.split(",")]:
+    for lanes in [int(s) for s in a.lanes.split(",")]:
+      for var in [int(s) for s in a.variants.split(",")]:
+        api.set_option("lanes_per_row", lanes)
+        api.set_option("variant", var)
+        try:
+            h = api.Handle(m, n, rp, ci, va, meth)
+        except api.SpmvError as e:
+            print("skip", meth, e); continue
+        info = h.info()
+        y.fill_(float("nan"))
+        mean, ms = api.time_launches(h.h, x, y, 5, a.iters)
+        torch.cuda.synchronize()
+        if yref is None:
+            yref = y.clone()
+        err = (y - yref).abs().max().item()
+        gb = info["alg_bytes"] / 1e9
+        print(json.dumps(dict(method=api.SPMV_METHODS(meth).name, sched=info["schedule_name"], lanes=info["lanes_per_row"], variant=var,
+              ms_mean=round(mean, 4), ms_min=round(float(ms.min()), 4), gbps_alg=round(float(gb / (ms.min() / 1e3)), 1),
+              frac_8TBs=round(float(gb / (ms.min() / 1e3) / 8000), 3), gflops=round(float(2 * nnz / ms.min() / 1e6), 1),
+              inspect_ms=round(info["inspect_ms"], 2), stored=info["stored_nnz"], maxdiff_vs_first=err, nan=int(torch.isnan(y).sum().item()))), flush=True)
+        h.close()
