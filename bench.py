@@ -1,0 +1,252 @@
+#!/usr/bin/env python3
+"""bench.py -- the reference's headline benchmark on MI355X (BASELINE.json metric).
+
+    python bench.py [--gpus N] [--steps K] [--warmup W]
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
+        --master-port P bench.py --gpus N --steps K --warmup W
+
+A "step" is one pass of the hot path: y = A x through the C ABI (spmv(), include/spmv.h) on a
+matrix that is already resident in HBM; x and y are device-resident (DESIGN.md gives the
+PCIe-inclusive host-pointer figure, it is never `value`).
+
+Workload at N = 1 = BASELINE config 2: CSR fp64, 1e7 x 1e7, exactly 32 nnz/row, banded
+(SURVEY 8d variant (i)), schedule Method_Parallel = CSR-vector.  At N > 1 = config 5 scaled
+weakly: every rank holds a 1e7-row block of the (N*1e7)^2 banded matrix (local int32 RowPtr,
+global columns) and the matching slice of x; each step first exchanges x over RCCL
+(spmv_amd.dist, mode --xchg, default "halo") and then multiplies.  No data-path collective
+besides that exchange; y stays distributed.
+
+Timing follows the driver contract: W untimed steps, then exactly K steps between
+barrier + torch.cuda.synchronize() pairs, MAX over ranks, rank 0 prints ONE JSON line.
+`value` = 2 * nnz(all ranks) * K / time (FLOPs per SpMV = 2 nnz: test_spmv.c:126).
+`roofline.achieved` = B_alg / mean launch duration, the duration taken from HIP events recorded
+around every launch of the timed region on the stream the kernel runs on;
+B_alg = 4(m+1) + nnz(4+s) + s n + s m.
+`cpu_baseline` (rank 0, N = 1): the real reference's OpenMP path (oracle/_ref, Method_Parallel,
+kind "reference") or, if that library is absent, the oracle's OpenMP port, on the first
+--cpu-rows rows of the same matrix, with the GPU result checked against it.
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+os.environ.setdefault("OMP_PROC_BIND", "true")   # unbound Method_Parallel is 4x slower
+os.environ.setdefault("OMP_PLACES", "cores")
+os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+
+import numpy as np  # noqa: E402
+import torch  # noqa: E402
+import torch.distributed as dist  # noqa: E402
+
+HBM_PEAK_GBPS = 8000.0  # MI355X_MICROARCH.md "HBM3E peak BW 8.0 TB/s spec"
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=100)   # test_spmv.c:103-124: 10 warm + 100 timed
+    ap.add_argument("--warmup", type=int, default=10)
+    ap.add_argument("--rows", type=int, default=10_000_000, help="rows per GPU")
+    ap.add_argument("--nnz-per-row", type=int, default=32)
+    ap.add_argument("--dtype", default="f64", choices=["f64", "f32"])
+    ap.add_argument("--workload", default="banded", choices=["banded", "random"])
+    ap.add_argument("--method", type=int, default=1, help="SPMV_METHODS id (1 = Method_Parallel = CSR-vector)")
+    ap.add_argument("--xchg", default="halo", choices=["halo", "allgather", "bcast", "none"])
+    ap.add_argument("--cpu-rows", type=int, default=1_000_000)
+    ap.add_argument("--cpu-seconds", type=float, default=15.0)
+    ap.add_argument("--no-cpu", action="store_true")
+    return ap.parse_args()
+
+
+def cpu_baseline(args, rp, ci, va, x, y_gpu, n_cols):
+    """Time the reference's OpenMP CSR path on a bounded sample of the same workload (host cores
+    of this box) and check the GPU result against it.  The oracle package is used here only as the
+    thing being timed/checked against -- never by the product path."""
+    import ctypes as C
+    import oracle
+    rows = min(args.cpu_rows, rp.numel() - 1)
+    p1 = int(rp[rows].item())
+    from spmv_amd.synth import CSR
+    csr = CSR(rows, n_cols, rp[: rows + 1].cpu().numpy(), ci[:p1].cpu().numpy(), va[:p1].cpu().numpy())
+    xh = x.cpu().numpy()
+    cores = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    try:
+        gomp = C.CDLL("libgomp.so.1")
+        gomp.omp_set_num_threads(int(cores))
+    except OSError:
+        pass
+    kind = "reference" if oracle.have_ref() else "port"
+    I = C.POINTER(C.c_int)
+    y = np.full(rows, np.nan, dtype=csr.val.dtype)
+    if kind == "reference":
+        L = oracle.ref_lib()
+        h = C.POINTER(oracle.RefHandle)()
+        L.spmv_create_handle_all_in_one(C.byref(h), rows, n_cols, csr.rowptr.ctypes.data_as(I), csr.colidx.ctypes.data_as(I),
+                                        csr.val.ctypes.data_as(C.c_void_p), cores, 1, csr.val.dtype.itemsize, 0, None)
+        def run():
+            L.spmv(h, rows, csr.rowptr.ctypes.data_as(I), csr.colidx.ctypes.data_as(I), csr.val.ctypes.data_as(C.c_void_p),
+                   xh.ctypes.data_as(C.c_void_p), y.ctypes.data_as(C.c_void_p))
+    else:
+        L = oracle.lib()
+        def run():
+            L.oracle_spmv_omp(rows, csr.rowptr.ctypes.data_as(I), csr.colidx.ctypes.data_as(I), csr.val.ctypes.data_as(C.c_void_p),
+                              xh.ctypes.data_as(C.c_void_p), y.ctypes.data_as(C.c_void_p), csr.val.dtype.itemsize)
+    for _ in range(3):
+        run()
+    times = []
+    t_end = time.perf_counter() + args.cpu_seconds
+    while len(times) < 100 and (time.perf_counter() < t_end or len(times) < 5):
+        t0 = time.perf_counter()
+        run()
+        times.append(time.perf_counter() - t0)
+    if kind == "reference":
+        L.spmv_destory_handle(h)
+    mean = float(np.mean(times))
+    # parity of the GPU result on the sample rows (tolerance of north_star, scaled per row)
+    s = oracle.row_abs_sum(csr, xh)
+    err = np.abs(y_gpu[:rows].cpu().numpy().astype(np.float64) - y.astype(np.float64))
+    tol = 1e-6 if csr.val.dtype == np.float64 else 1e-3
+    rel = float((err / np.maximum(s, 1e-300)).max())
+    return {
+        "value": round(2.0 * p1 / mean / 1e9, 3), "unit": "GFLOP/s", "cores": int(cores), "kind": kind,
+        "sample": f"first {rows} rows ({p1} nnz) of the same matrix, {len(times)} timed calls of "
+                  f"{'reference Method_Parallel' if kind == 'reference' else 'oracle OpenMP row loop'}, mean {mean * 1e3:.2f} ms",
+        "ms": round(mean * 1e3, 3), "gpu_vs_cpu_max_rel_err": rel, "parity_ok": bool(rel <= tol),
+    }
+
+
+def traffic_from_profiles(kernel_name):
+    """HBM bytes per launch of the dominant kernel from the committed rocprofv3 --pmc passes
+    (tools/profile_bench.sh writes profiles/traffic_latest.json); None if never collected."""
+    path = os.path.join(ROOT, "profiles", "traffic_latest.json")
+    try:
+        with open(path) as f:
+            t = json.load(f)
+        if t.get("kernel") and kernel_name and kernel_name in t["kernel"]:
+            return t.get("hbm_bytes_per_launch")
+    except (OSError, ValueError):
+        pass
+    return None
+
+
+def main():
+    args = parse()
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world > 1:
+        torch.cuda.set_device(local_rank)
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+    assert world == args.gpus or world == 1, f"--gpus {args.gpus} but WORLD_SIZE {world}"
+    dev = torch.device("cuda", local_rank if world > 1 else 0)
+    torch.cuda.set_device(dev)
+
+    from spmv_amd import api, build, synth
+    from spmv_amd.dist import ShardedSpMV
+    if rank == 0:
+        build.build()
+    if world > 1:
+        dist.barrier()
+    api.load()
+
+    dt = torch.float64 if args.dtype == "f64" else torch.float32
+    s = 8 if args.dtype == "f64" else 4
+    m_loc, k = args.rows, args.nnz_per_row
+    n_glob = m_loc * world
+    if args.workload == "banded":
+        _, _, rp, ci, va = synth.banded_device(m_loc, n_glob, k, "uniform", dt, dev, seed=1 + rank, row0=rank * m_loc)
+    else:
+        _, _, rp, ci, va = synth.uniform_k_device(m_loc, n_glob, k, "uniform", dt, dev, seed=1 + rank)
+    nnz_loc = int(rp[-1].item())
+    g = torch.Generator(device=dev)
+    g.manual_seed(1234)                     # same full x on every rank, sliced by ownership
+    x_full = torch.rand(n_glob, generator=g, device=dev, dtype=dt) * 2 - 1
+    y = torch.full((m_loc,), float("nan"), dtype=dt, device=dev)
+
+    t0 = time.perf_counter()
+    sh = ShardedSpMV(rp, ci, va, n_glob, xchg=args.xchg, method=args.method)
+    if sh.xchg in ("none", "bcast"):
+        if sh.xchg == "none" or rank == 0:
+            sh.set_full_x(x_full)
+    x_loc = sh.x_local_view()            # x lives where the kernel reads it: exchange() is copy-free
+    x_loc.copy_(x_full[sh.c0:sh.c1])
+    if world > 1:
+        del x_full
+    torch.cuda.synchronize()
+    create_s = time.perf_counter() - t0
+    info = sh.handle.info()
+
+    def sync_all():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        sh.step(x_loc, y)
+    K = args.steps
+    ev = [torch.cuda.Event(enable_timing=True) for _ in range(2 * K)]
+    sync_all()
+    t0 = time.perf_counter()
+    for i in range(K):
+        sh.exchange(x_loc)
+        ev[2 * i].record()          # torch's current stream == the handle's stream (attach_stream)
+        sh.multiply(y)
+        ev[2 * i + 1].record()
+    sync_all()
+    elapsed = time.perf_counter() - t0
+    launch_ms = np.array([ev[2 * i].elapsed_time(ev[2 * i + 1]) for i in range(K)])
+    if world > 1:
+        tt = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        elapsed = float(tt.item())
+        nn = torch.tensor([nnz_loc], dtype=torch.int64, device=dev)
+        dist.all_reduce(nn, op=dist.ReduceOp.SUM)
+        nnz_all = int(nn.item())
+    else:
+        nnz_all = nnz_loc
+
+    if rank == 0:
+        ms_step = elapsed / K * 1e3
+        gflops = 2.0 * nnz_all * K / elapsed / 1e9
+        # per-launch algorithmic bytes of THIS rank's kernel: its x footprint is what it reads
+        alg_bytes = 4 * (m_loc + 1) + nnz_loc * (4 + s) + s * sh.n_x + s * m_loc
+        mean_launch = float(launch_ms.mean())
+        achieved = alg_bytes / (mean_launch * 1e-3) / 1e9
+        out = {
+            "metric": "SpMV GFLOP/s (fp64 CSR, y = A x through spmv())" if s == 8 else "SpMV GFLOP/s (fp32 CSR)",
+            "value": round(gflops, 2), "unit": "GFLOP/s", "n_gpus": world, "steps": K, "warmup": args.warmup,
+            "ms_per_step": round(ms_step, 5), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": args.dtype, "data": "synthetic",
+            "config": {
+                "workload": f"config {'2' if world == 1 else '5 (weak)'}: {args.workload} CSR {m_loc * world}x{n_glob}, "
+                            f"{k} nnz/row, {m_loc} rows per GPU",
+                "schedule": f"{api.SPMV_METHODS(args.method).name} -> {info['schedule_name']}"
+                            + (f" L={info['lanes_per_row']}" if info['lanes_per_row'] else ""),
+                "x_exchange": sh.xchg, "ghost_columns_rank0": sh.n_ghost, "vectors": "device-resident x, y",
+                "nnz_total": nnz_all, "create_seconds": round(create_s, 3), "inspect_ms": round(info["inspect_ms"], 3),
+            },
+            "hbm_gbps_alg": round(achieved, 1),
+            "roofline": {
+                "bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
+                "frac": round(achieved / HBM_PEAK_GBPS, 4), "traffic": traffic_from_profiles(info["kernel_name"]),
+                "kernel": info["kernel_name"], "alg_bytes_per_launch": alg_bytes,
+                "launch_ms_mean": round(mean_launch, 5), "launch_ms_min": round(float(launch_ms.min()), 5),
+            },
+        }
+        if world == 1 and not args.no_cpu:
+            out["cpu_baseline"] = cpu_baseline(args, rp, ci, va, sh.x_ext, y, sh.n_x)
+        print(json.dumps(out), flush=True)
+    sh.close()
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,172 @@
+"""Row-block partitioned SpMV across the GPUs of one node (BASELINE config 5).
+
+One process per GPU (torch.distributed; backend "nccl" = RCCL over xGMI, "gloo" in CPU tests).
+Rank r owns a contiguous block of rows AND the matching slice of x and y -- the GPU analogue of
+the reference's only distribution idea, the NUMA experiment's row blocks with x cut into
+contiguous slices and owner = col / slice (src/samples/numa.c:277-304, 149-152).  y stays
+distributed; the one exchange step of the path is x.
+
+Exchange modes (`xchg`):
+  "halo"       (default) inspector: the distinct remote columns a shard references are found once
+               (torch.unique on the device), requested from their owners, and ColIdx is renumbered
+               into [own slice | ghosts].  Per step each rank packs the entries its peers asked
+               for and ONE all_to_all_single delivers every ghost -- point-to-point volumes only,
+               which is what xGMI's 7 direct links want (a banded shard needs 2 x 16 values per
+               step, a random one degenerates to the full vector).
+  "allgather"  every step all ranks gather the whole x (n values per rank): solver-style loop with
+               no inspector.
+  "bcast"      north_star's literal form: the full x lives on rank 0 and is broadcast every step.
+  "none"       x is static and already complete on every rank (the reference harness re-uses one
+               x for 110 calls, test_spmv.c:103-124): no per-step communication.
+
+The local multiply is always the HIP library through the C ABI (spmv_amd.api); `compute=` exists
+so the CPU gloo tests can drive the partition/exchange logic without a GPU.
+"""
+from __future__ import annotations
+
+import torch
+import torch.distributed as dist
+
+from . import api
+
+__all__ = ["slice_bounds", "ShardedSpMV"]
+
+
+def slice_bounds(n, world, rank):
+    """Contiguous near-equal slices: first (n % world) ranks get one extra element."""
+    base, extra = divmod(int(n), int(world))
+    lo = rank * base + min(rank, extra)
+    return lo, lo + base + (1 if rank < extra else 0)
+
+
+def _owner_of(cols, n, world):
+    base, extra = divmod(int(n), int(world))
+    if base == 0:
+        return cols.clone()
+    cut = extra * (base + 1)
+    return torch.where(cols < cut, cols // (base + 1), extra + (cols - cut) // max(base, 1))
+
+
+class ShardedSpMV:
+    """y_local = A[rows of this rank, :] @ x   with x distributed like the rows.
+
+    rowptr / colidx / val describe THIS rank's shard: local int32 RowPtr, GLOBAL int32 column
+    indices (never a monolithic 2.56e9-nnz array: SURVEY 7 "int32 limits").  n_global is the
+    column count; this rank owns x[c0:c1] with (c0, c1) = slice_bounds(n_global, world, rank).
+    """
+
+    def __init__(self, rowptr, colidx, val, n_global, xchg="halo", method=api.SPMV_METHODS.Method_Parallel,
+                 group=None, compute=None):
+        assert xchg in ("halo", "allgather", "bcast", "none")
+        self.group = group
+        self.world = dist.get_world_size(group) if dist.is_initialized() else 1
+        self.rank = dist.get_rank(group) if dist.is_initialized() else 0
+        self.xchg = xchg if self.world > 1 else "none"
+        self.n_global = int(n_global)
+        self.m_local = int(rowptr.shape[0] - 1)
+        self.c0, self.c1 = slice_bounds(self.n_global, self.world, self.rank)
+        self.n_local = self.c1 - self.c0
+        self.device, self.dtype = val.device, val.dtype
+        self.rowptr, self.val = rowptr, val
+        self.send_idx = None
+        self.send_counts = self.recv_counts = None
+        if self.xchg == "halo":
+            colidx = self._plan_halo(colidx)
+            self.n_x = self.n_local + self.n_ghost
+        else:
+            self.n_ghost = 0
+            self.n_x = self.n_global
+        self.colidx = colidx
+        self.x_ext = torch.zeros(self.n_x, dtype=self.dtype, device=self.device)
+        self._compute = compute
+        self.handle = None
+        if compute is None:
+            self.handle = api.Handle(self.m_local, self.n_x, rowptr, colidx, val, method)
+            if self.device.type == "cuda":
+                self.handle.attach_stream(torch.cuda.current_stream(self.device).cuda_stream, async_=True)
+
+    # ------------------------------------------------------------------ inspector (halo)
+    def _plan_halo(self, colidx):
+        world, rank, dev = self.world, self.rank, self.device
+        cols = colidx.to(torch.int64)
+        remote_mask = (cols < self.c0) | (cols >= self.c1)
+        ghosts = torch.unique(cols[remote_mask])                       # sorted distinct remote columns
+        self.n_ghost = int(ghosts.numel())
+        owner = _owner_of(ghosts, self.n_global, world)
+        recv_counts = torch.bincount(owner, minlength=world).to(torch.int64)   # what I need, per owner
+        send_counts = torch.empty_like(recv_counts)
+        cpu = recv_counts.device.type == "cpu"
+        dist.all_to_all_single(send_counts, recv_counts, group=self.group)       # what peers need from me
+        self.recv_counts = [int(v) for v in recv_counts.tolist()]
+        self.send_counts = [int(v) for v in send_counts.tolist()]
+        # tell each owner WHICH of its entries I need (ghosts is sorted => grouped by owner)
+        want = torch.empty(int(sum(self.send_counts)), dtype=torch.int64, device=dev)
+        dist.all_to_all_single(want, ghosts, output_split_sizes=self.send_counts,
+                               input_split_sizes=self.recv_counts, group=self.group)
+        self.send_idx = (want - self.c0).contiguous()                 # positions in my slice, peer-major
+        assert self.send_idx.numel() == 0 or (int(self.send_idx.min()) >= 0 and int(self.send_idx.max()) < self.n_local)
+        # renumber: own column c -> c - c0 ; remote column -> n_local + rank in `ghosts`
+        new = torch.where(remote_mask, torch.zeros_like(cols), cols - self.c0)
+        if self.n_ghost:
+            new[remote_mask] = self.n_local + torch.searchsorted(ghosts, cols[remote_mask])
+        assert self.n_local + self.n_ghost < 2**31
+        del cpu
+        return new.to(torch.int32).contiguous()
+
+    # ------------------------------------------------------------------ per step
+    def x_local_view(self):
+        """This rank's slice of x inside the buffer the kernel reads ("halo": the head of
+        [own slice | ghosts]).  Writing x here makes exchange() copy-free."""
+        if self.xchg == "halo":
+            return self.x_ext[: self.n_local]
+        return self.x_ext[self.c0:self.c1]
+
+    def exchange(self, x_local):
+        """Bring this step's x where the shard's columns point.  x_local: this rank's slice."""
+        if self.xchg == "halo":
+            if x_local.data_ptr() != self.x_ext.data_ptr():
+                self.x_ext[: self.n_local].copy_(x_local)
+            if self.n_ghost or self.send_idx.numel():
+                send = x_local[self.send_idx] if self.send_idx.numel() else x_local.new_empty(0)
+                dist.all_to_all_single(self.x_ext[self.n_local:], send, output_split_sizes=self.recv_counts,
+                                       input_split_sizes=self.send_counts, group=self.group)
+        elif self.xchg == "allgather":
+            if self.n_global % self.world == 0:
+                dist.all_gather_into_tensor(self.x_ext, x_local.contiguous(), group=self.group)
+            else:  # uneven slices: gather equal-sized padded pieces, then compact
+                width = -(-self.n_global // self.world)
+                piece = x_local.new_zeros(width)
+                piece[: self.n_local].copy_(x_local)
+                tmp = x_local.new_empty(width * self.world)
+                dist.all_gather_into_tensor(tmp, piece, group=self.group)
+                for r in range(self.world):
+                    lo, hi = slice_bounds(self.n_global, self.world, r)
+                    self.x_ext[lo:hi].copy_(tmp[r * width: r * width + hi - lo])
+        elif self.xchg == "bcast":
+            # rank 0 holds the whole vector; the slices are first collected there only if the
+            # caller passes slices (bench passes rank 0's full x through set_full_x instead)
+            dist.broadcast(self.x_ext, src=0, group=self.group)
+        else:  # none: x_ext was filled once by set_full_x / the caller
+            pass
+        return self.x_ext
+
+    def set_full_x(self, x_full):
+        """For "none"/"bcast": install a complete x (length n_global) on this rank."""
+        assert self.xchg in ("none", "bcast", "allgather")
+        self.x_ext.copy_(x_full)
+
+    def multiply(self, y_local):
+        if self._compute is not None:
+            self._compute(self.rowptr, self.colidx, self.val, self.x_ext, y_local)
+        else:
+            self.handle.spmv(self.x_ext, y_local)
+        return y_local
+
+    def step(self, x_local, y_local):
+        self.exchange(x_local)
+        return self.multiply(y_local)
+
+    def close(self):
+        if self.handle is not None:
+            self.handle.close()
+            self.handle = None

@@ -1,0 +1,89 @@
+"""CPU, world_size 2 over gloo: the row-block partition + x-exchange logic of spmv_amd.dist for
+every exchange mode, with the local multiply injected from the oracle (tests may use it; the
+product default is the HIP handle).  y gathered from the ranks must equal the oracle on the
+whole matrix bit for bit (eighths fill)."""
+import os
+import socket
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+import oracle
+from spmv_amd import synth
+from spmv_amd.dist import ShardedSpMV, slice_bounds
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _oracle_compute(rowptr, colidx, val, x, y):
+    csr = synth.CSR(rowptr.numel() - 1, x.numel(), rowptr.numpy(), colidx.numpy(), val.numpy())
+    y.copy_(torch.from_numpy(oracle.spmv_serial(csr, x.numpy())))
+
+
+def _worker(rank, world, port, kind, xchg, out):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        m = n = 1001 if kind != "rect" else 900
+        if kind == "banded":
+            A = synth.banded(m, n, 8, 7, "eighths", np.float64, seed=3)
+        elif kind == "rect":
+            A = synth.uniform_k(900, 1300, 9, "eighths", np.float64, seed=4)
+            n = 1300
+        else:
+            A = synth.powerlaw(m, n, 6.0, 500, 1.5, "eighths", np.float64, seed=5)
+        x = synth.fill_x(n, "eighths", np.float64, 7)
+        r0, r1 = slice_bounds(A.m, world, rank)
+        p0, p1 = int(A.rowptr[r0]), int(A.rowptr[r1])
+        rp = torch.from_numpy((A.rowptr[r0:r1 + 1] - p0).astype(np.int32))
+        ci = torch.from_numpy(A.colidx[p0:p1].copy())
+        va = torch.from_numpy(A.val[p0:p1].copy())
+        sh = ShardedSpMV(rp, ci, va, n, xchg=xchg, compute=_oracle_compute)
+        c0, c1 = slice_bounds(n, world, rank)
+        assert (sh.c0, sh.c1) == (c0, c1)
+        xt = torch.from_numpy(x)
+        if xchg == "none":
+            sh.set_full_x(xt)
+        if xchg == "bcast" and rank == 0:
+            sh.set_full_x(xt)
+        y = torch.full((r1 - r0,), float("nan"), dtype=torch.float64)
+        for _ in range(2):
+            sh.step(xt[c0:c1].clone(), y)
+        want = oracle.spmv_serial(A, x)[r0:r1]
+        ok = np.array_equal(y.numpy(), want)
+        ghosts = sh.n_ghost
+        dist.barrier()
+        out[rank] = (ok, ghosts, sh.n_x)
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("xchg", ["halo", "allgather", "bcast", "none"])
+@pytest.mark.parametrize("kind", ["banded", "powerlaw", "rect"])
+def test_world2_matches_oracle(kind, xchg):
+    world = 2
+    mgr = mp.Manager()
+    out = mgr.dict()
+    mp.spawn(_worker, args=(world, _free_port(), kind, xchg, out), nprocs=world, join=True)
+    assert all(out[r][0] for r in range(world)), dict(out)
+    if xchg == "halo" and kind == "banded":
+        # a 16-wide band needs only the few columns next to the cut, not the other half of x
+        assert all(0 < out[r][1] <= 16 for r in range(world)), dict(out)
+
+
+def test_slice_bounds_cover_and_are_contiguous():
+    for n in (0, 1, 7, 64, 1001):
+        for world in (1, 2, 3, 8):
+            cuts = [slice_bounds(n, world, r) for r in range(world)]
+            assert cuts[0][0] == 0 and cuts[-1][1] == n
+            assert all(cuts[i][1] == cuts[i + 1][0] for i in range(world - 1))
+            assert max(c[1] - c[0] for c in cuts) - min(c[1] - c[0] for c in cuts) <= 1
