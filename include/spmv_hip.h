@@ -45,7 +45,7 @@ int spmv_hip_set_async(spmv_Handle_t handle, int async);
 int spmv_hip_synchronize(spmv_Handle_t handle);
 
 /* ---- options (process-wide; read at create) ---------------------------------------------- */
-/* keys: "lanes_per_row" (CSR-vector, 0 = auto, else 2..64 power of two)
+/* keys: "lanes_per_row" (CSR-vector, 0 = auto, else 1..64 power of two)
  *       "sell_c" (64)  "sell_sigma" (1024)  "sell_lds_x" (0/1: stage narrow x windows in LDS)
  *       "csr5_sigma" (0 = auto)  "rowblock_nnz" (nnz capacity of a Balanced row block, 0 = auto)
  *       "variant" (kernel variant selector used by the tuning harness, 0 = default)

@@ -1,0 +1,195 @@
+// csr_vector4.hpp -- CSR-vector with 16-byte lane loads: the production kernel of Method_Parallel.
+//
+// Same schedule as csr_vector_kernel (L lanes per row; reference: parallel_spmv.c:12-18 fans
+// "y[i] = dot(row i)" over workers, the dot being inner_spmv.h:232-286), re-shaped for the CDNA4
+// memory pipe:
+//   - every lane reads FOUR consecutive elements per step: one 16 B load of ColIdx and 16 B (fp32)
+//     / 2 x 16 B (fp64) of Val, starting at the row start rounded DOWN to a multiple of 4 elements,
+//     so all matrix-stream loads are 16 B aligned whatever RowPtr holds; slots in front of the row
+//     start or behind the row end are masked (and never touch x).  The library's HBM copy of
+//     ColIdx/Val is padded so the rounded-up tail read stays inside the allocation;
+//   - the lane sums are combined with DPP row operations (quad_perm / row_half_mirror /
+//     row_mirror: register-to-register, no LDS crossbar traffic) instead of ds_bpermute shuffles;
+//   - U independent row groups are in flight per wave and step (memory-level parallelism).
+// A wave covers (64/L)*U rows per step; with L*4 = mean row length one step is one pass.
+#pragma once
+#include "common.hpp"
+
+namespace spmv {
+
+// ---- DPP butterfly pieces (all lanes of the group end up with the group total) ----------------
+template <int CTRL>
+__device__ __forceinline__ float dpp_mov(float v)
+{
+    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, 0xF, 0xF, true));
+}
+template <int CTRL>
+__device__ __forceinline__ double dpp_mov(double v)
+{
+    const long long b = __builtin_bit_cast(long long, v);
+    const int lo = __builtin_amdgcn_update_dpp(0, (int) (b & 0xFFFFFFFFll), CTRL, 0xF, 0xF, true);
+    const int hi = __builtin_amdgcn_update_dpp(0, (int) (b >> 32), CTRL, 0xF, 0xF, true);
+    return __builtin_bit_cast(double, ((long long) hi << 32) | (unsigned) lo);
+}
+
+// Sum over groups of W consecutive lanes, W in {1,2,4,8,16,32,64}; result valid in every lane of the
+// group for W <= 16, and at least in the group's first lane for W = 32 / 64.
+template <int W, typename T>
+__device__ __forceinline__ T group_sum_dpp(T v)
+{
+    if (W >= 2) v += dpp_mov<0xB1>(v);   // quad_perm [1,0,3,2]
+    if (W >= 4) v += dpp_mov<0x4E>(v);   // quad_perm [2,3,0,1]
+    if (W >= 8) v += dpp_mov<0x141>(v);  // row_half_mirror: the other quad of each 8
+    if (W >= 16) v += dpp_mov<0x140>(v); // row_mirror: the other half of each 16
+    if (W >= 32) v += __shfl_xor(v, 16, kWave);
+    if (W >= 64) v += __shfl_xor(v, 32, kWave);
+    return v;
+}
+
+template <typename T, int L, int RED, int U, int ABL = 0>
+__global__ __launch_bounds__(kBlock) void csr_vector4_kernel(int m, const int *__restrict__ rowptr,
+                                                             const int *__restrict__ colidx,
+                                                             const T *__restrict__ val,
+                                                             const T *__restrict__ x, T *__restrict__ y)
+{
+    constexpr int kRows = kBlock / L;       // rows per workgroup and sub-step
+    const int lane = threadIdx.x % L;
+    const int sub = threadIdx.x / L;
+    const long long groups = ((long long) m + kRows * U - 1) / (kRows * U);
+    for (long long g = blockIdx.x; g < groups; g += gridDim.x) {
+        int p0[U], p1[U];
+        T sum[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const long long row = (g * U + u) * kRows + sub;
+            const bool ok = row < m;
+            if (ABL & 1) { p0[u] = ok ? (int) row * 32 : 0; p1[u] = ok ? (int) row * 32 + 32 : 0; } // ablation: no RowPtr chain
+            else { p0[u] = ok ? rowptr[row] : 0; p1[u] = ok ? rowptr[row + 1] : 0; }
+            sum[u] = 0;
+        }
+        bool more = true;
+        int a[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) a[u] = (p0[u] & ~3) + lane * 4;
+        while (more) {
+            int c[U][4];
+            T v[U][4];
+            bool act[U];
+            more = false;
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                act[u] = a[u] < p1[u];
+                if (act[u]) { ld_stream4(colidx + a[u], c[u]); ld_stream4(val + a[u], v[u]); }
+            }
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                if (act[u]) {
+                    if (a[u] >= p0[u] && a[u] + 4 <= p1[u]) { // interior: no masking
+                        T xv[4];
+#pragma unroll
+                        for (int k = 0; k < 4; ++k) xv[k] = (ABL & 8) ? (T) c[u][k] : ((ABL & 2) ? x[(c[u][k] & 1) + threadIdx.x] : x[c[u][k]]); // ablation: no gather / no x
+#pragma unroll
+                        for (int k = 0; k < 4; ++k) sum[u] = fmadd(v[u][k], xv[k], sum[u]);
+                    } else {
+#pragma unroll
+                        for (int k = 0; k < 4; ++k) {
+                            const int i = a[u] + k;
+                            if (i >= p0[u] && i < p1[u]) sum[u] = fmadd(v[u][k], x[c[u][k]], sum[u]);
+                        }
+                    }
+                    a[u] += 4 * L;
+                    more |= a[u] < p1[u];
+                }
+            }
+            more = __any(more);
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const T tot = (ABL & 4) ? sum[u] : (RED ? group_sum_dpp<L>(sum[u]) : group_sum<L>(sum[u])); // ablation: no reduce
+            const long long row = (g * U + u) * kRows + sub;
+            if ((ABL & 16) ? (tot == T(1.2345)) : (lane == 0 && row < m)) y[row] = tot; // ablation: no store
+        }
+    }
+}
+
+} // namespace spmv
+
+namespace spmv {
+
+// Elements a lane may touch beyond nnz when its 16 B step is rounded up: the library pads its HBM
+// copies of ColIdx / Val by this many elements.
+constexpr int kStreamPad = 4 * kWave + 8;
+
+// Software-pipelined form: a wave owns NB consecutive row groups; RowPtr of all of them is read
+// first, the 16 B stream loads of group j+1 are issued before group j is consumed, and y stores
+// are never waited for inside the wave -- so a wave keeps two groups of matrix stream in flight for
+// most of its life and only the last store's acknowledgement is exposed.  The hot path is straight
+// line (masks by select, clamped row index) so the compiler can hoist every load; rows longer than
+// 4L fall into the loop at the end of each group.
+template <typename T, int L, int NB, bool NTSTORE = false, int ABL = 0>
+__global__ __launch_bounds__(kBlock) void csr_vector_pipe_kernel(int m, const int *__restrict__ rowptr,
+                                                                 const int *__restrict__ colidx,
+                                                                 const T *__restrict__ val,
+                                                                 const T *__restrict__ x, T *__restrict__ y)
+{
+    constexpr int kRows = kBlock / L;
+    const int lane = threadIdx.x % L;
+    const int sub = threadIdx.x / L;
+    const long long row0 = (long long) blockIdx.x * (kRows * NB) + sub;
+    int p0[NB], p1[NB];
+#pragma unroll
+    for (int j = 0; j < NB; ++j) {
+        long long r = row0 + (long long) j * kRows;
+        if (r > m - 1) r = m - 1;
+        if (ABL & 1) { p0[j] = (int) r * 32; p1[j] = (int) r * 32 + 32; } // ablation: no RowPtr chain
+        else { p0[j] = rowptr[r]; p1[j] = rowptr[r + 1]; }
+    }
+    int c[2][4];
+    T v[2][4];
+    {
+        const int a = (p0[0] & ~3) + lane * 4;
+        ld_stream4(colidx + a, c[0]);
+        ld_stream4(val + a, v[0]);
+    }
+#pragma unroll
+    for (int j = 0; j < NB; ++j) {
+        const int cur = j & 1;
+        if (j + 1 < NB) {
+            const int an = (p0[j + 1] & ~3) + lane * 4;
+            ld_stream4(colidx + an, c[cur ^ 1]);
+            ld_stream4(val + an, v[cur ^ 1]);
+        }
+        const int a = (p0[j] & ~3) + lane * 4;
+        T xv[4], vv[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const bool ok = (a + k >= p0[j]) & (a + k < p1[j]);
+            xv[k] = (ABL & 8) ? (T) c[cur][k] : ((ABL & 2) ? x[(c[cur][k] & 1) + threadIdx.x] : x[ok ? c[cur][k] : 0]);
+            vv[k] = ok ? v[cur][k] : T(0);
+        }
+        T sum = 0;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) sum = fmadd(vv[k], xv[k], sum);
+        if (__any(a + 4 * L < p1[j])) { // some row of this group is longer than one step
+            for (int aa = a + 4 * L; __any(aa < p1[j]); aa += 4 * L) {
+                if (aa < p1[j]) {
+                    int cc[4];
+                    T v2[4];
+                    ld_stream4(colidx + aa, cc);
+                    ld_stream4(val + aa, v2);
+#pragma unroll
+                    for (int k = 0; k < 4; ++k)
+                        if (aa + k < p1[j]) sum = fmadd(v2[k], x[cc[k]], sum);
+                }
+            }
+        }
+        if (!(ABL & 4)) sum = group_sum_dpp<L>(sum);
+        const long long row = row0 + (long long) j * kRows;
+        if ((ABL & 16) ? (sum == T(1.2345)) : (lane == 0 && row < m)) {
+            if (NTSTORE) __builtin_nontemporal_store(sum, y + row);
+            else y[row] = sum;
+        }
+    }
+}
+
+} // namespace spmv

@@ -104,10 +104,9 @@ void spmv_plan_choose(SPMV_METHODS requested, const spmv_stats *st, size_t value
     plan->csr5_sigma = (int) spmv_hip_get_option("csr5_sigma");
     /* one workgroup's equal-nnz share: 2048 products = 16 KiB of fp64 (8 KiB fp32) in LDS */
     plan->rowblock_nnz = rb > 0 ? (int) rb : 2048;
-    /* CSR-vector: lanes per row = power of two >= mean row length / 2 (each lane then takes
-     * about two elements, i.e. 16 B of fp64 values), within [2, 64] */
-    plan->lanes_per_row = lanes > 0 ? (int) lanes : pow2_at_least(st->mean_row_len / 2.0, 2, 64);
-    if (plan->lanes_per_row < 2) plan->lanes_per_row = 2;
+    /* CSR-vector: every lane takes 4 consecutive elements per step (16 B loads), so L = power of
+     * two >= mean row length / 4 covers a mean-length row in one step; within [1, 64] */
+    plan->lanes_per_row = lanes > 0 ? (int) lanes : pow2_at_least(st->mean_row_len / 4.0, 1, 64);
     (void) value_size;
     *actual = requested;
     switch (requested) {

@@ -22,6 +22,7 @@
 #include "spmv_shim.h"
 #include "kernels/common.hpp"
 #include "kernels/csr_rows.hpp"
+#include "kernels/csr_vector4.hpp"
 #include "kernels/nnz_split.hpp"
 #include "kernels/rowblock.hpp"
 #include "kernels/sell.hpp"
@@ -242,8 +243,11 @@ extern "C" int spmv_shim_matrix_create(spmv_dev **out, int m, int n, const int *
     d->stats.empty_rows = hs.empty;
     d->stats.mean_row_len = m > 0 ? (double) d->nnz / m : 0.0;
 
-    if ((rc = dev_alloc(d, (void **) &d->colidx, sizeof(int) * (size_t) d->nnz, false))) return bail(rc);
-    if ((rc = dev_alloc(d, &d->val, d->vsize * (size_t) d->nnz, false))) return bail(rc);
+    // padded by kStreamPad elements: the 16 B-per-lane kernels round a row's tail read up
+    if ((rc = dev_alloc(d, (void **) &d->colidx, sizeof(int) * ((size_t) d->nnz + kStreamPad), false))) return bail(rc);
+    if ((rc = dev_alloc(d, &d->val, d->vsize * ((size_t) d->nnz + kStreamPad), false))) return bail(rc);
+    (void) hipMemset(d->colidx + d->nnz, 0, sizeof(int) * kStreamPad);
+    (void) hipMemset((char *) d->val + d->vsize * (size_t) d->nnz, 0, d->vsize * kStreamPad);
     if (d->nnz > 0) {
         if (hipMemcpy(d->colidx, colidx, sizeof(int) * (size_t) d->nnz, hipMemcpyDefault) != hipSuccess ||
             hipMemcpy(d->val, val, d->vsize * (size_t) d->nnz, hipMemcpyDefault) != hipSuccess)
@@ -360,7 +364,7 @@ extern "C" int spmv_shim_build(spmv_dev *d, const spmv_plan *plan)
     case SPMV_SCHED_CSR_SCALAR: break;
     case SPMV_SCHED_CSR_VECTOR: {
         const int L = plan->lanes_per_row;
-        if (L < 2 || L > 64 || (L & (L - 1))) return fail(SPMV_HIP_E_ARG, "lanes_per_row must be a power of two in [2, 64], got %d", L);
+        if (L < 1 || L > 64 || (L & (L - 1))) return fail(SPMV_HIP_E_ARG, "lanes_per_row must be a power of two in [1, 64], got %d", L);
         break;
     }
     case SPMV_SCHED_NNZ_SPLIT: rc = f64 ? build_nnz_split<double>(d) : build_nnz_split<float>(d); break;
@@ -379,12 +383,20 @@ extern "C" int spmv_shim_build(spmv_dev *d, const spmv_plan *plan)
 }
 
 // ------------------------------------------------------------------------------------ executors
+// One workgroup per kVecNB * (256/L) consecutive rows, dispatched in row order: measured on the
+// config-2 shape a plain in-order grid beats a persistent grid-stride loop by ~10 %.
+constexpr int kVecNB = 4;
 template <typename T, int L>
 static void launch_vector(spmv_dev *d, const T *x, T *y)
 {
-    constexpr int rows = kBlock / L;
-    const int grid = grid_for(d->m, rows, d->cus * 8 * 4);
-    csr_vector_kernel<T, L><<<grid, kBlock, 0, d->stream>>>(d->m, d->rowptr, d->colidx, (const T *) d->val, x, y);
+    if (d->plan.variant == 1) { // A/B: the first-round strided kernel
+        csr_vector_kernel<T, (L < 2 ? 2 : L)><<<grid_for(d->m, kBlock / (L < 2 ? 2 : L), d->cus * 32), kBlock, 0, d->stream>>>(
+            d->m, d->rowptr, d->colidx, (const T *) d->val, x, y);
+        return;
+    }
+    constexpr int rows = kBlock / L * kVecNB;
+    const int grid = grid_for(d->m, rows, INT_MAX);
+    csr_vector_pipe_kernel<T, L, kVecNB><<<grid, kBlock, 0, d->stream>>>(d->m, d->rowptr, d->colidx, (const T *) d->val, x, y);
 }
 
 template <typename T>
@@ -403,6 +415,7 @@ static int launch(spmv_dev *d, const T *x, T *y)
         break;
     case SPMV_SCHED_CSR_VECTOR:
         switch (d->plan.lanes_per_row) {
+        case 1: launch_vector<T, 1>(d, x, y); break;
         case 2: launch_vector<T, 2>(d, x, y); break;
         case 4: launch_vector<T, 4>(d, x, y); break;
         case 8: launch_vector<T, 8>(d, x, y); break;
@@ -412,7 +425,7 @@ static int launch(spmv_dev *d, const T *x, T *y)
         }
         break;
     case SPMV_SCHED_NNZ_SPLIT: {
-        const int grid = grid_for(d->ntiles, kBlock / kWave, d->cus * 8);
+        const int grid = grid_for(d->ntiles, kBlock / kWave, d->plan.variant == 1 ? d->cus * 8 : INT_MAX);
         nnz_split_kernel<T><<<grid, kBlock, 0, d->stream>>>(d->m, (int) d->nnz, d->ntiles, d->rowptr, d->colidx, val, x, y,
                                                              d->tile_first, (T *) d->carry);
         if (d->need_fixup && d->ntiles > 1)
@@ -425,7 +438,7 @@ static int launch(spmv_dev *d, const T *x, T *y)
             d->rb_split, d->rowptr, d->colidx, val, x, y);
         break;
     case SPMV_SCHED_SELL:
-        sell_kernel<T><<<grid_for(d->nchunks, kBlock / kWave, d->cus * 8), kBlock, 0, d->stream>>>(
+        sell_kernel<T><<<grid_for(d->nchunks, kBlock / kWave, d->plan.variant == 1 ? d->cus * 8 : INT_MAX), kBlock, 0, d->stream>>>(
             d->nchunks, d->chunk_ptr, d->scol, (const T *) d->sval, d->perm, x, y);
         if (d->nlong > 0)
             sell_long_rows_kernel<T><<<grid_for(d->nlong, kBlock / kWave, INT_MAX), kBlock, 0, d->stream>>>(
@@ -520,7 +533,7 @@ extern "C" double spmv_shim_time(spmv_dev *d, const void *x, void *y, int warmup
 
 // ------------------------------------------------------------------------------------ info
 static const char *kSchedNames[] = {"csr-scalar", "csr-vector", "row-block", "nnz-split", "sell-c-sigma", "csr5"};
-static const char *kKernelNames[] = {"csr_scalar_kernel", "csr_vector_kernel", "rowblock_kernel",
+static const char *kKernelNames[] = {"csr_scalar_kernel", "csr_vector_pipe_kernel", "rowblock_kernel",
                                      "nnz_split_kernel", "sell_kernel", "csr5_kernel"};
 
 extern "C" int spmv_shim_info(const spmv_dev *d, spmv_hip_info *o)

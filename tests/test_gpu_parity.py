@@ -148,7 +148,7 @@ def test_spmv_with_other_csr_arrays_reinspects(monkeypatch):
     api.spmv_destory_handle(h)
 
 
-@pytest.mark.parametrize("lanes", [2, 4, 8, 16, 32, 64])
+@pytest.mark.parametrize("lanes", [1, 2, 4, 8, 16, 32, 64])
 def test_csr_vector_every_lane_width(lanes):
     csr, x, y_ref = load_golden("rowlen_sweep_f64_eighths")
     api.set_option("lanes_per_row", lanes)
