@@ -1,0 +1,100 @@
+#!/usr/bin/env python3
+"""Condense gpurun_out/prof_<tag>/ (rocprofv3 CSVs) into tracked files under profiles/.
+
+  profiles/<tag>_kernel_stats.csv   the --stats table, our kernels + the top of the rest
+  profiles/<tag>_pmc.json           per-kernel FETCH_SIZE / WRITE_SIZE per launch, the calibration
+                                    ratio, and the corrected HBM bytes per launch
+  profiles/traffic_latest.json      what bench.py reads for roofline.traffic
+
+Counter units and corrections follow MI355X_MICROARCH.md "HBM": FETCH_SIZE / WRITE_SIZE are in
+KiB; on gfx950 FETCH_SIZE reports HALF the bytes of wide (16 B/lane) coalesced reads, so it is
+doubled -- and the doubling is checked here against a stream kernel that reads a known byte count
+with the same load width (tools/kbench.hip: stream_read, 12 B x nnz)."""
+import csv
+import glob
+import json
+import os
+import sys
+
+tag = sys.argv[1] if len(sys.argv) > 1 else "r01"
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+src = os.path.join(ROOT, "gpurun_out", f"prof_{tag}")
+dst = os.path.join(ROOT, "profiles")
+os.makedirs(dst, exist_ok=True)
+
+
+def find(sub, suffix):
+    hits = glob.glob(os.path.join(src, sub, "**", f"*{suffix}"), recursive=True)
+    return hits[0] if hits else None
+
+
+def counter_per_kernel(sub, counter):
+    """-> {kernel name: [values per dispatch]} from a counter_collection csv."""
+    path = find(sub, "counter_collection.csv")
+    out = {}
+    if not path:
+        return out
+    with open(path) as f:
+        for row in csv.DictReader(f):
+            if row.get("Counter_Name") != counter:
+                continue
+            out.setdefault(row["Kernel_Name"], []).append(float(row["Counter_Value"]))
+    return out
+
+
+summary = {"tag": tag, "units": "FETCH_SIZE/WRITE_SIZE in KiB (rocprofv3); bytes = KiB * 1024"}
+stats = find("stats", "kernel_stats.csv")
+if stats:
+    rows = list(csv.DictReader(open(stats)))
+    ours = [r for r in rows if "spmv::" in r["Name"]]
+    rest = [r for r in rows if "spmv::" not in r["Name"]][:6]
+    with open(os.path.join(dst, f"{tag}_kernel_stats.csv"), "w", newline="") as f:
+        w = csv.DictWriter(f, fieldnames=rows[0].keys())
+        w.writeheader()
+        for r in ours + rest:
+            w.writerow(r)
+    summary["kernel_stats"] = [{"name": r["Name"][:120], "calls": int(r["Calls"]), "avg_ns": float(r["AverageNs"]),
+                                "min_ns": float(r["MinNs"]), "max_ns": float(r["MaxNs"])} for r in ours]
+
+fetch = counter_per_kernel("fetch", "FETCH_SIZE")
+write = counter_per_kernel("write", "WRITE_SIZE")
+calib = counter_per_kernel("calib", "FETCH_SIZE")
+
+cal = None
+for name, vals in calib.items():
+    if "stream_read<true>" in name or ("stream_read" in name and "true" in name):
+        known = 10_000_000 * 32 * 12.0
+        raw = sum(vals) / len(vals) * 1024.0
+        cal = {"kernel": name[:100], "known_bytes": known, "fetch_size_bytes_raw": raw, "ratio_known_over_raw": known / raw}
+        break
+summary["calibration"] = cal
+factor = 2.0  # guide's gfx950 correction for wide coalesced reads
+if cal:
+    summary["calibration"]["note"] = ("guide factor 2.0 applied; measured ratio on 16 B/lane nt loads = %.3f" % cal["ratio_known_over_raw"])
+
+kernels = {}
+for name in sorted(set(fetch) | set(write)):
+    if "spmv::" not in name:
+        continue
+    fv, wv = fetch.get(name, []), write.get(name, [])
+    f_raw = (sum(fv) / len(fv) * 1024.0) if fv else None
+    w_raw = (sum(wv) / len(wv) * 1024.0) if wv else None
+    kernels[name] = {"launches_fetch_pass": len(fv), "launches_write_pass": len(wv),
+                     "fetch_bytes_raw": f_raw, "write_bytes": w_raw,
+                     "fetch_bytes_corrected": f_raw * factor if f_raw is not None else None,
+                     "hbm_bytes_per_launch": (f_raw * factor if f_raw is not None else 0) + (w_raw or 0)}
+summary["kernels"] = kernels
+with open(os.path.join(dst, f"{tag}_pmc.json"), "w") as f:
+    json.dump(summary, f, indent=1)
+
+dom = None
+for name, k in kernels.items():
+    if dom is None or (k["hbm_bytes_per_launch"] or 0) > (kernels[dom]["hbm_bytes_per_launch"] or 0):
+        dom = name
+if dom:
+    with open(os.path.join(dst, "traffic_latest.json"), "w") as f:
+        json.dump({"tag": tag, "kernel": dom, "hbm_bytes_per_launch": kernels[dom]["hbm_bytes_per_launch"],
+                   "fetch_bytes_raw": kernels[dom]["fetch_bytes_raw"], "write_bytes": kernels[dom]["write_bytes"],
+                   "correction": "2 x FETCH_SIZE (gfx950 wide-read under-count) + WRITE_SIZE, KiB -> bytes",
+                   "calibration": cal}, f, indent=1)
+print(json.dumps(summary, indent=1)[:3000])
