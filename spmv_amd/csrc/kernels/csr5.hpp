@@ -1,0 +1,292 @@
+// csr5.hpp -- CSR5 with omega = 64 (one wavefront per tile).
+//
+// GPU schedule of Method_CSR5SPMV.  Reference: the vendored CSR5 (csr5_spmv.cpp:16-52 glue;
+// csr5_avx2/anonymouslib_avx2.h:112-242 asCSR5; avx2/format_avx2.h:7-425 tile pointer, tile
+// descriptor, empty-row offsets, in-place transpose; avx2/csr5_spmv_avx2.h:7-410 tile kernel,
+// calibrator, tail) with omega = 4 AVX2 lanes and sigma = 16.  The idea is kept -- equal-nnz
+// tiles of omega x sigma elements, lane x owns sigma consecutive nnz, row starts kept as bit flags
+// in a per-lane descriptor, tile storage transposed so that element i of all lanes is one
+// contiguous line -- and re-designed for a 64-lane wavefront (SURVEY A.4 "GPU re-design"):
+//
+//   tile          64 lanes x SIGMA elements (SIGMA in {4, 8, 16}); p = ceil(nnz / (64 SIGMA))
+//   tile_ptr[t]   int32, row that holds the tile's first nnz (format_avx2.h:14-24)
+//   desc[t][x]    uint32 per lane: bits 0..SIGMA-1 = "a row starts at my element i",
+//                 bits 16..25 = y_offset = number of row starts in lanes < x  (the reference packs
+//                 y_offset | scansum_offset | flags into one word too, format_avx2.h:94-110,
+//                 196-213; scansum_offset is not stored here: the cross-lane combine uses a
+//                 ballot mask of "lane has a start" instead)
+//   col/val       COPIES in tile-transposed order, element i of lane x at t*64*SIGMA + i*64 + x
+//                 (the reference transposes the CALLER's arrays in place, format_avx2.h:347-400;
+//                 here the caller's arrays are never touched).  The last tile is padded with
+//                 col = -1 / val = 0, so there is no separate "tail" kernel
+//                 (csr5_spmv_avx2.h:337-366 in the reference).
+//   run_len[t]    int32: if the row that is open at the start of tile t began in tile t-1,
+//                 the number of tiles it continues through; else 0.  Drives the deterministic
+//                 carry fix-up that replaces the reference's per-thread calibrator
+//                 (csr5_spmv_avx2.h:320-335).
+//   empty rows    the reference keeps per-tile offset tables for tiles whose row span contains
+//                 empty rows (format_avx2.h:256-326) and never writes y for empty rows
+//                 (SURVEY 4.3).  Here, if the matrix has empty rows, CSR5 is built over the
+//                 COMPACTED row space (row_map[k] = k-th non-empty row) and y is zero-filled
+//                 first; without empty rows row_map is not allocated and no indirection runs.
+// fp32 is native (the reference silently falls back to SELL for fp32, common.c:174-181).
+// Extra HBM traffic on top of B_alg per tile of 64*SIGMA nnz: 256 B desc + 4 B tile_ptr + s carry.
+#pragma once
+#include "common.hpp"
+
+namespace spmv {
+
+constexpr unsigned kCsr5FlagMask = 0xFFFFu;
+constexpr int kCsr5YoffShift = 16;
+
+// ---------------------------------------------------------------------------- inspector kernels
+// flags[r] = row r is non-empty
+__global__ __launch_bounds__(kBlock) void csr5_nonempty_kernel(int m, const int *__restrict__ rowptr, int *__restrict__ flags)
+{
+    const long long stride = (long long) gridDim.x * kBlock;
+    for (long long r = (long long) blockIdx.x * kBlock + threadIdx.x; r < m; r += stride)
+        flags[r] = rowptr[r + 1] > rowptr[r];
+}
+
+// Three-pass exclusive scan of int32 (block sums, scan of the sums by one workgroup, apply).
+constexpr int kScanTile = kBlock * 4;
+__global__ __launch_bounds__(kBlock) void scan_block_sums_kernel(long long n, const int *__restrict__ in, int *__restrict__ sums)
+{
+    __shared__ int wsum[kBlock / kWave];
+    const long long base = (long long) blockIdx.x * kScanTile;
+    int s = 0;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const long long i = base + threadIdx.x + k * kBlock;
+        s += i < n ? in[i] : 0;
+    }
+#pragma unroll
+    for (int o = kWave / 2; o > 0; o >>= 1) s += __shfl_xor(s, o, kWave);
+    if ((threadIdx.x & (kWave - 1)) == 0) wsum[threadIdx.x / kWave] = s;
+    __syncthreads();
+    if (threadIdx.x == 0) sums[blockIdx.x] = wsum[0] + wsum[1] + wsum[2] + wsum[3];
+}
+__global__ __launch_bounds__(kBlock) void scan_sums_inplace_kernel(int nb, int *__restrict__ sums, int *__restrict__ total)
+{
+    __shared__ int wave_tot[kBlock / kWave];
+    __shared__ int carry_s;
+    const int lane = threadIdx.x & (kWave - 1), wave = threadIdx.x / kWave;
+    if (threadIdx.x == 0) carry_s = 0;
+    __syncthreads();
+    for (int base = 0; base < nb; base += kBlock) {
+        const int i = base + threadIdx.x;
+        const int v = i < nb ? sums[i] : 0;
+        int inc = v;
+#pragma unroll
+        for (int d = 1; d < kWave; d <<= 1) {
+            const int o = __shfl_up(inc, d, kWave);
+            if (lane >= d) inc += o;
+        }
+        if (lane == kWave - 1) wave_tot[wave] = inc;
+        __syncthreads();
+        int off = carry_s;
+        for (int w = 0; w < wave; ++w) off += wave_tot[w];
+        if (i < nb) sums[i] = off + inc - v;
+        __syncthreads();
+        if (threadIdx.x == kBlock - 1) carry_s = off + inc;
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) *total = carry_s;
+}
+// Compaction: for every non-empty row r (flag 1) at compacted position k: rp2[k] = rowptr[r],
+// row_map[k] = r.  One thread handles 4 strided-by-block elements in order, so positions are
+// block_offset + (prefix inside the block), computed with a workgroup scan per 256-element slab.
+__global__ __launch_bounds__(kBlock) void csr5_compact_kernel(long long m, const int *__restrict__ flags,
+                                                              const int *__restrict__ block_off,
+                                                              const int *__restrict__ rowptr,
+                                                              int *__restrict__ rp2, int *__restrict__ row_map)
+{
+    __shared__ int wave_tot[kBlock / kWave];
+    __shared__ int slab_base;
+    const int lane = threadIdx.x & (kWave - 1), wave = threadIdx.x / kWave;
+    if (threadIdx.x == 0) slab_base = block_off[blockIdx.x];
+    __syncthreads();
+    for (int k = 0; k < 4; ++k) {
+        const long long r = (long long) blockIdx.x * kScanTile + k * kBlock + threadIdx.x;
+        const int f = r < m ? flags[r] : 0;
+        int inc = f;
+#pragma unroll
+        for (int d = 1; d < kWave; d <<= 1) {
+            const int o = __shfl_up(inc, d, kWave);
+            if (lane >= d) inc += o;
+        }
+        if (lane == kWave - 1) wave_tot[wave] = inc;
+        __syncthreads();
+        int off = slab_base;
+        for (int w = 0; w < wave; ++w) off += wave_tot[w];
+        if (f) {
+            const int pos = off + inc - 1;
+            rp2[pos] = rowptr[r];
+            row_map[pos] = (int) r;
+        }
+        __syncthreads();
+        if (threadIdx.x == kBlock - 1) slab_base = off + inc;
+        __syncthreads();
+    }
+}
+
+// tile_ptr[t] = last row r (of the m2-row space) with rp[r] <= min(t*T, nnz), t = 0..p
+__global__ __launch_bounds__(kBlock) void csr5_tile_ptr_kernel(int m2, int nnz, int p, int tile_nnz,
+                                                               const int *__restrict__ rp, int *__restrict__ tile_ptr)
+{
+    const int t = blockIdx.x * kBlock + threadIdx.x;
+    if (t > p) return;
+    long long key = (long long) t * tile_nnz;
+    if (key > nnz) key = nnz;
+    int r = upper_bound_dev(rp, m2 + 1, key) - 1;
+    if (r > m2 - 1) r = m2 - 1; // key == nnz: clamp to the last row
+    tile_ptr[t] = r;
+}
+
+// One wavefront per tile: bit flags of the row starts inside each lane's SIGMA elements, y_offset =
+// exclusive count of starts over the lanes.  Also the run length of the row open at the tile start.
+template <int SIGMA>
+__global__ __launch_bounds__(kBlock) void csr5_desc_kernel(int m2, int nnz, int p, const int *__restrict__ rp,
+                                                           const int *__restrict__ tile_ptr,
+                                                           unsigned *__restrict__ desc, int *__restrict__ run_len,
+                                                           int *__restrict__ any_head)
+{
+    constexpr int T = kWave * SIGMA;
+    __shared__ unsigned fl[kBlock / kWave][kWave];
+    const int lane = threadIdx.x & (kWave - 1), wave = threadIdx.x / kWave;
+    const int t = blockIdx.x * (kBlock / kWave) + wave;
+    if (t >= p) return;
+    const long long base = (long long) t * T;
+    fl[wave][lane] = 0;
+    wave_lds_sync();
+    const int r_lo = tile_ptr[t], r_hi = tile_ptr[t + 1];
+    for (int r = r_lo + lane; r <= r_hi && r < m2; r += kWave) {
+        const long long ptr = rp[r];
+        if (ptr >= base && ptr < base + T && ptr < nnz) {
+            const int o = (int) (ptr - base);
+            atomicOr(&fl[wave][o / SIGMA], 1u << (o % SIGMA));
+        }
+    }
+    wave_lds_sync();
+    const unsigned f = fl[wave][lane];
+    const int cnt = __popc(f);
+    int inc = cnt;
+#pragma unroll
+    for (int d = 1; d < kWave; d <<= 1) {
+        const int o = __shfl_up(inc, d, kWave);
+        if (lane >= d) inc += o;
+    }
+    desc[(long long) t * kWave + lane] = f | ((unsigned) (inc - cnt) << kCsr5YoffShift);
+    if (lane == 0) {
+        int rl = 0;
+        if (t > 0 && !(f & 1u)) { // the tile opens inside row r_lo
+            *any_head = 1;
+            if ((long long) rp[r_lo] >= base - T) { // ... which began in the previous tile: run start
+                const long long hend = rp[r_lo + 1];
+                rl = (int) ((hend - 1) / T) - t + 1;
+            }
+        }
+        run_len[t] = rl;
+    }
+}
+
+// Tile-transposed copies: dst[t*T + i*64 + x] = src[t*T + x*SIGMA + i]; padding col = -1, val = 0.
+template <typename T, int SIGMA>
+__global__ __launch_bounds__(kBlock) void csr5_transpose_kernel(int nnz, int p, const int *__restrict__ colidx,
+                                                                const T *__restrict__ val,
+                                                                int *__restrict__ tcol, T *__restrict__ tval)
+{
+    constexpr int TN = kWave * SIGMA;
+    const int lane = threadIdx.x & (kWave - 1);
+    const int t = blockIdx.x * (kBlock / kWave) + threadIdx.x / kWave;
+    if (t >= p) return;
+    const long long base = (long long) t * TN;
+#pragma unroll
+    for (int i = 0; i < SIGMA; ++i) {
+        const long long src = base + (long long) lane * SIGMA + i;
+        const bool in = src < nnz;
+        tcol[base + i * kWave + lane] = in ? colidx[src] : -1;
+        tval[base + i * kWave + lane] = in ? val[src] : T(0);
+    }
+}
+
+// ---------------------------------------------------------------------------- executor
+template <typename T, int SIGMA, bool MAPPED>
+__global__ __launch_bounds__(kBlock) void csr5_kernel(int p, const int *__restrict__ tile_ptr,
+                                                      const unsigned *__restrict__ desc,
+                                                      const int *__restrict__ tcol, const T *__restrict__ tval,
+                                                      const int *__restrict__ row_map,
+                                                      const T *__restrict__ x, T *__restrict__ y,
+                                                      T *__restrict__ carry)
+{
+    constexpr int TN = kWave * SIGMA;
+    const int lane = threadIdx.x & (kWave - 1);
+    const int t = blockIdx.x * (kBlock / kWave) + threadIdx.x / kWave;
+    if (t >= p) return;
+    const long long base = (long long) t * TN + lane;
+    int c[SIGMA];
+    T v[SIGMA];
+#pragma unroll
+    for (int i = 0; i < SIGMA; ++i) {
+        c[i] = ld_stream(tcol + base + i * kWave);
+        v[i] = ld_stream(tval + base + i * kWave);
+    }
+    const unsigned d = desc[(long long) t * kWave + lane];
+    const unsigned flags = d & kCsr5FlagMask;
+    const int r0 = tile_ptr[t];
+    // row of the tile's first row start: r0 itself if the tile begins on a row boundary
+    const unsigned f0 = (unsigned) __builtin_amdgcn_readfirstlane((int) flags);
+    int seg_row = r0 + ((f0 & 1u) ? 0 : 1) + (int) (d >> kCsr5YoffShift);
+    T xv[SIGMA];
+#pragma unroll
+    for (int i = 0; i < SIGMA; ++i) xv[i] = x[c[i] >= 0 ? c[i] : 0];
+
+    T head = 0, acc = 0;
+    bool started = false;
+#pragma unroll
+    for (int i = 0; i < SIGMA; ++i) {
+        if (flags & (1u << i)) {
+            if (started) {
+                y[MAPPED ? row_map[seg_row] : seg_row] = acc; // began and ended inside this lane
+                ++seg_row;
+            } else {
+                head = acc;
+                started = true;
+            }
+            acc = 0;
+        }
+        if (c[i] >= 0) acc = fmadd(v[i], xv[i], acc);
+    }
+    if (!started) { head = acc; acc = 0; }
+
+    const unsigned long long starts = __ballot(started);
+    T B = head;
+#pragma unroll
+    for (int dd = 1; dd < kWave; dd <<= 1) {
+        const T nb = __shfl_down(B, dd, kWave);
+        const bool cut = ((starts >> lane) & ((1ull << dd) - 1ull)) != 0ull;
+        if (!cut && lane + dd < kWave) B += nb;
+    }
+    T next = __shfl_down(B, 1, kWave);
+    if (lane == kWave - 1) next = 0;
+    if (started) y[MAPPED ? row_map[seg_row] : seg_row] = acc + next;
+    if (lane == 0) carry[t] = B;
+}
+
+template <typename T, bool MAPPED>
+__global__ __launch_bounds__(kBlock) void csr5_fixup_kernel(int p, const int *__restrict__ tile_ptr,
+                                                            const int *__restrict__ run_len,
+                                                            const int *__restrict__ row_map,
+                                                            const T *__restrict__ carry, T *__restrict__ y)
+{
+    const int t = blockIdx.x * kBlock + threadIdx.x + 1;
+    if (t >= p) return;
+    const int n = run_len[t];
+    if (n <= 0) return;
+    T sum = 0;
+    for (int u = t; u < t + n; ++u) sum += carry[u];
+    const int r = tile_ptr[t];
+    y[MAPPED ? row_map[r] : r] += sum;
+}
+
+} // namespace spmv

@@ -164,7 +164,8 @@ __global__ __launch_bounds__(kBlock) void csr_vector_pipe_kernel(int m, const in
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
             const bool ok = (a + k >= p0[j]) & (a + k < p1[j]);
-            xv[k] = (ABL & 8) ? (T) c[cur][k] : ((ABL & 2) ? x[(c[cur][k] & 1) + threadIdx.x] : x[ok ? c[cur][k] : 0]);
+            const T xl = (ABL & 8) ? (T) c[cur][k] : ((ABL & 2) ? x[(c[cur][k] & 1) + threadIdx.x] : x[ok ? c[cur][k] : 0]);
+            xv[k] = ok ? xl : T(0); // a masked slot contributes 0 * 0, never 0 * x[0] (x[0] may be NaN/Inf)
             vv[k] = ok ? v[cur][k] : T(0);
         }
         T sum = 0;

@@ -32,7 +32,7 @@ static opt_t g_opts[] = {
     {"sell_c", 64, 64, 64, 1, 0},          /* one wavefront per chunk: C is the wave width */
     {"sell_sigma", 1024, 64, 1 << 20, 1, 0},
     {"sell_lds_x", 0, 0, 1, 0, 0},
-    {"csr5_sigma", 0, 0, 32, 0, 0},
+    {"csr5_sigma", 0, 0, 16, 0, 0},
     {"rowblock_nnz", 0, 0, 4096, 0, 0},   /* 2*4096 fp64 products = 64 KiB of LDS */
     {"variant", 0, 0, 1 << 20, 0, 0},
 };

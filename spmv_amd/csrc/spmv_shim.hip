@@ -26,6 +26,7 @@
 #include "kernels/nnz_split.hpp"
 #include "kernels/rowblock.hpp"
 #include "kernels/sell.hpp"
+#include "kernels/csr5.hpp"
 
 using namespace spmv;
 
@@ -85,6 +86,11 @@ struct spmv_dev {
     int *perm = nullptr, *scol = nullptr, *long_rows = nullptr;
     long long *chunk_ptr = nullptr;
     void *sval = nullptr;
+    // csr5
+    int c5_sigma = 0, c5_tiles = 0, c5_m2 = 0, c5_fixup = 0;
+    int *c5_tile_ptr = nullptr, *c5_run_len = nullptr, *c5_row_map = nullptr, *c5_col = nullptr;
+    unsigned *c5_desc = nullptr;
+    void *c5_val = nullptr, *c5_carry = nullptr;
     // staging for host x / y
     void *x_stage = nullptr, *y_stage = nullptr;
     long long device_bytes = 0;
@@ -114,6 +120,8 @@ static void free_schedule(spmv_dev *d)
     d->tile_first = nullptr; d->carry = nullptr; d->rb_split = nullptr;
     d->perm = d->scol = d->long_rows = nullptr; d->chunk_ptr = nullptr; d->sval = nullptr;
     d->ntiles = d->nblocks = d->nchunks = d->nlong = 0;
+    d->c5_tile_ptr = d->c5_run_len = d->c5_row_map = d->c5_col = nullptr; d->c5_desc = nullptr;
+    d->c5_val = d->c5_carry = nullptr; d->c5_tiles = d->c5_m2 = d->c5_fixup = 0;
     d->built = false;
 }
 
@@ -351,6 +359,73 @@ static int build_sell(spmv_dev *d)
     return SPMV_HIP_OK;
 }
 
+template <typename T, int SIGMA>
+static int build_csr5_sigma(spmv_dev *d, const int *rp, int m2)
+{
+    constexpr int TN = kWave * SIGMA;
+    const int p = (int) ((d->nnz + TN - 1) / TN);
+    d->c5_tiles = p;
+    ALLOC_TRY(d, &d->c5_tile_ptr, sizeof(int) * ((size_t) p + 1), true);
+    ALLOC_TRY(d, &d->c5_desc, sizeof(unsigned) * (size_t) p * kWave, true);
+    ALLOC_TRY(d, &d->c5_run_len, sizeof(int) * (size_t) p, true);
+    ALLOC_TRY(d, &d->c5_carry, sizeof(T) * (size_t) p, true);
+    ALLOC_TRY(d, &d->c5_col, sizeof(int) * (size_t) p * TN, true);
+    ALLOC_TRY(d, &d->c5_val, sizeof(T) * (size_t) p * TN, true);
+    int *flag = nullptr;
+    ALLOC_TRY(d, &flag, sizeof(int), true);
+    HIP_TRY(hipMemsetAsync(flag, 0, sizeof(int), d->stream));
+    csr5_tile_ptr_kernel<<<grid_for((long long) p + 1, kBlock, INT_MAX), kBlock, 0, d->stream>>>(m2, (int) d->nnz, p, TN, rp, d->c5_tile_ptr);
+    HIP_TRY(hipGetLastError());
+    csr5_desc_kernel<SIGMA><<<grid_for(p, kBlock / kWave, INT_MAX), kBlock, 0, d->stream>>>(m2, (int) d->nnz, p, rp, d->c5_tile_ptr, d->c5_desc,
+                                                                                           d->c5_run_len, flag);
+    HIP_TRY(hipGetLastError());
+    csr5_transpose_kernel<T, SIGMA><<<grid_for(p, kBlock / kWave, INT_MAX), kBlock, 0, d->stream>>>((int) d->nnz, p, d->colidx, (const T *) d->val,
+                                                                                                  d->c5_col, (T *) d->c5_val);
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipMemcpyAsync(&d->c5_fixup, flag, sizeof(int), hipMemcpyDeviceToHost, d->stream));
+    HIP_TRY(hipStreamSynchronize(d->stream));
+    return SPMV_HIP_OK;
+}
+
+template <typename T>
+static int build_csr5(spmv_dev *d)
+{
+    int sigma = d->plan.csr5_sigma;
+    if (sigma == 0) sigma = d->stats.mean_row_len <= 4.0 ? 4 : (d->stats.mean_row_len <= 12.0 ? 8 : 16);
+    if (sigma != 4 && sigma != 8 && sigma != 16) return fail(SPMV_HIP_E_ARG, "csr5_sigma must be 4, 8 or 16 (0 = auto), got %d", sigma);
+    d->c5_sigma = sigma;
+    if (d->nnz == 0) return SPMV_HIP_OK;
+    const int *rp = d->rowptr;
+    int m2 = d->m;
+    if (d->stats.empty_rows > 0) { // build over the compacted (non-empty) row space
+        const int nb = (int) (((long long) d->m + kScanTile - 1) / kScanTile);
+        int *flags = nullptr, *sums = nullptr, *total = nullptr, *rp2 = nullptr;
+        HIP_TRY(hipMalloc((void **) &flags, sizeof(int) * (size_t) d->m));
+        auto cleanup = [&]() { (void) hipFree(flags); };
+        if (dev_alloc(d, (void **) &sums, sizeof(int) * (size_t) nb, true) || dev_alloc(d, (void **) &total, sizeof(int), true)) { cleanup(); return SPMV_HIP_E_ALLOC; }
+        csr5_nonempty_kernel<<<grid_for(d->m, kBlock, d->cus * 8), kBlock, 0, d->stream>>>(d->m, d->rowptr, flags);
+        scan_block_sums_kernel<<<nb, kBlock, 0, d->stream>>>(d->m, flags, sums);
+        scan_sums_inplace_kernel<<<1, kBlock, 0, d->stream>>>(nb, sums, total);
+        if (hipMemcpyAsync(&m2, total, sizeof(int), hipMemcpyDeviceToHost, d->stream) != hipSuccess ||
+            hipStreamSynchronize(d->stream) != hipSuccess) { cleanup(); return fail(SPMV_HIP_E_RUNTIME, "csr5 compaction scan failed"); }
+        if (dev_alloc(d, (void **) &rp2, sizeof(int) * ((size_t) m2 + 1), true) ||
+            dev_alloc(d, (void **) &d->c5_row_map, sizeof(int) * (size_t) (m2 > 0 ? m2 : 1), true)) { cleanup(); return SPMV_HIP_E_ALLOC; }
+        csr5_compact_kernel<<<nb, kBlock, 0, d->stream>>>(d->m, flags, sums, d->rowptr, rp2, d->c5_row_map);
+        const int nnz32 = (int) d->nnz;
+        hipError_t e = hipMemcpyAsync(rp2 + m2, &nnz32, sizeof(int), hipMemcpyHostToDevice, d->stream);
+        if (e == hipSuccess) e = hipStreamSynchronize(d->stream);
+        cleanup();
+        if (e != hipSuccess) return fail(SPMV_HIP_E_RUNTIME, "csr5 compaction: %s", hipGetErrorString(e));
+        rp = rp2;
+    }
+    d->c5_m2 = m2;
+    switch (sigma) {
+    case 4: return build_csr5_sigma<T, 4>(d, rp, m2);
+    case 8: return build_csr5_sigma<T, 8>(d, rp, m2);
+    default: return build_csr5_sigma<T, 16>(d, rp, m2);
+    }
+}
+
 extern "C" int spmv_shim_build(spmv_dev *d, const spmv_plan *plan)
 {
     if (!d || !plan) return fail(SPMV_HIP_E_ARG, "build: NULL");
@@ -374,7 +449,7 @@ extern "C" int spmv_shim_build(spmv_dev *d, const spmv_plan *plan)
         rc = build_rowblock(d);
         break;
     case SPMV_SCHED_SELL: rc = f64 ? build_sell<double>(d) : build_sell<float>(d); break;
-    case SPMV_SCHED_CSR5: return fail(SPMV_HIP_E_ARG, "CSR5 schedule: not built in this round yet");
+    case SPMV_SCHED_CSR5: rc = f64 ? build_csr5<double>(d) : build_csr5<float>(d); break;
     }
     if (rc) { free_schedule(d); return rc; }
     d->inspect_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
@@ -397,6 +472,18 @@ static void launch_vector(spmv_dev *d, const T *x, T *y)
     constexpr int rows = kBlock / L * kVecNB;
     const int grid = grid_for(d->m, rows, INT_MAX);
     csr_vector_pipe_kernel<T, L, kVecNB><<<grid, kBlock, 0, d->stream>>>(d->m, d->rowptr, d->colidx, (const T *) d->val, x, y);
+}
+
+template <typename T, int SIGMA>
+static void launch_csr5(spmv_dev *d, const T *x, T *y)
+{
+    const int grid = grid_for(d->c5_tiles, kBlock / kWave, INT_MAX);
+    if (d->c5_row_map)
+        csr5_kernel<T, SIGMA, true><<<grid, kBlock, 0, d->stream>>>(d->c5_tiles, d->c5_tile_ptr, d->c5_desc, d->c5_col, (const T *) d->c5_val,
+                                                                   d->c5_row_map, x, y, (T *) d->c5_carry);
+    else
+        csr5_kernel<T, SIGMA, false><<<grid, kBlock, 0, d->stream>>>(d->c5_tiles, d->c5_tile_ptr, d->c5_desc, d->c5_col, (const T *) d->c5_val,
+                                                                    nullptr, x, y, (T *) d->c5_carry);
 }
 
 template <typename T>
@@ -443,6 +530,19 @@ static int launch(spmv_dev *d, const T *x, T *y)
         if (d->nlong > 0)
             sell_long_rows_kernel<T><<<grid_for(d->nlong, kBlock / kWave, INT_MAX), kBlock, 0, d->stream>>>(
                 d->nlong, d->long_rows, d->rowptr, d->colidx, val, x, y);
+        break;
+    case SPMV_SCHED_CSR5:
+        if (d->c5_row_map) HIP_TRY(hipMemsetAsync(y, 0, sizeof(T) * (size_t) d->m, d->stream)); // empty rows
+        switch (d->c5_sigma) {
+        case 4: launch_csr5<T, 4>(d, x, y); break;
+        case 8: launch_csr5<T, 8>(d, x, y); break;
+        default: launch_csr5<T, 16>(d, x, y); break;
+        }
+        if (d->c5_fixup && d->c5_tiles > 1) {
+            const int g = grid_for(d->c5_tiles - 1, kBlock, INT_MAX);
+            if (d->c5_row_map) csr5_fixup_kernel<T, true><<<g, kBlock, 0, d->stream>>>(d->c5_tiles, d->c5_tile_ptr, d->c5_run_len, d->c5_row_map, (const T *) d->c5_carry, y);
+            else csr5_fixup_kernel<T, false><<<g, kBlock, 0, d->stream>>>(d->c5_tiles, d->c5_tile_ptr, d->c5_run_len, nullptr, (const T *) d->c5_carry, y);
+        }
         break;
     default: return fail(SPMV_HIP_E_ARG, "schedule %d has no executor", d->plan.sched);
     }
@@ -545,11 +645,11 @@ extern "C" int spmv_shim_info(const spmv_dev *d, spmv_hip_info *o)
     o->lanes_per_row = d->plan.sched == SPMV_SCHED_CSR_VECTOR ? d->plan.lanes_per_row : 0;
     o->sell_c = d->plan.sched == SPMV_SCHED_SELL ? kSellC : 0;
     o->sell_sigma = d->plan.sched == SPMV_SCHED_SELL ? d->plan.sell_sigma : 0;
-    o->tile_nnz = d->plan.sched == SPMV_SCHED_NNZ_SPLIT ? kSplitTile : (d->plan.sched == SPMV_SCHED_ROWBLOCK ? d->rb_stride : 0);
+    o->tile_nnz = d->plan.sched == SPMV_SCHED_NNZ_SPLIT ? kSplitTile : (d->plan.sched == SPMV_SCHED_ROWBLOCK ? d->rb_stride : (d->plan.sched == SPMV_SCHED_CSR5 ? kWave * d->c5_sigma : 0));
     o->m = d->m;
     o->n = d->n;
     o->nnz = d->nnz;
-    o->stored_nnz = d->plan.sched == SPMV_SCHED_SELL ? d->sell_cols * kSellC + (long long) 0 : d->nnz;
+    o->stored_nnz = d->plan.sched == SPMV_SCHED_SELL ? d->sell_cols * kSellC : (d->plan.sched == SPMV_SCHED_CSR5 ? (long long) d->c5_tiles * kWave * d->c5_sigma : d->nnz);
     o->max_row_len = d->stats.max_row_len;
     o->min_row_len = d->stats.min_row_len;
     o->empty_rows = d->stats.empty_rows;
