@@ -20,9 +20,13 @@ _I = C.POINTER(C.c_int)
 _V = C.c_void_p
 
 
+HARNESS = os.path.join(HERE, "_ref", "test_spmv_hip")
+
+
 def build(quiet=True):
-    """make -C oracle  (restatement always; _ref only when /root/reference is present)."""
-    out = subprocess.run(["make", "-C", HERE, "all"], capture_output=True, text=True)
+    """make -C oracle  (restatement always; _ref and the reference harness only when
+    /root/reference is present)."""
+    out = subprocess.run(["make", "-C", HERE, "all", "harness"], capture_output=True, text=True)
     if out.returncode != 0:
         raise RuntimeError("oracle build failed:\n" + out.stdout + out.stderr)
     if not quiet:

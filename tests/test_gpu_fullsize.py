@@ -1,0 +1,142 @@
+"""GPU, BASELINE.json's full sizes: size-independent properties instead of a CPU oracle pass.
+
+  * exact-arithmetic inputs (values and x are multiples of 1/8): every schedule must give the SAME
+    BITS, and those bits must equal a torch fp64 evaluation of the definition of y = A x;
+  * linearity A(a x + b z) = a A x + b A z on random data (tolerance scaled by |A||x|);
+  * checksum of checksums: sum(y) for x = 1 equals sum(Val);
+  * int32 edge: nnz a few thousand below 2^31 on one GPU (288 GB of HBM makes that a normal size).
+"""
+import numpy as np
+import pytest
+import torch
+
+from spmv_amd import api, build, synth
+
+pytestmark = pytest.mark.gpu
+M = api.SPMV_METHODS
+DEV = "cuda:0"
+
+
+@pytest.fixture(scope="module", autouse=True)
+def _lib():
+    build.build()
+    api.load()
+
+
+def _run(m, n, rp, ci, va, x, method):
+    y = torch.full((m,), float("nan"), dtype=va.dtype, device=va.device)
+    with api.Handle(m, n, rp, ci, va, method) as h:
+        h.spmv(x, y)
+        sched = h.info()["schedule_name"]
+    torch.cuda.synchronize()
+    return y, sched
+
+
+def _definition_regular(m, k, ci, va, x):
+    """y from the definition for exactly k nnz per row (fp64 accumulate), chunked."""
+    out = torch.empty(m, dtype=torch.float64, device=va.device)
+    step = 1 << 21
+    for r0 in range(0, m, step):
+        r1 = min(m, r0 + step)
+        c = ci[r0 * k:r1 * k].long()
+        out[r0:r1] = (va[r0 * k:r1 * k].double() * x[c].double()).view(r1 - r0, k).sum(1)
+    return out
+
+
+def _definition_segments(rp, ci, va, x):
+    """y from the definition for arbitrary row lengths: exact fp64 prefix sums, differenced at RowPtr."""
+    nnz = ci.numel()
+    cs = torch.zeros(nnz + 1, dtype=torch.float64, device=va.device)
+    step = 1 << 26
+    carry = torch.zeros((), dtype=torch.float64, device=va.device)
+    for p0 in range(0, nnz, step):
+        p1 = min(nnz, p0 + step)
+        prod = va[p0:p1].double() * x[ci[p0:p1].long()].double()
+        torch.cumsum(prod, 0, out=cs[p0 + 1:p1 + 1])
+        cs[p0 + 1:p1 + 1] += carry
+        carry = cs[p1].clone()
+    r = rp.long()
+    return cs[r[1:]] - cs[r[:-1]]
+
+
+def test_config2_all_schedules_bit_identical_and_equal_definition():
+    m = n = 10_000_000
+    k = 32
+    _, _, rp, ci, va = synth.banded_device(m, n, k, "eighths", torch.float64, DEV, seed=3)
+    g = torch.Generator(device=DEV); g.manual_seed(5)
+    x = torch.randint(0, 8, (n,), generator=g, device=DEV).double() * 0.125
+    want = _definition_regular(m, k, ci, va, x)
+    seen = {}
+    for method in (M.Method_Parallel, M.Method_Balanced, M.Method_Balanced_Yid, M.Method_SellCSigma, M.Method_CSR5SPMV):
+        y, sched = _run(m, n, rp, ci, va, x, method)
+        assert not torch.isnan(y).any(), sched
+        assert torch.equal(y, want), (sched, float((y - want).abs().max()))
+        seen[sched] = True
+    assert {"csr-vector", "row-block", "nnz-split", "sell-c-sigma", "csr5"} <= set(seen)
+
+
+def test_config2_random_columns_and_linearity():
+    m = n = 10_000_000
+    k = 32
+    _, _, rp, ci, va = synth.uniform_k_device(m, n, k, "uniform", torch.float64, DEV, seed=7)
+    g = torch.Generator(device=DEV); g.manual_seed(11)
+    x = torch.rand(n, generator=g, device=DEV, dtype=torch.float64) * 2 - 1
+    z = torch.rand(n, generator=g, device=DEV, dtype=torch.float64) * 2 - 1
+    a, b = 0.75, -1.5
+    with api.Handle(m, n, rp, ci, va, M.Method_Parallel) as h:
+        yx = torch.empty(m, dtype=torch.float64, device=DEV); h.spmv(x, yx)
+        yz = torch.empty(m, dtype=torch.float64, device=DEV); h.spmv(z, yz)
+        yc = torch.empty(m, dtype=torch.float64, device=DEV); h.spmv(a * x + b * z, yc)
+        ones = torch.ones(n, dtype=torch.float64, device=DEV)
+        y1 = torch.empty(m, dtype=torch.float64, device=DEV); h.spmv(ones, y1)
+    torch.cuda.synchronize()
+    scale = k * 2.5  # |a||A||x| + |b||A||z| <= 32 * (0.75 + 1.5)
+    assert float((yc - (a * yx + b * yz)).abs().max()) <= 1e-6 * scale     # north_star fp64 tolerance
+    assert float((yc - (a * yx + b * yz)).abs().max()) <= 64 * 2.3e-16 * scale
+    # checksum of checksums: sum_i (A 1)_i = sum of all values
+    assert abs(float(y1.sum()) - float(va.sum())) <= 1e-9 * float(va.abs().sum())
+    want = _definition_regular(m, k, ci, va, x)
+    assert float((yx - want).abs().max()) <= 64 * 2.3e-16 * k
+
+
+def test_config4_skewed_fp32_schedules_bit_identical():
+    m = n = 10_000_000
+    lens = synth.skewed_lengths_device(m, DEV, seed=2)
+    _, _, rp, ci, va = synth.from_row_lengths_device(lens, n, "eighths", torch.float32, DEV, seed=4, local=4096)
+    g = torch.Generator(device=DEV); g.manual_seed(6)
+    x = (torch.randint(0, 8, (n,), generator=g, device=DEV).float() * 0.125)
+    want = _definition_segments(rp, ci, va, x).float()   # row sums < 2^12 in units of 1/64: exact in fp32
+    info = None
+    for method in (M.Method_SellCSigma, M.Method_CSR5SPMV, M.Method_Balanced2, M.Method_Parallel):
+        y, sched = _run(m, n, rp, ci, va, x, method)
+        assert torch.equal(y, want), (sched, float((y - want).abs().max()))
+    with api.Handle(m, n, rp, ci, va, M.Method_SellCSigma) as h:
+        info = h.info()
+    assert info["sell_c"] == 64 and info["sell_sigma"] == 1024
+    assert info["stored_nnz"] < 1.6 * info["nnz"]          # padding stays bounded on skewed rows
+
+
+def test_config5_shard_shape_global_columns():
+    """One rank's shard of the 8e7 x 8e7 matrix: 1e7 local rows, global columns, n = 8e7."""
+    m, n, k = 10_000_000, 80_000_000, 32
+    _, _, rp, ci, va = synth.banded_device(m, n, k, "eighths", torch.float64, DEV, seed=9, row0=3 * m)
+    assert int(ci.min()) >= 3 * m - 16 and int(ci.max()) <= 4 * m + 16
+    g = torch.Generator(device=DEV); g.manual_seed(8)
+    x = torch.randint(0, 8, (n,), generator=g, device=DEV).double() * 0.125
+    y, _ = _run(m, n, rp, ci, va, x, M.Method_Parallel)
+    assert torch.equal(y, _definition_regular(m, k, ci, va, x))
+
+
+def test_nnz_just_below_int32_limit():
+    k = 32
+    m = 67_108_000                     # nnz = 2 147 456 000 = 2^31 - 27 648
+    n = m
+    _, _, rp, ci, va = synth.banded_device(m, n, k, "eighths", torch.float32, DEV, seed=1)
+    assert int(rp[-1].item()) == m * k < 2**31
+    x = torch.ones(n, dtype=torch.float32, device=DEV)
+    want = va.view(m, k).double().sum(1).float()
+    for method in (M.Method_Parallel, M.Method_Balanced_Yid, M.Method_CSR5SPMV):
+        y, sched = _run(m, n, rp, ci, va, x, method)
+        assert torch.equal(y, want), sched
+        del y
+        torch.cuda.empty_cache()

@@ -14,6 +14,9 @@ ap.add_argument("--methods", default="1,2,3,4,5,0")
 ap.add_argument("--lanes", default="0")
 ap.add_argument("--variants", default="0")
 ap.add_argument("--iters", type=int, default=30)
+ap.add_argument("--alpha", type=float, default=1.6)
+ap.add_argument("--maxlen", type=int, default=100000)
+ap.add_argument("--hostptr", action="store_true")
 a = ap.parse_args()
 build.build()
 dt = torch.float64 if a.dtype == "f64" else torch.float32
@@ -26,7 +29,7 @@ elif a.kind == "random":
 elif a.kind == "skewed":
     m, n, rp, ci, va = synth.from_row_lengths_device(synth.skewed_lengths_device(a.m, dev, 1), a.m, "uniform", dt, dev, 1, local=4096)
 elif a.kind == "powerlaw":
-    m, n, rp, ci, va = synth.from_row_lengths_device(synth.powerlaw_lengths_device(a.m, a.k, 100000, 1.6, dev, 1), a.m, "uniform", dt, dev, 1)
+    m, n, rp, ci, va = synth.from_row_lengths_device(synth.powerlaw_lengths_device(a.m, a.k, a.maxlen, a.alpha, dev, 1), a.m, "uniform", dt, dev, 1)
 torch.cuda.synchronize()
 x = torch.rand(n, dtype=dt, device=dev) * 2 - 1
 y = torch.empty(m, dtype=dt, device=dev)
@@ -54,4 +57,11 @@ for meth in [int(s) for s in a.methods.split(",")]:
               ms_mean=round(mean, 4), ms_min=round(float(ms.min()), 4), gbps_alg=round(float(gb / (ms.min() / 1e3)), 1),
               frac_8TBs=round(float(gb / (ms.min() / 1e3) / 8000), 3), gflops=round(float(2 * nnz / ms.min() / 1e6), 1),
               inspect_ms=round(info["inspect_ms"], 2), stored=info["stored_nnz"], maxdiff_vs_first=err, nan=int(torch.isnan(y).sum().item()))), flush=True)
+        if a.hostptr:
+            xh, yh = x.cpu().numpy(), y.cpu().numpy().copy()
+            api.set_stream(h.h, None, async_=False)
+            t0 = time.time()
+            for _ in range(5):
+                api.spmv(h.h, m, rp, ci, va, xh, yh)
+            print(json.dumps(dict(hostptr_ms=round((time.time() - t0) / 5 * 1e3, 3), ok=bool(abs(yh - y.cpu().numpy()).max() == 0))), flush=True)
         h.close()
