@@ -125,9 +125,10 @@ constexpr int kStreamPad = 4 * kWave + 8;
 // are never waited for inside the wave -- so a wave keeps two groups of matrix stream in flight for
 // most of its life and only the last store's acknowledgement is exposed.  The hot path is straight
 // line (masks by select, clamped row index) so the compiler can hoist every load; rows longer than
-// 4L fall into the loop at the end of each group.
+// 4L fall into the loop at the end of each group, rows longer than long_thr are left to the
+// whole-wavefront long-row kernels (kernels/long_rows.hpp).
 template <typename T, int L, int NB, bool NTSTORE = false, int ABL = 0>
-__global__ __launch_bounds__(kBlock) void csr_vector_pipe_kernel(int m, const int *__restrict__ rowptr,
+__global__ __launch_bounds__(kBlock) void csr_vector_pipe_kernel(int m, int long_thr, const int *__restrict__ rowptr,
                                                                  const int *__restrict__ colidx,
                                                                  const T *__restrict__ val,
                                                                  const T *__restrict__ x, T *__restrict__ y)
@@ -137,12 +138,14 @@ __global__ __launch_bounds__(kBlock) void csr_vector_pipe_kernel(int m, const in
     const int sub = threadIdx.x / L;
     const long long row0 = (long long) blockIdx.x * (kRows * NB) + sub;
     int p0[NB], p1[NB];
+    unsigned skip = 0; // bit j: row is past m, or longer than long_thr (kernels/long_rows.hpp computes it)
 #pragma unroll
     for (int j = 0; j < NB; ++j) {
         long long r = row0 + (long long) j * kRows;
-        if (r > m - 1) r = m - 1;
+        if (r > m - 1) { r = m - 1; skip |= 1u << j; }
         if (ABL & 1) { p0[j] = (int) r * 32; p1[j] = (int) r * 32 + 32; } // ablation: no RowPtr chain
         else { p0[j] = rowptr[r]; p1[j] = rowptr[r + 1]; }
+        if (p1[j] - p0[j] > long_thr) { p1[j] = p0[j]; skip |= 1u << j; }
     }
     int c[2][4];
     T v[2][4];
@@ -186,7 +189,7 @@ __global__ __launch_bounds__(kBlock) void csr_vector_pipe_kernel(int m, const in
         }
         if (!(ABL & 4)) sum = group_sum_dpp<L>(sum);
         const long long row = row0 + (long long) j * kRows;
-        if ((ABL & 16) ? (sum == T(1.2345)) : (lane == 0 && row < m)) {
+        if ((ABL & 16) ? (sum == T(1.2345)) : (lane == 0 && !((skip >> j) & 1u))) {
             if (NTSTORE) __builtin_nontemporal_store(sum, y + row);
             else y[row] = sum;
         }

@@ -27,20 +27,23 @@
 
 namespace spmv {
 
-constexpr int kSplitK = 4;                    // consecutive elements per lane
-constexpr int kSplitTile = kWave * kSplitK;   // 256 nnz per wavefront tile
+// consecutive elements per lane: 4 for fp64 (32 B of Val + 16 B of ColIdx per lane), 8 for fp32
+// (32 B + 32 B) -- the same bytes in flight per wave for both types
+template <typename T> struct SplitCfg { static constexpr int K = sizeof(T) == 4 ? 8 : 4; static constexpr int Tile = kWave * K; };
+constexpr int kSplitK = 4;
+constexpr int kSplitTile = kWave * kSplitK;   // fp64 tile (256 nnz); fp32 uses SplitCfg<float>::Tile = 512
 
 // tile_first[t] = first row r with RowPtr[r] >= t*TILE, t = 0..ntiles-1; tile_first[ntiles] = m
 // (the last tile also owns trailing empty rows).  *any_head is set when some row crosses a tile
 // boundary, i.e. the fix-up pass has work.
-__global__ __launch_bounds__(kBlock) void nnz_tile_first_kernel(int m, int ntiles, const int *__restrict__ rowptr,
+__global__ __launch_bounds__(kBlock) void nnz_tile_first_kernel(int m, int ntiles, int tile_nnz, const int *__restrict__ rowptr,
                                                                 int *__restrict__ tile_first,
                                                                 int *__restrict__ any_head)
 {
     const int t = blockIdx.x * kBlock + threadIdx.x;
     if (t > ntiles) return;
     if (t == ntiles) { tile_first[t] = m; return; }
-    const long long base = (long long) t * kSplitTile;
+    const long long base = (long long) t * tile_nnz;
     const int r = lower_bound_dev(rowptr, m + 1, base);
     tile_first[t] = r;
     if (t > 0 && (long long) rowptr[r] > base) *any_head = 1; // row r-1 runs into this tile
@@ -55,7 +58,9 @@ __global__ __launch_bounds__(kBlock) void nnz_split_kernel(int m, int nnz, int n
                                                            const int *__restrict__ tile_first,
                                                            T *__restrict__ carry)
 {
-    __shared__ int seg_lds[kBlock / kWave][kSplitTile]; // row-start marks of the wave's tile
+    constexpr int kSplitK = SplitCfg<T>::K;
+    constexpr int kSplitTile = SplitCfg<T>::Tile;
+    __shared__ __attribute__((aligned(16))) int seg_lds[kBlock / kWave][kSplitTile]; // row-start marks of the wave's tile
     const int lane = threadIdx.x & (kWave - 1);
     const int wave = threadIdx.x / kWave;
     int *seg = seg_lds[wave];
@@ -69,8 +74,11 @@ __global__ __launch_bounds__(kBlock) void nnz_split_kernel(int m, int nnz, int n
         int c[kSplitK];
         T v[kSplitK];
         if (base + kSplitTile <= nnz) {
-            ld_stream4(colidx + p, c);
-            ld_stream4(val + p, v);
+#pragma unroll
+            for (int q = 0; q < kSplitK; q += 4) {
+                ld_stream4(colidx + p + q, *reinterpret_cast<int(*)[4]>(&c[q]));
+                ld_stream4(val + p + q, *reinterpret_cast<T(*)[4]>(&v[q]));
+            }
         } else { // last, partial tile
 #pragma unroll
             for (int k = 0; k < kSplitK; ++k) {
@@ -89,8 +97,9 @@ __global__ __launch_bounds__(kBlock) void nnz_split_kernel(int m, int nnz, int n
         const int rf = tile_first[t];
         const int rl = tile_first[t + 1];
         {
-            i32x4 minus1 = {-1, -1, -1, -1};
-            *reinterpret_cast<i32x4 *>(seg + lane * kSplitK) = minus1;
+            const i32x4 minus1 = {-1, -1, -1, -1};
+#pragma unroll
+            for (int q = 0; q < kSplitK; q += 4) *reinterpret_cast<i32x4 *>(seg + lane * kSplitK + q) = minus1;
         }
         wave_lds_sync();
         for (int i = lane; i < rl - rf; i += kWave) {
@@ -100,8 +109,12 @@ __global__ __launch_bounds__(kBlock) void nnz_split_kernel(int m, int nnz, int n
             else seg[s - (int) base] = i;
         }
         wave_lds_sync();
-        const i32x4 mk4 = *reinterpret_cast<const i32x4 *>(seg + lane * kSplitK);
-        const int mk[kSplitK] = {mk4.x, mk4.y, mk4.z, mk4.w};
+        int mk[kSplitK];
+#pragma unroll
+        for (int q = 0; q < kSplitK; q += 4) {
+            const i32x4 mk4 = *reinterpret_cast<const i32x4 *>(seg + lane * kSplitK + q);
+            mk[q] = mk4.x; mk[q + 1] = mk4.y; mk[q + 2] = mk4.z; mk[q + 3] = mk4.w;
+        }
         wave_lds_sync(); // marks are in registers before the next tile clears the array
 
         // 4. per-lane running sum, cut at row starts
@@ -145,6 +158,7 @@ __global__ __launch_bounds__(kBlock) void nnz_fixup_kernel(int ntiles, const int
                                                            const int *__restrict__ tile_first,
                                                            const T *__restrict__ carry, T *__restrict__ y)
 {
+    constexpr int kSplitTile = SplitCfg<T>::Tile;
     const int t = blockIdx.x * kBlock + threadIdx.x + 1;
     if (t >= ntiles) return;
     const long long base = (long long) t * kSplitTile;

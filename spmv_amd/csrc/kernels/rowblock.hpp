@@ -48,13 +48,30 @@ __global__ __launch_bounds__(kBlock) void rowblock_kernel(const int *__restrict_
     const int nrows = r1 - r0;
     if (nrows <= 0) return;
     const int p0 = rowptr[r0];
-    const int cnt = rowptr[r1] - p0; // < 2*stride by construction
+    const int p1 = rowptr[r1];
+    const int cnt = p1 - p0; // < 2*stride by construction
 
-    for (int i = threadIdx.x; i < cnt; i += kBlock)
-        prod[i] = ld_stream(val + p0 + i) * x[ld_stream(colidx + p0 + i)];
+    // phase 1: 16 B lane loads from the 16 B-aligned start below p0; two steps in flight
+    for (int a = (p0 & ~3) + threadIdx.x * 4; a < p1; a += 2 * kBlock * 4) {
+        int c0[4], c1[4];
+        T v0[4], v1[4];
+        const int a1 = a + kBlock * 4;
+        const bool second = a1 < p1;
+        ld_stream4(colidx + a, c0);
+        ld_stream4(val + a, v0);
+        if (second) { ld_stream4(colidx + a1, c1); ld_stream4(val + a1, v1); }
+#pragma unroll
+        for (int k = 0; k < 4; ++k)
+            if (a + k >= p0 && a + k < p1) prod[a + k - p0] = v0[k] * x[c0[k]];
+        if (second) {
+#pragma unroll
+            for (int k = 0; k < 4; ++k)
+                if (a1 + k < p1) prod[a1 + k - p0] = v1[k] * x[c1[k]];
+        }
+    }
     __syncthreads();
 
-    // lanes per row: power of two >= mean row length of this block, in [1, 64]
+    // phase 2: G lanes per row, G = power of two >= mean row length of this block, in [1, 64]
     int G = 1;
     while (G < kWave && G * nrows < cnt) G <<= 1;
     const int rows_per_pass = kBlock / G;

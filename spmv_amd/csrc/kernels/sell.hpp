@@ -9,17 +9,19 @@
 //
 // HBM layout (global arrays instead of the reference's per-window mallocs):
 //   perm      int32[nchunks*64]   original row of each sorted slot, -1 = no row (padding slot,
-//                                 or a LONG row handled by sell_long_rows_kernel)
+//                                 or a LONG row handled by kernels/long_rows.hpp)
 //   chunk_ptr int64[nchunks+1]    prefix sum of chunk widths (in columns; element offset = *64)
 //   col / val [chunk_ptr[nchunks]*64]  column-major inside a chunk: (row slot l, j) at
 //                                 (chunk_ptr[c] + j)*64 + l;  padding: col = -1, val = 0
-//   long_rows int32[nlong]        rows longer than `long_thr`: excluded from the slabs (they would
-//                                 pad their whole chunk to their length) and computed one
-//                                 wavefront per row straight from CSR -- the analogue of the
-//                                 reference's CSR remainder loop (sell_C_Sigma_spmv.c:289-298).
+//   long rows                     rows longer than `long_thr` are excluded from the slabs (they would
+//                                 pad their whole chunk to their length) and computed by whole
+//                                 wavefronts straight from CSR (kernels/long_rows.hpp) -- the
+//                                 analogue of the reference's CSR remainder loop
+//                                 (sell_C_Sigma_spmv.c:289-298).
 // Rows are sorted DESCENDING by length inside a window (the reference sorts ascending; either is
 // fine) so a chunk's width is the length of its first slot.
 #pragma once
+#include <climits>
 #include "common.hpp"
 
 namespace spmv {
@@ -30,9 +32,7 @@ constexpr int kSellC = kWave;
 __global__ __launch_bounds__(kBlock) void sell_sort_kernel(int m, int sigma, int long_thr,
                                                            const int *__restrict__ rowptr,
                                                            int *__restrict__ perm,
-                                                           int *__restrict__ chunk_width,
-                                                           int *__restrict__ long_rows,
-                                                           int *__restrict__ long_count)
+                                                           int *__restrict__ chunk_width)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char sell_lds[];
     unsigned long long *keys = reinterpret_cast<unsigned long long *>(sell_lds);
@@ -43,8 +43,7 @@ __global__ __launch_bounds__(kBlock) void sell_sort_kernel(int m, int sigma, int
         if (row < m) {
             len = (unsigned) (rowptr[row + 1] - rowptr[row]);
             valid = 1;
-            if ((int) len > long_thr) {
-                long_rows[atomicAdd(long_count, 1)] = (int) row;
+            if ((int) len > long_thr) { // handled by kernels/long_rows.hpp, not by the slabs
                 len = 0;
                 valid = 0;
             }
@@ -168,23 +167,103 @@ __global__ __launch_bounds__(kBlock) void sell_kernel(int nchunks, const long lo
     }
 }
 
-// One wavefront per long row, straight from CSR.
-template <typename T>
-__global__ __launch_bounds__(kBlock) void sell_long_rows_kernel(int nlong, const int *__restrict__ long_rows,
-                                                                const int *__restrict__ rowptr,
-                                                                const int *__restrict__ colidx,
-                                                                const T *__restrict__ val,
-                                                                const T *__restrict__ x, T *__restrict__ y)
+// ---- LDS-staged x tiles (north_star: "SELL-C-sigma ... LDS-staged x tiles") ---------------------
+// Sorting rows by length inside a sigma window puts rows that are up to sigma apart into adjacent
+// lanes, so one gather instruction touches up to 64 different cache lines of x -- on a GPU that, not
+// the padding, is what makes SELL slow on skewed matrices (measured 0.7 TB/s on config 4).  But the
+// window as a whole only references x[lo, lo+span): when that span fits in LDS the workgroup stages
+// it once (coalesced) and every gather becomes an LDS read.
+//
+// Inspector: per window the min / max column over its slab entries.
+__global__ __launch_bounds__(kBlock) void sell_window_span_kernel(int chunks_per_win, int max_span,
+                                                                  const long long *__restrict__ chunk_ptr,
+                                                                  const int *__restrict__ scol,
+                                                                  int *__restrict__ win_lo, int *__restrict__ win_span,
+                                                                  int *__restrict__ staged_windows /* [0] count, [1] max span */)
 {
+    __shared__ int smin[kBlock / kWave], smax[kBlock / kWave];
+    const int w = blockIdx.x;
+    const long long b = chunk_ptr[(long long) w * chunks_per_win] * kSellC;
+    const long long e = chunk_ptr[(long long) (w + 1) * chunks_per_win] * kSellC;
+    int mn = INT_MAX, mx = -1;
+    for (long long i = b + threadIdx.x; i < e; i += kBlock) {
+        const int c = scol[i];
+        if (c >= 0) { mn = min(mn, c); mx = max(mx, c); }
+    }
+#pragma unroll
+    for (int o = kWave / 2; o > 0; o >>= 1) {
+        mn = min(mn, __shfl_xor(mn, o, kWave));
+        mx = max(mx, __shfl_xor(mx, o, kWave));
+    }
+    if ((threadIdx.x & (kWave - 1)) == 0) { smin[threadIdx.x / kWave] = mn; smax[threadIdx.x / kWave] = mx; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        for (int k = 1; k < kBlock / kWave; ++k) { mn = min(mn, smin[k]); mx = max(mx, smax[k]); }
+        const long long span = mx >= mn ? (long long) mx - mn + 1 : 0;
+        const bool ok = span > 0 && span <= max_span;
+        win_lo[w] = ok ? mn : 0;
+        win_span[w] = ok ? (int) span : 0; // 0: gather from global memory
+        if (ok) { atomicAdd(staged_windows, 1); atomicMax(staged_windows + 1, (int) span); }
+    }
+}
+
+constexpr int kSellWinThreads = 512; // 8 wavefronts per sigma window
+
+template <typename T, bool STAGED>
+__device__ __forceinline__ void sell_chunk(const int *__restrict__ pc, const T *__restrict__ pv, int width, int lo,
+                                           const T *__restrict__ xs, const T *__restrict__ x, T &sum)
+{
+    constexpr int U = 8;
+    int j = 0;
+    for (; j + U <= width; j += U) {
+        int cc[U];
+        T vv[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            cc[u] = ld_stream(pc + (size_t) (j + u) * kSellC);
+            vv[u] = ld_stream(pv + (size_t) (j + u) * kSellC);
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u)
+            if (cc[u] >= 0) sum = fmadd(vv[u], STAGED ? xs[cc[u] - lo] : x[cc[u]], sum);
+    }
+    for (; j < width; ++j) {
+        const int cc = ld_stream(pc + (size_t) j * kSellC);
+        const T vv = ld_stream(pv + (size_t) j * kSellC);
+        if (cc >= 0) sum = fmadd(vv, STAGED ? xs[cc - lo] : x[cc], sum);
+    }
+}
+
+// One workgroup per sigma window; the window's x span is staged in LDS when it fits.
+template <typename T>
+__global__ __launch_bounds__(kSellWinThreads) void sell_window_kernel(int chunks_per_win,
+                                                                      const long long *__restrict__ chunk_ptr,
+                                                                      const int *__restrict__ scol,
+                                                                      const T *__restrict__ sval,
+                                                                      const int *__restrict__ perm,
+                                                                      const int *__restrict__ win_lo,
+                                                                      const int *__restrict__ win_span,
+                                                                      const T *__restrict__ x, T *__restrict__ y)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char sell_x_lds[];
+    T *xs = reinterpret_cast<T *>(sell_x_lds);
+    const int w = blockIdx.x;
+    const int lo = win_lo[w], span = win_span[w];
+    for (int i = threadIdx.x; i < span; i += kSellWinThreads) xs[i] = x[lo + i];
+    if (span > 0) __syncthreads();
     const int lane = threadIdx.x & (kWave - 1);
-    const int i = blockIdx.x * (kBlock / kWave) + threadIdx.x / kWave;
-    if (i >= nlong) return;
-    const int row = long_rows[i];
-    const int p0 = rowptr[row], p1 = rowptr[row + 1];
-    T sum = 0;
-    for (int p = p0 + lane; p < p1; p += kWave) sum = fmadd(ld_stream(val + p), x[ld_stream(colidx + p)], sum);
-    sum = group_sum<kWave>(sum);
-    if (lane == 0) y[row] = sum;
+    for (int k = threadIdx.x / kWave; k < chunks_per_win; k += kSellWinThreads / kWave) {
+        const long long c = (long long) w * chunks_per_win + k;
+        const long long c0 = chunk_ptr[c];
+        const int width = (int) (chunk_ptr[c + 1] - c0);
+        const int *pc = scol + (size_t) c0 * kSellC + lane;
+        const T *pv = sval + (size_t) c0 * kSellC + lane;
+        T sum = 0;
+        if (span > 0) sell_chunk<T, true>(pc, pv, width, lo, xs, x, sum);
+        else sell_chunk<T, false>(pc, pv, width, lo, xs, x, sum);
+        const int row = perm[c * kSellC + lane];
+        if (row >= 0) y[row] = sum;
+    }
 }
 
 } // namespace spmv

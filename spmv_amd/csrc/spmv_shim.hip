@@ -27,6 +27,7 @@
 #include "kernels/rowblock.hpp"
 #include "kernels/sell.hpp"
 #include "kernels/csr5.hpp"
+#include "kernels/long_rows.hpp"
 
 using namespace spmv;
 
@@ -80,10 +81,16 @@ struct spmv_dev {
     // row blocks
     int nblocks = 0, rb_stride = 0;
     int *rb_split = nullptr;
+    // long rows (csr-vector, sell)
+    int nlong = 0, long_thr = INT_MAX, lr_segs = 0;
+    int *long_rows = nullptr, *lr_seg_lr = nullptr;
+    long long *lr_seg_start = nullptr;
+    void *lr_part = nullptr;
     // sell
-    int nchunks = 0, nlong = 0, long_thr = 0;
+    int nchunks = 0;
     long long sell_cols = 0; // sum of chunk widths
-    int *perm = nullptr, *scol = nullptr, *long_rows = nullptr;
+    int *perm = nullptr, *scol = nullptr, *win_lo = nullptr, *win_span = nullptr;
+    int sell_nwin = 0, sell_staged = 0, sell_xcap = 0, sell_maxspan = 0; // windows, windows with x staged in LDS, LDS capacity in elements
     long long *chunk_ptr = nullptr;
     void *sval = nullptr;
     // csr5
@@ -118,8 +125,10 @@ static void free_schedule(spmv_dev *d)
     for (void *p : d->sched_allocs) (void) hipFree(p);
     d->sched_allocs.clear();
     d->tile_first = nullptr; d->carry = nullptr; d->rb_split = nullptr;
-    d->perm = d->scol = d->long_rows = nullptr; d->chunk_ptr = nullptr; d->sval = nullptr;
-    d->ntiles = d->nblocks = d->nchunks = d->nlong = 0;
+    d->perm = d->scol = d->long_rows = d->lr_seg_lr = d->win_lo = d->win_span = nullptr; d->sell_staged = d->sell_nwin = 0; d->chunk_ptr = d->lr_seg_start = nullptr;
+    d->sval = d->lr_part = nullptr;
+    d->ntiles = d->nblocks = d->nchunks = d->nlong = d->lr_segs = 0;
+    d->long_thr = INT_MAX;
     d->c5_tile_ptr = d->c5_run_len = d->c5_row_map = d->c5_col = nullptr; d->c5_desc = nullptr;
     d->c5_val = d->c5_carry = nullptr; d->c5_tiles = d->c5_m2 = d->c5_fixup = 0;
     d->built = false;
@@ -288,7 +297,8 @@ extern "C" void spmv_shim_matrix_destroy(spmv_dev *d)
 template <typename T>
 static int build_nnz_split(spmv_dev *d)
 {
-    d->ntiles = (int) ((d->nnz + kSplitTile - 1) / kSplitTile);
+    constexpr int tile = SplitCfg<T>::Tile;
+    d->ntiles = (int) ((d->nnz + tile - 1) / tile);
     if (d->ntiles == 0) return SPMV_HIP_OK;
     ALLOC_TRY(d, &d->tile_first, sizeof(int) * ((size_t) d->ntiles + 1), true);
     ALLOC_TRY(d, &d->carry, sizeof(T) * (size_t) d->ntiles, true);
@@ -296,7 +306,7 @@ static int build_nnz_split(spmv_dev *d)
     ALLOC_TRY(d, &flag, sizeof(int), true);
     HIP_TRY(hipMemsetAsync(flag, 0, sizeof(int), d->stream));
     nnz_tile_first_kernel<<<grid_for((long long) d->ntiles + 1, kBlock, INT_MAX), kBlock, 0, d->stream>>>(
-        d->m, d->ntiles, d->rowptr, d->tile_first, flag);
+        d->m, d->ntiles, tile, d->rowptr, d->tile_first, flag);
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipMemcpyAsync(&d->need_fixup, flag, sizeof(int), hipMemcpyDeviceToHost, d->stream));
     HIP_TRY(hipStreamSynchronize(d->stream));
@@ -316,6 +326,58 @@ static int build_rowblock(spmv_dev *d)
     return SPMV_HIP_OK;
 }
 
+// LDS budget of one SELL window's x tile: 96 KiB of the CU's 160 KiB (one 512-thread workgroup per
+// window; fp32 24576 columns, fp64 12288 columns).
+constexpr size_t kSellXTileBytes = 96 * 1024;
+
+// Rows longer than thr -> long_rows[], cut into kLongSeg segments (kernels/long_rows.hpp).
+template <typename T>
+static int build_long_rows(spmv_dev *d, int thr)
+{
+    d->long_thr = thr;
+    d->nlong = 0;
+    d->lr_segs = 0;
+    if (d->stats.max_row_len <= thr) return SPMV_HIP_OK;
+    int *cnt = nullptr, *seg_cnt = nullptr;
+    ALLOC_TRY(d, &cnt, sizeof(int), true);
+    HIP_TRY(hipMemsetAsync(cnt, 0, sizeof(int), d->stream));
+    count_longer_kernel<<<grid_for(d->m, kBlock, d->cus * 8), kBlock, 0, d->stream>>>(d->m, thr, d->rowptr, cnt);
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipMemcpyAsync(&d->nlong, cnt, sizeof(int), hipMemcpyDeviceToHost, d->stream));
+    HIP_TRY(hipStreamSynchronize(d->stream));
+    if (d->nlong == 0) return SPMV_HIP_OK;
+    ALLOC_TRY(d, &d->long_rows, sizeof(int) * (size_t) d->nlong, true);
+    ALLOC_TRY(d, &seg_cnt, sizeof(int) * (size_t) d->nlong, true);
+    ALLOC_TRY(d, &d->lr_seg_start, sizeof(long long) * ((size_t) d->nlong + 1), true);
+    HIP_TRY(hipMemsetAsync(cnt, 0, sizeof(int), d->stream));
+    long_rows_collect_kernel<<<grid_for(d->m, kBlock, d->cus * 8), kBlock, 0, d->stream>>>(d->m, thr, d->rowptr, d->long_rows, cnt);
+    long_rows_segcount_kernel<<<grid_for(d->nlong, kBlock, INT_MAX), kBlock, 0, d->stream>>>(d->nlong, d->long_rows, d->rowptr, seg_cnt);
+    scan_i32_to_i64_kernel<<<1, kBlock, 0, d->stream>>>(d->nlong, seg_cnt, d->lr_seg_start);
+    HIP_TRY(hipGetLastError());
+    long long nsegs = 0;
+    HIP_TRY(hipMemcpyAsync(&nsegs, d->lr_seg_start + d->nlong, sizeof(long long), hipMemcpyDeviceToHost, d->stream));
+    HIP_TRY(hipStreamSynchronize(d->stream));
+    d->lr_segs = (int) nsegs;
+    ALLOC_TRY(d, &d->lr_seg_lr, sizeof(int) * (size_t) nsegs, true);
+    ALLOC_TRY(d, &d->lr_part, sizeof(T) * (size_t) nsegs, true);
+    long_rows_segfill_kernel<<<grid_for(d->nlong, kBlock, INT_MAX), kBlock, 0, d->stream>>>(d->nlong, d->lr_seg_start, d->lr_seg_lr);
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipStreamSynchronize(d->stream));
+    return SPMV_HIP_OK;
+}
+
+template <typename T>
+static void launch_long_rows(spmv_dev *d, const T *x, T *y)
+{
+    if (d->nlong <= 0) return;
+    constexpr size_t xbytes = 48 * 1024; // LDS x tile of one long-row segment
+    long_rows_kernel<T><<<d->lr_segs, kBlock, xbytes, d->stream>>>(
+        d->lr_segs, (int) (xbytes / sizeof(T)), d->lr_seg_lr, d->lr_seg_start, d->long_rows, d->rowptr, d->colidx, (const T *) d->val, x, y, (T *) d->lr_part);
+    if (d->lr_segs > d->nlong)
+        long_rows_combine_kernel<T><<<grid_for(d->nlong, kBlock, INT_MAX), kBlock, 0, d->stream>>>(d->nlong, d->lr_seg_start, d->long_rows,
+                                                                                                  (const T *) d->lr_part, y);
+}
+
 template <typename T>
 static int build_sell(spmv_dev *d)
 {
@@ -329,21 +391,16 @@ static int build_sell(spmv_dev *d)
     // rows that would pad a whole chunk to their length are kept in CSR (see sell.hpp)
     double thr = 8.0 * d->stats.mean_row_len;
     if (thr < 64.0) thr = 64.0;
-    d->long_thr = thr > (double) INT_MAX ? INT_MAX : (int) thr;
-    int *cnt = nullptr, *width = nullptr;
-    ALLOC_TRY(d, &cnt, sizeof(int), true);
-    HIP_TRY(hipMemsetAsync(cnt, 0, sizeof(int), d->stream));
-    count_longer_kernel<<<grid_for(d->m, kBlock, d->cus * 8), kBlock, 0, d->stream>>>(d->m, d->long_thr, d->rowptr, cnt);
-    HIP_TRY(hipGetLastError());
-    HIP_TRY(hipMemcpyAsync(&d->nlong, cnt, sizeof(int), hipMemcpyDeviceToHost, d->stream));
-    HIP_TRY(hipStreamSynchronize(d->stream));
-    ALLOC_TRY(d, &d->long_rows, sizeof(int) * (size_t) (d->nlong > 0 ? d->nlong : 1), true);
+    {
+        const int rc = build_long_rows<T>(d, thr > (double) INT_MAX ? INT_MAX : (int) thr);
+        if (rc) return rc;
+    }
+    int *width = nullptr;
     ALLOC_TRY(d, &d->perm, sizeof(int) * (size_t) nwin * sigma, true);
     ALLOC_TRY(d, &width, sizeof(int) * (size_t) d->nchunks, true);
     ALLOC_TRY(d, &d->chunk_ptr, sizeof(long long) * ((size_t) d->nchunks + 1), true);
-    HIP_TRY(hipMemsetAsync(cnt, 0, sizeof(int), d->stream));
     sell_sort_kernel<<<nwin, kBlock, sizeof(unsigned long long) * (size_t) sigma, d->stream>>>(
-        d->m, sigma, d->long_thr, d->rowptr, d->perm, width, d->long_rows, cnt);
+        d->m, sigma, d->long_thr, d->rowptr, d->perm, width);
     HIP_TRY(hipGetLastError());
     scan_i32_to_i64_kernel<<<1, kBlock, 0, d->stream>>>(d->nchunks, width, d->chunk_ptr);
     HIP_TRY(hipGetLastError());
@@ -355,6 +412,24 @@ static int build_sell(spmv_dev *d)
     sell_fill_kernel<T><<<grid_for(d->nchunks, kBlock / kWave, INT_MAX), kBlock, 0, d->stream>>>(
         d->nchunks, d->rowptr, d->colidx, (const T *) d->val, d->perm, d->chunk_ptr, d->scol, (T *) d->sval);
     HIP_TRY(hipGetLastError());
+    d->sell_nwin = nwin;
+    d->sell_staged = 0;
+    if (d->plan.sell_lds_x) { // x span of every window; windows that fit are staged in LDS by the executor
+        d->sell_xcap = (int) (kSellXTileBytes / sizeof(T));
+        int *cnt = nullptr;
+        ALLOC_TRY(d, &cnt, 2 * sizeof(int), true);
+        ALLOC_TRY(d, &d->win_lo, sizeof(int) * (size_t) nwin, true);
+        ALLOC_TRY(d, &d->win_span, sizeof(int) * (size_t) nwin, true);
+        HIP_TRY(hipMemsetAsync(cnt, 0, 2 * sizeof(int), d->stream));
+        sell_window_span_kernel<<<nwin, kBlock, 0, d->stream>>>(sigma / kSellC, d->sell_xcap, d->chunk_ptr, d->scol, d->win_lo, d->win_span, cnt);
+        HIP_TRY(hipGetLastError());
+        int host2[2] = {0, 0};
+        HIP_TRY(hipMemcpyAsync(host2, cnt, 2 * sizeof(int), hipMemcpyDeviceToHost, d->stream));
+        HIP_TRY(hipStreamSynchronize(d->stream));
+        d->sell_staged = host2[0];
+        d->sell_maxspan = host2[1];
+        HIP_TRY(hipFuncSetAttribute((const void *) sell_window_kernel<T>, hipFuncAttributeMaxDynamicSharedMemorySize, (int) kSellXTileBytes));
+    }
     HIP_TRY(hipStreamSynchronize(d->stream));
     return SPMV_HIP_OK;
 }
@@ -440,6 +515,8 @@ extern "C" int spmv_shim_build(spmv_dev *d, const spmv_plan *plan)
     case SPMV_SCHED_CSR_VECTOR: {
         const int L = plan->lanes_per_row;
         if (L < 1 || L > 64 || (L & (L - 1))) return fail(SPMV_HIP_E_ARG, "lanes_per_row must be a power of two in [1, 64], got %d", L);
+        // a lane group takes 4L elements per step; beyond ~64 steps a whole wavefront per row segment wins
+        rc = f64 ? build_long_rows<double>(d, L * 64 > 256 ? L * 64 : 256) : build_long_rows<float>(d, L * 64 > 256 ? L * 64 : 256);
         break;
     }
     case SPMV_SCHED_NNZ_SPLIT: rc = f64 ? build_nnz_split<double>(d) : build_nnz_split<float>(d); break;
@@ -471,7 +548,8 @@ static void launch_vector(spmv_dev *d, const T *x, T *y)
     }
     constexpr int rows = kBlock / L * kVecNB;
     const int grid = grid_for(d->m, rows, INT_MAX);
-    csr_vector_pipe_kernel<T, L, kVecNB><<<grid, kBlock, 0, d->stream>>>(d->m, d->rowptr, d->colidx, (const T *) d->val, x, y);
+    csr_vector_pipe_kernel<T, L, kVecNB><<<grid, kBlock, 0, d->stream>>>(d->m, d->plan.variant == 2 ? INT_MAX : d->long_thr, d->rowptr, d->colidx,
+                                                                       (const T *) d->val, x, y);
 }
 
 template <typename T, int SIGMA>
@@ -510,6 +588,7 @@ static int launch(spmv_dev *d, const T *x, T *y)
         case 32: launch_vector<T, 32>(d, x, y); break;
         default: launch_vector<T, 64>(d, x, y); break;
         }
+        if (d->plan.variant == 0) launch_long_rows<T>(d, x, y);
         break;
     case SPMV_SCHED_NNZ_SPLIT: {
         const int grid = grid_for(d->ntiles, kBlock / kWave, d->plan.variant == 1 ? d->cus * 8 : INT_MAX);
@@ -525,11 +604,15 @@ static int launch(spmv_dev *d, const T *x, T *y)
             d->rb_split, d->rowptr, d->colidx, val, x, y);
         break;
     case SPMV_SCHED_SELL:
-        sell_kernel<T><<<grid_for(d->nchunks, kBlock / kWave, d->plan.variant == 1 ? d->cus * 8 : INT_MAX), kBlock, 0, d->stream>>>(
-            d->nchunks, d->chunk_ptr, d->scol, (const T *) d->sval, d->perm, x, y);
-        if (d->nlong > 0)
-            sell_long_rows_kernel<T><<<grid_for(d->nlong, kBlock / kWave, INT_MAX), kBlock, 0, d->stream>>>(
-                d->nlong, d->long_rows, d->rowptr, d->colidx, val, x, y);
+        // staged path when at least half of the windows fit their x span in LDS; the LDS request is
+        // sized by the largest staged span actually present (rounded to 16 KiB) to keep occupancy
+        if (d->plan.sell_lds_x && d->sell_staged * 2 >= d->sell_nwin && d->plan.variant != 3)
+            sell_window_kernel<T><<<d->sell_nwin, kSellWinThreads, (((size_t) d->sell_maxspan * sizeof(T)) + 1023) & ~(size_t) 1023, d->stream>>>(
+                d->plan.sell_sigma / kSellC, d->chunk_ptr, d->scol, (const T *) d->sval, d->perm, d->win_lo, d->win_span, x, y);
+        else
+            sell_kernel<T><<<grid_for(d->nchunks, kBlock / kWave, d->plan.variant == 1 ? d->cus * 8 : INT_MAX), kBlock, 0, d->stream>>>(
+                d->nchunks, d->chunk_ptr, d->scol, (const T *) d->sval, d->perm, x, y);
+        launch_long_rows<T>(d, x, y);
         break;
     case SPMV_SCHED_CSR5:
         if (d->c5_row_map) HIP_TRY(hipMemsetAsync(y, 0, sizeof(T) * (size_t) d->m, d->stream)); // empty rows
@@ -645,7 +728,7 @@ extern "C" int spmv_shim_info(const spmv_dev *d, spmv_hip_info *o)
     o->lanes_per_row = d->plan.sched == SPMV_SCHED_CSR_VECTOR ? d->plan.lanes_per_row : 0;
     o->sell_c = d->plan.sched == SPMV_SCHED_SELL ? kSellC : 0;
     o->sell_sigma = d->plan.sched == SPMV_SCHED_SELL ? d->plan.sell_sigma : 0;
-    o->tile_nnz = d->plan.sched == SPMV_SCHED_NNZ_SPLIT ? kSplitTile : (d->plan.sched == SPMV_SCHED_ROWBLOCK ? d->rb_stride : (d->plan.sched == SPMV_SCHED_CSR5 ? kWave * d->c5_sigma : 0));
+    o->tile_nnz = d->plan.sched == SPMV_SCHED_NNZ_SPLIT ? (d->vsize == 8 ? SplitCfg<double>::Tile : SplitCfg<float>::Tile) : (d->plan.sched == SPMV_SCHED_ROWBLOCK ? d->rb_stride : (d->plan.sched == SPMV_SCHED_CSR5 ? kWave * d->c5_sigma : 0));
     o->m = d->m;
     o->n = d->n;
     o->nnz = d->nnz;

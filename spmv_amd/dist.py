@@ -47,6 +47,32 @@ def _owner_of(cols, n, world):
     return torch.where(cols < cut, cols // (base + 1), extra + (cols - cut) // max(base, 1))
 
 
+def _staged(fn):
+    """RCCL moves device tensors directly.  Under the gloo backend (CPU tests, or a box where RCCL is
+    not usable) device tensors are staged through host copies around the same collective."""
+    def wrapped(out, inp, *args, **kw):
+        if dist.get_backend(kw.get("group")) == "gloo" and (out.is_cuda or inp.is_cuda):
+            o, i = out.cpu(), inp.cpu()
+            fn(o, i, *args, **kw)
+            out.copy_(o)
+        else:
+            fn(out, inp, *args, **kw)
+    return wrapped
+
+
+_all_to_all_single = _staged(dist.all_to_all_single)
+_all_gather_into_tensor = _staged(dist.all_gather_into_tensor)
+
+
+def _broadcast(t, src, group=None):
+    if dist.get_backend(group) == "gloo" and t.is_cuda:
+        h = t.cpu()
+        dist.broadcast(h, src=src, group=group)
+        t.copy_(h)
+    else:
+        dist.broadcast(t, src=src, group=group)
+
+
 class ShardedSpMV:
     """y_local = A[rows of this rank, :] @ x   with x distributed like the rows.
 
@@ -95,14 +121,13 @@ class ShardedSpMV:
         owner = _owner_of(ghosts, self.n_global, world)
         recv_counts = torch.bincount(owner, minlength=world).to(torch.int64)   # what I need, per owner
         send_counts = torch.empty_like(recv_counts)
-        cpu = recv_counts.device.type == "cpu"
-        dist.all_to_all_single(send_counts, recv_counts, group=self.group)       # what peers need from me
+        _all_to_all_single(send_counts, recv_counts, group=self.group)       # what peers need from me
         self.recv_counts = [int(v) for v in recv_counts.tolist()]
         self.send_counts = [int(v) for v in send_counts.tolist()]
         # tell each owner WHICH of its entries I need (ghosts is sorted => grouped by owner)
         want = torch.empty(int(sum(self.send_counts)), dtype=torch.int64, device=dev)
-        dist.all_to_all_single(want, ghosts, output_split_sizes=self.send_counts,
-                               input_split_sizes=self.recv_counts, group=self.group)
+        _all_to_all_single(want, ghosts, output_split_sizes=self.send_counts,
+                           input_split_sizes=self.recv_counts, group=self.group)
         self.send_idx = (want - self.c0).contiguous()                 # positions in my slice, peer-major
         assert self.send_idx.numel() == 0 or (int(self.send_idx.min()) >= 0 and int(self.send_idx.max()) < self.n_local)
         # renumber: own column c -> c - c0 ; remote column -> n_local + rank in `ghosts`
@@ -110,7 +135,6 @@ class ShardedSpMV:
         if self.n_ghost:
             new[remote_mask] = self.n_local + torch.searchsorted(ghosts, cols[remote_mask])
         assert self.n_local + self.n_ghost < 2**31
-        del cpu
         return new.to(torch.int32).contiguous()
 
     # ------------------------------------------------------------------ per step
@@ -128,24 +152,24 @@ class ShardedSpMV:
                 self.x_ext[: self.n_local].copy_(x_local)
             if self.n_ghost or self.send_idx.numel():
                 send = x_local[self.send_idx] if self.send_idx.numel() else x_local.new_empty(0)
-                dist.all_to_all_single(self.x_ext[self.n_local:], send, output_split_sizes=self.recv_counts,
-                                       input_split_sizes=self.send_counts, group=self.group)
+                _all_to_all_single(self.x_ext[self.n_local:], send, output_split_sizes=self.recv_counts,
+                                   input_split_sizes=self.send_counts, group=self.group)
         elif self.xchg == "allgather":
             if self.n_global % self.world == 0:
-                dist.all_gather_into_tensor(self.x_ext, x_local.contiguous(), group=self.group)
+                _all_gather_into_tensor(self.x_ext, x_local.contiguous(), group=self.group)
             else:  # uneven slices: gather equal-sized padded pieces, then compact
                 width = -(-self.n_global // self.world)
                 piece = x_local.new_zeros(width)
                 piece[: self.n_local].copy_(x_local)
                 tmp = x_local.new_empty(width * self.world)
-                dist.all_gather_into_tensor(tmp, piece, group=self.group)
+                _all_gather_into_tensor(tmp, piece, group=self.group)
                 for r in range(self.world):
                     lo, hi = slice_bounds(self.n_global, self.world, r)
                     self.x_ext[lo:hi].copy_(tmp[r * width: r * width + hi - lo])
         elif self.xchg == "bcast":
             # rank 0 holds the whole vector; the slices are first collected there only if the
             # caller passes slices (bench passes rank 0's full x through set_full_x instead)
-            dist.broadcast(self.x_ext, src=0, group=self.group)
+            _broadcast(self.x_ext, 0, group=self.group)
         else:  # none: x_ext was filled once by set_full_x / the caller
             pass
         return self.x_ext

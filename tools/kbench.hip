@@ -73,6 +73,9 @@ __global__ __launch_bounds__(256) void stream_store(long long nnz, const int *co
     if (MODE == 8 && (w & 7) == 0) out[(w >> 3) * 64 + lane] = acc;      // same bytes, dense target (y region 1/8 size... no: same size)
     if (MODE == 9 && (w & 255) == 0) { for (int i = 0; i < 32; ++i) out[w * 8 + i * 64 + lane] = acc; }   // 16 KB bursts, same bytes
     if (MODE == 10 && (w & 2047) == 0) { for (int i = 0; i < 256; ++i) out[w * 8 + i * 64 + lane] = acc; } // 128 KB bursts
+    if (MODE == 11 && (lane & 7) == 0) out[(w * 8 + (lane >> 3)) & 131071] = acc;          // same stores into a 1 MB window (L2-resident)
+    if (MODE == 12 && (lane & 7) == 0) out[(w * 8 + (lane >> 3)) & 4194303] = acc;         // 32 MB window (MALL-resident)
+    if (MODE == 13 && (lane & 7) == 0) atomicAdd(out + w * 8 + (lane >> 3), acc);          // memory-side atomics instead of stores
     if (MODE == 0 && acc == 1.2345) out[0] = acc;
 }
 // write-only and copy references
@@ -95,7 +98,7 @@ int main(int argc, char **argv)
     const int ntiles = (int) ((nnz + kSplitTile - 1) / kSplitTile);
     int *tile_first, *flag; double *carry;
     CK(hipMalloc(&tile_first, sizeof(int) * (ntiles + 1))); CK(hipMalloc(&carry, sizeof(double) * ntiles)); CK(hipMalloc(&flag, 4));
-    nnz_tile_first_kernel<<<(ntiles + 256) / 256, 256>>>(m, ntiles, rowptr, tile_first, flag); CK(hipDeviceSynchronize());
+    nnz_tile_first_kernel<<<(ntiles + 256) / 256, 256>>>(m, ntiles, kSplitTile, rowptr, tile_first, flag); CK(hipDeviceSynchronize());
 
     csr_scalar_kernel<double><<<cus * 8, 256>>>(m, rowptr, col, val, x, yref); CK(hipDeviceSynchronize());
 
@@ -109,8 +112,8 @@ int main(int argc, char **argv)
 #define V4(L, RED, U, CAP) vs.push_back({"vec4 L" #L " red" #RED " U" #U " cap" #CAP, [&] { csr_vector4_kernel<double, L, RED, U><<<grid_rows(256 / L * U, cus * CAP), 256>>>(m, rowptr, col, val, x, y); }})
     V4(8, 0, 1, 8); V4(8, 1, 1, 8); V4(8, 1, 2, 8); V4(8, 1, 1, 16); V4(8, 1, 1, 4096);
     V4(8, 1, 2, 4096);
-#define VP(L, NB, NT) vs.push_back({"pipe L" #L " NB" #NB " nt" #NT, [&] { constexpr int rpb = 256 / L * NB; csr_vector_pipe_kernel<double, L, NB, NT><<<(int) (((long long) m + rpb - 1) / rpb), 256>>>(m, rowptr, col, val, x, y); }})
-#define VPA(L, NB, ABL) vs.push_back({"pipe L" #L " NB" #NB " ABL" #ABL, [&] { constexpr int rpb = 256 / L * NB; csr_vector_pipe_kernel<double, L, NB, false, ABL><<<(int) (((long long) m + rpb - 1) / rpb), 256>>>(m, rowptr, col, val, x, y); }})
+#define VP(L, NB, NT) vs.push_back({"pipe L" #L " NB" #NB " nt" #NT, [&] { constexpr int rpb = 256 / L * NB; csr_vector_pipe_kernel<double, L, NB, NT><<<(int) (((long long) m + rpb - 1) / rpb), 256>>>(m, 1 << 30, rowptr, col, val, x, y); }})
+#define VPA(L, NB, ABL) vs.push_back({"pipe L" #L " NB" #NB " ABL" #ABL, [&] { constexpr int rpb = 256 / L * NB; csr_vector_pipe_kernel<double, L, NB, false, ABL><<<(int) (((long long) m + rpb - 1) / rpb), 256>>>(m, 1 << 30, rowptr, col, val, x, y); }})
     VPA(8, 4, 1); VPA(8, 4, 2); VPA(8, 4, 8); VPA(8, 4, 4); VPA(8, 4, 16); VPA(8, 4, 31); VPA(8, 4, 9); VPA(8, 4, 17);
     VP(8, 1, false); VP(8, 2, false); VP(8, 4, false); VP(8, 8, false); VP(8, 16, false); VP(8, 4, true); VP(8, 1, true); VP(16, 4, false); VP(4, 4, false);
 #define V4A(L, U, CAP, ABL) vs.push_back({"vec4 L" #L " U" #U " cap" #CAP " ABL" #ABL, [&] { csr_vector4_kernel<double, L, 1, U, ABL><<<grid_rows(256 / L * U, cus * CAP), 256>>>(m, rowptr, col, val, x, y); }})
@@ -118,7 +121,7 @@ int main(int argc, char **argv)
     vs.push_back({"stream_read nt x2blocks", [&] { stream_read<true><<<cus * 16, 256>>>(nnz, col, val, y); }});
     vs.push_back({"stream_read nt nonpersist", [&] { stream_read<true><<<(int) (nnz / 4 / 256), 256>>>(nnz, col, val, y); }});
 #define SS(M) vs.push_back({"stream_store mode" #M, [&] { stream_store<M><<<(int) (nnz / 4 / 256), 256>>>(nnz, col, val, y); }})
-    SS(0); SS(1); SS(3); SS(9); SS(10);
+    SS(0); SS(1); SS(11); SS(12); SS(13);
     if (0) vs.push_back({"fill 2.56GB (as stream bytes)", [&] { fill_k<<<(int) (nnz / 2 / 256), 256>>>(nnz / 2, (f64x2 *) val); }});
     if (0) vs.push_back({"copy 1.28GB->1.28GB", [&] { copy_k<<<(int) (nnz / 4 / 256), 256>>>(nnz / 4, (const f64x2 *) val, (f64x2 *) val + nnz / 4); }});
     vs.push_back({"nnz_split nonpersist", [&] { nnz_split_kernel<double><<<(ntiles + 3) / 4, 256>>>(m, (int) nnz, ntiles, rowptr, col, val, x, y, tile_first, carry); }});

@@ -17,6 +17,8 @@ ap.add_argument("--iters", type=int, default=30)
 ap.add_argument("--alpha", type=float, default=1.6)
 ap.add_argument("--maxlen", type=int, default=100000)
 ap.add_argument("--hostptr", action="store_true")
+ap.add_argument("--local", type=int, default=4096)
+ap.add_argument("--sortcols", action="store_true")
 a = ap.parse_args()
 build.build()
 dt = torch.float64 if a.dtype == "f64" else torch.float32
@@ -27,9 +29,15 @@ if a.kind == "banded":
 elif a.kind == "random":
     m, n, rp, ci, va = synth.uniform_k_device(a.m, a.m, a.k, "uniform", dt, dev, 1)
 elif a.kind == "skewed":
-    m, n, rp, ci, va = synth.from_row_lengths_device(synth.skewed_lengths_device(a.m, dev, 1), a.m, "uniform", dt, dev, 1, local=4096)
+    m, n, rp, ci, va = synth.from_row_lengths_device(synth.skewed_lengths_device(a.m, dev, 1), a.m, "uniform", dt, dev, 1, local=a.local)
 elif a.kind == "powerlaw":
     m, n, rp, ci, va = synth.from_row_lengths_device(synth.powerlaw_lengths_device(a.m, a.k, a.maxlen, a.alpha, dev, 1), a.m, "uniform", dt, dev, 1)
+if a.sortcols:   # sort columns inside each row (key = row * n + col)
+    lens = (rp[1:] - rp[:-1]).long()
+    rows = torch.repeat_interleave(torch.arange(m, device=dev), lens)
+    key = rows * n + ci.long()
+    ci = (torch.sort(key).values % n).to(torch.int32)
+    del rows, key
 torch.cuda.synchronize()
 x = torch.rand(n, dtype=dt, device=dev) * 2 - 1
 y = torch.empty(m, dtype=dt, device=dev)
