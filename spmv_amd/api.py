@@ -84,6 +84,13 @@ FUNCTIONS = {
     "spmv_hip_get_option": (C.c_long, [C.c_char_p]),
     "spmv_hip_get_info": (C.c_int, [spmv_Handle_t, C.POINTER(spmv_hip_info)]),
     "spmv_hip_time_launches": (C.c_double, [spmv_Handle_t, _V, _V, C.c_int, C.c_int, C.POINTER(C.c_float)]),
+    # include/spmv_io.h (host only)
+    "spmv_io_read_mtx": (C.c_int, [C.c_char_p, C.c_size_t, _I, _I, _I, _I, C.POINTER(_I), C.POINTER(_I), C.POINTER(_V)]),
+    "spmv_io_cache_path": (C.c_int, [C.c_char_p, C.c_char_p, C.c_size_t]),
+    "spmv_io_write_bin": (C.c_int, [C.c_char_p, C.c_int, C.c_int, C.c_int, _V, _V, _V, C.c_size_t]),
+    "spmv_io_read_bin": (C.c_int, [C.c_char_p, C.c_size_t, _I, _I, _I, C.POINTER(_I), C.POINTER(_I), C.POINTER(_V)]),
+    "spmv_io_load": (C.c_int, [C.c_char_p, C.c_size_t, _I, _I, _I, _I, C.POINTER(_I), C.POINTER(_I), C.POINTER(_V), _I]),
+    "spmv_io_free": (None, [_V]),
 }
 DATA_SYMBOLS = ("Methods_names", "Vectorized_names", "funcNames")
 
@@ -224,6 +231,57 @@ def time_launches(handle, x, y, warmup=10, iters=100):
     if mean < 0:
         _raise_if_error("spmv_hip_time_launches")
     return mean, np.frombuffer(ms, dtype=np.float32).copy()
+
+
+def _take_csr(m, n, nnz, rp, ci, va, dtype):
+    """Copy malloc'ed C arrays into numpy arrays and free the C side."""
+    from .synth import CSR
+    lib = load()
+    rowptr = np.ctypeslib.as_array(rp, shape=(m.value + 1,)).copy()
+    colidx = np.ctypeslib.as_array(ci, shape=(max(nnz.value, 1),))[: nnz.value].copy()
+    vt = C.c_double if dtype == np.float64 else C.c_float
+    val = np.ctypeslib.as_array(C.cast(va, C.POINTER(vt)), shape=(max(nnz.value, 1),))[: nnz.value].copy()
+    for p in (rp, ci, va):
+        lib.spmv_io_free(C.cast(p, _V))
+    return CSR(m.value, n.value, rowptr, colidx, val)
+
+
+def read_mtx(path, dtype=np.float64):
+    """Matrix Market coordinate file -> (CSR, is_symmetric)   [spmv_io_read_mtx]."""
+    lib = load()
+    m, n, nnz, sym = C.c_int(), C.c_int(), C.c_int(), C.c_int()
+    rp, ci, va = _I(), _I(), _V()
+    rc = lib.spmv_io_read_mtx(os.fsencode(path), np.dtype(dtype).itemsize, C.byref(m), C.byref(n), C.byref(nnz), C.byref(sym),
+                              C.byref(rp), C.byref(ci), C.byref(va))
+    if rc != 0:
+        raise OSError(f"spmv_io_read_mtx({path!r}) failed with {rc}")
+    return _take_csr(m, n, nnz, rp, ci, va, np.dtype(dtype)), bool(sym.value)
+
+
+def write_bin(path, csr):
+    rc = load().spmv_io_write_bin(os.fsencode(path), csr.m, csr.n, csr.nnz, _ptr(np.ascontiguousarray(csr.rowptr, np.int32)),
+                                  _ptr(np.ascontiguousarray(csr.colidx, np.int32)), _ptr(np.ascontiguousarray(csr.val)),
+                                  csr.val.dtype.itemsize)
+    if rc != 0:
+        raise OSError(f"spmv_io_write_bin({path!r}) failed with {rc}")
+
+
+def read_bin(path, dtype=np.float64):
+    lib = load()
+    m, n, nnz = C.c_int(), C.c_int(), C.c_int()
+    rp, ci, va = _I(), _I(), _V()
+    rc = lib.spmv_io_read_bin(os.fsencode(path), np.dtype(dtype).itemsize, C.byref(m), C.byref(n), C.byref(nnz),
+                              C.byref(rp), C.byref(ci), C.byref(va))
+    if rc != 0:
+        raise OSError(f"spmv_io_read_bin({path!r}) failed with {rc}")
+    return _take_csr(m, n, nnz, rp, ci, va, np.dtype(dtype))
+
+
+def cache_path(mtx_path):
+    buf = C.create_string_buffer(4096)
+    if load().spmv_io_cache_path(os.fsencode(mtx_path), buf, len(buf)) != 0:
+        raise ValueError("path too long")
+    return buf.value.decode()
 
 
 class Handle:

@@ -26,7 +26,10 @@ HIPCC = os.environ.get("HIPCC") or shutil.which("hipcc") or "/opt/rocm/bin/hipcc
 CC = os.environ.get("CC") or "gcc"
 ARCH = "gfx950"
 
-C_SOURCES = ["spmv_api.c", "spmv_plan.c"]
+C_SOURCES = ["spmv_api.c", "spmv_plan.c", os.path.join("io", "mtx_io.c")]
+TOOL_SOURCES = {"test_spmv": os.path.join("tools", "test_spmv_csv.c")}   # -> spmv_amd/bin/<name>
+BINDIR = os.path.join(PKG, "bin")
+ROCM = os.environ.get("ROCM_PATH", "/opt/rocm")
 HIP_SOURCES = ["spmv_shim.hip"]
 HIP_FLAGS = ["-O3", "-std=c++17", "-fPIC", f"--offload-arch={ARCH}", "-Wall", "-Wno-unused-function",
              "-ffp-contract=fast"]
@@ -56,13 +59,15 @@ def _run(cmd):
 def build(force=False, verbose=False):
     os.makedirs(LIBDIR, exist_ok=True)
     os.makedirs(OBJDIR, exist_ok=True)
-    if not force and os.path.exists(LIB) and os.path.getmtime(LIB) >= _newest(_deps()):
+    os.makedirs(BINDIR, exist_ok=True)
+    tools = [os.path.join(BINDIR, t) for t in TOOL_SOURCES]
+    if not force and all(os.path.exists(p) for p in [LIB] + tools) and min(os.path.getmtime(p) for p in [LIB] + tools) >= _newest(_deps()):
         return LIB
     if not os.path.exists(HIPCC):
         raise RuntimeError(f"hipcc not found ({HIPCC}); libspmv_hip.so cannot be built")
     objs = []
     for src in C_SOURCES:
-        obj = os.path.join(OBJDIR, src + ".o")
+        obj = os.path.join(OBJDIR, src.replace(os.sep, "_") + ".o")
         cmd = [CC, *C_FLAGS, f"-I{INC}", f"-I{CSRC}", "-c", os.path.join(CSRC, src), "-o", obj]
         if verbose:
             print(" ".join(cmd))
@@ -79,6 +84,14 @@ def build(force=False, verbose=False):
     if verbose:
         print(" ".join(cmd))
     _run(cmd)
+    # host-side C tools that link the library (the reference builds its harness the same way)
+    for name, src in TOOL_SOURCES.items():
+        cmd = [CC, *C_FLAGS, "-D__HIP_PLATFORM_AMD__", f"-I{INC}", f"-I{ROCM}/include", os.path.join(CSRC, src),
+               f"-L{LIBDIR}", "-lspmv_hip", f"-L{ROCM}/lib", "-lamdhip64", "-lm",
+               "-Wl,-rpath,$ORIGIN/../lib", f"-Wl,-rpath,{ROCM}/lib", "-o", os.path.join(BINDIR, name)]
+        if verbose:
+            print(" ".join(cmd))
+        _run(cmd)
     return LIB
 
 
