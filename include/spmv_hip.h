@@ -49,6 +49,8 @@ int spmv_hip_synchronize(spmv_Handle_t handle);
  *       "sell_c" (64)  "sell_sigma" (1024)  "sell_lds_x" (0/1: stage narrow x windows in LDS)
  *       "csr5_sigma" (0 = auto)  "rowblock_nnz" (nnz capacity of a Balanced row block, 0 = auto)
  *       "variant" (kernel variant selector used by the tuning harness, 0 = default)
+ *       "auto_method" (0/1: create() replaces the requested method by the one its row statistics
+ *                      favour -- CSR-vector for regular rows, CSR5 otherwise; the handle reports it)
  * Each key can also be preset with the environment variable SPMV_HIP_<KEY IN CAPS>.
  * Returns 0, or SPMV_HIP_E_ARG for an unknown key / illegal value. */
 int spmv_hip_set_option(const char *key, long value);

@@ -32,6 +32,7 @@
 // fp32 is native (the reference silently falls back to SELL for fp32, common.c:174-181).
 // Extra HBM traffic on top of B_alg per tile of 64*SIGMA nnz: 256 B desc + 4 B tile_ptr + s carry.
 #pragma once
+#include <climits>
 #include "common.hpp"
 
 namespace spmv {
@@ -211,18 +212,15 @@ __global__ __launch_bounds__(kBlock) void csr5_transpose_kernel(int nnz, int p, 
 }
 
 // ---------------------------------------------------------------------------- executor
-template <typename T, int SIGMA, bool MAPPED>
-__global__ __launch_bounds__(kBlock) void csr5_kernel(int p, const int *__restrict__ tile_ptr,
-                                                      const unsigned *__restrict__ desc,
-                                                      const int *__restrict__ tcol, const T *__restrict__ tval,
-                                                      const int *__restrict__ row_map,
-                                                      const T *__restrict__ x, T *__restrict__ y,
-                                                      T *__restrict__ carry)
+// One tile by one wavefront.  STAGED: x[lo, lo+span) of the workgroup's tiles is in LDS (xs).
+template <typename T, int SIGMA, bool MAPPED, bool STAGED>
+__device__ __forceinline__ void csr5_tile(int t, int lane, const int *__restrict__ tile_ptr,
+                                          const unsigned *__restrict__ desc, const int *__restrict__ tcol,
+                                          const T *__restrict__ tval, const int *__restrict__ row_map,
+                                          const T *__restrict__ x, const T *__restrict__ xs, int lo,
+                                          T *__restrict__ y, T *__restrict__ carry)
 {
     constexpr int TN = kWave * SIGMA;
-    const int lane = threadIdx.x & (kWave - 1);
-    const int t = blockIdx.x * (kBlock / kWave) + threadIdx.x / kWave;
-    if (t >= p) return;
     const long long base = (long long) t * TN + lane;
     int c[SIGMA];
     T v[SIGMA];
@@ -239,7 +237,10 @@ __global__ __launch_bounds__(kBlock) void csr5_kernel(int p, const int *__restri
     int seg_row = r0 + ((f0 & 1u) ? 0 : 1) + (int) (d >> kCsr5YoffShift);
     T xv[SIGMA];
 #pragma unroll
-    for (int i = 0; i < SIGMA; ++i) xv[i] = x[c[i] >= 0 ? c[i] : 0];
+    for (int i = 0; i < SIGMA; ++i) {
+        const int ci = c[i] >= 0 ? c[i] : (STAGED ? lo : 0);
+        xv[i] = STAGED ? xs[ci - lo] : x[ci];
+    }
 
     T head = 0, acc = 0;
     bool started = false;
@@ -271,6 +272,83 @@ __global__ __launch_bounds__(kBlock) void csr5_kernel(int p, const int *__restri
     if (lane == kWave - 1) next = 0;
     if (started) y[MAPPED ? row_map[seg_row] : seg_row] = acc + next;
     if (lane == 0) carry[t] = B;
+}
+
+template <typename T, int SIGMA, bool MAPPED>
+__global__ __launch_bounds__(kBlock) void csr5_kernel(int p, const int *__restrict__ tile_ptr,
+                                                      const unsigned *__restrict__ desc,
+                                                      const int *__restrict__ tcol, const T *__restrict__ tval,
+                                                      const int *__restrict__ row_map,
+                                                      const T *__restrict__ x, T *__restrict__ y,
+                                                      T *__restrict__ carry)
+{
+    const int lane = threadIdx.x & (kWave - 1);
+    const int t = blockIdx.x * (kBlock / kWave) + threadIdx.x / kWave;
+    if (t >= p) return;
+    csr5_tile<T, SIGMA, MAPPED, false>(t, lane, tile_ptr, desc, tcol, tval, row_map, x, nullptr, 0, y, carry);
+}
+
+// ---- LDS-staged x tiles ------------------------------------------------------------------------
+// A workgroup owns kCsr5GroupTiles consecutive tiles.  When the columns those tiles reference span
+// at most the LDS budget, x[lo, lo+span) is staged once (coalesced, from L2) and the gathers of all
+// its tiles become LDS reads; otherwise the workgroup gathers from global memory as before.
+constexpr int kCsr5GroupTiles = 16;
+
+__global__ __launch_bounds__(kBlock) void csr5_group_span_kernel(int p, int tile_nnz, int max_span,
+                                                                 const int *__restrict__ tcol,
+                                                                 int *__restrict__ grp_lo, int *__restrict__ grp_span,
+                                                                 int *__restrict__ staged /* [0] count, [1] max span */)
+{
+    __shared__ int smin[kBlock / kWave], smax[kBlock / kWave];
+    const int g = blockIdx.x;
+    const long long b = (long long) g * kCsr5GroupTiles * tile_nnz;
+    long long e = b + (long long) kCsr5GroupTiles * tile_nnz;
+    const long long total = (long long) p * tile_nnz;
+    if (e > total) e = total;
+    int mn = INT_MAX, mx = -1;
+    for (long long i = b + threadIdx.x; i < e; i += kBlock) {
+        const int c = tcol[i];
+        if (c >= 0) { mn = min(mn, c); mx = max(mx, c); }
+    }
+#pragma unroll
+    for (int o = kWave / 2; o > 0; o >>= 1) {
+        mn = min(mn, __shfl_xor(mn, o, kWave));
+        mx = max(mx, __shfl_xor(mx, o, kWave));
+    }
+    if ((threadIdx.x & (kWave - 1)) == 0) { smin[threadIdx.x / kWave] = mn; smax[threadIdx.x / kWave] = mx; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        for (int k = 1; k < kBlock / kWave; ++k) { mn = min(mn, smin[k]); mx = max(mx, smax[k]); }
+        const long long span = mx >= mn ? (long long) mx - mn + 1 : 0;
+        const bool ok = span > 0 && span <= max_span;
+        grp_lo[g] = ok ? mn : 0;
+        grp_span[g] = ok ? (int) span : 0;
+        if (ok) { atomicAdd(staged, 1); atomicMax(staged + 1, (int) span); }
+    }
+}
+
+template <typename T, int SIGMA, bool MAPPED>
+__global__ __launch_bounds__(kBlock) void csr5_group_kernel(int p, const int *__restrict__ tile_ptr,
+                                                            const unsigned *__restrict__ desc,
+                                                            const int *__restrict__ tcol, const T *__restrict__ tval,
+                                                            const int *__restrict__ row_map,
+                                                            const int *__restrict__ grp_lo, const int *__restrict__ grp_span,
+                                                            const T *__restrict__ x, T *__restrict__ y,
+                                                            T *__restrict__ carry)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char csr5_x_lds[];
+    T *xs = reinterpret_cast<T *>(csr5_x_lds);
+    const int lo = grp_lo[blockIdx.x], span = grp_span[blockIdx.x];
+    for (int i = threadIdx.x; i < span; i += kBlock) xs[i] = x[lo + i];
+    if (span > 0) __syncthreads();
+    const int lane = threadIdx.x & (kWave - 1);
+    const int t0 = blockIdx.x * kCsr5GroupTiles;
+    for (int k = threadIdx.x / kWave; k < kCsr5GroupTiles; k += kBlock / kWave) {
+        const int t = t0 + k;
+        if (t >= p) break;
+        if (span > 0) csr5_tile<T, SIGMA, MAPPED, true>(t, lane, tile_ptr, desc, tcol, tval, row_map, x, xs, lo, y, carry);
+        else csr5_tile<T, SIGMA, MAPPED, false>(t, lane, tile_ptr, desc, tcol, tval, row_map, x, xs, lo, y, carry);
+    }
 }
 
 template <typename T, bool MAPPED>

@@ -35,6 +35,7 @@ static opt_t g_opts[] = {
     {"csr5_sigma", 0, 0, 16, 0, 0},
     {"rowblock_nnz", 0, 0, 4096, 0, 0},   /* 2*4096 fp64 products = 64 KiB of LDS */
     {"variant", 0, 0, 1 << 20, 0, 0},
+    {"auto_method", 0, 0, 1, 0, 0},        /* 1: create() picks the schedule from the row statistics */
 };
 #define N_OPTS ((int) (sizeof g_opts / sizeof g_opts[0]))
 
@@ -109,6 +110,17 @@ void spmv_plan_choose(SPMV_METHODS requested, const spmv_stats *st, size_t value
      * two >= mean row length / 4 covers a mean-length row in one step; within [1, 64] */
     plan->lanes_per_row = lanes > 0 ? (int) lanes : pow2_at_least(st->mean_row_len / 4.0, 1, 64);
     (void) value_size;
+    /* the reference's README ends on an empty "Matrix inspect and choose best
+     * method to run" heading (README.md:222).  With auto_method = 1 the request is replaced by:
+     *   regular rows (longest row <= 4 x mean, mean >= 4, < 1 % empty rows)  -> CSR-vector
+     *   everything else (skewed, very short or many empty rows)              -> CSR5
+     * (measured: CSR-vector leads on regular shapes without inspector cost, CSR5 on skewed and
+     * power-law shapes -- DESIGN.md section 3).  The handle reports the method actually used. */
+    if (spmv_hip_get_option("auto_method") == 1 && st->m > 0) {
+        const int regular = st->mean_row_len >= 4.0 && (double) st->max_row_len <= 4.0 * st->mean_row_len &&
+                            (double) st->empty_rows <= 0.01 * (double) st->m;
+        requested = regular ? Method_Parallel : Method_CSR5SPMV;
+    }
     *actual = requested;
     switch (requested) {
     case Method_Parallel:

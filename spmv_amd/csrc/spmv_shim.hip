@@ -94,7 +94,8 @@ struct spmv_dev {
     long long *chunk_ptr = nullptr;
     void *sval = nullptr;
     // csr5
-    int c5_sigma = 0, c5_tiles = 0, c5_m2 = 0, c5_fixup = 0;
+    int c5_sigma = 0, c5_tiles = 0, c5_m2 = 0, c5_fixup = 0, c5_groups = 0, c5_staged = 0, c5_maxspan = 0;
+    int *c5_grp_lo = nullptr, *c5_grp_span = nullptr;
     int *c5_tile_ptr = nullptr, *c5_run_len = nullptr, *c5_row_map = nullptr, *c5_col = nullptr;
     unsigned *c5_desc = nullptr;
     void *c5_val = nullptr, *c5_carry = nullptr;
@@ -131,6 +132,7 @@ static void free_schedule(spmv_dev *d)
     d->long_thr = INT_MAX;
     d->c5_tile_ptr = d->c5_run_len = d->c5_row_map = d->c5_col = nullptr; d->c5_desc = nullptr;
     d->c5_val = d->c5_carry = nullptr; d->c5_tiles = d->c5_m2 = d->c5_fixup = 0;
+    d->c5_grp_lo = d->c5_grp_span = nullptr; d->c5_groups = d->c5_staged = d->c5_maxspan = 0;
     d->built = false;
 }
 
@@ -251,6 +253,8 @@ extern "C" int spmv_shim_matrix_create(spmv_dev **out, int m, int n, const int *
     if (m > 0 && (hs.bad || hs.first != 0 || hs.last < 0))
         return bail(fail(SPMV_HIP_E_ARG, "RowPtr must start at 0 and be non-decreasing (RowPtr[0]=%d)", hs.first));
     d->nnz = m > 0 ? hs.last : 0;
+    if (d->nnz > (long long) INT_MAX - 4096)
+        return bail(fail(SPMV_HIP_E_RANGE, "nnz = %lld is within 4096 of INT_MAX: 16 B tail reads would overflow int32 indices", d->nnz));
     if (d->nnz > 0 && (!colidx || !val)) return bail(fail(SPMV_HIP_E_ARG, "ColIdx / Matrix_Val is NULL"));
     d->stats.m = m;
     d->stats.n = n;
@@ -434,6 +438,8 @@ static int build_sell(spmv_dev *d)
     return SPMV_HIP_OK;
 }
 
+constexpr size_t kCsr5XTileBytes = 64 * 1024; // LDS budget of one tile group's x span
+
 template <typename T, int SIGMA>
 static int build_csr5_sigma(spmv_dev *d, const int *rp, int m2)
 {
@@ -459,6 +465,23 @@ static int build_csr5_sigma(spmv_dev *d, const int *rp, int m2)
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipMemcpyAsync(&d->c5_fixup, flag, sizeof(int), hipMemcpyDeviceToHost, d->stream));
     HIP_TRY(hipStreamSynchronize(d->stream));
+    // x span of every group of kCsr5GroupTiles tiles (LDS-staged x tiles, csr5.hpp)
+    d->c5_groups = (p + kCsr5GroupTiles - 1) / kCsr5GroupTiles;
+    {
+        int *cnt = nullptr;
+        int host2[2] = {0, 0};
+        ALLOC_TRY(d, &cnt, 2 * sizeof(int), true);
+        ALLOC_TRY(d, &d->c5_grp_lo, sizeof(int) * (size_t) d->c5_groups, true);
+        ALLOC_TRY(d, &d->c5_grp_span, sizeof(int) * (size_t) d->c5_groups, true);
+        HIP_TRY(hipMemsetAsync(cnt, 0, 2 * sizeof(int), d->stream));
+        csr5_group_span_kernel<<<d->c5_groups, kBlock, 0, d->stream>>>(p, TN, (int) (kCsr5XTileBytes / sizeof(T)), d->c5_col, d->c5_grp_lo,
+                                                                        d->c5_grp_span, cnt);
+        HIP_TRY(hipGetLastError());
+        HIP_TRY(hipMemcpyAsync(host2, cnt, 2 * sizeof(int), hipMemcpyDeviceToHost, d->stream));
+        HIP_TRY(hipStreamSynchronize(d->stream));
+        d->c5_staged = host2[0];
+        d->c5_maxspan = host2[1];
+    }
     return SPMV_HIP_OK;
 }
 
@@ -555,6 +578,16 @@ static void launch_vector(spmv_dev *d, const T *x, T *y)
 template <typename T, int SIGMA>
 static void launch_csr5(spmv_dev *d, const T *x, T *y)
 {
+    if (d->c5_staged * 2 >= d->c5_groups && d->plan.variant != 3) { // most groups fit their x span in LDS
+        const size_t lds = (((size_t) d->c5_maxspan * sizeof(T)) + 1023) & ~(size_t) 1023;
+        if (d->c5_row_map)
+            csr5_group_kernel<T, SIGMA, true><<<d->c5_groups, kBlock, lds, d->stream>>>(d->c5_tiles, d->c5_tile_ptr, d->c5_desc, d->c5_col,
+                (const T *) d->c5_val, d->c5_row_map, d->c5_grp_lo, d->c5_grp_span, x, y, (T *) d->c5_carry);
+        else
+            csr5_group_kernel<T, SIGMA, false><<<d->c5_groups, kBlock, lds, d->stream>>>(d->c5_tiles, d->c5_tile_ptr, d->c5_desc, d->c5_col,
+                (const T *) d->c5_val, nullptr, d->c5_grp_lo, d->c5_grp_span, x, y, (T *) d->c5_carry);
+        return;
+    }
     const int grid = grid_for(d->c5_tiles, kBlock / kWave, INT_MAX);
     if (d->c5_row_map)
         csr5_kernel<T, SIGMA, true><<<grid, kBlock, 0, d->stream>>>(d->c5_tiles, d->c5_tile_ptr, d->c5_desc, d->c5_col, (const T *) d->c5_val,

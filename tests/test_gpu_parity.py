@@ -177,3 +177,18 @@ def test_handle_info_and_alg_bytes():
         info = h.info()
     assert info["schedule_name"] == "csr-vector" and info["nnz"] == csr.nnz
     assert info["alg_bytes"] == 4 * (csr.m + 1) + csr.nnz * 12 + 8 * csr.n + 8 * csr.m
+
+
+def test_auto_method_picks_schedule_from_row_statistics():
+    """SURVEY 8f f-3 (the reference only has an empty README heading for it, README.md:222)."""
+    reg, xr, yr = load_golden("banded_wide_f64_eighths")
+    skw, xs, ys = load_golden("powerlaw_f64_eighths")
+    api.set_option("auto_method", 1)
+    try:
+        y, actual = run_host(reg, xr, M.Method_Serial)
+        assert actual == M.Method_Parallel and np.array_equal(y, yr)
+        y, actual = run_host(skw, xs, M.Method_Serial)
+        assert actual == M.Method_CSR5SPMV and np.array_equal(y, ys)
+    finally:
+        api.set_option("auto_method", 0)
+    assert run_host(reg, xr, M.Method_Serial)[1] == M.Method_Serial
