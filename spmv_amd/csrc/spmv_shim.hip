@@ -28,6 +28,7 @@
 #include "kernels/sell.hpp"
 #include "kernels/csr5.hpp"
 #include "kernels/long_rows.hpp"
+#include "kernels/csr_vector_tile.hpp"
 
 using namespace spmv;
 
@@ -81,6 +82,9 @@ struct spmv_dev {
     // row blocks
     int nblocks = 0, rb_stride = 0;
     int *rb_split = nullptr;
+    // csr-vector x tiles
+    int vt_tiles = 0, vt_staged = 0, vt_maxspan = 0;
+    int *vt_lo = nullptr, *vt_span = nullptr;
     // long rows (csr-vector, sell)
     int nlong = 0, long_thr = INT_MAX, lr_segs = 0;
     int *long_rows = nullptr, *lr_seg_lr = nullptr;
@@ -130,6 +134,7 @@ static void free_schedule(spmv_dev *d)
     d->sval = d->lr_part = nullptr;
     d->ntiles = d->nblocks = d->nchunks = d->nlong = d->lr_segs = 0;
     d->long_thr = INT_MAX;
+    d->vt_lo = d->vt_span = nullptr; d->vt_tiles = d->vt_staged = d->vt_maxspan = 0;
     d->c5_tile_ptr = d->c5_run_len = d->c5_row_map = d->c5_col = nullptr; d->c5_desc = nullptr;
     d->c5_val = d->c5_carry = nullptr; d->c5_tiles = d->c5_m2 = d->c5_fixup = 0;
     d->c5_grp_lo = d->c5_grp_span = nullptr; d->c5_groups = d->c5_staged = d->c5_maxspan = 0;
@@ -370,6 +375,31 @@ static int build_long_rows(spmv_dev *d, int thr)
     return SPMV_HIP_OK;
 }
 
+constexpr size_t kVecXTileBytes = 48 * 1024; // LDS budget of one 256-row tile's x span (CSR-vector)
+
+// x span of every 256-row tile (kernels/csr_vector_tile.hpp)
+template <typename T>
+static int build_vector_tiles(spmv_dev *d)
+{
+    d->vt_tiles = (int) (((long long) d->m + kVecTileRows - 1) / kVecTileRows);
+    d->vt_staged = d->vt_maxspan = 0;
+    if (d->vt_tiles == 0 || d->nnz == 0) return SPMV_HIP_OK;
+    int *cnt = nullptr;
+    int host2[2] = {0, 0};
+    ALLOC_TRY(d, &cnt, 2 * sizeof(int), true);
+    ALLOC_TRY(d, &d->vt_lo, sizeof(int) * (size_t) d->vt_tiles, true);
+    ALLOC_TRY(d, &d->vt_span, sizeof(int) * (size_t) d->vt_tiles, true);
+    HIP_TRY(hipMemsetAsync(cnt, 0, 2 * sizeof(int), d->stream));
+    csr_tile_span_kernel<<<d->vt_tiles, kBlock, 0, d->stream>>>(d->m, d->long_thr, (int) (kVecXTileBytes / sizeof(T)), d->rowptr, d->colidx,
+                                                                d->vt_lo, d->vt_span, cnt);
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipMemcpyAsync(host2, cnt, 2 * sizeof(int), hipMemcpyDeviceToHost, d->stream));
+    HIP_TRY(hipStreamSynchronize(d->stream));
+    d->vt_staged = host2[0];
+    d->vt_maxspan = host2[1];
+    return SPMV_HIP_OK;
+}
+
 template <typename T>
 static void launch_long_rows(spmv_dev *d, const T *x, T *y)
 {
@@ -540,6 +570,7 @@ extern "C" int spmv_shim_build(spmv_dev *d, const spmv_plan *plan)
         if (L < 1 || L > 64 || (L & (L - 1))) return fail(SPMV_HIP_E_ARG, "lanes_per_row must be a power of two in [1, 64], got %d", L);
         // a lane group takes 4L elements per step; beyond ~64 steps a whole wavefront per row segment wins
         rc = f64 ? build_long_rows<double>(d, L * 64 > 256 ? L * 64 : 256) : build_long_rows<float>(d, L * 64 > 256 ? L * 64 : 256);
+        if (!rc) rc = f64 ? build_vector_tiles<double>(d) : build_vector_tiles<float>(d);
         break;
     }
     case SPMV_SCHED_NNZ_SPLIT: rc = f64 ? build_nnz_split<double>(d) : build_nnz_split<float>(d); break;
@@ -567,6 +598,19 @@ static void launch_vector(spmv_dev *d, const T *x, T *y)
     if (d->plan.variant == 1) { // A/B: the first-round strided kernel
         csr_vector_kernel<T, (L < 2 ? 2 : L)><<<grid_for(d->m, kBlock / (L < 2 ? 2 : L), d->cus * 32), kBlock, 0, d->stream>>>(
             d->m, d->rowptr, d->colidx, (const T *) d->val, x, y);
+        return;
+    }
+    if (d->vt_staged * 2 >= d->vt_tiles && d->vt_tiles > 0 && d->plan.variant != 4) { // x tiles fit LDS: tile kernel
+        const size_t lds = (((size_t) d->vt_maxspan * sizeof(T)) + 1023) & ~(size_t) 1023;
+        if (d->plan.variant == 5) // A/B: two steps in flight
+            csr_vector_tile_kernel<T, L, 2><<<d->vt_tiles, kBlock, lds, d->stream>>>(d->m, d->long_thr, d->rowptr, d->colidx, (const T *) d->val,
+                                                                                    d->vt_lo, d->vt_span, x, y);
+        else if (d->plan.variant == 6) // A/B: eight steps in flight
+            csr_vector_tile_kernel<T, L, 8><<<d->vt_tiles, kBlock, lds, d->stream>>>(d->m, d->long_thr, d->rowptr, d->colidx, (const T *) d->val,
+                                                                                    d->vt_lo, d->vt_span, x, y);
+        else // measured best: 4 steps (fp64) / 2 steps (fp32) of matrix stream in flight per wave
+            csr_vector_tile_kernel<T, L, (sizeof(T) == 8 ? 4 : 2)><<<d->vt_tiles, kBlock, lds, d->stream>>>(
+                d->m, d->plan.variant == 2 ? INT_MAX : d->long_thr, d->rowptr, d->colidx, (const T *) d->val, d->vt_lo, d->vt_span, x, y);
         return;
     }
     constexpr int rows = kBlock / L * kVecNB;
@@ -621,7 +665,7 @@ static int launch(spmv_dev *d, const T *x, T *y)
         case 32: launch_vector<T, 32>(d, x, y); break;
         default: launch_vector<T, 64>(d, x, y); break;
         }
-        if (d->plan.variant == 0) launch_long_rows<T>(d, x, y);
+        if (d->plan.variant != 2) launch_long_rows<T>(d, x, y);
         break;
     case SPMV_SCHED_NNZ_SPLIT: {
         const int grid = grid_for(d->ntiles, kBlock / kWave, d->plan.variant == 1 ? d->cus * 8 : INT_MAX);
@@ -776,5 +820,8 @@ extern "C" int spmv_shim_info(const spmv_dev *d, spmv_hip_info *o)
     o->inspect_ms = d->inspect_ms;
     o->schedule_name = kSchedNames[d->plan.sched];
     o->kernel_name = kKernelNames[d->plan.sched];
+    if (d->plan.sched == SPMV_SCHED_CSR_VECTOR && d->vt_tiles > 0 && d->vt_staged * 2 >= d->vt_tiles) o->kernel_name = "csr_vector_tile_kernel";
+    if (d->plan.sched == SPMV_SCHED_CSR5 && d->c5_staged * 2 >= d->c5_groups && d->c5_groups > 0) o->kernel_name = "csr5_group_kernel";
+    if (d->plan.sched == SPMV_SCHED_SELL && d->plan.sell_lds_x && d->sell_staged * 2 >= d->sell_nwin && d->sell_nwin > 0) o->kernel_name = "sell_window_kernel";
     return SPMV_HIP_OK;
 }
