@@ -23,6 +23,7 @@
 //
 // Extra HBM traffic on top of B_alg: 4 B (tile_first) + s B (carry) per 256 nnz  (< 0.5 %).
 #pragma once
+#include <climits>
 #include "common.hpp"
 
 namespace spmv {
@@ -49,6 +50,98 @@ __global__ __launch_bounds__(kBlock) void nnz_tile_first_kernel(int m, int ntile
     if (t > 0 && (long long) rowptr[r] > base) *any_head = 1; // row r-1 runs into this tile
 }
 
+// One tile by one wavefront.  seg: the wave's LDS mark array.  STAGED: x[lo, lo+span) is in LDS (xs).
+template <typename T, bool STAGED>
+__device__ __forceinline__ void nnz_tile(int t, int lane, int *__restrict__ seg, int nnz,
+                                         const int *__restrict__ rowptr, const int *__restrict__ colidx,
+                                         const T *__restrict__ val, const T *__restrict__ x,
+                                         const T *__restrict__ xs, int lo, T *__restrict__ y,
+                                         const int *__restrict__ tile_first, T *__restrict__ carry)
+{
+    constexpr int kSplitK = SplitCfg<T>::K;
+    constexpr int kSplitTile = SplitCfg<T>::Tile;
+    const long long base = (long long) t * kSplitTile;
+    const long long p = base + lane * kSplitK;
+
+    // 1. matrix stream: K consecutive elements per lane, 16 B loads
+    int c[kSplitK];
+    T v[kSplitK];
+    if (base + kSplitTile <= nnz) {
+#pragma unroll
+        for (int q = 0; q < kSplitK; q += 4) {
+            ld_stream4(colidx + p + q, *reinterpret_cast<int(*)[4]>(&c[q]));
+            ld_stream4(val + p + q, *reinterpret_cast<T(*)[4]>(&v[q]));
+        }
+    } else { // last, partial tile
+#pragma unroll
+        for (int k = 0; k < kSplitK; ++k) {
+            const bool in = p + k < nnz;
+            c[k] = in ? colidx[p + k] : (STAGED ? lo : 0);
+            v[k] = in ? val[p + k] : T(0);
+        }
+    }
+    // 2. gather x (slots past nnz are masked in step 4, so x[0] / xs[0] can never leak)
+    T xv[kSplitK];
+#pragma unroll
+    for (int k = 0; k < kSplitK; ++k) xv[k] = STAGED ? xs[c[k] - lo] : x[c[k]];
+
+    // 3. rows owned by this tile: zero the empty ones, mark the start of the others
+    const int rf = tile_first[t];
+    const int rl = tile_first[t + 1];
+    {
+        const i32x4 minus1 = {-1, -1, -1, -1};
+#pragma unroll
+        for (int q = 0; q < kSplitK; q += 4) *reinterpret_cast<i32x4 *>(seg + lane * kSplitK + q) = minus1;
+    }
+    wave_lds_sync();
+    for (int i = lane; i < rl - rf; i += kWave) {
+        const int r = rf + i;
+        const int s = rowptr[r], e = rowptr[r + 1];
+        if (e == s) y[r] = T(0);
+        else seg[s - (int) base] = i;
+    }
+    wave_lds_sync();
+    int mk[kSplitK];
+#pragma unroll
+    for (int q = 0; q < kSplitK; q += 4) {
+        const i32x4 mk4 = *reinterpret_cast<const i32x4 *>(seg + lane * kSplitK + q);
+        mk[q] = mk4.x; mk[q + 1] = mk4.y; mk[q + 2] = mk4.z; mk[q + 3] = mk4.w;
+    }
+    wave_lds_sync(); // marks are in registers before the next tile clears the array
+
+    // 4. per-lane running sum, cut at row starts
+    T head = 0, acc = 0;
+    int cur = -1; // row offset (from rf) of the segment open in this lane, -1: none started here
+#pragma unroll
+    for (int k = 0; k < kSplitK; ++k) {
+        if (mk[k] >= 0) {
+            if (cur >= 0) y[rf + cur] = acc; // segment began and ended inside this lane
+            else head = acc;                 // piece of a segment begun in an earlier lane/tile
+            cur = mk[k];
+            acc = 0;
+        }
+        if (p + k < nnz) acc = fmadd(v[k], xv[k], acc);
+    }
+    if (cur < 0) { head = acc; acc = 0; }
+
+    // 5. backward segmented scan of the heads: B[i] = head[i] + ... + head[j], j = first lane
+    //    >= i that holds a row start (or 63)
+    const unsigned long long starts = __ballot(cur >= 0);
+    T B = head;
+#pragma unroll
+    for (int d = 1; d < kWave; d <<= 1) {
+        const T nb = __shfl_down(B, d, kWave);
+        const bool cut = ((starts >> lane) & ((1ull << d) - 1ull)) != 0ull;
+        if (!cut && lane + d < kWave) B += nb;
+    }
+    T next = __shfl_down(B, 1, kWave);
+    if (lane == kWave - 1) next = 0;
+    // 6. each lane's last row start owns everything up to the next start (or the tile end:
+    //    then the following tiles' carries complete the row in the fix-up pass)
+    if (cur >= 0) y[rf + cur] = acc + next;
+    if (lane == 0) carry[t] = B; // piece in front of the tile's first row start (0 if none)
+}
+
 template <typename T>
 __global__ __launch_bounds__(kBlock) void nnz_split_kernel(int m, int nnz, int ntiles,
                                                            const int *__restrict__ rowptr,
@@ -58,96 +151,71 @@ __global__ __launch_bounds__(kBlock) void nnz_split_kernel(int m, int nnz, int n
                                                            const int *__restrict__ tile_first,
                                                            T *__restrict__ carry)
 {
-    constexpr int kSplitK = SplitCfg<T>::K;
-    constexpr int kSplitTile = SplitCfg<T>::Tile;
-    __shared__ __attribute__((aligned(16))) int seg_lds[kBlock / kWave][kSplitTile]; // row-start marks of the wave's tile
+    __shared__ __attribute__((aligned(16))) int seg_lds[kBlock / kWave][SplitCfg<T>::Tile];
     const int lane = threadIdx.x & (kWave - 1);
     const int wave = threadIdx.x / kWave;
-    int *seg = seg_lds[wave];
     const int waves_total = gridDim.x * (kBlock / kWave);
+    (void) m;
+    for (int t = blockIdx.x * (kBlock / kWave) + wave; t < ntiles; t += waves_total)
+        nnz_tile<T, false>(t, lane, seg_lds[wave], nnz, rowptr, colidx, val, x, nullptr, 0, y, tile_first, carry);
+}
 
-    for (int t = blockIdx.x * (kBlock / kWave) + wave; t < ntiles; t += waves_total) {
-        const long long base = (long long) t * kSplitTile;
-        const long long p = base + lane * kSplitK;
+// ---- LDS-staged x tiles: a workgroup owns kSplitGroupTiles consecutive tiles and stages the column
+// span of their nnz range when it fits (same idea as csr5_group_kernel).
+constexpr int kSplitGroupTiles = 16;
 
-        // 1. matrix stream: 4 consecutive elements per lane (16 B of ColIdx, 16/32 B of Val)
-        int c[kSplitK];
-        T v[kSplitK];
-        if (base + kSplitTile <= nnz) {
+__global__ __launch_bounds__(kBlock) void nnz_group_span_kernel(int nnz, int group_nnz, int max_span,
+                                                                const int *__restrict__ colidx,
+                                                                int *__restrict__ grp_lo, int *__restrict__ grp_span,
+                                                                int *__restrict__ staged /* [0] count, [1] max span */)
+{
+    __shared__ int smin[kBlock / kWave], smax[kBlock / kWave];
+    const long long b = (long long) blockIdx.x * group_nnz;
+    long long e = b + group_nnz;
+    if (e > nnz) e = nnz;
+    int mn = INT_MAX, mx = -1;
+    for (long long i = b + threadIdx.x; i < e; i += kBlock) {
+        const int c = colidx[i];
+        mn = min(mn, c);
+        mx = max(mx, c);
+    }
 #pragma unroll
-            for (int q = 0; q < kSplitK; q += 4) {
-                ld_stream4(colidx + p + q, *reinterpret_cast<int(*)[4]>(&c[q]));
-                ld_stream4(val + p + q, *reinterpret_cast<T(*)[4]>(&v[q]));
-            }
-        } else { // last, partial tile
-#pragma unroll
-            for (int k = 0; k < kSplitK; ++k) {
-                const bool in = p + k < nnz;
-                c[k] = in ? colidx[p + k] : 0;
-                v[k] = in ? val[p + k] : T(0);
-            }
-        }
-        // 2. gather x (n > 0 whenever nnz > 0; padded slots read x[0] and multiply by 0... they are
-        //    masked below instead, so a NaN/Inf in x[0] cannot leak)
-        T xv[kSplitK];
-#pragma unroll
-        for (int k = 0; k < kSplitK; ++k) xv[k] = x[c[k]];
+    for (int o = kWave / 2; o > 0; o >>= 1) {
+        mn = min(mn, __shfl_xor(mn, o, kWave));
+        mx = max(mx, __shfl_xor(mx, o, kWave));
+    }
+    if ((threadIdx.x & (kWave - 1)) == 0) { smin[threadIdx.x / kWave] = mn; smax[threadIdx.x / kWave] = mx; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        for (int k = 1; k < kBlock / kWave; ++k) { mn = min(mn, smin[k]); mx = max(mx, smax[k]); }
+        const long long span = mx >= mn ? (long long) mx - mn + 1 : 0;
+        const bool ok = span > 0 && span <= max_span;
+        grp_lo[blockIdx.x] = ok ? mn : 0;
+        grp_span[blockIdx.x] = ok ? (int) span : 0;
+        if (ok) { atomicAdd(staged, 1); atomicMax(staged + 1, (int) span); }
+    }
+}
 
-        // 3. rows owned by this tile: zero the empty ones, mark the start of the others
-        const int rf = tile_first[t];
-        const int rl = tile_first[t + 1];
-        {
-            const i32x4 minus1 = {-1, -1, -1, -1};
-#pragma unroll
-            for (int q = 0; q < kSplitK; q += 4) *reinterpret_cast<i32x4 *>(seg + lane * kSplitK + q) = minus1;
-        }
-        wave_lds_sync();
-        for (int i = lane; i < rl - rf; i += kWave) {
-            const int r = rf + i;
-            const int s = rowptr[r], e = rowptr[r + 1];
-            if (e == s) y[r] = T(0);
-            else seg[s - (int) base] = i;
-        }
-        wave_lds_sync();
-        int mk[kSplitK];
-#pragma unroll
-        for (int q = 0; q < kSplitK; q += 4) {
-            const i32x4 mk4 = *reinterpret_cast<const i32x4 *>(seg + lane * kSplitK + q);
-            mk[q] = mk4.x; mk[q + 1] = mk4.y; mk[q + 2] = mk4.z; mk[q + 3] = mk4.w;
-        }
-        wave_lds_sync(); // marks are in registers before the next tile clears the array
-
-        // 4. per-lane running sum, cut at row starts
-        T head = 0, acc = 0;
-        int cur = -1; // row offset (from rf) of the segment open in this lane, -1: none started here
-#pragma unroll
-        for (int k = 0; k < kSplitK; ++k) {
-            if (mk[k] >= 0) {
-                if (cur >= 0) y[rf + cur] = acc; // segment began and ended inside this lane
-                else head = acc;                 // piece of a segment begun in an earlier lane/tile
-                cur = mk[k];
-                acc = 0;
-            }
-            if (p + k < nnz) acc = fmadd(v[k], xv[k], acc);
-        }
-        if (cur < 0) { head = acc; acc = 0; }
-
-        // 5. backward segmented scan of the heads: B[i] = head[i] + ... + head[j], j = first lane
-        //    >= i that holds a row start (or 63)
-        const unsigned long long starts = __ballot(cur >= 0);
-        T B = head;
-#pragma unroll
-        for (int d = 1; d < kWave; d <<= 1) {
-            const T nb = __shfl_down(B, d, kWave);
-            const bool cut = ((starts >> lane) & ((1ull << d) - 1ull)) != 0ull;
-            if (!cut && lane + d < kWave) B += nb;
-        }
-        T next = __shfl_down(B, 1, kWave);
-        if (lane == kWave - 1) next = 0;
-        // 6. each lane's last row start owns everything up to the next start (or the tile end:
-        //    then the following tiles' carries complete the row in the fix-up pass)
-        if (cur >= 0) y[rf + cur] = acc + next;
-        if (lane == 0) carry[t] = B; // piece in front of the tile's first row start (0 if none)
+template <typename T>
+__global__ __launch_bounds__(kBlock) void nnz_group_kernel(int nnz, int ntiles, const int *__restrict__ rowptr,
+                                                           const int *__restrict__ colidx, const T *__restrict__ val,
+                                                           const int *__restrict__ grp_lo, const int *__restrict__ grp_span,
+                                                           const T *__restrict__ x, T *__restrict__ y,
+                                                           const int *__restrict__ tile_first, T *__restrict__ carry)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char nnz_x_lds[];
+    T *xs = reinterpret_cast<T *>(nnz_x_lds);
+    __shared__ __attribute__((aligned(16))) int seg_lds[kBlock / kWave][SplitCfg<T>::Tile];
+    const int lo = grp_lo[blockIdx.x], span = grp_span[blockIdx.x];
+    for (int i = threadIdx.x; i < span; i += kBlock) xs[i] = x[lo + i];
+    if (span > 0) __syncthreads();
+    const int lane = threadIdx.x & (kWave - 1), wave = threadIdx.x / kWave;
+    const int t0 = blockIdx.x * kSplitGroupTiles;
+    for (int k = wave; k < kSplitGroupTiles; k += kBlock / kWave) {
+        const int t = t0 + k;
+        if (t >= ntiles) break;
+        if (span > 0) nnz_tile<T, true>(t, lane, seg_lds[wave], nnz, rowptr, colidx, val, x, xs, lo, y, tile_first, carry);
+        else nnz_tile<T, false>(t, lane, seg_lds[wave], nnz, rowptr, colidx, val, x, xs, lo, y, tile_first, carry);
     }
 }
 

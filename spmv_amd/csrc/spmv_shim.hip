@@ -79,6 +79,8 @@ struct spmv_dev {
     int ntiles = 0, need_fixup = 0;
     int *tile_first = nullptr;
     void *carry = nullptr;
+    int ns_groups = 0, ns_staged = 0, ns_maxspan = 0;
+    int *ns_lo = nullptr, *ns_span = nullptr;
     // row blocks
     int nblocks = 0, rb_stride = 0;
     int *rb_split = nullptr;
@@ -129,7 +131,7 @@ static void free_schedule(spmv_dev *d)
 {
     for (void *p : d->sched_allocs) (void) hipFree(p);
     d->sched_allocs.clear();
-    d->tile_first = nullptr; d->carry = nullptr; d->rb_split = nullptr;
+    d->tile_first = nullptr; d->carry = nullptr; d->rb_split = nullptr; d->ns_lo = d->ns_span = nullptr; d->ns_groups = d->ns_staged = 0;
     d->perm = d->scol = d->long_rows = d->lr_seg_lr = d->win_lo = d->win_span = nullptr; d->sell_staged = d->sell_nwin = 0; d->chunk_ptr = d->lr_seg_start = nullptr;
     d->sval = d->lr_part = nullptr;
     d->ntiles = d->nblocks = d->nchunks = d->nlong = d->lr_segs = 0;
@@ -303,6 +305,8 @@ extern "C" void spmv_shim_matrix_destroy(spmv_dev *d)
 }
 
 // ------------------------------------------------------------------------------------ inspectors
+constexpr size_t kSplitXTileBytes = 48 * 1024; // LDS budget of one nnz-split tile group's x span
+
 template <typename T>
 static int build_nnz_split(spmv_dev *d)
 {
@@ -319,6 +323,23 @@ static int build_nnz_split(spmv_dev *d)
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipMemcpyAsync(&d->need_fixup, flag, sizeof(int), hipMemcpyDeviceToHost, d->stream));
     HIP_TRY(hipStreamSynchronize(d->stream));
+    // column span of every group of kSplitGroupTiles tiles (LDS-staged x tiles)
+    d->ns_groups = (d->ntiles + kSplitGroupTiles - 1) / kSplitGroupTiles;
+    {
+        int *cnt = nullptr;
+        int host2[2] = {0, 0};
+        ALLOC_TRY(d, &cnt, 2 * sizeof(int), true);
+        ALLOC_TRY(d, &d->ns_lo, sizeof(int) * (size_t) d->ns_groups, true);
+        ALLOC_TRY(d, &d->ns_span, sizeof(int) * (size_t) d->ns_groups, true);
+        HIP_TRY(hipMemsetAsync(cnt, 0, 2 * sizeof(int), d->stream));
+        nnz_group_span_kernel<<<d->ns_groups, kBlock, 0, d->stream>>>((int) d->nnz, kSplitGroupTiles * tile, (int) (kSplitXTileBytes / sizeof(T)),
+                                                                      d->colidx, d->ns_lo, d->ns_span, cnt);
+        HIP_TRY(hipGetLastError());
+        HIP_TRY(hipMemcpyAsync(host2, cnt, 2 * sizeof(int), hipMemcpyDeviceToHost, d->stream));
+        HIP_TRY(hipStreamSynchronize(d->stream));
+        d->ns_staged = host2[0];
+        d->ns_maxspan = host2[1];
+    }
     return SPMV_HIP_OK;
 }
 
@@ -668,9 +689,15 @@ static int launch(spmv_dev *d, const T *x, T *y)
         if (d->plan.variant != 2) launch_long_rows<T>(d, x, y);
         break;
     case SPMV_SCHED_NNZ_SPLIT: {
-        const int grid = grid_for(d->ntiles, kBlock / kWave, d->plan.variant == 1 ? d->cus * 8 : INT_MAX);
-        nnz_split_kernel<T><<<grid, kBlock, 0, d->stream>>>(d->m, (int) d->nnz, d->ntiles, d->rowptr, d->colidx, val, x, y,
-                                                             d->tile_first, (T *) d->carry);
+        if (d->ns_staged * 2 >= d->ns_groups && d->ns_groups > 0 && d->plan.variant != 3) {
+            const size_t lds = (((size_t) d->ns_maxspan * sizeof(T)) + 1023) & ~(size_t) 1023;
+            nnz_group_kernel<T><<<d->ns_groups, kBlock, lds, d->stream>>>((int) d->nnz, d->ntiles, d->rowptr, d->colidx, val, d->ns_lo, d->ns_span,
+                                                                         x, y, d->tile_first, (T *) d->carry);
+        } else {
+            const int grid = grid_for(d->ntiles, kBlock / kWave, d->plan.variant == 1 ? d->cus * 8 : INT_MAX);
+            nnz_split_kernel<T><<<grid, kBlock, 0, d->stream>>>(d->m, (int) d->nnz, d->ntiles, d->rowptr, d->colidx, val, x, y,
+                                                                 d->tile_first, (T *) d->carry);
+        }
         if (d->need_fixup && d->ntiles > 1)
             nnz_fixup_kernel<T><<<grid_for(d->ntiles - 1, kBlock, INT_MAX), kBlock, 0, d->stream>>>(
                 d->ntiles, d->rowptr, d->tile_first, (const T *) d->carry, y);
@@ -821,6 +848,7 @@ extern "C" int spmv_shim_info(const spmv_dev *d, spmv_hip_info *o)
     o->schedule_name = kSchedNames[d->plan.sched];
     o->kernel_name = kKernelNames[d->plan.sched];
     if (d->plan.sched == SPMV_SCHED_CSR_VECTOR && d->vt_tiles > 0 && d->vt_staged * 2 >= d->vt_tiles) o->kernel_name = "csr_vector_tile_kernel";
+    if (d->plan.sched == SPMV_SCHED_NNZ_SPLIT && d->ns_groups > 0 && d->ns_staged * 2 >= d->ns_groups) o->kernel_name = "nnz_group_kernel";
     if (d->plan.sched == SPMV_SCHED_CSR5 && d->c5_staged * 2 >= d->c5_groups && d->c5_groups > 0) o->kernel_name = "csr5_group_kernel";
     if (d->plan.sched == SPMV_SCHED_SELL && d->plan.sell_lds_x && d->sell_staged * 2 >= d->sell_nwin && d->sell_nwin > 0) o->kernel_name = "sell_window_kernel";
     return SPMV_HIP_OK;

@@ -192,3 +192,70 @@ def test_auto_method_picks_schedule_from_row_statistics():
     finally:
         api.set_option("auto_method", 0)
     assert run_host(reg, xr, M.Method_Serial)[1] == M.Method_Serial
+
+
+@pytest.mark.parametrize("key,values,method", [
+    ("sell_sigma", [64, 256, 4096], M.Method_SellCSigma),
+    ("sell_lds_x", [0, 1], M.Method_SellCSigma),
+    ("csr5_sigma", [4, 8, 16], M.Method_CSR5SPMV),
+    ("rowblock_nnz", [64, 333, 4096], M.Method_Balanced),
+])
+@pytest.mark.parametrize("name", ["skewed_f64_eighths", "empty_mix_f32_eighths", "banded_wide_f64_eighths"])
+def test_tuning_options_do_not_change_results(key, values, method, name):
+    """The reference hard-wires C / sigma / CSR5 sigma (common.c:139-140, csr5_spmv.cpp:30); here they
+    are options -- results must be bit-identical for every legal value."""
+    csr, x, y_ref = load_golden(name)
+    default = api.get_option(key)
+    try:
+        for v in values:
+            api.set_option(key, v)
+            y, _ = run_host(csr, x, method)
+            assert np.array_equal(y.view(np.uint8), y_ref.view(np.uint8)), (key, v)
+    finally:
+        api.set_option(key, default)
+
+
+def test_illegal_option_values_are_reported_at_create():
+    csr, x, _ = load_golden("tiny_f64_eighths")
+    api.set_option("csr5_sigma", 5)
+    try:
+        with pytest.raises(api.SpmvError, match="csr5_sigma"):
+            api.Handle(csr.m, csr.n, csr.rowptr, csr.colidx, csr.val, M.Method_CSR5SPMV)
+    finally:
+        api.set_option("csr5_sigma", 0)
+
+
+def test_two_handles_on_two_streams_and_async_mode():
+    """One handle = one stream (SURVEY 8b "Threading"): two handles on two non-default streams run
+    concurrently and stay correct; async mode returns before completion and is stream-ordered."""
+    import torch
+    dev = torch.device("cuda:0")
+    a, xa, ya = load_golden("skewed_f64_eighths")
+    b, xb, yb = load_golden("banded_wide_f64_eighths")
+    s1, s2 = torch.cuda.Stream(), torch.cuda.Stream()
+    outs = []
+    handles = []
+    for csr, x, stream, method in ((a, xa, s1, M.Method_CSR5SPMV), (b, xb, s2, M.Method_Parallel)):
+        rp, ci = torch.from_numpy(csr.rowptr).to(dev), torch.from_numpy(csr.colidx).to(dev)
+        va, xd = torch.from_numpy(csr.val).to(dev), torch.from_numpy(x).to(dev)
+        h = api.Handle(csr.m, csr.n, rp, ci, va, method)
+        h.attach_stream(stream.cuda_stream, async_=True)
+        handles.append((h, xd, torch.full((csr.m,), float("nan"), dtype=va.dtype, device=dev)))
+    torch.cuda.synchronize()
+    for _ in range(20):
+        for h, xd, yd in handles:
+            h.spmv(xd, yd)
+    for h, _, _ in handles:
+        assert api.load().spmv_hip_synchronize(h.h) == 0
+    assert np.array_equal(handles[0][2].cpu().numpy(), ya) and np.array_equal(handles[1][2].cpu().numpy(), yb)
+    for h, _, _ in handles:
+        h.close()
+
+
+def test_m_zero_and_n_zero():
+    lib = api.load()
+    rp = np.zeros(1, dtype=np.int32)
+    h = api.spmv_create_handle_all_in_one(0, 0, rp, np.zeros(0, np.int32), np.zeros(0), 1, M.Method_Parallel, 8)
+    api.spmv(h, 0, rp, np.zeros(0, np.int32), np.zeros(0), np.zeros(0), np.zeros(0))
+    assert lib.spmv_hip_last_error() == 0
+    api.spmv_destory_handle(h)
