@@ -19,7 +19,8 @@
 
 namespace spmv {
 
-constexpr int kVecTileRows = kBlock; // rows per workgroup
+constexpr int kVecTileThreads = 256;           // 4 wavefronts per workgroup (512 measured no better)
+constexpr int kVecTileRows = kVecTileThreads; // rows per workgroup (64 per wave)
 
 // Inspector: per 256-row tile, min / max column over its rows with len <= long_thr.
 __global__ __launch_bounds__(kBlock) void csr_tile_span_kernel(int m, int long_thr, int max_span,
@@ -126,7 +127,7 @@ __device__ __forceinline__ void csr_vector_tile_wave(int m, int long_thr, long l
 }
 
 template <typename T, int L, int DEPTH = 4>
-__global__ __launch_bounds__(kBlock) void csr_vector_tile_kernel(int m, int long_thr, const int *__restrict__ rowptr,
+__global__ __launch_bounds__(kVecTileThreads) void csr_vector_tile_kernel(int m, int long_thr, const int *__restrict__ rowptr,
                                                                  const int *__restrict__ colidx,
                                                                  const T *__restrict__ val,
                                                                  const int *__restrict__ tile_lo,
@@ -135,8 +136,8 @@ __global__ __launch_bounds__(kBlock) void csr_vector_tile_kernel(int m, int long
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char vec_x_lds[]; // span elements of x
     T *xs = reinterpret_cast<T *>(vec_x_lds);
-    __shared__ int rp_lds[kBlock / kWave][kWave + 2];
-    __shared__ T y_lds[kBlock / kWave][kWave];
+    __shared__ int rp_lds[kVecTileThreads / kWave][kWave + 2];
+    __shared__ T y_lds[kVecTileThreads / kWave][kWave];
     constexpr int RW = kWave / L;
     const int lane = threadIdx.x & (kWave - 1), wave = threadIdx.x / kWave;
     const long long rw0 = (long long) blockIdx.x * kVecTileRows + wave * kWave;
@@ -163,7 +164,7 @@ __global__ __launch_bounds__(kBlock) void csr_vector_tile_kernel(int m, int long
     }
     rp_lds[wave][lane] = rp;
     if (lane == 0) rp_lds[wave][kWave] = rpe;
-    for (int i = threadIdx.x; i < span; i += kBlock) xs[i] = x[lo + i];
+    for (int i = threadIdx.x; i < span; i += kVecTileThreads) xs[i] = x[lo + i];
     __syncthreads();
     if (rw0 >= m) return;
     if (span > 0) csr_vector_tile_wave<T, L, true, DEPTH>(m, long_thr, rw0, lane, rp_lds[wave], y_lds[wave], colidx, val, x, xs, lo, y, c0, v0);

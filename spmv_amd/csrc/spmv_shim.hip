@@ -624,13 +624,13 @@ static void launch_vector(spmv_dev *d, const T *x, T *y)
     if (d->vt_staged * 2 >= d->vt_tiles && d->vt_tiles > 0 && d->plan.variant != 4) { // x tiles fit LDS: tile kernel
         const size_t lds = (((size_t) d->vt_maxspan * sizeof(T)) + 1023) & ~(size_t) 1023;
         if (d->plan.variant == 5) // A/B: two steps in flight
-            csr_vector_tile_kernel<T, L, 2><<<d->vt_tiles, kBlock, lds, d->stream>>>(d->m, d->long_thr, d->rowptr, d->colidx, (const T *) d->val,
+            csr_vector_tile_kernel<T, L, 2><<<d->vt_tiles, kVecTileThreads, lds, d->stream>>>(d->m, d->long_thr, d->rowptr, d->colidx, (const T *) d->val,
                                                                                     d->vt_lo, d->vt_span, x, y);
         else if (d->plan.variant == 6) // A/B: eight steps in flight
-            csr_vector_tile_kernel<T, L, 8><<<d->vt_tiles, kBlock, lds, d->stream>>>(d->m, d->long_thr, d->rowptr, d->colidx, (const T *) d->val,
+            csr_vector_tile_kernel<T, L, 8><<<d->vt_tiles, kVecTileThreads, lds, d->stream>>>(d->m, d->long_thr, d->rowptr, d->colidx, (const T *) d->val,
                                                                                     d->vt_lo, d->vt_span, x, y);
         else // measured best: 4 steps (fp64) / 2 steps (fp32) of matrix stream in flight per wave
-            csr_vector_tile_kernel<T, L, (sizeof(T) == 8 ? 4 : 2)><<<d->vt_tiles, kBlock, lds, d->stream>>>(
+            csr_vector_tile_kernel<T, L, (sizeof(T) == 8 ? 4 : 2)><<<d->vt_tiles, kVecTileThreads, lds, d->stream>>>(
                 d->m, d->plan.variant == 2 ? INT_MAX : d->long_thr, d->rowptr, d->colidx, (const T *) d->val, d->vt_lo, d->vt_span, x, y);
         return;
     }
