@@ -47,7 +47,7 @@ int spmv_hip_synchronize(spmv_Handle_t handle);
 /* ---- options (process-wide; read at create) ---------------------------------------------- */
 /* keys: "lanes_per_row" (CSR-vector, 0 = auto, else 1..64 power of two)
  *       "sell_c" (64)  "sell_sigma" (1024)  "sell_lds_x" (0/1: stage narrow x windows in LDS)
- *       "csr5_sigma" (0 = auto)  "rowblock_nnz" (nnz capacity of a Balanced row block, 0 = auto)
+ *       "csr5_sigma" (0 = auto)  "rowblock_nnz" (equal-nnz share of one Balanced row block, 0 = auto = 8192)
  *       "variant" (kernel variant selector used by the tuning harness, 0 = default)
  *       "auto_method" (0/1: create() replaces the requested method by the one its row statistics
  *                      favour -- CSR-vector for regular rows, CSR5 otherwise; the handle reports it)

@@ -62,8 +62,8 @@ __global__ __launch_bounds__(kBlock) void csr_tile_span_kernel(int m, int long_t
     }
 }
 
-template <typename T, int L, bool STAGED, int DEPTH>
-__device__ __forceinline__ void csr_vector_tile_wave(int m, int long_thr, long long rw0, int lane,
+template <typename T, int L, bool STAGED, int DEPTH, bool PRE = true>
+__device__ __forceinline__ void csr_vector_tile_wave(long long row_end, int long_thr, long long rw0, int lane,
                                                      const int *__restrict__ rp_lds, T *__restrict__ y_lds,
                                                      const int *__restrict__ colidx, const T *__restrict__ val,
                                                      const T *__restrict__ x, const T *__restrict__ xs, int lo,
@@ -76,13 +76,13 @@ __device__ __forceinline__ void csr_vector_tile_wave(int m, int long_thr, long l
     T v[D][4];
     int pp0[D], pp1[D];
 #pragma unroll
-    for (int k = 0; k < 4; ++k) { c[0][k] = c0[k]; v[0][k] = v0[k]; } // step 0 was issued before the barrier
+    for (int k = 0; k < 4; ++k) { c[0][k] = c0[k]; v[0][k] = v0[k]; } // PRE: step 0 was issued before the barrier
     auto issue = [&](int s) { // RowPtr pair of step s from LDS, then its 16 B stream loads
         const int slot = s % D;
         pp0[slot] = rp_lds[s * RW + sub];
         pp1[slot] = rp_lds[s * RW + sub + 1];
         if (pp1[slot] - pp0[slot] > long_thr) pp1[slot] = pp0[slot];
-        if (s > 0) {
+        if (s > 0 || !PRE) {
             const int an = (pp0[slot] & ~3) + l * 4;
             ld_stream4(colidx + an, c[slot]);
             ld_stream4(val + an, v[slot]);
@@ -123,7 +123,7 @@ __device__ __forceinline__ void csr_vector_tile_wave(int m, int long_thr, long l
     wave_lds_sync();
     const long long row = rw0 + lane;
     const int len = rp_lds[lane + 1] - rp_lds[lane];
-    if (row < m && len <= long_thr) y[row] = y_lds[lane]; // one coalesced 64-row store per wave
+    if (row < row_end && len <= long_thr) y[row] = y_lds[lane]; // one coalesced 64-row store per wave
 }
 
 template <typename T, int L, int DEPTH = 4>
@@ -167,9 +167,83 @@ __global__ __launch_bounds__(kVecTileThreads) void csr_vector_tile_kernel(int m,
     for (int i = threadIdx.x; i < span; i += kVecTileThreads) xs[i] = x[lo + i];
     __syncthreads();
     if (rw0 >= m) return;
-    if (span > 0) csr_vector_tile_wave<T, L, true, DEPTH>(m, long_thr, rw0, lane, rp_lds[wave], y_lds[wave], colidx, val, x, xs, lo, y, c0, v0);
-    else csr_vector_tile_wave<T, L, false, DEPTH>(m, long_thr, rw0, lane, rp_lds[wave], y_lds[wave], colidx, val, x, xs, lo, y, c0, v0);
+    if (span > 0) csr_vector_tile_wave<T, L, true, DEPTH>((long long) m, long_thr, rw0, lane, rp_lds[wave], y_lds[wave], colidx, val, x, xs, lo, y, c0, v0);
+    else csr_vector_tile_wave<T, L, false, DEPTH>((long long) m, long_thr, rw0, lane, rp_lds[wave], y_lds[wave], colidx, val, x, xs, lo, y, c0, v0);
     (void) RW;
+}
+
+// Balanced form (Method_Balanced): the same wave program over EQUAL-NNZ row blocks.  Block b owns
+// rows [split[b], split[b+1]) (init_csrSplitter_balanced2 semantics, parallel_balanced2_spmv.c:41-53,
+// built by rowblock_split_kernel) and walks them in 256-row slabs, 64 rows per wave; the x span of
+// the whole block is staged once.  Replaces the LDS-products kernel of rowblock.hpp as executor.
+template <typename T, int L, int DEPTH = 4>
+__global__ __launch_bounds__(kVecTileThreads) void csr_vector_rows_kernel(int long_thr, const int *__restrict__ split,
+                                                                          const int *__restrict__ rowptr,
+                                                                          const int *__restrict__ colidx,
+                                                                          const T *__restrict__ val,
+                                                                          const int *__restrict__ tile_lo,
+                                                                          const int *__restrict__ tile_span,
+                                                                          const T *__restrict__ x, T *__restrict__ y)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char vec_x_lds[];
+    T *xs = reinterpret_cast<T *>(vec_x_lds);
+    __shared__ int rp_lds[kVecTileThreads / kWave][kWave + 2];
+    __shared__ T y_lds[kVecTileThreads / kWave][kWave];
+    const int lane = threadIdx.x & (kWave - 1), wave = threadIdx.x / kWave;
+    const long long r_begin = split[blockIdx.x], r_end = split[blockIdx.x + 1];
+    const int lo = tile_lo[blockIdx.x], span = tile_span[blockIdx.x];
+    for (int i = threadIdx.x; i < span; i += kVecTileThreads) xs[i] = x[lo + i];
+    __syncthreads();
+    const int c0[4] = {0, 0, 0, 0};
+    const T v0[4] = {T(0), T(0), T(0), T(0)};
+    for (long long rw0 = r_begin + (long long) wave * kWave; rw0 < r_end; rw0 += kVecTileRows) {
+        long long r = rw0 + lane, re = rw0 + kWave;
+        if (r > r_end) r = r_end;
+        if (re > r_end) re = r_end;
+        rp_lds[wave][lane] = rowptr[r];
+        if (lane == 0) rp_lds[wave][kWave] = rowptr[re];
+        wave_lds_sync();
+        if (span > 0) csr_vector_tile_wave<T, L, true, DEPTH, false>(r_end, long_thr, rw0, lane, rp_lds[wave], y_lds[wave], colidx, val, x, xs, lo, y, c0, v0);
+        else csr_vector_tile_wave<T, L, false, DEPTH, false>(r_end, long_thr, rw0, lane, rp_lds[wave], y_lds[wave], colidx, val, x, xs, lo, y, c0, v0);
+        wave_lds_sync(); // y_lds / rp_lds are reused by the next slab
+    }
+}
+
+// Inspector for the balanced form: column span of rows [split[b], split[b+1]) with len <= long_thr.
+__global__ __launch_bounds__(kBlock) void csr_rows_span_kernel(int long_thr, int max_span, const int *__restrict__ split,
+                                                               const int *__restrict__ rowptr,
+                                                               const int *__restrict__ colidx,
+                                                               int *__restrict__ tile_lo, int *__restrict__ tile_span,
+                                                               int *__restrict__ staged)
+{
+    __shared__ int smin[kBlock / kWave], smax[kBlock / kWave];
+    const int r0 = split[blockIdx.x], r1 = split[blockIdx.x + 1];
+    int mn = INT_MAX, mx = -1;
+    const int sub = threadIdx.x / 16, l = threadIdx.x % 16;
+    for (int r = r0 + sub; r < r1; r += kBlock / 16) {
+        const int p0 = rowptr[r], p1 = rowptr[r + 1];
+        if (p1 - p0 > long_thr) continue;
+        for (int p = p0 + l; p < p1; p += 16) {
+            const int c = colidx[p];
+            mn = min(mn, c);
+            mx = max(mx, c);
+        }
+    }
+#pragma unroll
+    for (int o = kWave / 2; o > 0; o >>= 1) {
+        mn = min(mn, __shfl_xor(mn, o, kWave));
+        mx = max(mx, __shfl_xor(mx, o, kWave));
+    }
+    if ((threadIdx.x & (kWave - 1)) == 0) { smin[threadIdx.x / kWave] = mn; smax[threadIdx.x / kWave] = mx; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        for (int k = 1; k < kBlock / kWave; ++k) { mn = min(mn, smin[k]); mx = max(mx, smax[k]); }
+        const long long span = mx >= mn ? (long long) mx - mn + 1 : 0;
+        const bool ok = span > 0 && span <= max_span;
+        tile_lo[blockIdx.x] = ok ? mn : 0;
+        tile_span[blockIdx.x] = ok ? (int) span : 0;
+        if (ok) { atomicAdd(staged, 1); atomicMax(staged + 1, (int) span); }
+    }
 }
 
 } // namespace spmv

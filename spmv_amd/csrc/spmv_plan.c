@@ -33,7 +33,7 @@ static opt_t g_opts[] = {
     {"sell_sigma", 1024, 64, 1 << 20, 1, 0},
     {"sell_lds_x", 1, 0, 1, 0, 0},
     {"csr5_sigma", 0, 0, 16, 0, 0},
-    {"rowblock_nnz", 0, 0, 4096, 0, 0},   /* 2*4096 fp64 products = 64 KiB of LDS */
+    {"rowblock_nnz", 0, 0, 1 << 20, 0, 0},
     {"variant", 0, 0, 1 << 20, 0, 0},
     {"auto_method", 0, 0, 1, 0, 0},        /* 1: create() picks the schedule from the row statistics */
 };
@@ -103,9 +103,9 @@ void spmv_plan_choose(SPMV_METHODS requested, const spmv_stats *st, size_t value
     plan->sell_sigma = (int) spmv_hip_get_option("sell_sigma");
     plan->sell_lds_x = (int) spmv_hip_get_option("sell_lds_x");
     plan->csr5_sigma = (int) spmv_hip_get_option("csr5_sigma");
-    /* one workgroup's equal-nnz share: a block stages < 2*1024 products = 16 KiB of fp64 in LDS,
-     * so 8+ workgroups fit a CU */
-    plan->rowblock_nnz = rb > 0 ? (int) rb : 1024;
+    /* one workgroup's equal-nnz share (Method_Balanced): 8192 nnz ~ the 256 rows x 32 of a CSR-vector
+     * tile; a row longer than the share flips the handle to Method_Balanced2 like the reference */
+    plan->rowblock_nnz = rb > 0 ? (int) rb : 8192;
     /* CSR-vector: every lane takes 4 consecutive elements per step (16 B loads), so L = power of
      * two >= mean row length / 4 covers a mean-length row in one step; within [1, 64] */
     plan->lanes_per_row = lanes > 0 ? (int) lanes : pow2_at_least(st->mean_row_len / 4.0, 1, 64);

@@ -305,6 +305,9 @@ extern "C" void spmv_shim_matrix_destroy(spmv_dev *d)
 }
 
 // ------------------------------------------------------------------------------------ inspectors
+constexpr size_t kVecXTileBytes = 48 * 1024; // LDS budget of one row tile's x span (CSR-vector, Balanced)
+template <typename T> static int build_long_rows(spmv_dev *d, int thr);
+
 constexpr size_t kSplitXTileBytes = 48 * 1024; // LDS budget of one nnz-split tile group's x span
 
 template <typename T>
@@ -356,6 +359,30 @@ static int build_rowblock(spmv_dev *d)
     return SPMV_HIP_OK;
 }
 
+// Balanced executor = the CSR-vector wave program over the equal-nnz row blocks: long rows + x spans
+template <typename T>
+static int build_rowblock_tiles(spmv_dev *d)
+{
+    const int L = d->plan.lanes_per_row;
+    int rc = build_long_rows<T>(d, L * 64 > 256 ? L * 64 : 256);
+    if (rc) return rc;
+    int *cnt = nullptr;
+    int host2[2] = {0, 0};
+    ALLOC_TRY(d, &cnt, 2 * sizeof(int), true);
+    ALLOC_TRY(d, &d->vt_lo, sizeof(int) * (size_t) d->nblocks, true);
+    ALLOC_TRY(d, &d->vt_span, sizeof(int) * (size_t) d->nblocks, true);
+    HIP_TRY(hipMemsetAsync(cnt, 0, 2 * sizeof(int), d->stream));
+    csr_rows_span_kernel<<<d->nblocks, kBlock, 0, d->stream>>>(d->long_thr, (int) (kVecXTileBytes / sizeof(T)), d->rb_split, d->rowptr, d->colidx,
+                                                               d->vt_lo, d->vt_span, cnt);
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipMemcpyAsync(host2, cnt, 2 * sizeof(int), hipMemcpyDeviceToHost, d->stream));
+    HIP_TRY(hipStreamSynchronize(d->stream));
+    d->vt_tiles = d->nblocks;
+    d->vt_staged = host2[0];
+    d->vt_maxspan = host2[1];
+    return SPMV_HIP_OK;
+}
+
 // LDS budget of one SELL window's x tile: 96 KiB of the CU's 160 KiB (one 512-thread workgroup per
 // window; fp32 24576 columns, fp64 12288 columns).
 constexpr size_t kSellXTileBytes = 96 * 1024;
@@ -396,7 +423,6 @@ static int build_long_rows(spmv_dev *d, int thr)
     return SPMV_HIP_OK;
 }
 
-constexpr size_t kVecXTileBytes = 48 * 1024; // LDS budget of one 256-row tile's x span (CSR-vector)
 
 // x span of every 256-row tile (kernels/csr_vector_tile.hpp)
 template <typename T>
@@ -596,9 +622,10 @@ extern "C" int spmv_shim_build(spmv_dev *d, const spmv_plan *plan)
     }
     case SPMV_SCHED_NNZ_SPLIT: rc = f64 ? build_nnz_split<double>(d) : build_nnz_split<float>(d); break;
     case SPMV_SCHED_ROWBLOCK:
-        if (plan->rowblock_nnz < 64 || plan->rowblock_nnz > 4096) return fail(SPMV_HIP_E_ARG, "rowblock_nnz must be in [64, 4096]");
+        if (plan->rowblock_nnz < 64) return fail(SPMV_HIP_E_ARG, "rowblock_nnz must be >= 64");
         if (d->stats.max_row_len > plan->rowblock_nnz) return fail(SPMV_HIP_E_ARG, "row-block schedule needs max_row_len <= rowblock_nnz");
         rc = build_rowblock(d);
+        if (!rc) rc = f64 ? build_rowblock_tiles<double>(d) : build_rowblock_tiles<float>(d);
         break;
     case SPMV_SCHED_SELL: rc = f64 ? build_sell<double>(d) : build_sell<float>(d); break;
     case SPMV_SCHED_CSR5: rc = f64 ? build_csr5<double>(d) : build_csr5<float>(d); break;
@@ -662,6 +689,14 @@ static void launch_csr5(spmv_dev *d, const T *x, T *y)
                                                                     nullptr, x, y, (T *) d->c5_carry);
 }
 
+template <typename T, int L>
+static void launch_rows(spmv_dev *d, const T *x, T *y)
+{
+    const size_t lds = (((size_t) d->vt_maxspan * sizeof(T)) + 1023) & ~(size_t) 1023;
+    csr_vector_rows_kernel<T, L, (sizeof(T) == 8 ? 4 : 2)><<<d->nblocks, kVecTileThreads, lds, d->stream>>>(
+        d->long_thr, d->rb_split, d->rowptr, d->colidx, (const T *) d->val, d->vt_lo, d->vt_span, x, y);
+}
+
 template <typename T>
 static int launch(spmv_dev *d, const T *x, T *y)
 {
@@ -704,8 +739,20 @@ static int launch(spmv_dev *d, const T *x, T *y)
         break;
     }
     case SPMV_SCHED_ROWBLOCK:
-        rowblock_kernel<T><<<d->nblocks, kBlock, 2 * (size_t) d->rb_stride * sizeof(T), d->stream>>>(
-            d->rb_split, d->rowptr, d->colidx, val, x, y);
+        if (d->plan.variant == 7 && d->rb_stride <= 4096) { // A/B: the first-round LDS-products kernel
+            rowblock_kernel<T><<<d->nblocks, kBlock, 2 * (size_t) d->rb_stride * sizeof(T), d->stream>>>(d->rb_split, d->rowptr, d->colidx, val, x, y);
+            break;
+        }
+        switch (d->plan.lanes_per_row) {
+        case 1: launch_rows<T, 1>(d, x, y); break;
+        case 2: launch_rows<T, 2>(d, x, y); break;
+        case 4: launch_rows<T, 4>(d, x, y); break;
+        case 8: launch_rows<T, 8>(d, x, y); break;
+        case 16: launch_rows<T, 16>(d, x, y); break;
+        case 32: launch_rows<T, 32>(d, x, y); break;
+        default: launch_rows<T, 64>(d, x, y); break;
+        }
+        launch_long_rows<T>(d, x, y);
         break;
     case SPMV_SCHED_SELL:
         // staged path when at least half of the windows fit their x span in LDS; the LDS request is
@@ -820,7 +867,7 @@ extern "C" double spmv_shim_time(spmv_dev *d, const void *x, void *y, int warmup
 
 // ------------------------------------------------------------------------------------ info
 static const char *kSchedNames[] = {"csr-scalar", "csr-vector", "row-block", "nnz-split", "sell-c-sigma", "csr5"};
-static const char *kKernelNames[] = {"csr_scalar_kernel", "csr_vector_pipe_kernel", "rowblock_kernel",
+static const char *kKernelNames[] = {"csr_scalar_kernel", "csr_vector_pipe_kernel", "csr_vector_rows_kernel",
                                      "nnz_split_kernel", "sell_kernel", "csr5_kernel"};
 
 extern "C" int spmv_shim_info(const spmv_dev *d, spmv_hip_info *o)

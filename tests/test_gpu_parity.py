@@ -107,10 +107,16 @@ def test_balanced_request_is_rewritten_like_the_reference():
     """parallel_balanced2_spmv.c:72-92: Balanced/Balanced2 become Balanced2 when some row is longer
     than one equal-nnz share, Balanced otherwise."""
     short, x1, _ = load_golden("banded_f64_eighths")
-    long_, x2, _ = load_golden("single_long_f64_eighths")
+    long_, x2, _ = load_golden("single_long_f64_eighths")       # one row of 5000 nnz
     for req in (M.Method_Balanced, M.Method_Balanced2):
         assert run_host(short, x1, req)[1] == M.Method_Balanced
-        assert run_host(long_, x2, req)[1] == M.Method_Balanced2
+        assert run_host(long_, x2, req)[1] == M.Method_Balanced      # default share 8192 >= 5000
+    api.set_option("rowblock_nnz", 1024)                            # share smaller than the row
+    try:
+        for req in (M.Method_Balanced, M.Method_Balanced2):
+            assert run_host(long_, x2, req)[1] == M.Method_Balanced2
+    finally:
+        api.set_option("rowblock_nnz", 0)
 
 
 @pytest.mark.parametrize("method", ALL_METHODS, ids=lambda m: m.name)
@@ -198,7 +204,7 @@ def test_auto_method_picks_schedule_from_row_statistics():
     ("sell_sigma", [64, 256, 4096], M.Method_SellCSigma),
     ("sell_lds_x", [0, 1], M.Method_SellCSigma),
     ("csr5_sigma", [4, 8, 16], M.Method_CSR5SPMV),
-    ("rowblock_nnz", [64, 333, 4096], M.Method_Balanced),
+    ("rowblock_nnz", [64, 333, 4096, 100000], M.Method_Balanced),
 ])
 @pytest.mark.parametrize("name", ["skewed_f64_eighths", "empty_mix_f32_eighths", "banded_wide_f64_eighths"])
 def test_tuning_options_do_not_change_results(key, values, method, name):
