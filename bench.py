@@ -61,6 +61,7 @@ def parse():
     ap.add_argument("--cpu-rows", type=int, default=1_000_000)
     ap.add_argument("--cpu-seconds", type=float, default=15.0)
     ap.add_argument("--no-cpu", action="store_true")
+    ap.add_argument("--no-overlap", action="store_true", help="halo mode: do not split interior / boundary rows")
     return ap.parse_args()
 
 
@@ -170,7 +171,7 @@ def main():
     y = torch.full((m_loc,), float("nan"), dtype=dt, device=dev)
 
     t0 = time.perf_counter()
-    sh = ShardedSpMV(rp, ci, va, n_glob, xchg=args.xchg, method=args.method)
+    sh = ShardedSpMV(rp, ci, va, n_glob, xchg=args.xchg, method=args.method, overlap=not args.no_overlap)
     if sh.xchg in ("none", "bcast"):
         if sh.xchg == "none" or rank == 0:
             sh.set_full_x(x_full)
@@ -180,7 +181,7 @@ def main():
         del x_full
     torch.cuda.synchronize()
     create_s = time.perf_counter() - t0
-    info = sh.handle.info()
+    info = sh.handle.info()                 # split mode: the interior handle (dominant kernel)
 
     def sync_all():
         if world > 1:
@@ -193,11 +194,8 @@ def main():
     ev = [torch.cuda.Event(enable_timing=True) for _ in range(2 * K)]
     sync_all()
     t0 = time.perf_counter()
-    for i in range(K):
-        sh.exchange(x_loc)
-        ev[2 * i].record()          # torch's current stream == the handle's stream (attach_stream)
-        sh.multiply(y)
-        ev[2 * i + 1].record()
+    for i in range(K):              # events: torch's current stream == the handle's stream (attach_stream)
+        sh.step(x_loc, y, events=(ev[2 * i], ev[2 * i + 1]))
     sync_all()
     elapsed = time.perf_counter() - t0
     launch_ms = np.array([ev[2 * i].elapsed_time(ev[2 * i + 1]) for i in range(K)])
@@ -214,8 +212,10 @@ def main():
     if rank == 0:
         ms_step = elapsed / K * 1e3
         gflops = 2.0 * nnz_all * K / elapsed / 1e9
-        # per-launch algorithmic bytes of THIS rank's kernel: its x footprint is what it reads
-        alg_bytes = 4 * (m_loc + 1) + nnz_loc * (4 + s) + s * sh.n_x + s * m_loc
+        # per-launch algorithmic bytes of THIS rank's dominant kernel: its x footprint is what it reads
+        # (split mode: the interior kernel covers all rows but the few boundary ones)
+        nnz_k = int(sh._A_int[1].numel()) if sh.split else nnz_loc
+        alg_bytes = 4 * (m_loc + 1) + nnz_k * (4 + s) + s * (sh.n_local if sh.split else sh.n_x) + s * m_loc
         mean_launch = float(launch_ms.mean())
         achieved = alg_bytes / (mean_launch * 1e-3) / 1e9
         out = {
@@ -228,7 +228,8 @@ def main():
                             f"{k} nnz/row, {m_loc} rows per GPU",
                 "schedule": f"{api.SPMV_METHODS(args.method).name} -> {info['schedule_name']}"
                             + (f" L={info['lanes_per_row']}" if info['lanes_per_row'] else ""),
-                "x_exchange": sh.xchg, "ghost_columns_rank0": sh.n_ghost, "vectors": "device-resident x, y",
+                "x_exchange": sh.xchg, "ghost_columns_rank0": sh.n_ghost, "overlap_split": bool(sh.split),
+                "boundary_rows_rank0": int(sh.bnd_rows.numel()) if sh.split else 0, "vectors": "device-resident x, y",
                 "nnz_total": nnz_all, "create_seconds": round(create_s, 3), "inspect_ms": round(info["inspect_ms"], 3),
             },
             "hbm_gbps_alg": round(achieved, 1),

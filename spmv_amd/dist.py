@@ -82,7 +82,7 @@ class ShardedSpMV:
     """
 
     def __init__(self, rowptr, colidx, val, n_global, xchg="halo", method=api.SPMV_METHODS.Method_Parallel,
-                 group=None, compute=None):
+                 group=None, compute=None, overlap=True):
         assert xchg in ("halo", "allgather", "bcast", "none")
         self.group = group
         self.world = dist.get_world_size(group) if dist.is_initialized() else 1
@@ -105,11 +105,60 @@ class ShardedSpMV:
         self.colidx = colidx
         self.x_ext = torch.zeros(self.n_x, dtype=self.dtype, device=self.device)
         self._compute = compute
+        self._method = method
         self.handle = None
-        if compute is None:
-            self.handle = api.Handle(self.m_local, self.n_x, rowptr, colidx, val, method)
-            if self.device.type == "cuda":
-                self.handle.attach_stream(torch.cuda.current_stream(self.device).cuda_stream, async_=True)
+        # Overlap (halo mode): rows that reference no ghost column ("interior") are multiplied while
+        # the halo is in flight, the few boundary rows after it has landed.  Only worth it when the
+        # boundary is a small part of the shard.
+        self.split = False
+        if self.xchg == "halo" and overlap and self.n_ghost > 0:
+            self._plan_overlap(rowptr, colidx, val)
+        if not self.split:
+            self._A = (rowptr, colidx, val)
+            if compute is None:
+                self.handle = self._make_handle(self.m_local, rowptr, colidx, val)
+
+    def _make_handle(self, m, rowptr, colidx, val):
+        h = api.Handle(m, self.n_x, rowptr, colidx, val, self._method)
+        if self.device.type == "cuda":
+            h.attach_stream(torch.cuda.current_stream(self.device).cuda_stream, async_=True)
+        return h
+
+    def _plan_overlap(self, rowptr, colidx, val, max_boundary_fraction=0.1):
+        m = self.m_local
+        lens = (rowptr[1:] - rowptr[:-1]).to(torch.int64)
+        ghost_nnz = torch.nonzero(colidx >= self.n_local).flatten()          # positions of ghost references
+        # row of each ghost reference: RowPtr is sorted -> searchsorted (no nnz-sized row index array)
+        rows = torch.searchsorted(rowptr.to(torch.int64), ghost_nnz, right=True) - 1
+        bnd = torch.unique(rows)
+        if bnd.numel() == 0 or bnd.numel() > max_boundary_fraction * max(m, 1):
+            return
+        is_bnd = torch.zeros(m, dtype=torch.bool, device=self.device)
+        is_bnd[bnd] = True
+        # interior matrix: same m rows, boundary rows emptied (they come out as 0 and are overwritten)
+        lens_i = torch.where(is_bnd, torch.zeros_like(lens), lens)
+        rp_i = torch.zeros(m + 1, dtype=torch.int64, device=self.device)
+        torch.cumsum(lens_i, 0, out=rp_i[1:])
+        keep = torch.ones(colidx.numel(), dtype=torch.bool, device=self.device)
+        rp64 = rowptr.to(torch.int64)
+        for r in bnd.tolist() if bnd.numel() <= 4096 else []:
+            keep[int(rp64[r]):int(rp64[r + 1])] = False
+        if bnd.numel() > 4096:                                               # many boundary rows: vectorised mask
+            row_of = torch.repeat_interleave(torch.arange(m, device=self.device), lens)
+            keep = ~is_bnd[row_of]
+            del row_of
+        # boundary matrix: the boundary rows only, compacted
+        lens_b = lens[bnd]
+        rp_b = torch.zeros(bnd.numel() + 1, dtype=torch.int64, device=self.device)
+        torch.cumsum(lens_b, 0, out=rp_b[1:])
+        self._A_int = (rp_i.to(torch.int32), colidx[keep].contiguous(), val[keep].contiguous())
+        self._A_bnd = (rp_b.to(torch.int32), colidx[~keep].contiguous(), val[~keep].contiguous())
+        self.bnd_rows = bnd
+        self.y_bnd = torch.zeros(bnd.numel(), dtype=self.dtype, device=self.device)
+        self.split = True
+        if self._compute is None:
+            self.handle = self._make_handle(m, *self._A_int)
+            self.handle_bnd = self._make_handle(int(bnd.numel()), *self._A_bnd)
 
     # ------------------------------------------------------------------ inspector (halo)
     def _plan_halo(self, colidx):
@@ -179,18 +228,59 @@ class ShardedSpMV:
         assert self.xchg in ("none", "bcast", "allgather")
         self.x_ext.copy_(x_full)
 
-    def multiply(self, y_local):
+    def _mul(self, which, x, y):
         if self._compute is not None:
-            self._compute(self.rowptr, self.colidx, self.val, self.x_ext, y_local)
+            self._compute(*which, x, y)
         else:
-            self.handle.spmv(self.x_ext, y_local)
+            (self.handle if which is not getattr(self, "_A_bnd", None) else self.handle_bnd).spmv(x, y)
+
+    def multiply(self, y_local):
+        """Multiply with whatever exchange() left in x_ext (non-overlapped form)."""
+        if self.split:
+            self._mul(self._A_int, self.x_ext, y_local)
+            self._mul(self._A_bnd, self.x_ext, self.y_bnd)
+            y_local.index_copy_(0, self.bnd_rows, self.y_bnd)
+        else:
+            self._mul(self._A, self.x_ext, y_local)
         return y_local
 
-    def step(self, x_local, y_local):
-        self.exchange(x_local)
-        return self.multiply(y_local)
+    def step(self, x_local, y_local, events=None):
+        """One SpMV step: exchange x, multiply.  In split (overlap) mode the interior rows run while
+        the halo all_to_all is in flight; the boundary rows follow once it has landed.
+        events = (e0, e1): recorded on the current stream around the dominant multiply."""
+        if not self.split:
+            self.exchange(x_local)
+            if events:
+                events[0].record()
+            self.multiply(y_local)
+            if events:
+                events[1].record()
+            return y_local
+        if x_local.data_ptr() != self.x_ext.data_ptr():
+            self.x_ext[: self.n_local].copy_(x_local)
+        send = x_local[self.send_idx]
+        staged = dist.get_backend(self.group) == "gloo" and send.is_cuda
+        if staged:                                    # gloo cannot take device tensors: no async overlap
+            _all_to_all_single(self.x_ext[self.n_local:], send, output_split_sizes=self.recv_counts,
+                               input_split_sizes=self.send_counts, group=self.group)
+            work = None
+        else:
+            work = dist.all_to_all_single(self.x_ext[self.n_local:], send, output_split_sizes=self.recv_counts,
+                                          input_split_sizes=self.send_counts, group=self.group, async_op=True)
+        if events:
+            events[0].record()
+        self._mul(self._A_int, self.x_ext, y_local)   # touches x_ext[:n_local] only
+        if events:
+            events[1].record()
+        if work is not None:
+            work.wait()                               # current stream now waits for the halo
+        self._mul(self._A_bnd, self.x_ext, self.y_bnd)
+        y_local.index_copy_(0, self.bnd_rows, self.y_bnd)
+        return y_local
 
     def close(self):
-        if self.handle is not None:
-            self.handle.close()
-            self.handle = None
+        for name in ("handle", "handle_bnd"):
+            h = getattr(self, name, None)
+            if h is not None:
+                h.close()
+                setattr(self, name, None)

@@ -62,7 +62,7 @@ def _worker(rank, world, port, kind, xchg, out):
         ok = np.array_equal(y.numpy(), want)
         ghosts = sh.n_ghost
         dist.barrier()
-        out[rank] = (ok, ghosts, sh.n_x)
+        out[rank] = (ok, ghosts, sh.n_x, bool(sh.split), int(sh.bnd_rows.numel()) if sh.split else 0)
     finally:
         dist.destroy_process_group()
 
@@ -78,6 +78,10 @@ def test_world2_matches_oracle(kind, xchg):
     if xchg == "halo" and kind == "banded":
         # a 16-wide band needs only the few columns next to the cut, not the other half of x
         assert all(0 < out[r][1] <= 16 for r in range(world)), dict(out)
+        # ... and only the rows next to the cut wait for the halo: interior / boundary overlap split
+        assert all(out[r][3] and 0 < out[r][4] <= 16 for r in range(world)), dict(out)
+    if xchg == "halo" and kind == "powerlaw":
+        assert not any(out[r][3] for r in range(world))      # most rows touch ghosts: no split
 
 
 def test_slice_bounds_cover_and_are_contiguous():
