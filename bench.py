@@ -62,6 +62,8 @@ def parse():
     ap.add_argument("--cpu-seconds", type=float, default=15.0)
     ap.add_argument("--no-cpu", action="store_true")
     ap.add_argument("--no-overlap", action="store_true", help="halo mode: do not split interior / boundary rows")
+    ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
+                    help="nccl = RCCL over xGMI (the judged path); gloo + SPMV_BENCH_ONE_DEVICE=1 rehearses N>1 on a 1-GPU box")
     return ap.parse_args()
 
 
@@ -141,11 +143,16 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    one_device = bool(os.environ.get("SPMV_BENCH_ONE_DEVICE"))      # rehearsal only: every rank on cuda:0
+    dev_index = 0 if (one_device or world == 1) else local_rank
     if world > 1:
-        torch.cuda.set_device(local_rank)
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        torch.cuda.set_device(dev_index)
+        if args.backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device("cuda", dev_index))
+        else:
+            dist.init_process_group("gloo")
     assert world == args.gpus or world == 1, f"--gpus {args.gpus} but WORLD_SIZE {world}"
-    dev = torch.device("cuda", local_rank if world > 1 else 0)
+    dev = torch.device("cuda", dev_index)
     torch.cuda.set_device(dev)
 
     from spmv_amd import api, build, synth
@@ -200,10 +207,11 @@ def main():
     elapsed = time.perf_counter() - t0
     launch_ms = np.array([ev[2 * i].elapsed_time(ev[2 * i + 1]) for i in range(K)])
     if world > 1:
-        tt = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        rdev = dev if args.backend == "nccl" else torch.device("cpu")
+        tt = torch.tensor([elapsed], dtype=torch.float64, device=rdev)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         elapsed = float(tt.item())
-        nn = torch.tensor([nnz_loc], dtype=torch.int64, device=dev)
+        nn = torch.tensor([nnz_loc], dtype=torch.int64, device=rdev)
         dist.all_reduce(nn, op=dist.ReduceOp.SUM)
         nnz_all = int(nn.item())
     else:
