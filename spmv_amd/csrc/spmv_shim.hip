@@ -515,7 +515,7 @@ static int build_sell(spmv_dev *d)
     return SPMV_HIP_OK;
 }
 
-constexpr size_t kCsr5XTileBytes = 64 * 1024; // LDS budget of one tile group's x span
+constexpr size_t kCsr5XTileBytes = 128 * 1024; // LDS budget of one tile group's x span (a CU has 160 KiB)
 
 template <typename T, int SIGMA>
 static int build_csr5_sigma(spmv_dev *d, const int *rp, int m2)
@@ -656,9 +656,12 @@ static void launch_vector(spmv_dev *d, const T *x, T *y)
         else if (d->plan.variant == 6) // A/B: eight steps in flight
             csr_vector_tile_kernel<T, L, 8><<<d->vt_tiles, kVecTileThreads, lds, d->stream>>>(d->m, d->long_thr, d->rowptr, d->colidx, (const T *) d->val,
                                                                                     d->vt_lo, d->vt_span, x, y);
-        else // measured best: 4 steps (fp64) / 2 steps (fp32) of matrix stream in flight per wave
+        else { // measured best: 4 steps (fp64) / 2 steps (fp32) of matrix stream in flight per wave
+            if (lds > 64 * 1024)
+                (void) hipFuncSetAttribute((const void *) csr_vector_tile_kernel<T, L, (sizeof(T) == 8 ? 4 : 2)>, hipFuncAttributeMaxDynamicSharedMemorySize, (int) lds);
             csr_vector_tile_kernel<T, L, (sizeof(T) == 8 ? 4 : 2)><<<d->vt_tiles, kVecTileThreads, lds, d->stream>>>(
                 d->m, d->plan.variant == 2 ? INT_MAX : d->long_thr, d->rowptr, d->colidx, (const T *) d->val, d->vt_lo, d->vt_span, x, y);
+        }
         return;
     }
     constexpr int rows = kBlock / L * kVecNB;
@@ -672,6 +675,10 @@ static void launch_csr5(spmv_dev *d, const T *x, T *y)
 {
     if (d->c5_staged * 2 >= d->c5_groups && d->plan.variant != 3) { // most groups fit their x span in LDS
         const size_t lds = (((size_t) d->c5_maxspan * sizeof(T)) + 1023) & ~(size_t) 1023;
+        if (lds > 64 * 1024) { // above the default dynamic-LDS limit: raise it for this instantiation (idempotent, cheap)
+            if (d->c5_row_map) (void) hipFuncSetAttribute((const void *) csr5_group_kernel<T, SIGMA, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int) lds);
+            else (void) hipFuncSetAttribute((const void *) csr5_group_kernel<T, SIGMA, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int) lds);
+        }
         if (d->c5_row_map)
             csr5_group_kernel<T, SIGMA, true><<<d->c5_groups, kBlock, lds, d->stream>>>(d->c5_tiles, d->c5_tile_ptr, d->c5_desc, d->c5_col,
                 (const T *) d->c5_val, d->c5_row_map, d->c5_grp_lo, d->c5_grp_span, x, y, (T *) d->c5_carry);
@@ -693,6 +700,8 @@ template <typename T, int L>
 static void launch_rows(spmv_dev *d, const T *x, T *y)
 {
     const size_t lds = (((size_t) d->vt_maxspan * sizeof(T)) + 1023) & ~(size_t) 1023;
+    if (lds > 64 * 1024)
+        (void) hipFuncSetAttribute((const void *) csr_vector_rows_kernel<T, L, (sizeof(T) == 8 ? 4 : 2)>, hipFuncAttributeMaxDynamicSharedMemorySize, (int) lds);
     csr_vector_rows_kernel<T, L, (sizeof(T) == 8 ? 4 : 2)><<<d->nblocks, kVecTileThreads, lds, d->stream>>>(
         d->long_thr, d->rb_split, d->rowptr, d->colidx, (const T *) d->val, d->vt_lo, d->vt_span, x, y);
 }
