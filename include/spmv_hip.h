@@ -49,6 +49,8 @@ int spmv_hip_synchronize(spmv_Handle_t handle);
  *       "sell_c" (64)  "sell_sigma" (1024)  "sell_lds_x" (0/1: stage narrow x windows in LDS)
  *       "csr5_sigma" (0 = auto)  "rowblock_nnz" (equal-nnz share of one Balanced row block, 0 = auto = 8192)
  *       "variant" (kernel variant selector used by the tuning harness, 0 = default)
+ *       "autotune" (0/1, default 1: for matrices above 2^24 nnz create() times the applicable CSR-vector
+ *                   kernel forms once on the resident matrix and keeps the fastest, ~10 ms)
  *       "auto_method" (0/1: create() replaces the requested method by the one its row statistics
  *                      favour -- CSR-vector for regular rows, CSR5 otherwise; the handle reports it)
  * Each key can also be preset with the environment variable SPMV_HIP_<KEY IN CAPS>.
@@ -73,6 +75,8 @@ typedef struct spmv_hip_info {
     double inspect_ms;          /* wall time of the inspector inside create */
     const char *schedule_name;
     const char *kernel_name;    /* symbol of the dominant kernel (as rocprofv3 shows it) */
+    int tuned_choice;           /* csr-vector autotune: 0 none, 10 tile/4-deep, 5 tile/2-deep, 4 pipe */
+    float tune_ms[3];           /* measured ms of {tile/4-deep, tile/2-deep, pipe} at create (0 if not tuned) */
 } spmv_hip_info;
 int spmv_hip_get_info(spmv_Handle_t handle, spmv_hip_info *out);
 

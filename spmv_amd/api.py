@@ -63,7 +63,8 @@ class spmv_hip_info(C.Structure):
                 ("max_row_len", C.c_int), ("min_row_len", C.c_int), ("empty_rows", C.c_int),
                 ("mean_row_len", C.c_double), ("device_bytes", C.c_longlong),
                 ("alg_bytes", C.c_longlong), ("inspect_ms", C.c_double),
-                ("schedule_name", C.c_char_p), ("kernel_name", C.c_char_p)]
+                ("schedule_name", C.c_char_p), ("kernel_name", C.c_char_p),
+                ("tuned_choice", C.c_int), ("tune_ms", C.c_float * 3)]
 
 
 # Every symbol include/*.h declares: functions with their prototypes, then data symbols.
@@ -214,6 +215,7 @@ def get_info(handle):
     out = {k: getattr(info, k) for k, _ in spmv_hip_info._fields_}
     out["schedule_name"] = (out["schedule_name"] or b"").decode()
     out["kernel_name"] = (out["kernel_name"] or b"").decode()
+    out["tune_ms"] = [float(v) for v in out["tune_ms"]]
     return out
 
 

@@ -35,7 +35,8 @@ static opt_t g_opts[] = {
     {"csr5_sigma", 0, 0, 16, 0, 0},
     {"rowblock_nnz", 0, 0, 1 << 20, 0, 0},
     {"variant", 0, 0, 1 << 20, 0, 0},
-    {"auto_method", 0, 0, 1, 0, 0},        /* 1: create() picks the schedule from the row statistics */
+    {"auto_method", 0, 0, 1, 0, 0},
+    {"autotune", 1, 0, 1, 0, 0},           /* 1: create() times the CSR-vector kernel forms on big matrices */        /* 1: create() picks the schedule from the row statistics */
 };
 #define N_OPTS ((int) (sizeof g_opts / sizeof g_opts[0]))
 
@@ -99,6 +100,7 @@ void spmv_plan_choose(SPMV_METHODS requested, const spmv_stats *st, size_t value
     long rb = spmv_hip_get_option("rowblock_nnz");
     memset(plan, 0, sizeof *plan);
     plan->variant = (int) spmv_hip_get_option("variant");
+    plan->autotune = (int) spmv_hip_get_option("autotune");
     plan->sell_c = (int) spmv_hip_get_option("sell_c");
     plan->sell_sigma = (int) spmv_hip_get_option("sell_sigma");
     plan->sell_lds_x = (int) spmv_hip_get_option("sell_lds_x");

@@ -40,6 +40,7 @@ typedef struct spmv_plan {
     int csr5_sigma;
     int rowblock_nnz;
     int variant;
+    int autotune;       /* csr-vector: time the applicable kernel forms at create and keep the fastest */
 } spmv_plan;
 
 /* All functions return SPMV_HIP_OK or an SPMV_HIP_E_* code and record a message retrievable

@@ -85,7 +85,8 @@ struct spmv_dev {
     int nblocks = 0, rb_stride = 0;
     int *rb_split = nullptr;
     // csr-vector x tiles
-    int vt_tiles = 0, vt_staged = 0, vt_maxspan = 0;
+    int vt_tiles = 0, vt_staged = 0, vt_maxspan = 0, vec_choice = 0;
+    float tune_ms[3] = {0, 0, 0}; // tile D4, tile D2, pipe (autotune_vector)
     int *vt_lo = nullptr, *vt_span = nullptr;
     // long rows (csr-vector, sell)
     int nlong = 0, long_thr = INT_MAX, lr_segs = 0;
@@ -203,6 +204,13 @@ __global__ __launch_bounds__(kBlock) void count_longer_kernel(int m, int thr, co
 }
 
 template <typename T>
+__global__ __launch_bounds__(kBlock) void fill_value_kernel(long long n, T *y, T v)
+{
+    const long long stride = (long long) gridDim.x * kBlock;
+    for (long long i = (long long) blockIdx.x * kBlock + threadIdx.x; i < n; i += stride) y[i] = v;
+}
+
+template <typename T>
 __global__ __launch_bounds__(kBlock) void fill_zero_kernel(long long n, T *y)
 {
     const long long stride = (long long) gridDim.x * kBlock;
@@ -307,6 +315,7 @@ extern "C" void spmv_shim_matrix_destroy(spmv_dev *d)
 // ------------------------------------------------------------------------------------ inspectors
 constexpr size_t kVecXTileBytes = 48 * 1024; // LDS budget of one row tile's x span (CSR-vector, Balanced)
 template <typename T> static int build_long_rows(spmv_dev *d, int thr);
+template <typename T> static int autotune_vector(spmv_dev *d);
 
 constexpr size_t kSplitXTileBytes = 48 * 1024; // LDS budget of one nnz-split tile group's x span
 
@@ -618,6 +627,7 @@ extern "C" int spmv_shim_build(spmv_dev *d, const spmv_plan *plan)
         // a lane group takes 4L elements per step; beyond ~64 steps a whole wavefront per row segment wins
         rc = f64 ? build_long_rows<double>(d, L * 64 > 256 ? L * 64 : 256) : build_long_rows<float>(d, L * 64 > 256 ? L * 64 : 256);
         if (!rc) rc = f64 ? build_vector_tiles<double>(d) : build_vector_tiles<float>(d);
+        if (!rc && plan->autotune) rc = f64 ? autotune_vector<double>(d) : autotune_vector<float>(d);
         break;
     }
     case SPMV_SCHED_NNZ_SPLIT: rc = f64 ? build_nnz_split<double>(d) : build_nnz_split<float>(d); break;
@@ -640,34 +650,101 @@ extern "C" int spmv_shim_build(spmv_dev *d, const spmv_plan *plan)
 // One workgroup per kVecNB * (256/L) consecutive rows, dispatched in row order: measured on the
 // config-2 shape a plain in-order grid beats a persistent grid-stride loop by ~10 %.
 constexpr int kVecNB = 4;
+// Kernel forms of the CSR-vector schedule.  Which one is fastest differs between MI355X boxes by a
+// few percent, so create() times the applicable ones once on the resident matrix
+// (autotune_vector) and keeps the winner in d->vec_choice; plan.variant overrides for A/B runs.
+enum { VEC_AUTO = 0, VEC_STRIDED = 1, VEC_NO_LONG = 2, VEC_PIPE = 4, VEC_TILE_D2 = 5, VEC_TILE_D8 = 6, VEC_TILE_D4 = 10 };
+
+template <typename T, int L, int DEPTH>
+static void launch_vector_tile(spmv_dev *d, const T *x, T *y, int long_thr)
+{
+    const size_t lds = (((size_t) d->vt_maxspan * sizeof(T)) + 1023) & ~(size_t) 1023;
+    if (lds > 64 * 1024)
+        (void) hipFuncSetAttribute((const void *) csr_vector_tile_kernel<T, L, DEPTH>, hipFuncAttributeMaxDynamicSharedMemorySize, (int) lds);
+    csr_vector_tile_kernel<T, L, DEPTH><<<d->vt_tiles, kVecTileThreads, lds, d->stream>>>(d->m, long_thr, d->rowptr, d->colidx, (const T *) d->val,
+                                                                                      d->vt_lo, d->vt_span, x, y);
+}
+
 template <typename T, int L>
 static void launch_vector(spmv_dev *d, const T *x, T *y)
 {
-    if (d->plan.variant == 1) { // A/B: the first-round strided kernel
+    const int v = d->plan.variant ? d->plan.variant : d->vec_choice;
+    const int long_thr = v == VEC_NO_LONG ? INT_MAX : d->long_thr;
+    if (v == VEC_STRIDED) { // A/B: the first-round strided kernel
         csr_vector_kernel<T, (L < 2 ? 2 : L)><<<grid_for(d->m, kBlock / (L < 2 ? 2 : L), d->cus * 32), kBlock, 0, d->stream>>>(
             d->m, d->rowptr, d->colidx, (const T *) d->val, x, y);
         return;
     }
-    if (d->vt_staged * 2 >= d->vt_tiles && d->vt_tiles > 0 && d->plan.variant != 4) { // x tiles fit LDS: tile kernel
-        const size_t lds = (((size_t) d->vt_maxspan * sizeof(T)) + 1023) & ~(size_t) 1023;
-        if (d->plan.variant == 5) // A/B: two steps in flight
-            csr_vector_tile_kernel<T, L, 2><<<d->vt_tiles, kVecTileThreads, lds, d->stream>>>(d->m, d->long_thr, d->rowptr, d->colidx, (const T *) d->val,
-                                                                                    d->vt_lo, d->vt_span, x, y);
-        else if (d->plan.variant == 6) // A/B: eight steps in flight
-            csr_vector_tile_kernel<T, L, 8><<<d->vt_tiles, kVecTileThreads, lds, d->stream>>>(d->m, d->long_thr, d->rowptr, d->colidx, (const T *) d->val,
-                                                                                    d->vt_lo, d->vt_span, x, y);
-        else { // measured best: 4 steps (fp64) / 2 steps (fp32) of matrix stream in flight per wave
-            if (lds > 64 * 1024)
-                (void) hipFuncSetAttribute((const void *) csr_vector_tile_kernel<T, L, (sizeof(T) == 8 ? 4 : 2)>, hipFuncAttributeMaxDynamicSharedMemorySize, (int) lds);
-            csr_vector_tile_kernel<T, L, (sizeof(T) == 8 ? 4 : 2)><<<d->vt_tiles, kVecTileThreads, lds, d->stream>>>(
-                d->m, d->plan.variant == 2 ? INT_MAX : d->long_thr, d->rowptr, d->colidx, (const T *) d->val, d->vt_lo, d->vt_span, x, y);
-        }
+    if (d->vt_staged * 2 >= d->vt_tiles && d->vt_tiles > 0 && v != VEC_PIPE) { // x tiles fit LDS: tile kernel
+        if (v == VEC_TILE_D2) launch_vector_tile<T, L, 2>(d, x, y, long_thr);
+        else if (v == VEC_TILE_D8) launch_vector_tile<T, L, 8>(d, x, y, long_thr);
+        else if (v == VEC_TILE_D4) launch_vector_tile<T, L, 4>(d, x, y, long_thr);
+        else launch_vector_tile<T, L, (sizeof(T) == 8 ? 4 : 2)>(d, x, y, long_thr); // measured default
         return;
     }
     constexpr int rows = kBlock / L * kVecNB;
     const int grid = grid_for(d->m, rows, INT_MAX);
-    csr_vector_pipe_kernel<T, L, kVecNB><<<grid, kBlock, 0, d->stream>>>(d->m, d->plan.variant == 2 ? INT_MAX : d->long_thr, d->rowptr, d->colidx,
-                                                                       (const T *) d->val, x, y);
+    csr_vector_pipe_kernel<T, L, kVecNB><<<grid, kBlock, 0, d->stream>>>(d->m, long_thr, d->rowptr, d->colidx, (const T *) d->val, x, y);
+}
+
+template <typename T>
+static void launch_vector_any(spmv_dev *d, const T *x, T *y)
+{
+    switch (d->plan.lanes_per_row) {
+    case 1: launch_vector<T, 1>(d, x, y); break;
+    case 2: launch_vector<T, 2>(d, x, y); break;
+    case 4: launch_vector<T, 4>(d, x, y); break;
+    case 8: launch_vector<T, 8>(d, x, y); break;
+    case 16: launch_vector<T, 16>(d, x, y); break;
+    case 32: launch_vector<T, 32>(d, x, y); break;
+    default: launch_vector<T, 64>(d, x, y); break;
+    }
+}
+
+// Time the applicable CSR-vector forms on the resident matrix (x = 1) and keep the fastest.
+template <typename T>
+static int autotune_vector(spmv_dev *d)
+{
+    d->vec_choice = VEC_AUTO;
+    if (d->nnz < (1ll << 24) || d->plan.variant != 0 || !(d->vt_staged * 2 >= d->vt_tiles && d->vt_tiles > 0)) return SPMV_HIP_OK;
+    T *x = nullptr, *y = nullptr;
+    if (hipMalloc((void **) &x, sizeof(T) * (size_t) d->n) != hipSuccess || hipMalloc((void **) &y, sizeof(T) * (size_t) d->m) != hipSuccess) {
+        (void) hipGetLastError();
+        if (x) (void) hipFree(x);
+        return SPMV_HIP_OK; // no room to tune: keep the default
+    }
+    fill_value_kernel<T><<<grid_for(d->n, kBlock, d->cus * 8), kBlock, 0, d->stream>>>(d->n, x, T(1));
+    hipEvent_t e0, e1;
+    (void) hipEventCreate(&e0);
+    (void) hipEventCreate(&e1);
+    const int cand[3] = {VEC_TILE_D4, VEC_TILE_D2, VEC_PIPE};
+    float tmin[3] = {1e30f, 1e30f, 1e30f};
+    for (int c : cand) { d->vec_choice = c; launch_vector_any<T>(d, x, y); } // warm every form once
+    for (int round = 0; round < 4; ++round) // interleaved rounds (one process, same clocks): min per form
+        for (int k = 0; k < 3; ++k) {
+            d->vec_choice = cand[k];
+            (void) hipEventRecord(e0, d->stream);
+            launch_vector_any<T>(d, x, y);
+            launch_vector_any<T>(d, x, y);
+            (void) hipEventRecord(e1, d->stream);
+            (void) hipEventSynchronize(e1);
+            float ms = 0;
+            (void) hipEventElapsedTime(&ms, e0, e1);
+            if (ms * 0.5f < tmin[k]) tmin[k] = ms * 0.5f;
+        }
+    float best = 1e30f;
+    int best_c = VEC_AUTO;
+    for (int k = 0; k < 3; ++k) {
+        d->tune_ms[k] = tmin[k];
+        if (tmin[k] < best) { best = tmin[k]; best_c = cand[k]; }
+    }
+    d->vec_choice = best_c;
+    (void) hipEventDestroy(e0);
+    (void) hipEventDestroy(e1);
+    (void) hipFree(x);
+    (void) hipFree(y);
+    if (hipGetLastError() != hipSuccess) d->vec_choice = VEC_AUTO;
+    return SPMV_HIP_OK;
 }
 
 template <typename T, int SIGMA>
@@ -721,15 +798,7 @@ static int launch(spmv_dev *d, const T *x, T *y)
         csr_scalar_kernel<T><<<grid_for(d->m, kBlock, d->cus * 8), kBlock, 0, d->stream>>>(d->m, d->rowptr, d->colidx, val, x, y);
         break;
     case SPMV_SCHED_CSR_VECTOR:
-        switch (d->plan.lanes_per_row) {
-        case 1: launch_vector<T, 1>(d, x, y); break;
-        case 2: launch_vector<T, 2>(d, x, y); break;
-        case 4: launch_vector<T, 4>(d, x, y); break;
-        case 8: launch_vector<T, 8>(d, x, y); break;
-        case 16: launch_vector<T, 16>(d, x, y); break;
-        case 32: launch_vector<T, 32>(d, x, y); break;
-        default: launch_vector<T, 64>(d, x, y); break;
-        }
+        launch_vector_any<T>(d, x, y);
         if (d->plan.variant != 2) launch_long_rows<T>(d, x, y);
         break;
     case SPMV_SCHED_NNZ_SPLIT: {
@@ -901,9 +970,12 @@ extern "C" int spmv_shim_info(const spmv_dev *d, spmv_hip_info *o)
     const long long s = (long long) d->vsize;
     o->alg_bytes = 4ll * ((long long) d->m + 1) + d->nnz * (4 + s) + s * d->n + s * d->m;
     o->inspect_ms = d->inspect_ms;
+    o->tuned_choice = d->vec_choice;
+    for (int k = 0; k < 3; ++k) o->tune_ms[k] = d->tune_ms[k];
     o->schedule_name = kSchedNames[d->plan.sched];
     o->kernel_name = kKernelNames[d->plan.sched];
-    if (d->plan.sched == SPMV_SCHED_CSR_VECTOR && d->vt_tiles > 0 && d->vt_staged * 2 >= d->vt_tiles) o->kernel_name = "csr_vector_tile_kernel";
+    if (d->plan.sched == SPMV_SCHED_CSR_VECTOR && d->vt_tiles > 0 && d->vt_staged * 2 >= d->vt_tiles && d->vec_choice != VEC_PIPE)
+        o->kernel_name = "csr_vector_tile_kernel";
     if (d->plan.sched == SPMV_SCHED_NNZ_SPLIT && d->ns_groups > 0 && d->ns_staged * 2 >= d->ns_groups) o->kernel_name = "nnz_group_kernel";
     if (d->plan.sched == SPMV_SCHED_CSR5 && d->c5_staged * 2 >= d->c5_groups && d->c5_groups > 0) o->kernel_name = "csr5_group_kernel";
     if (d->plan.sched == SPMV_SCHED_SELL && d->plan.sell_lds_x && d->sell_staged * 2 >= d->sell_nwin && d->sell_nwin > 0) o->kernel_name = "sell_window_kernel";

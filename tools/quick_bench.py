@@ -64,7 +64,7 @@ for meth in [int(s) for s in a.methods.split(",")]:
         print(json.dumps(dict(method=api.SPMV_METHODS(meth).name, sched=info["schedule_name"], lanes=info["lanes_per_row"], variant=var,
               ms_mean=round(mean, 4), ms_min=round(float(ms.min()), 4), gbps_alg=round(float(gb / (ms.min() / 1e3)), 1),
               frac_8TBs=round(float(gb / (ms.min() / 1e3) / 8000), 3), gflops=round(float(2 * nnz / ms.min() / 1e6), 1),
-              inspect_ms=round(info["inspect_ms"], 2), stored=info["stored_nnz"], maxdiff_vs_first=err, nan=int(torch.isnan(y).sum().item()))), flush=True)
+              inspect_ms=round(info["inspect_ms"], 2), tuned=info["tuned_choice"], tune_ms=[round(v, 4) for v in info["tune_ms"]], stored=info["stored_nnz"], maxdiff_vs_first=err, nan=int(torch.isnan(y).sum().item()))), flush=True)
         if a.hostptr:
             xh, yh = x.cpu().numpy(), y.cpu().numpy().copy()
             api.set_stream(h.h, None, async_=False)
