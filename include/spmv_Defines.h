@@ -76,10 +76,12 @@ extern const char *funcNames[];
  *                    (reference does the same: parallel_balanced2_spmv.c:87-92, common.c:177-180)
  *   data_size        sizeof(double) or sizeof(float); anything != 8 is float (serial_spmv.c:48-54)
  *   nthreads         stored as given; the GPU schedules do not use host threads
- *   Level_3_opt_used always 0 (the METIS path is out of scope)
+ *   Level_3_opt_used 1 when option "reorder" produced a row/column permutation (then `index` is set), else 0
  *   RowPtr/ColIdx/Matrix_Val  the CALLER's pointers as passed to create (borrowed, never freed,
  *                    never written) -- used only to recognise the same matrix in spmv()
- *   index            always NULL (no row permutation is imposed on the caller)
+ *   index            NULL, or with option "reorder" the permutation (m ints, owned by the handle): the
+ *                    caller gathers XX[i] = X[index[i]] and scatters Y[index[i]] = YY[i] like the
+ *                    reference's harness does (test_spmv.c:95-101, 130-137)
  *   Y_temp           always NULL
  *   extraHandle      opaque device-side state (struct spmv_hip_state, private)
  */

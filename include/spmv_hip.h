@@ -51,6 +51,10 @@ int spmv_hip_synchronize(spmv_Handle_t handle);
  *       "variant" (kernel variant selector used by the tuning harness, 0 = default)
  *       "autotune" (0/1, default 1: for matrices above 2^24 nnz create() times the applicable CSR-vector
  *                   kernel forms once on the resident matrix and keeps the fastest, ~10 ms)
+ *       "reorder" (0/1, default 0: square matrices are RCM-reordered at create, B = P A P^T is what stays
+ *                  resident, and handle->index holds the permutation -- the caller gathers
+ *                  XX[i] = X[index[i]] and scatters Y[index[i]] = YY[i] exactly as the reference's harness
+ *                  does for its OPT_LEVEL 3 path, test_spmv.c:95-101, 130-137)
  *       "auto_method" (0/1: create() replaces the requested method by the one its row statistics
  *                      favour -- CSR-vector for regular rows, CSR5 otherwise; the handle reports it)
  * Each key can also be preset with the environment variable SPMV_HIP_<KEY IN CAPS>.

@@ -303,6 +303,14 @@ class Handle:
     def info(self):
         return get_info(self.h)
 
+    @property
+    def index(self):
+        """handle->index as a numpy array (the RCM permutation when option "reorder" is on), else None."""
+        p = self.h.contents.index
+        if not p:
+            return None
+        return np.ctypeslib.as_array(p, shape=(self.m,)).copy()
+
     def spmv(self, x, y):
         rp, ci, va = self._keep
         spmv(self.h, self.m, rp, ci, va, x, y)

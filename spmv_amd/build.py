@@ -26,7 +26,7 @@ HIPCC = os.environ.get("HIPCC") or shutil.which("hipcc") or "/opt/rocm/bin/hipcc
 CC = os.environ.get("CC") or "gcc"
 ARCH = "gfx950"
 
-C_SOURCES = ["spmv_api.c", "spmv_plan.c", os.path.join("io", "mtx_io.c")]
+C_SOURCES = ["spmv_api.c", "spmv_plan.c", os.path.join("io", "mtx_io.c"), os.path.join("reorder", "rcm.c")]
 TOOL_SOURCES = {"test_spmv": os.path.join("tools", "test_spmv_csv.c")}   # -> spmv_amd/bin/<name>
 BINDIR = os.path.join(PKG, "bin")
 ROCM = os.environ.get("ROCM_PATH", "/opt/rocm")

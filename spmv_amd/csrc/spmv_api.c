@@ -22,6 +22,7 @@
 #include "spmv_hip.h"
 #include "spmv_internal.h"
 #include "spmv_shim.h"
+#include "reorder/rcm.h"
 
 /* ---------------------------------------------------------------- name tables (ABI data symbols) */
 const char *Methods_names[] = {
@@ -68,8 +69,16 @@ static void handle_reset(spmv_Handle_t h) /* common.c:18-29 */
     h->extraHandle = NULL;
 }
 
+static void index_free(spmv_Handle_t h)
+{
+    if (h->Level_3_opt_used && h->index) free(h->index); /* the permutation is owned by the handle (common.c:44-50) */
+    h->index = NULL;
+    h->Level_3_opt_used = 0;
+}
+
 static void state_free(spmv_Handle_t h)
 {
+    index_free(h);
     spmv_hip_state *st = (spmv_hip_state *) h->extraHandle;
     if (st) {
         if (st->dev) spmv_shim_matrix_destroy(st->dev);
@@ -92,6 +101,37 @@ void spmv_destory_handle(spmv_Handle_t h) /* common.c:54-61 */
     free(h);
 }
 
+/* Option "reorder" (SURVEY 8f f-4): RCM on host copies of the pattern, B = P A P^T uploaded instead
+ * of A, the permutation published in handle->index -- the protocol of the reference's OPT_LEVEL 3
+ * path (common.c:144-156: permuted copy + index; test_spmv.c:95-101,130-137: the caller gathers
+ * XX[i] = X[index[i]] before spmv() and scatters Y[index[i]] = YY[i] after).  Returns 0 when the
+ * permuted matrix is resident, non-zero to fall back to the unpermuted upload. */
+static int upload_reordered(spmv_Handle_t h, spmv_hip_state *st, int m, int n, const int *RowPtr,
+                            const int *ColIdx, const void *Val)
+{
+    const size_t vs = h->data_size == sizeof(double) ? sizeof(double) : sizeof(float);
+    int *rp = (int *) malloc(sizeof(int) * ((size_t) m + 1)), *ci = NULL, *perm = NULL, *rp2 = NULL, *ci2 = NULL;
+    void *va = NULL, *va2 = NULL;
+    int rc = 1, nnz;
+    if (!rp || spmv_shim_copy_to_host(rp, RowPtr, sizeof(int) * ((size_t) m + 1))) goto out;
+    nnz = rp[m];
+    if (rp[0] != 0 || nnz < 0) goto out;
+    ci = (int *) malloc(sizeof(int) * (size_t) (nnz ? nnz : 1));
+    va = malloc(vs * (size_t) (nnz ? nnz : 1));
+    perm = (int *) malloc(sizeof(int) * (size_t) m);
+    if (!ci || !va || !perm) goto out;
+    if (spmv_shim_copy_to_host(ci, ColIdx, sizeof(int) * (size_t) nnz) || spmv_shim_copy_to_host(va, Val, vs * (size_t) nnz)) goto out;
+    if (spmv_rcm_order(m, rp, ci, perm) || spmv_permute_csr(m, rp, ci, va, vs, perm, &rp2, &ci2, &va2)) goto out;
+    if (spmv_shim_matrix_create(&st->dev, m, n, rp2, ci2, va2, vs) != SPMV_HIP_OK) goto out;
+    h->index = perm;
+    h->Level_3_opt_used = 1;
+    perm = NULL;
+    rc = 0;
+out:
+    free(rp); free(ci); free(va); free(perm); free(rp2); free(ci2); free(va2);
+    return rc;
+}
+
 /* Upload + plan + inspect.  Used by create and by spmv() when it is handed another matrix. */
 static int state_build(spmv_Handle_t h, spmv_hip_state *st, int m, int n, const int *RowPtr,
                        const int *ColIdx, const void *Val)
@@ -104,7 +144,11 @@ static int state_build(spmv_Handle_t h, spmv_hip_state *st, int m, int n, const 
         spmv_set_error(SPMV_HIP_E_ARG, "create", "negative size or NULL RowPtr");
         return SPMV_HIP_E_ARG;
     }
-    rc = spmv_shim_matrix_create(&st->dev, m, n, RowPtr, ColIdx, Val, (size_t) h->data_size);
+    index_free(h);
+    rc = -1;
+    if (spmv_hip_get_option("reorder") == 1 && m == n && m > 1 && RowPtr && ColIdx && Val)
+        rc = upload_reordered(h, st, m, n, RowPtr, ColIdx, Val); /* 0 = uploaded the permuted matrix */
+    if (rc != 0) rc = spmv_shim_matrix_create(&st->dev, m, n, RowPtr, ColIdx, Val, (size_t) h->data_size);
     if (rc) { spmv_set_error(rc, "create/upload", spmv_shim_error_text()); return rc; }
     rc = spmv_shim_matrix_stats(st->dev, &stats);
     if (rc) { spmv_set_error(rc, "create/stats", spmv_shim_error_text()); return rc; }

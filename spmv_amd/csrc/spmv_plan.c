@@ -36,7 +36,8 @@ static opt_t g_opts[] = {
     {"rowblock_nnz", 0, 0, 1 << 20, 0, 0},
     {"variant", 0, 0, 1 << 20, 0, 0},
     {"auto_method", 0, 0, 1, 0, 0},
-    {"autotune", 1, 0, 1, 0, 0},           /* 1: create() times the CSR-vector kernel forms on big matrices */        /* 1: create() picks the schedule from the row statistics */
+    {"autotune", 1, 0, 1, 0, 0},
+    {"reorder", 0, 0, 1, 0, 0},            /* 1: square matrices are RCM-reordered at create; handle->index = permutation */           /* 1: create() times the CSR-vector kernel forms on big matrices */        /* 1: create() picks the schedule from the row statistics */
 };
 #define N_OPTS ((int) (sizeof g_opts / sizeof g_opts[0]))
 

@@ -293,6 +293,14 @@ extern "C" int spmv_shim_matrix_create(spmv_dev **out, int m, int n, const int *
     return SPMV_HIP_OK;
 }
 
+extern "C" int spmv_shim_copy_to_host(void *dst, const void *src, size_t bytes)
+{
+    if (bytes == 0) return SPMV_HIP_OK;
+    if (!dst || !src) return fail(SPMV_HIP_E_ARG, "copy_to_host: NULL");
+    HIP_TRY(hipMemcpy(dst, src, bytes, hipMemcpyDefault));
+    return SPMV_HIP_OK;
+}
+
 extern "C" int spmv_shim_matrix_stats(const spmv_dev *d, spmv_stats *out)
 {
     if (!d || !out) return fail(SPMV_HIP_E_ARG, "stats: NULL");

@@ -55,6 +55,7 @@ static int run_method(const char *name, int m, int n, int nnz, int *rowptr, int 
     struct timeval t1, t2;
     spmv_Handle_t h = NULL;
     void *xd = NULL, *yd = NULL, *yh = malloc(vs * (size_t) (m ? m : 1));
+    void *x_perm = malloc(vs * (size_t) ((m > n ? m : n) + 1));
     const void *xa;
     void *ya;
     double create_ms, total = 0, best = 1e9, rmse = 0;
@@ -65,6 +66,11 @@ static int run_method(const char *name, int m, int n, int nnz, int *rowptr, int 
     gettimeofday(&t2, NULL);
     create_ms = ms_between(&t1, &t2);
     if (spmv_hip_last_error()) { fprintf(stderr, "%s\n", spmv_hip_last_error_string()); spmv_destory_handle(h); free(yh); return 1; }
+    if (h->index) { /* reordered handle: gather x like test_spmv.c:95-101 (x = 1 here, kept for form) */
+        int i;
+        for (i = 0; i < m; ++i) put(x_perm, vs, i, get(x_host, vs, h->index[i]));
+        x_host = x_perm;
+    }
     if (host_vectors) {
         xa = x_host;
         ya = yh;
@@ -89,8 +95,8 @@ static int run_method(const char *name, int m, int n, int nnz, int *rowptr, int 
     }
     total /= 100.0;
     if (!host_vectors) (void) hipMemcpy(yh, yd, vs * (size_t) m, hipMemcpyDeviceToHost);
-    for (it = 0; it < m; ++it) {
-        const double d = get(yh, vs, it) - golden[it];
+    for (it = 0; it < m; ++it) { /* scatter back through index like test_spmv.c:130-137 */
+        const double d = get(yh, vs, it) - golden[h->index ? h->index[it] : it];
         rmse += d / m * d;
     }
     rmse = sqrt(rmse);
@@ -100,6 +106,7 @@ static int run_method(const char *name, int m, int n, int nnz, int *rowptr, int 
     if (xd) (void) hipFree(xd);
     if (yd) (void) hipFree(yd);
     free(yh);
+    free(x_perm);
     return spmv_hip_last_error() != 0;
 }
 

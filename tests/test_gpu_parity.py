@@ -265,3 +265,43 @@ def test_m_zero_and_n_zero():
     api.spmv(h, 0, rp, np.zeros(0, np.int32), np.zeros(0), np.zeros(0), np.zeros(0))
     assert lib.spmv_hip_last_error() == 0
     api.spmv_destory_handle(h)
+
+
+def test_reorder_option_follows_the_reference_index_protocol():
+    """SURVEY 8f f-4.  A band matrix scrambled by a random symmetric permutation: with option
+    "reorder" create() RCM-reorders it, publishes the permutation in handle->index, and the caller
+    gathers x / scatters y exactly as test_spmv.c:95-101, 130-137 does for OPT_LEVEL 3."""
+    rng = np.random.default_rng(3)
+    m = 20000                                    # scrambled column spans (~m) must exceed the 48 KiB LDS x budget
+    band = synth.banded(m, m, 6, 5, "eighths", np.float64, seed=8)
+    sc = rng.permutation(m)                      # scrambled row r = band row sc[r]
+    inv = np.empty(m, dtype=np.int64); inv[sc] = np.arange(m)
+    lens = np.diff(band.rowptr)[sc]
+    rp = np.zeros(m + 1, dtype=np.int32); np.cumsum(lens, out=rp[1:])
+    ci = np.empty(band.nnz, dtype=np.int32); va = np.empty(band.nnz)
+    for r in range(m):
+        s0, s1 = band.rowptr[sc[r]], band.rowptr[sc[r] + 1]
+        ci[rp[r]:rp[r + 1]] = inv[band.colidx[s0:s1]]
+        va[rp[r]:rp[r + 1]] = band.val[s0:s1]
+    A = synth.CSR(m, m, rp, ci, va)
+    x = synth.fill_x(m, "eighths", np.float64, 5)
+    want = oracle.spmv_serial(A, x)
+    api.set_option("reorder", 1)
+    try:
+        for method in (M.Method_Parallel, M.Method_CSR5SPMV, M.Method_SellCSigma):
+            with api.Handle(m, m, A.rowptr, A.colidx, A.val, method) as h:
+                index = h.index
+                assert index is not None and h.h.contents.Level_3_opt_used == 1
+                assert np.array_equal(np.sort(index), np.arange(m))
+                xx = x[index]                                   # XX[i] = X[index[i]]
+                yy = np.full(m, np.nan)
+                h.spmv(xx, yy)
+                y = np.empty(m); y[index] = yy                   # Y[index[i]] = YY[i]
+                assert np.array_equal(y, want), method
+                if method == M.Method_Parallel:
+                    assert h.info()["kernel_name"] == "csr_vector_tile_kernel"   # band recovered: x tiles fit LDS
+    finally:
+        api.set_option("reorder", 0)
+    with api.Handle(m, m, A.rowptr, A.colidx, A.val, M.Method_Parallel) as h:
+        assert h.index is None and h.h.contents.Level_3_opt_used == 0
+        assert h.info()["kernel_name"] == "csr_vector_pipe_kernel"               # scrambled: spans too wide
