@@ -9,9 +9,9 @@
  *   Method_Parallel      -> CSR-vector, L lanes per row from the mean row length
  *   Method_Balanced(2)   -> same rule as the reference's parallel_balanced2_get_handle
  *                           (parallel_balanced2_spmv.c:72-92): if some row is longer than one
- *                           equal-nnz share ("stride") the handle becomes Method_Balanced2 =
- *                           nnz-split with carries, otherwise Method_Balanced = equal-nnz row
- *                           blocks.  On the GPU the share is the nnz capacity of one workgroup.
+ *                           worker's share the handle becomes Method_Balanced2 = nnz-split with
+ *                           carries, otherwise Method_Balanced = equal-nnz row blocks.  On the GPU
+ *                           the worker is a lane group (64 steps of 4L elements).
  *   Method_Balanced_Yid  -> nnz-split with carries (parallel_balanced_Yid_spmv.c:16-53 semantics)
  *   Method_SellCSigma    -> SELL-C-sigma, C = 64, sigma = 1024
  *   Method_CSR5SPMV      -> CSR5, omega = 64 (fp32 too: the reference falls back to SELL for
@@ -130,8 +130,14 @@ void spmv_plan_choose(SPMV_METHODS requested, const spmv_stats *st, size_t value
         plan->sched = SPMV_SCHED_CSR_VECTOR;
         break;
     case Method_Balanced:
-    case Method_Balanced2:
-        if (st->max_row_len > plan->rowblock_nnz) {
+    case Method_Balanced2: {
+        /* the reference flips to Balanced2 when some row is longer than one worker's equal-nnz share
+         * (parallel_balanced2_spmv.c:72-92).  Here a worker of the row-granular schedule is one lane
+         * group: 64 steps of 4L elements (beyond that the long-row kernels take over), capped by the
+         * workgroup share. */
+        int worker_share = plan->lanes_per_row * 64 > 256 ? plan->lanes_per_row * 64 : 256;
+        if (worker_share > plan->rowblock_nnz) worker_share = plan->rowblock_nnz;
+        if (st->max_row_len > worker_share) {
             *actual = Method_Balanced2;
             plan->sched = SPMV_SCHED_NNZ_SPLIT;
         } else {
@@ -139,6 +145,7 @@ void spmv_plan_choose(SPMV_METHODS requested, const spmv_stats *st, size_t value
             plan->sched = SPMV_SCHED_ROWBLOCK;
         }
         break;
+    }
     case Method_Balanced_Yid:
         plan->sched = SPMV_SCHED_NNZ_SPLIT;
         break;

@@ -108,15 +108,11 @@ def test_balanced_request_is_rewritten_like_the_reference():
     than one equal-nnz share, Balanced otherwise."""
     short, x1, _ = load_golden("banded_f64_eighths")
     long_, x2, _ = load_golden("single_long_f64_eighths")       # one row of 5000 nnz
+    skew, x3, _ = load_golden("skewed_f64_eighths")            # mean 55, rows up to 4000
     for req in (M.Method_Balanced, M.Method_Balanced2):
         assert run_host(short, x1, req)[1] == M.Method_Balanced
-        assert run_host(long_, x2, req)[1] == M.Method_Balanced      # default share 8192 >= 5000
-    api.set_option("rowblock_nnz", 1024)                            # share smaller than the row
-    try:
-        for req in (M.Method_Balanced, M.Method_Balanced2):
-            assert run_host(long_, x2, req)[1] == M.Method_Balanced2
-    finally:
-        api.set_option("rowblock_nnz", 0)
+        assert run_host(long_, x2, req)[1] == M.Method_Balanced2    # 5000 > 64 steps x 4 x 64 lanes... of one lane group
+        assert run_host(skew, x3, req)[1] == M.Method_Balanced2
 
 
 @pytest.mark.parametrize("method", ALL_METHODS, ids=lambda m: m.name)

@@ -19,6 +19,7 @@ ap.add_argument("--maxlen", type=int, default=100000)
 ap.add_argument("--hostptr", action="store_true")
 ap.add_argument("--local", type=int, default=4096)
 ap.add_argument("--sortcols", action="store_true")
+ap.add_argument("--reorder", default="0")
 a = ap.parse_args()
 build.build()
 dt = torch.float64 if a.dtype == "f64" else torch.float32
@@ -26,6 +27,15 @@ dev = "cuda:0"
 t0 = time.time()
 if a.kind == "banded":
     m, n, rp, ci, va = synth.banded_device(a.m, a.m, a.k, "uniform", dt, dev, 1)
+elif a.kind == "scrambled":   # banded, then a random symmetric permutation of rows and columns
+    m = n = a.m
+    g = torch.Generator(device=dev); g.manual_seed(5)
+    sc = torch.randperm(m, generator=g, device=dev)
+    inv = torch.empty_like(sc); inv[sc] = torch.arange(m, device=dev)
+    offs = torch.arange(a.k, device=dev) - a.k // 2
+    ci = inv[(sc[:, None] + offs[None, :]) % n].reshape(-1).to(torch.int32)
+    rp = torch.arange(0, (m + 1) * a.k, a.k, dtype=torch.int32, device=dev)
+    va = torch.rand(m * a.k, generator=g, device=dev, dtype=dt) * 2 - 1
 elif a.kind == "random":
     m, n, rp, ci, va = synth.uniform_k_device(a.m, a.m, a.k, "uniform", dt, dev, 1)
 elif a.kind == "skewed":
@@ -47,24 +57,31 @@ yref = None
 for meth in [int(s) for s in a.methods.split(",")]:
     for lanes in [int(s) for s in a.lanes.split(",")]:
       for var in [int(s) for s in a.variants.split(",")]:
+       for reo in [int(s) for s in a.reorder.split(",")]:
+        api.set_option("reorder", reo)
         api.set_option("lanes_per_row", lanes)
         api.set_option("variant", var)
+        tcr = time.time()
         try:
             h = api.Handle(m, n, rp, ci, va, meth)
         except api.SpmvError as e:
             print("skip", meth, e); continue
+        tcreate = time.time() - tcr
         info = h.info()
         y.fill_(float("nan"))
         mean, ms = api.time_launches(h.h, x, y, 5, a.iters)
         torch.cuda.synchronize()
-        if yref is None:
+        yc = y
+        if h.index is not None:     # reordered handle: y came out permuted (and x was not gathered: timing only)
+            yc = None
+        if yref is None and yc is not None:
             yref = y.clone()
-        err = (y - yref).abs().max().item()
+        err = (y - yref).abs().max().item() if (yc is not None and yref is not None) else float("nan")
         gb = info["alg_bytes"] / 1e9
         print(json.dumps(dict(method=api.SPMV_METHODS(meth).name, sched=info["schedule_name"], lanes=info["lanes_per_row"], variant=var,
               ms_mean=round(mean, 4), ms_min=round(float(ms.min()), 4), gbps_alg=round(float(gb / (ms.min() / 1e3)), 1),
               frac_8TBs=round(float(gb / (ms.min() / 1e3) / 8000), 3), gflops=round(float(2 * nnz / ms.min() / 1e6), 1),
-              inspect_ms=round(info["inspect_ms"], 2), tuned=info["tuned_choice"], tune_ms=[round(v, 4) for v in info["tune_ms"]], stored=info["stored_nnz"], maxdiff_vs_first=err, nan=int(torch.isnan(y).sum().item()))), flush=True)
+              inspect_ms=round(info["inspect_ms"], 2), reorder=reo, tc0=round(tcreate, 2), kernel=info["kernel_name"], tuned=info["tuned_choice"], tune_ms=[round(v, 4) for v in info["tune_ms"]], stored=info["stored_nnz"], maxdiff_vs_first=err, nan=int(torch.isnan(y).sum().item()))), flush=True)
         if a.hostptr:
             xh, yh = x.cpu().numpy(), y.cpu().numpy().copy()
             api.set_stream(h.h, None, async_=False)
