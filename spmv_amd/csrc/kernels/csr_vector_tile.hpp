@@ -126,7 +126,7 @@ __device__ __forceinline__ void csr_vector_tile_wave(long long row_end, int long
     if (row < row_end && len <= long_thr) y[row] = y_lds[lane]; // one coalesced 64-row store per wave
 }
 
-template <typename T, int L, int DEPTH = 4>
+template <typename T, int L, int DEPTH = 4, bool PRE = true>
 __global__ __launch_bounds__(kVecTileThreads) void csr_vector_tile_kernel(int m, int long_thr, const int *__restrict__ rowptr,
                                                                  const int *__restrict__ colidx,
                                                                  const T *__restrict__ val,
@@ -150,9 +150,9 @@ __global__ __launch_bounds__(kVecTileThreads) void csr_vector_tile_kernel(int m,
     const int lo = tile_lo[blockIdx.x], span = tile_span[blockIdx.x];
     // step 0 of the matrix stream is issued straight from registers (RowPtr handed over by
     // shuffles), BEFORE the x staging and the barrier, so neither sits in front of the first loads
-    int c0[4];
-    T v0[4];
-    {
+    int c0[4] = {0, 0, 0, 0};
+    T v0[4] = {T(0), T(0), T(0), T(0)};
+    if (PRE) {
         const int sub = lane / L, l = lane % L;
         const int q0 = __shfl(rp, sub, kWave);
         const int nx = __shfl(rp, (sub + 1) & (kWave - 1), kWave);
@@ -167,8 +167,8 @@ __global__ __launch_bounds__(kVecTileThreads) void csr_vector_tile_kernel(int m,
     for (int i = threadIdx.x; i < span; i += kVecTileThreads) xs[i] = x[lo + i];
     __syncthreads();
     if (rw0 >= m) return;
-    if (span > 0) csr_vector_tile_wave<T, L, true, DEPTH>((long long) m, long_thr, rw0, lane, rp_lds[wave], y_lds[wave], colidx, val, x, xs, lo, y, c0, v0);
-    else csr_vector_tile_wave<T, L, false, DEPTH>((long long) m, long_thr, rw0, lane, rp_lds[wave], y_lds[wave], colidx, val, x, xs, lo, y, c0, v0);
+    if (span > 0) csr_vector_tile_wave<T, L, true, DEPTH, PRE>((long long) m, long_thr, rw0, lane, rp_lds[wave], y_lds[wave], colidx, val, x, xs, lo, y, c0, v0);
+    else csr_vector_tile_wave<T, L, false, DEPTH, PRE>((long long) m, long_thr, rw0, lane, rp_lds[wave], y_lds[wave], colidx, val, x, xs, lo, y, c0, v0);
     (void) RW;
 }
 

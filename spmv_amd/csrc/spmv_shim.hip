@@ -661,15 +661,16 @@ constexpr int kVecNB = 4;
 // Kernel forms of the CSR-vector schedule.  Which one is fastest differs between MI355X boxes by a
 // few percent, so create() times the applicable ones once on the resident matrix
 // (autotune_vector) and keeps the winner in d->vec_choice; plan.variant overrides for A/B runs.
-enum { VEC_AUTO = 0, VEC_STRIDED = 1, VEC_NO_LONG = 2, VEC_PIPE = 4, VEC_TILE_D2 = 5, VEC_TILE_D8 = 6, VEC_TILE_D4 = 10 };
+enum { VEC_AUTO = 0, VEC_STRIDED = 1, VEC_NO_LONG = 2, VEC_PIPE = 4, VEC_TILE_D2 = 5, VEC_TILE_D8 = 6, VEC_TILE_D4 = 10, VEC_TILE_D4_NOPRE = 11,
+       VEC_TILE_D2_NOPRE = 12 };
 
-template <typename T, int L, int DEPTH>
+template <typename T, int L, int DEPTH, bool PRE = true>
 static void launch_vector_tile(spmv_dev *d, const T *x, T *y, int long_thr)
 {
     const size_t lds = (((size_t) d->vt_maxspan * sizeof(T)) + 1023) & ~(size_t) 1023;
     if (lds > 64 * 1024)
-        (void) hipFuncSetAttribute((const void *) csr_vector_tile_kernel<T, L, DEPTH>, hipFuncAttributeMaxDynamicSharedMemorySize, (int) lds);
-    csr_vector_tile_kernel<T, L, DEPTH><<<d->vt_tiles, kVecTileThreads, lds, d->stream>>>(d->m, long_thr, d->rowptr, d->colidx, (const T *) d->val,
+        (void) hipFuncSetAttribute((const void *) csr_vector_tile_kernel<T, L, DEPTH, PRE>, hipFuncAttributeMaxDynamicSharedMemorySize, (int) lds);
+    csr_vector_tile_kernel<T, L, DEPTH, PRE><<<d->vt_tiles, kVecTileThreads, lds, d->stream>>>(d->m, long_thr, d->rowptr, d->colidx, (const T *) d->val,
                                                                                       d->vt_lo, d->vt_span, x, y);
 }
 
@@ -687,6 +688,8 @@ static void launch_vector(spmv_dev *d, const T *x, T *y)
         if (v == VEC_TILE_D2) launch_vector_tile<T, L, 2>(d, x, y, long_thr);
         else if (v == VEC_TILE_D8) launch_vector_tile<T, L, 8>(d, x, y, long_thr);
         else if (v == VEC_TILE_D4) launch_vector_tile<T, L, 4>(d, x, y, long_thr);
+        else if (v == VEC_TILE_D4_NOPRE) launch_vector_tile<T, L, 4, false>(d, x, y, long_thr);
+        else if (v == VEC_TILE_D2_NOPRE) launch_vector_tile<T, L, 2, false>(d, x, y, long_thr);
         else launch_vector_tile<T, L, (sizeof(T) == 8 ? 4 : 2)>(d, x, y, long_thr); // measured default
         return;
     }
