@@ -203,6 +203,24 @@ __global__ __launch_bounds__(kBlock) void count_longer_kernel(int m, int thr, co
     if ((threadIdx.x & (kWave - 1)) == 0 && c) atomicAdd(count, c);
 }
 
+// min / max of ColIdx (create-time validation: an index outside [0, n) would make a gather fault)
+__global__ __launch_bounds__(kBlock) void colidx_range_kernel(long long nnz, const int *__restrict__ colidx, int *__restrict__ mnmx)
+{
+    int mn = INT_MAX, mx = INT_MIN;
+    const long long stride = (long long) gridDim.x * kBlock;
+    for (long long i = (long long) blockIdx.x * kBlock + threadIdx.x; i < nnz; i += stride) {
+        const int c = ld_stream(colidx + i);
+        mn = min(mn, c);
+        mx = max(mx, c);
+    }
+#pragma unroll
+    for (int o = kWave / 2; o > 0; o >>= 1) {
+        mn = min(mn, __shfl_xor(mn, o, kWave));
+        mx = max(mx, __shfl_xor(mx, o, kWave));
+    }
+    if ((threadIdx.x & (kWave - 1)) == 0) { atomicMin(mnmx, mn); atomicMax(mnmx + 1, mx); }
+}
+
 template <typename T>
 __global__ __launch_bounds__(kBlock) void fill_value_kernel(long long n, T *y, T v)
 {
@@ -288,6 +306,17 @@ extern "C" int spmv_shim_matrix_create(spmv_dev **out, int m, int n, const int *
         if (hipMemcpy(d->colidx, colidx, sizeof(int) * (size_t) d->nnz, hipMemcpyDefault) != hipSuccess ||
             hipMemcpy(d->val, val, d->vsize * (size_t) d->nnz, hipMemcpyDefault) != hipSuccess)
             return bail(fail(SPMV_HIP_E_RUNTIME, "copy ColIdx/Val to HBM: %s", hipGetErrorString(hipGetLastError())));
+        // every column index must address x: the reference would read out of bounds, a GPU would fault
+        int host2[2] = {INT_MAX, INT_MIN};
+        int *mnmx = nullptr;
+        if (hipMalloc((void **) &mnmx, sizeof host2) != hipSuccess) return bail(fail(SPMV_HIP_E_ALLOC, "hipMalloc(colidx range)"));
+        (void) hipMemcpy(mnmx, host2, sizeof host2, hipMemcpyHostToDevice);
+        colidx_range_kernel<<<grid_for(d->nnz, kBlock * 16, d->cus * 8), kBlock>>>(d->nnz, d->colidx, mnmx);
+        const hipError_t e2 = hipMemcpy(host2, mnmx, sizeof host2, hipMemcpyDeviceToHost);
+        (void) hipFree(mnmx);
+        if (e2 != hipSuccess) return bail(fail(SPMV_HIP_E_RUNTIME, "colidx range kernel: %s", hipGetErrorString(e2)));
+        if (host2[0] < 0 || host2[1] >= n)
+            return bail(fail(SPMV_HIP_E_ARG, "ColIdx out of range: min %d, max %d, n = %d", host2[0], host2[1], n));
     }
     *out = d;
     return SPMV_HIP_OK;

@@ -301,3 +301,21 @@ def test_reorder_option_follows_the_reference_index_protocol():
     with api.Handle(m, m, A.rowptr, A.colidx, A.val, M.Method_Parallel) as h:
         assert h.index is None and h.h.contents.Level_3_opt_used == 0
         assert h.info()["kernel_name"] == "csr_vector_pipe_kernel"               # scrambled: spans too wide
+
+
+def test_out_of_range_column_index_is_rejected_at_create(monkeypatch):
+    """An index outside [0, n) makes the reference read out of bounds; on a GPU it would fault, so
+    create() validates ColIdx and reports SPMV_HIP_E_ARG instead."""
+    monkeypatch.setenv("SPMV_HIP_QUIET", "1")
+    csr, x, _ = load_golden("banded_f64_eighths")
+    bad = csr.colidx.copy()
+    bad[17] = csr.n
+    with pytest.raises(api.SpmvError, match="ColIdx out of range"):
+        api.Handle(csr.m, csr.n, csr.rowptr, bad, csr.val)
+    bad[17] = -1
+    with pytest.raises(api.SpmvError, match="ColIdx out of range"):
+        api.Handle(csr.m, csr.n, csr.rowptr, bad, csr.val)
+    rp = csr.rowptr.copy()
+    rp[5] = rp[6] + 1                                   # decreasing RowPtr
+    with pytest.raises(api.SpmvError, match="RowPtr"):
+        api.Handle(csr.m, csr.n, rp, csr.colidx, csr.val)
