@@ -1,17 +1,26 @@
-// csr_vector_tile.hpp -- CSR-vector over 256-row tiles with an LDS-staged x window.
+// csr_vector_tile.hpp -- CSR-vector over row tiles with LDS-staged x windows.
 //
 // Same schedule as csr_vector_pipe_kernel (L lanes per row over plain CSR; reference:
 // parallel_spmv.c:12-18 + inner_spmv.h:232-286), organised like the tile kernels that measured
 // best on this chip:
-//   - a 256-thread workgroup owns 256 consecutive rows, a wave 64 of them (L steps of 64/L rows);
+//   - a 256-thread workgroup owns a tile of consecutive rows (256 for Method_Parallel, one
+//     equal-nnz row block for Method_Balanced), a wave 64 of them at a time (L steps of 64/L rows);
 //   - the 65 RowPtr values a wave needs are read by ONE coalesced load and handed to the lane
 //     groups through LDS (no per-row dependent RowPtr load in front of the matrix stream);
-//   - the columns those 256 rows reference span [lo, lo+span) (found once by the inspector,
-//     csr_tile_span_kernel); when the span fits the LDS budget the workgroup stages x[lo..] once,
-//     coalesced, and every gather is an LDS read -- north_star's "LDS staging of x-vector tiles";
-//   - matrix stream: 16 B lane loads, two steps in flight (as in the pipe kernel);
+//   - x WINDOWS (north_star: "LDS staging of x-vector tiles"): the inspector
+//     (csr_tile_windows_kernel) finds, per tile, up to 16 column windows that cover every column
+//     its rows reference -- one window when the plain span [min, max] fits the LDS budget (banded
+//     matrices), several when the columns sit in a few far-apart bands (3-D stencils: 9 windows of
+//     ~260 columns for a 27-point stencil) -- and writes a tile-local copy of ColIdx in which each
+//     entry already IS the LDS slot of its column.  The executor stages the windows once per tile
+//     (coalesced) and every gather is xs[col_local], with no index arithmetic at all.  Tiles whose
+//     columns do not fit keep global indices in col_local and gather from L1/L2;
+//   - matrix stream: 16 B lane loads, DEPTH steps in flight per wave;
 //   - the 64 row sums of a wave are collected through LDS and written by ONE coalesced store.
-// Rows longer than long_thr are left to kernels/long_rows.hpp and excluded from the span.
+// Rows longer than long_thr are left to kernels/long_rows.hpp (which reads the ORIGINAL ColIdx) and
+// are excluded from the windows.
+// Extra HBM held: col_local int32[nnz] (read INSTEAD of ColIdx by this kernel: same traffic) and
+// 200 B of window table per tile.
 #pragma once
 #include <climits>
 #include "common.hpp"
@@ -20,23 +29,48 @@
 namespace spmv {
 
 constexpr int kVecTileThreads = 256;           // 4 wavefronts per workgroup (512 measured no better)
-constexpr int kVecTileRows = kVecTileThreads; // rows per workgroup (64 per wave)
+constexpr int kVecTileRows = kVecTileThreads;  // rows per workgroup slab (64 per wave)
+constexpr int kWinMax = 16;                    // windows per tile
+constexpr int kWinSegShift = 6;                // windows are built from 64-column segments
+constexpr int kWinBitmapWords = 1024;          // 32768 segments: spans up to 2M columns are analysed
 
-// Inspector: per 256-row tile, min / max column over its rows with len <= long_thr.
-__global__ __launch_bounds__(kBlock) void csr_tile_span_kernel(int m, int long_thr, int max_span,
-                                                               const int *__restrict__ rowptr,
-                                                               const int *__restrict__ colidx,
-                                                               int *__restrict__ tile_lo, int *__restrict__ tile_span,
-                                                               int *__restrict__ staged /* [0] count, [1] max span */)
+struct TileWindows {
+    int nwin;            // 0: tile not staged (col_local holds global columns)
+    int total;           // staged elements = sum of len
+    int start[kWinMax];  // first column of each window (ascending)
+    int len[kWinMax];
+    int base[kWinMax];   // LDS slot of the window's first column
+};
+
+// Row range of tile b: fixed 256-row tiles, or the equal-nnz blocks of `split` (Method_Balanced).
+__device__ __forceinline__ void tile_rows(int b, int m, const int *__restrict__ split, long long &r0, long long &r1)
 {
-    __shared__ int smin[kBlock / kWave], smax[kBlock / kWave];
-    const long long r0 = (long long) blockIdx.x * kVecTileRows;
+    if (split) { r0 = split[b]; r1 = split[b + 1]; }
+    else { r0 = (long long) b * kVecTileRows; r1 = r0 + kVecTileRows < m ? r0 + kVecTileRows : m; }
+}
+
+// Inspector: windows of one tile + the tile-local column copy.  col_local must be pre-filled with
+// a copy of ColIdx (entries of unstaged tiles and of long rows keep their global value).
+__global__ __launch_bounds__(kBlock) void csr_tile_windows_kernel(int m, int n, int long_thr, int max_cols,
+                                                                  const int *__restrict__ split,
+                                                                  const int *__restrict__ rowptr,
+                                                                  const int *__restrict__ colidx,
+                                                                  TileWindows *__restrict__ wins,
+                                                                  int *__restrict__ col_local,
+                                                                  int *__restrict__ staged /* [0] tiles staged, [1] max total */)
+{
+    __shared__ unsigned bitmap[kWinBitmapWords];
+    __shared__ int smin[kBlock / kWave], smax[kBlock / kWave], wave_cnt[kBlock / kWave];
+    __shared__ int s_start[kWinMax], s_end[kWinMax], s_base[kWinMax];
+    __shared__ int s_nwin, s_total, s_bits;
+    long long r0, r1;
+    tile_rows(blockIdx.x, m, split, r0, r1);
+    const int sub = threadIdx.x / 16, l = threadIdx.x % 16; // 16 lanes sweep a row
+    const int lane = threadIdx.x & (kWave - 1), wave = threadIdx.x / kWave;
+
+    // pass 1: column range of the tile's short rows
     int mn = INT_MAX, mx = -1;
-    // lanes sweep the tile's rows cooperatively: 16 lanes per row keeps the reads mostly coalesced
-    const int sub = threadIdx.x / 16, l = threadIdx.x % 16;
-    for (int rr = sub; rr < kVecTileRows; rr += kBlock / 16) {
-        const long long r = r0 + rr;
-        if (r >= m) break;
+    for (long long r = r0 + sub; r < r1; r += kBlock / 16) {
         const int p0 = rowptr[r], p1 = rowptr[r + 1];
         if (p1 - p0 > long_thr) continue;
         for (int p = p0 + l; p < p1; p += 16) {
@@ -50,23 +84,117 @@ __global__ __launch_bounds__(kBlock) void csr_tile_span_kernel(int m, int long_t
         mn = min(mn, __shfl_xor(mn, o, kWave));
         mx = max(mx, __shfl_xor(mx, o, kWave));
     }
-    if ((threadIdx.x & (kWave - 1)) == 0) { smin[threadIdx.x / kWave] = mn; smax[threadIdx.x / kWave] = mx; }
+    if (lane == 0) { smin[wave] = mn; smax[wave] = mx; }
+    if (threadIdx.x == 0) { s_nwin = 0; s_total = 0; s_bits = 0; }
     __syncthreads();
+    mn = min(min(smin[0], smin[1]), min(smin[2], smin[3]));
+    mx = max(max(smax[0], smax[1]), max(smax[2], smax[3]));
+    const long long span = mx >= mn ? (long long) mx - mn + 1 : 0;
+    const int seg_lo = mn >> kWinSegShift;
+    const int nseg = span > 0 ? (mx >> kWinSegShift) - seg_lo + 1 : 0;
+    const int nwords = (nseg + 31) / 32;
+
+    if (span > 0 && span <= max_cols) { // one window: the plain span
+        if (threadIdx.x == 0) { s_nwin = 1; s_total = (int) span; s_start[0] = mn; s_end[0] = mx + 1; s_base[0] = 0; }
+    } else if (span > 0 && nwords <= kWinBitmapWords) { // several windows: runs of touched 64-column segments
+        for (int w = threadIdx.x; w < nwords; w += kBlock) bitmap[w] = 0u;
+        __syncthreads();
+        for (long long r = r0 + sub; r < r1; r += kBlock / 16) {
+            const int p0 = rowptr[r], p1 = rowptr[r + 1];
+            if (p1 - p0 > long_thr) continue;
+            for (int p = p0 + l; p < p1; p += 16) {
+                const int s = (colidx[p] >> kWinSegShift) - seg_lo;
+                atomicOr(&bitmap[s >> 5], 1u << (s & 31));
+            }
+        }
+        __syncthreads();
+        // each thread owns 4 consecutive words: count run starts and set bits
+        int starts = 0, bits = 0;
+        for (int k = 0; k < 4; ++k) {
+            const int w = threadIdx.x * 4 + k;
+            if (w < nwords) {
+                const unsigned cur = bitmap[w];
+                const unsigned prev = w > 0 ? bitmap[w - 1] >> 31 : 0u;
+                starts += __popc(cur & ~((cur << 1) | prev));
+                bits += __popc(cur);
+            }
+        }
+        int inc = starts;
+#pragma unroll
+        for (int d = 1; d < kWave; d <<= 1) {
+            const int o = __shfl_up(inc, d, kWave);
+            if (lane >= d) inc += o;
+        }
+#pragma unroll
+        for (int o = kWave / 2; o > 0; o >>= 1) bits += __shfl_xor(bits, o, kWave);
+        if (lane == kWave - 1) wave_cnt[wave] = inc;
+        if (lane == 0) atomicAdd(&s_bits, bits);
+        __syncthreads();
+        int idx = inc - starts; // run starts in front of this thread's words
+        for (int w = 0; w < wave; ++w) idx += wave_cnt[w];
+        const int runs = wave_cnt[0] + wave_cnt[1] + wave_cnt[2] + wave_cnt[3];
+        if (runs <= kWinMax && ((long long) s_bits << kWinSegShift) <= max_cols) {
+            for (int k = 0; k < 4; ++k) {
+                const int w = threadIdx.x * 4 + k;
+                if (w >= nwords) break;
+                const unsigned cur = bitmap[w];
+                const unsigned prev = w > 0 ? bitmap[w - 1] >> 31 : 0u;
+                unsigned st = cur & ~((cur << 1) | prev);
+                while (st) { // run starts of this word, in ascending order
+                    const int b = __ffs((int) st) - 1;
+                    st &= st - 1;
+                    s_start[idx++] = (seg_lo + w * 32 + b) << kWinSegShift;
+                }
+            }
+            __syncthreads();
+            if (threadIdx.x == 0) { // run ends: walk each run (<= max_cols/64 set segments in total)
+                int base = 0;
+                for (int k = 0; k < runs; ++k) {
+                    int s = (s_start[k] >> kWinSegShift) - seg_lo;
+                    while (s < nseg && ((bitmap[s >> 5] >> (s & 31)) & 1u)) ++s;
+                    int end = (seg_lo + s) << kWinSegShift;
+                    if (end > n) end = n;
+                    s_end[k] = end;
+                    s_base[k] = base;
+                    base += end - s_start[k];
+                }
+                s_total = base;
+                s_nwin = runs;
+            }
+        }
+    }
+    __syncthreads();
+    const int nwin = s_nwin;
     if (threadIdx.x == 0) {
-        for (int k = 1; k < kBlock / kWave; ++k) { mn = min(mn, smin[k]); mx = max(mx, smax[k]); }
-        const long long span = mx >= mn ? (long long) mx - mn + 1 : 0;
-        const bool ok = span > 0 && span <= max_span;
-        tile_lo[blockIdx.x] = ok ? mn : 0;
-        tile_span[blockIdx.x] = ok ? (int) span : 0;
-        if (ok) { atomicAdd(staged, 1); atomicMax(staged + 1, (int) span); }
+        TileWindows &tw = wins[blockIdx.x];
+        tw.nwin = nwin;
+        tw.total = nwin ? s_total : 0;
+        for (int k = 0; k < kWinMax; ++k) {
+            tw.start[k] = k < nwin ? s_start[k] : 0;
+            tw.len[k] = k < nwin ? s_end[k] - s_start[k] : 0;
+            tw.base[k] = k < nwin ? s_base[k] : 0;
+        }
+        if (nwin) { atomicAdd(staged, 1); atomicMax(staged + 1, s_total); }
+    }
+    if (nwin == 0) return;
+    // pass 2: tile-local column = LDS slot
+    for (long long r = r0 + sub; r < r1; r += kBlock / 16) {
+        const int p0 = rowptr[r], p1 = rowptr[r + 1];
+        if (p1 - p0 > long_thr) continue;
+        for (int p = p0 + l; p < p1; p += 16) {
+            const int c = colidx[p];
+            int w = 0;
+            for (int k = 1; k < nwin; ++k) w = c >= s_start[k] ? k : w; // windows are sorted by start
+            col_local[p] = s_base[w] + (c - s_start[w]);
+        }
     }
 }
 
 template <typename T, int L, bool STAGED, int DEPTH, bool PRE = true>
 __device__ __forceinline__ void csr_vector_tile_wave(long long row_end, int long_thr, long long rw0, int lane,
                                                      const int *__restrict__ rp_lds, T *__restrict__ y_lds,
-                                                     const int *__restrict__ colidx, const T *__restrict__ val,
-                                                     const T *__restrict__ x, const T *__restrict__ xs, int lo,
+                                                     const int *__restrict__ col_local, const T *__restrict__ val,
+                                                     const T *__restrict__ x, const T *__restrict__ xs,
                                                      T *__restrict__ y, const int (&c0)[4], const T (&v0)[4])
 {
     constexpr int RW = kWave / L; // rows per step
@@ -84,7 +212,7 @@ __device__ __forceinline__ void csr_vector_tile_wave(long long row_end, int long
         if (pp1[slot] - pp0[slot] > long_thr) pp1[slot] = pp0[slot];
         if (s > 0 || !PRE) {
             const int an = (pp0[slot] & ~3) + l * 4;
-            ld_stream4(colidx + an, c[slot]);
+            ld_stream4(col_local + an, c[slot]);
             ld_stream4(val + an, v[slot]);
         }
     };
@@ -99,8 +227,8 @@ __device__ __forceinline__ void csr_vector_tile_wave(long long row_end, int long
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
             const bool ok = (a + k >= p0) & (a + k < p1);
-            const int ci = ok ? c[cur][k] : (STAGED ? lo : 0);
-            const T xl = STAGED ? xs[ci - lo] : x[ci];
+            const int ci = ok ? c[cur][k] : 0; // STAGED: an LDS slot; else a global column
+            const T xl = STAGED ? xs[ci] : x[ci];
             sum = fmadd(ok ? v[cur][k] : T(0), ok ? xl : T(0), sum);
         }
         if (__any(a + 4 * L < p1)) { // some row of this step is longer than 4L
@@ -108,11 +236,11 @@ __device__ __forceinline__ void csr_vector_tile_wave(long long row_end, int long
                 if (aa < p1) {
                     int cc[4];
                     T v2[4];
-                    ld_stream4(colidx + aa, cc);
+                    ld_stream4(col_local + aa, cc);
                     ld_stream4(val + aa, v2);
 #pragma unroll
                     for (int k = 0; k < 4; ++k)
-                        if (aa + k < p1) sum = fmadd(v2[k], STAGED ? xs[cc[k] - lo] : x[cc[k]], sum);
+                        if (aa + k < p1) sum = fmadd(v2[k], STAGED ? xs[cc[k]] : x[cc[k]], sum);
                 }
             }
         }
@@ -126,19 +254,28 @@ __device__ __forceinline__ void csr_vector_tile_wave(long long row_end, int long
     if (row < row_end && len <= long_thr) y[row] = y_lds[lane]; // one coalesced 64-row store per wave
 }
 
+// Stage the tile's windows: xs[base_w + i] = x[start_w + i].
+template <typename T>
+__device__ __forceinline__ void stage_windows(const TileWindows &tw, const T *__restrict__ x, T *__restrict__ xs)
+{
+    const int nwin = tw.nwin;
+    for (int w = 0; w < nwin; ++w) {
+        const int st = tw.start[w], ln = tw.len[w], bs = tw.base[w];
+        for (int i = threadIdx.x; i < ln; i += kVecTileThreads) xs[bs + i] = x[st + i];
+    }
+}
+
 template <typename T, int L, int DEPTH = 4, bool PRE = true>
 __global__ __launch_bounds__(kVecTileThreads) void csr_vector_tile_kernel(int m, int long_thr, const int *__restrict__ rowptr,
-                                                                 const int *__restrict__ colidx,
-                                                                 const T *__restrict__ val,
-                                                                 const int *__restrict__ tile_lo,
-                                                                 const int *__restrict__ tile_span,
-                                                                 const T *__restrict__ x, T *__restrict__ y)
+                                                                          const int *__restrict__ col_local,
+                                                                          const T *__restrict__ val,
+                                                                          const TileWindows *__restrict__ wins,
+                                                                          const T *__restrict__ x, T *__restrict__ y)
 {
-    extern __shared__ __attribute__((aligned(16))) unsigned char vec_x_lds[]; // span elements of x
+    extern __shared__ __attribute__((aligned(16))) unsigned char vec_x_lds[]; // the tile's staged x
     T *xs = reinterpret_cast<T *>(vec_x_lds);
     __shared__ int rp_lds[kVecTileThreads / kWave][kWave + 2];
     __shared__ T y_lds[kVecTileThreads / kWave][kWave];
-    constexpr int RW = kWave / L;
     const int lane = threadIdx.x & (kWave - 1), wave = threadIdx.x / kWave;
     const long long rw0 = (long long) blockIdx.x * kVecTileRows + wave * kWave;
     // RowPtr of the wave's 64 rows (+1): one coalesced load, rows past m repeat RowPtr[m]
@@ -147,7 +284,7 @@ __global__ __launch_bounds__(kVecTileThreads) void csr_vector_tile_kernel(int m,
     if (re > m) re = m;
     const int rp = rowptr[r];
     const int rpe = rowptr[re]; // wave-uniform
-    const int lo = tile_lo[blockIdx.x], span = tile_span[blockIdx.x];
+    const TileWindows &tw = wins[blockIdx.x];
     // step 0 of the matrix stream is issued straight from registers (RowPtr handed over by
     // shuffles), BEFORE the x staging and the barrier, so neither sits in front of the first loads
     int c0[4] = {0, 0, 0, 0};
@@ -155,34 +292,30 @@ __global__ __launch_bounds__(kVecTileThreads) void csr_vector_tile_kernel(int m,
     if (PRE) {
         const int sub = lane / L, l = lane % L;
         const int q0 = __shfl(rp, sub, kWave);
-        const int nx = __shfl(rp, (sub + 1) & (kWave - 1), kWave);
-        const int q1 = sub + 1 < kWave ? nx : rpe;
         const int a = (q0 & ~3) + l * 4;
-        (void) q1;
-        ld_stream4(colidx + a, c0);
+        ld_stream4(col_local + a, c0);
         ld_stream4(val + a, v0);
     }
     rp_lds[wave][lane] = rp;
     if (lane == 0) rp_lds[wave][kWave] = rpe;
-    for (int i = threadIdx.x; i < span; i += kVecTileThreads) xs[i] = x[lo + i];
+    const bool staged = tw.nwin > 0;
+    stage_windows<T>(tw, x, xs);
     __syncthreads();
     if (rw0 >= m) return;
-    if (span > 0) csr_vector_tile_wave<T, L, true, DEPTH, PRE>((long long) m, long_thr, rw0, lane, rp_lds[wave], y_lds[wave], colidx, val, x, xs, lo, y, c0, v0);
-    else csr_vector_tile_wave<T, L, false, DEPTH, PRE>((long long) m, long_thr, rw0, lane, rp_lds[wave], y_lds[wave], colidx, val, x, xs, lo, y, c0, v0);
-    (void) RW;
+    if (staged) csr_vector_tile_wave<T, L, true, DEPTH, PRE>((long long) m, long_thr, rw0, lane, rp_lds[wave], y_lds[wave], col_local, val, x, xs, y, c0, v0);
+    else csr_vector_tile_wave<T, L, false, DEPTH, PRE>((long long) m, long_thr, rw0, lane, rp_lds[wave], y_lds[wave], col_local, val, x, xs, y, c0, v0);
 }
 
 // Balanced form (Method_Balanced): the same wave program over EQUAL-NNZ row blocks.  Block b owns
 // rows [split[b], split[b+1]) (init_csrSplitter_balanced2 semantics, parallel_balanced2_spmv.c:41-53,
-// built by rowblock_split_kernel) and walks them in 256-row slabs, 64 rows per wave; the x span of
-// the whole block is staged once.  Replaces the LDS-products kernel of rowblock.hpp as executor.
+// built by rowblock_split_kernel) and walks them in 256-row slabs, 64 rows per wave; the x windows
+// of the whole block are staged once.
 template <typename T, int L, int DEPTH = 4>
 __global__ __launch_bounds__(kVecTileThreads) void csr_vector_rows_kernel(int long_thr, const int *__restrict__ split,
                                                                           const int *__restrict__ rowptr,
-                                                                          const int *__restrict__ colidx,
+                                                                          const int *__restrict__ col_local,
                                                                           const T *__restrict__ val,
-                                                                          const int *__restrict__ tile_lo,
-                                                                          const int *__restrict__ tile_span,
+                                                                          const TileWindows *__restrict__ wins,
                                                                           const T *__restrict__ x, T *__restrict__ y)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char vec_x_lds[];
@@ -191,8 +324,9 @@ __global__ __launch_bounds__(kVecTileThreads) void csr_vector_rows_kernel(int lo
     __shared__ T y_lds[kVecTileThreads / kWave][kWave];
     const int lane = threadIdx.x & (kWave - 1), wave = threadIdx.x / kWave;
     const long long r_begin = split[blockIdx.x], r_end = split[blockIdx.x + 1];
-    const int lo = tile_lo[blockIdx.x], span = tile_span[blockIdx.x];
-    for (int i = threadIdx.x; i < span; i += kVecTileThreads) xs[i] = x[lo + i];
+    const TileWindows &tw = wins[blockIdx.x];
+    const bool staged = tw.nwin > 0;
+    stage_windows<T>(tw, x, xs);
     __syncthreads();
     const int c0[4] = {0, 0, 0, 0};
     const T v0[4] = {T(0), T(0), T(0), T(0)};
@@ -203,46 +337,9 @@ __global__ __launch_bounds__(kVecTileThreads) void csr_vector_rows_kernel(int lo
         rp_lds[wave][lane] = rowptr[r];
         if (lane == 0) rp_lds[wave][kWave] = rowptr[re];
         wave_lds_sync();
-        if (span > 0) csr_vector_tile_wave<T, L, true, DEPTH, false>(r_end, long_thr, rw0, lane, rp_lds[wave], y_lds[wave], colidx, val, x, xs, lo, y, c0, v0);
-        else csr_vector_tile_wave<T, L, false, DEPTH, false>(r_end, long_thr, rw0, lane, rp_lds[wave], y_lds[wave], colidx, val, x, xs, lo, y, c0, v0);
+        if (staged) csr_vector_tile_wave<T, L, true, DEPTH, false>(r_end, long_thr, rw0, lane, rp_lds[wave], y_lds[wave], col_local, val, x, xs, y, c0, v0);
+        else csr_vector_tile_wave<T, L, false, DEPTH, false>(r_end, long_thr, rw0, lane, rp_lds[wave], y_lds[wave], col_local, val, x, xs, y, c0, v0);
         wave_lds_sync(); // y_lds / rp_lds are reused by the next slab
-    }
-}
-
-// Inspector for the balanced form: column span of rows [split[b], split[b+1]) with len <= long_thr.
-__global__ __launch_bounds__(kBlock) void csr_rows_span_kernel(int long_thr, int max_span, const int *__restrict__ split,
-                                                               const int *__restrict__ rowptr,
-                                                               const int *__restrict__ colidx,
-                                                               int *__restrict__ tile_lo, int *__restrict__ tile_span,
-                                                               int *__restrict__ staged)
-{
-    __shared__ int smin[kBlock / kWave], smax[kBlock / kWave];
-    const int r0 = split[blockIdx.x], r1 = split[blockIdx.x + 1];
-    int mn = INT_MAX, mx = -1;
-    const int sub = threadIdx.x / 16, l = threadIdx.x % 16;
-    for (int r = r0 + sub; r < r1; r += kBlock / 16) {
-        const int p0 = rowptr[r], p1 = rowptr[r + 1];
-        if (p1 - p0 > long_thr) continue;
-        for (int p = p0 + l; p < p1; p += 16) {
-            const int c = colidx[p];
-            mn = min(mn, c);
-            mx = max(mx, c);
-        }
-    }
-#pragma unroll
-    for (int o = kWave / 2; o > 0; o >>= 1) {
-        mn = min(mn, __shfl_xor(mn, o, kWave));
-        mx = max(mx, __shfl_xor(mx, o, kWave));
-    }
-    if ((threadIdx.x & (kWave - 1)) == 0) { smin[threadIdx.x / kWave] = mn; smax[threadIdx.x / kWave] = mx; }
-    __syncthreads();
-    if (threadIdx.x == 0) {
-        for (int k = 1; k < kBlock / kWave; ++k) { mn = min(mn, smin[k]); mx = max(mx, smax[k]); }
-        const long long span = mx >= mn ? (long long) mx - mn + 1 : 0;
-        const bool ok = span > 0 && span <= max_span;
-        tile_lo[blockIdx.x] = ok ? mn : 0;
-        tile_span[blockIdx.x] = ok ? (int) span : 0;
-        if (ok) { atomicAdd(staged, 1); atomicMax(staged + 1, (int) span); }
     }
 }
 

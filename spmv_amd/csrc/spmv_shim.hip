@@ -87,7 +87,8 @@ struct spmv_dev {
     // csr-vector x tiles
     int vt_tiles = 0, vt_staged = 0, vt_maxspan = 0, vec_choice = 0;
     float tune_ms[3] = {0, 0, 0}; // tile D4, tile D2, pipe (autotune_vector)
-    int *vt_lo = nullptr, *vt_span = nullptr;
+    int *vt_col = nullptr;          // tile-local ColIdx copy (LDS slots for staged tiles)
+    TileWindows *vt_wins = nullptr; // x windows of every tile
     // long rows (csr-vector, sell)
     int nlong = 0, long_thr = INT_MAX, lr_segs = 0;
     int *long_rows = nullptr, *lr_seg_lr = nullptr;
@@ -137,7 +138,7 @@ static void free_schedule(spmv_dev *d)
     d->sval = d->lr_part = nullptr;
     d->ntiles = d->nblocks = d->nchunks = d->nlong = d->lr_segs = 0;
     d->long_thr = INT_MAX;
-    d->vt_lo = d->vt_span = nullptr; d->vt_tiles = d->vt_staged = d->vt_maxspan = 0;
+    d->vt_col = nullptr; d->vt_wins = nullptr; d->vt_tiles = d->vt_staged = d->vt_maxspan = 0;
     d->c5_tile_ptr = d->c5_run_len = d->c5_row_map = d->c5_col = nullptr; d->c5_desc = nullptr;
     d->c5_val = d->c5_carry = nullptr; d->c5_tiles = d->c5_m2 = d->c5_fixup = 0;
     d->c5_grp_lo = d->c5_grp_span = nullptr; d->c5_groups = d->c5_staged = d->c5_maxspan = 0;
@@ -353,6 +354,7 @@ extern "C" void spmv_shim_matrix_destroy(spmv_dev *d)
 constexpr size_t kVecXTileBytes = 48 * 1024; // LDS budget of one row tile's x span (CSR-vector, Balanced)
 template <typename T> static int build_long_rows(spmv_dev *d, int thr);
 template <typename T> static int autotune_vector(spmv_dev *d);
+template <typename T> static int build_tile_windows(spmv_dev *d, int tiles, const int *split);
 
 constexpr size_t kSplitXTileBytes = 48 * 1024; // LDS budget of one nnz-split tile group's x span
 
@@ -412,18 +414,28 @@ static int build_rowblock_tiles(spmv_dev *d)
     const int L = d->plan.lanes_per_row;
     int rc = build_long_rows<T>(d, L * 64 > 256 ? L * 64 : 256);
     if (rc) return rc;
+    rc = build_tile_windows<T>(d, d->nblocks, d->rb_split);
+    if (rc) return rc;
+    return SPMV_HIP_OK;
+}
+
+// Windows of every row tile + the tile-local ColIdx copy (kernels/csr_vector_tile.hpp).
+template <typename T>
+static int build_tile_windows(spmv_dev *d, int tiles, const int *split)
+{
     int *cnt = nullptr;
     int host2[2] = {0, 0};
+    d->vt_tiles = tiles;
     ALLOC_TRY(d, &cnt, 2 * sizeof(int), true);
-    ALLOC_TRY(d, &d->vt_lo, sizeof(int) * (size_t) d->nblocks, true);
-    ALLOC_TRY(d, &d->vt_span, sizeof(int) * (size_t) d->nblocks, true);
+    ALLOC_TRY(d, &d->vt_col, sizeof(int) * ((size_t) d->nnz + kStreamPad), true);
+    ALLOC_TRY(d, &d->vt_wins, sizeof(TileWindows) * (size_t) tiles, true);
+    HIP_TRY(hipMemcpyAsync(d->vt_col, d->colidx, sizeof(int) * ((size_t) d->nnz + kStreamPad), hipMemcpyDeviceToDevice, d->stream));
     HIP_TRY(hipMemsetAsync(cnt, 0, 2 * sizeof(int), d->stream));
-    csr_rows_span_kernel<<<d->nblocks, kBlock, 0, d->stream>>>(d->long_thr, (int) (kVecXTileBytes / sizeof(T)), d->rb_split, d->rowptr, d->colidx,
-                                                               d->vt_lo, d->vt_span, cnt);
+    csr_tile_windows_kernel<<<tiles, kBlock, 0, d->stream>>>(d->m, d->n, d->long_thr, (int) (kVecXTileBytes / sizeof(T)), split, d->rowptr, d->colidx,
+                                                             d->vt_wins, d->vt_col, cnt);
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipMemcpyAsync(host2, cnt, 2 * sizeof(int), hipMemcpyDeviceToHost, d->stream));
     HIP_TRY(hipStreamSynchronize(d->stream));
-    d->vt_tiles = d->nblocks;
     d->vt_staged = host2[0];
     d->vt_maxspan = host2[1];
     return SPMV_HIP_OK;
@@ -470,27 +482,14 @@ static int build_long_rows(spmv_dev *d, int thr)
 }
 
 
-// x span of every 256-row tile (kernels/csr_vector_tile.hpp)
+// x windows of every 256-row tile (kernels/csr_vector_tile.hpp)
 template <typename T>
 static int build_vector_tiles(spmv_dev *d)
 {
-    d->vt_tiles = (int) (((long long) d->m + kVecTileRows - 1) / kVecTileRows);
     d->vt_staged = d->vt_maxspan = 0;
+    d->vt_tiles = (int) (((long long) d->m + kVecTileRows - 1) / kVecTileRows);
     if (d->vt_tiles == 0 || d->nnz == 0) return SPMV_HIP_OK;
-    int *cnt = nullptr;
-    int host2[2] = {0, 0};
-    ALLOC_TRY(d, &cnt, 2 * sizeof(int), true);
-    ALLOC_TRY(d, &d->vt_lo, sizeof(int) * (size_t) d->vt_tiles, true);
-    ALLOC_TRY(d, &d->vt_span, sizeof(int) * (size_t) d->vt_tiles, true);
-    HIP_TRY(hipMemsetAsync(cnt, 0, 2 * sizeof(int), d->stream));
-    csr_tile_span_kernel<<<d->vt_tiles, kBlock, 0, d->stream>>>(d->m, d->long_thr, (int) (kVecXTileBytes / sizeof(T)), d->rowptr, d->colidx,
-                                                                d->vt_lo, d->vt_span, cnt);
-    HIP_TRY(hipGetLastError());
-    HIP_TRY(hipMemcpyAsync(host2, cnt, 2 * sizeof(int), hipMemcpyDeviceToHost, d->stream));
-    HIP_TRY(hipStreamSynchronize(d->stream));
-    d->vt_staged = host2[0];
-    d->vt_maxspan = host2[1];
-    return SPMV_HIP_OK;
+    return build_tile_windows<T>(d, d->vt_tiles, nullptr);
 }
 
 template <typename T>
@@ -699,8 +698,8 @@ static void launch_vector_tile(spmv_dev *d, const T *x, T *y, int long_thr)
     const size_t lds = (((size_t) d->vt_maxspan * sizeof(T)) + 1023) & ~(size_t) 1023;
     if (lds > 64 * 1024)
         (void) hipFuncSetAttribute((const void *) csr_vector_tile_kernel<T, L, DEPTH, PRE>, hipFuncAttributeMaxDynamicSharedMemorySize, (int) lds);
-    csr_vector_tile_kernel<T, L, DEPTH, PRE><<<d->vt_tiles, kVecTileThreads, lds, d->stream>>>(d->m, long_thr, d->rowptr, d->colidx, (const T *) d->val,
-                                                                                      d->vt_lo, d->vt_span, x, y);
+    csr_vector_tile_kernel<T, L, DEPTH, PRE><<<d->vt_tiles, kVecTileThreads, lds, d->stream>>>(d->m, long_thr, d->rowptr, d->vt_col, (const T *) d->val,
+                                                                                           d->vt_wins, x, y);
 }
 
 template <typename T, int L>
@@ -713,7 +712,9 @@ static void launch_vector(spmv_dev *d, const T *x, T *y)
             d->m, d->rowptr, d->colidx, (const T *) d->val, x, y);
         return;
     }
-    if (d->vt_staged * 2 >= d->vt_tiles && d->vt_tiles > 0 && v != VEC_PIPE) { // x tiles fit LDS: tile kernel
+    const bool tile_default = d->vt_staged * 2 >= d->vt_tiles; // most x tiles fit LDS
+    const bool tile_forced = v == VEC_TILE_D2 || v == VEC_TILE_D4 || v == VEC_TILE_D8 || v == VEC_TILE_D4_NOPRE || v == VEC_TILE_D2_NOPRE;
+    if (d->vt_tiles > 0 && v != VEC_PIPE && (tile_default || tile_forced)) { // tile kernel (unstaged tiles gather from L1/L2)
         if (v == VEC_TILE_D2) launch_vector_tile<T, L, 2>(d, x, y, long_thr);
         else if (v == VEC_TILE_D8) launch_vector_tile<T, L, 8>(d, x, y, long_thr);
         else if (v == VEC_TILE_D4) launch_vector_tile<T, L, 4>(d, x, y, long_thr);
@@ -746,7 +747,7 @@ template <typename T>
 static int autotune_vector(spmv_dev *d)
 {
     d->vec_choice = VEC_AUTO;
-    if (d->nnz < (1ll << 24) || d->plan.variant != 0 || !(d->vt_staged * 2 >= d->vt_tiles && d->vt_tiles > 0)) return SPMV_HIP_OK;
+    if (d->nnz < (1ll << 24) || d->plan.variant != 0 || d->vt_tiles <= 0) return SPMV_HIP_OK;
     T *x = nullptr, *y = nullptr;
     if (hipMalloc((void **) &x, sizeof(T) * (size_t) d->n) != hipSuccess || hipMalloc((void **) &y, sizeof(T) * (size_t) d->m) != hipSuccess) {
         (void) hipGetLastError();
@@ -820,7 +821,7 @@ static void launch_rows(spmv_dev *d, const T *x, T *y)
     if (lds > 64 * 1024)
         (void) hipFuncSetAttribute((const void *) csr_vector_rows_kernel<T, L, (sizeof(T) == 8 ? 4 : 2)>, hipFuncAttributeMaxDynamicSharedMemorySize, (int) lds);
     csr_vector_rows_kernel<T, L, (sizeof(T) == 8 ? 4 : 2)><<<d->nblocks, kVecTileThreads, lds, d->stream>>>(
-        d->long_thr, d->rb_split, d->rowptr, d->colidx, (const T *) d->val, d->vt_lo, d->vt_span, x, y);
+        d->long_thr, d->rb_split, d->rowptr, d->vt_col, (const T *) d->val, d->vt_wins, x, y);
 }
 
 template <typename T>
@@ -1014,7 +1015,8 @@ extern "C" int spmv_shim_info(const spmv_dev *d, spmv_hip_info *o)
     for (int k = 0; k < 3; ++k) o->tune_ms[k] = d->tune_ms[k];
     o->schedule_name = kSchedNames[d->plan.sched];
     o->kernel_name = kKernelNames[d->plan.sched];
-    if (d->plan.sched == SPMV_SCHED_CSR_VECTOR && d->vt_tiles > 0 && d->vt_staged * 2 >= d->vt_tiles && d->vec_choice != VEC_PIPE)
+    if (d->plan.sched == SPMV_SCHED_CSR_VECTOR && d->vt_tiles > 0 && d->vec_choice != VEC_PIPE &&
+        (d->vt_staged * 2 >= d->vt_tiles || d->vec_choice == VEC_TILE_D4 || d->vec_choice == VEC_TILE_D2))
         o->kernel_name = "csr_vector_tile_kernel";
     if (d->plan.sched == SPMV_SCHED_NNZ_SPLIT && d->ns_groups > 0 && d->ns_staged * 2 >= d->ns_groups) o->kernel_name = "nnz_group_kernel";
     if (d->plan.sched == SPMV_SCHED_CSR5 && d->c5_staged * 2 >= d->c5_groups && d->c5_groups > 0) o->kernel_name = "csr5_group_kernel";

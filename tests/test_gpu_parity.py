@@ -319,3 +319,26 @@ def test_out_of_range_column_index_is_rejected_at_create(monkeypatch):
     rp[5] = rp[6] + 1                                   # decreasing RowPtr
     with pytest.raises(api.SpmvError, match="RowPtr"):
         api.Handle(csr.m, csr.n, rp, csr.colidx, csr.val)
+
+
+@pytest.mark.parametrize("dtype", [np.float64, np.float32])
+@pytest.mark.parametrize("method", [M.Method_Parallel, M.Method_Balanced])
+def test_multi_window_x_tiles_on_stencil_structure(method, dtype):
+    """27-point stencil on a 64^3 periodic grid: the columns of a 256-row tile sit in 9 windows that
+    are 4096 apart, so the plain span (> 8192 columns) exceeds the 48 KiB LDS budget in fp64 and
+    the tile is staged as several windows (csr_vector_tile.hpp).  Bit-exact against the oracle."""
+    nx = 64
+    m = nx ** 3
+    offs = np.array([dz * nx * nx + dy * nx + dx for dz in (-1, 0, 1) for dy in (-1, 0, 1) for dx in (-1, 0, 1)])
+    rowptr = np.arange(0, (m + 1) * 27, 27, dtype=np.int32)
+    colidx = ((np.arange(m)[:, None] + offs[None, :]) % m).astype(np.int32).reshape(-1)
+    val = synth.fill_values(m * 27, "eighths", dtype, 3)
+    csr = synth.CSR(m, m, rowptr, colidx, val)
+    x = synth.fill_x(m, "eighths", dtype, 4)
+    want = oracle.spmv_serial(csr, x)
+    y = np.full(m, np.nan, dtype=dtype)
+    with api.Handle(m, m, csr.rowptr, csr.colidx, csr.val, method) as h:
+        h.spmv(x, y)
+        name = h.info()["kernel_name"]
+    assert np.array_equal(y, want)
+    assert name in ("csr_vector_tile_kernel", "csr_vector_rows_kernel")

@@ -36,6 +36,16 @@ elif a.kind == "scrambled":   # banded, then a random symmetric permutation of r
     ci = inv[(sc[:, None] + offs[None, :]) % n].reshape(-1).to(torch.int32)
     rp = torch.arange(0, (m + 1) * a.k, a.k, dtype=torch.int32, device=dev)
     va = torch.rand(m * a.k, generator=g, device=dev, dtype=dt) * 2 - 1
+elif a.kind == "stencil27":   # 3-D 27-point stencil on an nx^3 grid (periodic): three far-apart bands
+    nx = round(a.m ** (1 / 3)); m = n = nx ** 3
+    offs = torch.tensor([dz * nx * nx + dy * nx + dx for dz in (-1, 0, 1) for dy in (-1, 0, 1) for dx in (-1, 0, 1)], device=dev)
+    rp = torch.arange(0, (m + 1) * 27, 27, dtype=torch.int32, device=dev)
+    ci = torch.empty(m * 27, dtype=torch.int32, device=dev)
+    for r0 in range(0, m, 1 << 22):
+        r1 = min(m, r0 + (1 << 22))
+        rows = torch.arange(r0, r1, device=dev)
+        ci[r0 * 27:r1 * 27] = ((rows[:, None] + offs[None, :]) % n).reshape(-1).to(torch.int32)
+    va = torch.rand(m * 27, device=dev, dtype=dt) * 2 - 1
 elif a.kind == "random":
     m, n, rp, ci, va = synth.uniform_k_device(a.m, a.m, a.k, "uniform", dt, dev, 1)
 elif a.kind == "skewed":
