@@ -34,6 +34,7 @@
 #pragma once
 #include <climits>
 #include "common.hpp"
+#include "xwindows.hpp"
 
 namespace spmv {
 
@@ -217,7 +218,7 @@ template <typename T, int SIGMA, bool MAPPED, bool STAGED>
 __device__ __forceinline__ void csr5_tile(int t, int lane, const int *__restrict__ tile_ptr,
                                           const unsigned *__restrict__ desc, const int *__restrict__ tcol,
                                           const T *__restrict__ tval, const int *__restrict__ row_map,
-                                          const T *__restrict__ x, const T *__restrict__ xs, int lo,
+                                          const T *__restrict__ x, const T *__restrict__ xs,
                                           T *__restrict__ y, T *__restrict__ carry)
 {
     constexpr int TN = kWave * SIGMA;
@@ -238,8 +239,8 @@ __device__ __forceinline__ void csr5_tile(int t, int lane, const int *__restrict
     T xv[SIGMA];
 #pragma unroll
     for (int i = 0; i < SIGMA; ++i) {
-        const int ci = c[i] >= 0 ? c[i] : (STAGED ? lo : 0);
-        xv[i] = STAGED ? xs[ci - lo] : x[ci];
+        const int ci = c[i] >= 0 ? c[i] : 0; // STAGED: tcol holds LDS slots (xwindows.hpp), else global columns
+        xv[i] = STAGED ? xs[ci] : x[ci];
     }
 
     T head = 0, acc = 0;
@@ -285,69 +286,38 @@ __global__ __launch_bounds__(kBlock) void csr5_kernel(int p, const int *__restri
     const int lane = threadIdx.x & (kWave - 1);
     const int t = blockIdx.x * (kBlock / kWave) + threadIdx.x / kWave;
     if (t >= p) return;
-    csr5_tile<T, SIGMA, MAPPED, false>(t, lane, tile_ptr, desc, tcol, tval, row_map, x, nullptr, 0, y, carry);
+    csr5_tile<T, SIGMA, MAPPED, false>(t, lane, tile_ptr, desc, tcol, tval, row_map, x, nullptr, y, carry);
 }
 
-// ---- LDS-staged x tiles ------------------------------------------------------------------------
-// A workgroup owns kCsr5GroupTiles consecutive tiles.  When the columns those tiles reference span
-// at most the LDS budget, x[lo, lo+span) is staged once (coalesced, from L2) and the gathers of all
-// its tiles become LDS reads; otherwise the workgroup gathers from global memory as before.
+// ---- LDS-staged x windows (xwindows.hpp) --------------------------------------------------------
+// A workgroup owns kCsr5GroupTiles consecutive tiles.  range_windows_kernel covers the columns of
+// those tiles with up to 16 windows and rewrites the group's part of tcol into LDS slots; the
+// executor stages the windows once and all gathers of its tiles are LDS reads.  Groups whose
+// columns do not fit keep global columns in tcol and gather from L1/L2.
 constexpr int kCsr5GroupTiles = 16;
-
-__global__ __launch_bounds__(kBlock) void csr5_group_span_kernel(int p, int tile_nnz, int max_span,
-                                                                 const int *__restrict__ tcol,
-                                                                 int *__restrict__ grp_lo, int *__restrict__ grp_span,
-                                                                 int *__restrict__ staged /* [0] count, [1] max span */)
-{
-    __shared__ int smin[kBlock / kWave], smax[kBlock / kWave];
-    const int g = blockIdx.x;
-    const long long b = (long long) g * kCsr5GroupTiles * tile_nnz;
-    long long e = b + (long long) kCsr5GroupTiles * tile_nnz;
-    const long long total = (long long) p * tile_nnz;
-    if (e > total) e = total;
-    int mn = INT_MAX, mx = -1;
-    for (long long i = b + threadIdx.x; i < e; i += kBlock) {
-        const int c = tcol[i];
-        if (c >= 0) { mn = min(mn, c); mx = max(mx, c); }
-    }
-#pragma unroll
-    for (int o = kWave / 2; o > 0; o >>= 1) {
-        mn = min(mn, __shfl_xor(mn, o, kWave));
-        mx = max(mx, __shfl_xor(mx, o, kWave));
-    }
-    if ((threadIdx.x & (kWave - 1)) == 0) { smin[threadIdx.x / kWave] = mn; smax[threadIdx.x / kWave] = mx; }
-    __syncthreads();
-    if (threadIdx.x == 0) {
-        for (int k = 1; k < kBlock / kWave; ++k) { mn = min(mn, smin[k]); mx = max(mx, smax[k]); }
-        const long long span = mx >= mn ? (long long) mx - mn + 1 : 0;
-        const bool ok = span > 0 && span <= max_span;
-        grp_lo[g] = ok ? mn : 0;
-        grp_span[g] = ok ? (int) span : 0;
-        if (ok) { atomicAdd(staged, 1); atomicMax(staged + 1, (int) span); }
-    }
-}
 
 template <typename T, int SIGMA, bool MAPPED>
 __global__ __launch_bounds__(kBlock) void csr5_group_kernel(int p, const int *__restrict__ tile_ptr,
                                                             const unsigned *__restrict__ desc,
                                                             const int *__restrict__ tcol, const T *__restrict__ tval,
                                                             const int *__restrict__ row_map,
-                                                            const int *__restrict__ grp_lo, const int *__restrict__ grp_span,
+                                                            const TileWindows *__restrict__ wins,
                                                             const T *__restrict__ x, T *__restrict__ y,
                                                             T *__restrict__ carry)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char csr5_x_lds[];
     T *xs = reinterpret_cast<T *>(csr5_x_lds);
-    const int lo = grp_lo[blockIdx.x], span = grp_span[blockIdx.x];
-    for (int i = threadIdx.x; i < span; i += kBlock) xs[i] = x[lo + i];
-    if (span > 0) __syncthreads();
+    const TileWindows &tw = wins[blockIdx.x];
+    const bool staged = tw.nwin > 0;
+    stage_windows<kBlock, T>(tw, x, xs);
+    if (staged) __syncthreads();
     const int lane = threadIdx.x & (kWave - 1);
     const int t0 = blockIdx.x * kCsr5GroupTiles;
     for (int k = threadIdx.x / kWave; k < kCsr5GroupTiles; k += kBlock / kWave) {
         const int t = t0 + k;
         if (t >= p) break;
-        if (span > 0) csr5_tile<T, SIGMA, MAPPED, true>(t, lane, tile_ptr, desc, tcol, tval, row_map, x, xs, lo, y, carry);
-        else csr5_tile<T, SIGMA, MAPPED, false>(t, lane, tile_ptr, desc, tcol, tval, row_map, x, xs, lo, y, carry);
+        if (staged) csr5_tile<T, SIGMA, MAPPED, true>(t, lane, tile_ptr, desc, tcol, tval, row_map, x, xs, y, carry);
+        else csr5_tile<T, SIGMA, MAPPED, false>(t, lane, tile_ptr, desc, tcol, tval, row_map, x, xs, y, carry);
     }
 }
 

@@ -25,23 +25,12 @@
 #include <climits>
 #include "common.hpp"
 #include "csr_vector4.hpp"
+#include "xwindows.hpp"
 
 namespace spmv {
 
 constexpr int kVecTileThreads = 256;           // 4 wavefronts per workgroup (512 measured no better)
 constexpr int kVecTileRows = kVecTileThreads;  // rows per workgroup slab (64 per wave)
-constexpr int kWinMax = 16;                    // windows per tile
-constexpr int kWinSegShift = 6;                // windows are built from 64-column segments
-constexpr int kWinBitmapWords = 1024;          // 32768 segments: spans up to 2M columns are analysed
-
-struct TileWindows {
-    int nwin;            // 0: tile not staged (col_local holds global columns)
-    int total;           // staged elements = sum of len
-    int start[kWinMax];  // first column of each window (ascending)
-    int len[kWinMax];
-    int base[kWinMax];   // LDS slot of the window's first column
-};
-
 // Row range of tile b: fixed 256-row tiles, or the equal-nnz blocks of `split` (Method_Balanced).
 __device__ __forceinline__ void tile_rows(int b, int m, const int *__restrict__ split, long long &r0, long long &r1)
 {
@@ -49,8 +38,8 @@ __device__ __forceinline__ void tile_rows(int b, int m, const int *__restrict__ 
     else { r0 = (long long) b * kVecTileRows; r1 = r0 + kVecTileRows < m ? r0 + kVecTileRows : m; }
 }
 
-// Inspector: windows of one tile + the tile-local column copy.  col_local must be pre-filled with
-// a copy of ColIdx (entries of unstaged tiles and of long rows keep their global value).
+// Inspector: windows of one row tile + the tile-local column copy.  col_local must be pre-filled
+// with a copy of ColIdx (entries of unstaged tiles and of long rows keep their global value).
 __global__ __launch_bounds__(kBlock) void csr_tile_windows_kernel(int m, int n, int long_thr, int max_cols,
                                                                   const int *__restrict__ split,
                                                                   const int *__restrict__ rowptr,
@@ -59,135 +48,17 @@ __global__ __launch_bounds__(kBlock) void csr_tile_windows_kernel(int m, int n, 
                                                                   int *__restrict__ col_local,
                                                                   int *__restrict__ staged /* [0] tiles staged, [1] max total */)
 {
-    __shared__ unsigned bitmap[kWinBitmapWords];
-    __shared__ int smin[kBlock / kWave], smax[kBlock / kWave], wave_cnt[kBlock / kWave];
-    __shared__ int s_start[kWinMax], s_end[kWinMax], s_base[kWinMax];
-    __shared__ int s_nwin, s_total, s_bits;
     long long r0, r1;
     tile_rows(blockIdx.x, m, split, r0, r1);
     const int sub = threadIdx.x / 16, l = threadIdx.x % 16; // 16 lanes sweep a row
-    const int lane = threadIdx.x & (kWave - 1), wave = threadIdx.x / kWave;
-
-    // pass 1: column range of the tile's short rows
-    int mn = INT_MAX, mx = -1;
-    for (long long r = r0 + sub; r < r1; r += kBlock / 16) {
-        const int p0 = rowptr[r], p1 = rowptr[r + 1];
-        if (p1 - p0 > long_thr) continue;
-        for (int p = p0 + l; p < p1; p += 16) {
-            const int c = colidx[p];
-            mn = min(mn, c);
-            mx = max(mx, c);
-        }
-    }
-#pragma unroll
-    for (int o = kWave / 2; o > 0; o >>= 1) {
-        mn = min(mn, __shfl_xor(mn, o, kWave));
-        mx = max(mx, __shfl_xor(mx, o, kWave));
-    }
-    if (lane == 0) { smin[wave] = mn; smax[wave] = mx; }
-    if (threadIdx.x == 0) { s_nwin = 0; s_total = 0; s_bits = 0; }
-    __syncthreads();
-    mn = min(min(smin[0], smin[1]), min(smin[2], smin[3]));
-    mx = max(max(smax[0], smax[1]), max(smax[2], smax[3]));
-    const long long span = mx >= mn ? (long long) mx - mn + 1 : 0;
-    const int seg_lo = mn >> kWinSegShift;
-    const int nseg = span > 0 ? (mx >> kWinSegShift) - seg_lo + 1 : 0;
-    const int nwords = (nseg + 31) / 32;
-
-    if (span > 0 && span <= max_cols) { // one window: the plain span
-        if (threadIdx.x == 0) { s_nwin = 1; s_total = (int) span; s_start[0] = mn; s_end[0] = mx + 1; s_base[0] = 0; }
-    } else if (span > 0 && nwords <= kWinBitmapWords) { // several windows: runs of touched 64-column segments
-        for (int w = threadIdx.x; w < nwords; w += kBlock) bitmap[w] = 0u;
-        __syncthreads();
+    auto loop = [&](auto body) {
         for (long long r = r0 + sub; r < r1; r += kBlock / 16) {
             const int p0 = rowptr[r], p1 = rowptr[r + 1];
-            if (p1 - p0 > long_thr) continue;
-            for (int p = p0 + l; p < p1; p += 16) {
-                const int s = (colidx[p] >> kWinSegShift) - seg_lo;
-                atomicOr(&bitmap[s >> 5], 1u << (s & 31));
-            }
+            if (p1 - p0 > long_thr) continue; // long rows are computed elsewhere, from the original ColIdx
+            for (int p = p0 + l; p < p1; p += 16) body(colidx[p], (long long) p);
         }
-        __syncthreads();
-        // each thread owns 4 consecutive words: count run starts and set bits
-        int starts = 0, bits = 0;
-        for (int k = 0; k < 4; ++k) {
-            const int w = threadIdx.x * 4 + k;
-            if (w < nwords) {
-                const unsigned cur = bitmap[w];
-                const unsigned prev = w > 0 ? bitmap[w - 1] >> 31 : 0u;
-                starts += __popc(cur & ~((cur << 1) | prev));
-                bits += __popc(cur);
-            }
-        }
-        int inc = starts;
-#pragma unroll
-        for (int d = 1; d < kWave; d <<= 1) {
-            const int o = __shfl_up(inc, d, kWave);
-            if (lane >= d) inc += o;
-        }
-#pragma unroll
-        for (int o = kWave / 2; o > 0; o >>= 1) bits += __shfl_xor(bits, o, kWave);
-        if (lane == kWave - 1) wave_cnt[wave] = inc;
-        if (lane == 0) atomicAdd(&s_bits, bits);
-        __syncthreads();
-        int idx = inc - starts; // run starts in front of this thread's words
-        for (int w = 0; w < wave; ++w) idx += wave_cnt[w];
-        const int runs = wave_cnt[0] + wave_cnt[1] + wave_cnt[2] + wave_cnt[3];
-        if (runs <= kWinMax && ((long long) s_bits << kWinSegShift) <= max_cols) {
-            for (int k = 0; k < 4; ++k) {
-                const int w = threadIdx.x * 4 + k;
-                if (w >= nwords) break;
-                const unsigned cur = bitmap[w];
-                const unsigned prev = w > 0 ? bitmap[w - 1] >> 31 : 0u;
-                unsigned st = cur & ~((cur << 1) | prev);
-                while (st) { // run starts of this word, in ascending order
-                    const int b = __ffs((int) st) - 1;
-                    st &= st - 1;
-                    s_start[idx++] = (seg_lo + w * 32 + b) << kWinSegShift;
-                }
-            }
-            __syncthreads();
-            if (threadIdx.x == 0) { // run ends: walk each run (<= max_cols/64 set segments in total)
-                int base = 0;
-                for (int k = 0; k < runs; ++k) {
-                    int s = (s_start[k] >> kWinSegShift) - seg_lo;
-                    while (s < nseg && ((bitmap[s >> 5] >> (s & 31)) & 1u)) ++s;
-                    int end = (seg_lo + s) << kWinSegShift;
-                    if (end > n) end = n;
-                    s_end[k] = end;
-                    s_base[k] = base;
-                    base += end - s_start[k];
-                }
-                s_total = base;
-                s_nwin = runs;
-            }
-        }
-    }
-    __syncthreads();
-    const int nwin = s_nwin;
-    if (threadIdx.x == 0) {
-        TileWindows &tw = wins[blockIdx.x];
-        tw.nwin = nwin;
-        tw.total = nwin ? s_total : 0;
-        for (int k = 0; k < kWinMax; ++k) {
-            tw.start[k] = k < nwin ? s_start[k] : 0;
-            tw.len[k] = k < nwin ? s_end[k] - s_start[k] : 0;
-            tw.base[k] = k < nwin ? s_base[k] : 0;
-        }
-        if (nwin) { atomicAdd(staged, 1); atomicMax(staged + 1, s_total); }
-    }
-    if (nwin == 0) return;
-    // pass 2: tile-local column = LDS slot
-    for (long long r = r0 + sub; r < r1; r += kBlock / 16) {
-        const int p0 = rowptr[r], p1 = rowptr[r + 1];
-        if (p1 - p0 > long_thr) continue;
-        for (int p = p0 + l; p < p1; p += 16) {
-            const int c = colidx[p];
-            int w = 0;
-            for (int k = 1; k < nwin; ++k) w = c >= s_start[k] ? k : w; // windows are sorted by start
-            col_local[p] = s_base[w] + (c - s_start[w]);
-        }
-    }
+    };
+    build_windows(n, max_cols, loop, col_local, wins[blockIdx.x], staged);
 }
 
 template <typename T, int L, bool STAGED, int DEPTH, bool PRE = true>
@@ -254,17 +125,6 @@ __device__ __forceinline__ void csr_vector_tile_wave(long long row_end, int long
     if (row < row_end && len <= long_thr) y[row] = y_lds[lane]; // one coalesced 64-row store per wave
 }
 
-// Stage the tile's windows: xs[base_w + i] = x[start_w + i].
-template <typename T>
-__device__ __forceinline__ void stage_windows(const TileWindows &tw, const T *__restrict__ x, T *__restrict__ xs)
-{
-    const int nwin = tw.nwin;
-    for (int w = 0; w < nwin; ++w) {
-        const int st = tw.start[w], ln = tw.len[w], bs = tw.base[w];
-        for (int i = threadIdx.x; i < ln; i += kVecTileThreads) xs[bs + i] = x[st + i];
-    }
-}
-
 template <typename T, int L, int DEPTH = 4, bool PRE = true>
 __global__ __launch_bounds__(kVecTileThreads) void csr_vector_tile_kernel(int m, int long_thr, const int *__restrict__ rowptr,
                                                                           const int *__restrict__ col_local,
@@ -299,7 +159,7 @@ __global__ __launch_bounds__(kVecTileThreads) void csr_vector_tile_kernel(int m,
     rp_lds[wave][lane] = rp;
     if (lane == 0) rp_lds[wave][kWave] = rpe;
     const bool staged = tw.nwin > 0;
-    stage_windows<T>(tw, x, xs);
+    stage_windows<kVecTileThreads, T>(tw, x, xs);
     __syncthreads();
     if (rw0 >= m) return;
     if (staged) csr_vector_tile_wave<T, L, true, DEPTH, PRE>((long long) m, long_thr, rw0, lane, rp_lds[wave], y_lds[wave], col_local, val, x, xs, y, c0, v0);
@@ -326,7 +186,7 @@ __global__ __launch_bounds__(kVecTileThreads) void csr_vector_rows_kernel(int lo
     const long long r_begin = split[blockIdx.x], r_end = split[blockIdx.x + 1];
     const TileWindows &tw = wins[blockIdx.x];
     const bool staged = tw.nwin > 0;
-    stage_windows<T>(tw, x, xs);
+    stage_windows<kVecTileThreads, T>(tw, x, xs);
     __syncthreads();
     const int c0[4] = {0, 0, 0, 0};
     const T v0[4] = {T(0), T(0), T(0), T(0)};

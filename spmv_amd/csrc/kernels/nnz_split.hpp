@@ -25,6 +25,7 @@
 #pragma once
 #include <climits>
 #include "common.hpp"
+#include "xwindows.hpp"
 
 namespace spmv {
 
@@ -55,7 +56,7 @@ template <typename T, bool STAGED>
 __device__ __forceinline__ void nnz_tile(int t, int lane, int *__restrict__ seg, int nnz,
                                          const int *__restrict__ rowptr, const int *__restrict__ colidx,
                                          const T *__restrict__ val, const T *__restrict__ x,
-                                         const T *__restrict__ xs, int lo, T *__restrict__ y,
+                                         const T *__restrict__ xs, T *__restrict__ y,
                                          const int *__restrict__ tile_first, T *__restrict__ carry)
 {
     constexpr int kSplitK = SplitCfg<T>::K;
@@ -76,14 +77,14 @@ __device__ __forceinline__ void nnz_tile(int t, int lane, int *__restrict__ seg,
 #pragma unroll
         for (int k = 0; k < kSplitK; ++k) {
             const bool in = p + k < nnz;
-            c[k] = in ? colidx[p + k] : (STAGED ? lo : 0);
+            c[k] = in ? colidx[p + k] : 0;
             v[k] = in ? val[p + k] : T(0);
         }
     }
     // 2. gather x (slots past nnz are masked in step 4, so x[0] / xs[0] can never leak)
     T xv[kSplitK];
 #pragma unroll
-    for (int k = 0; k < kSplitK; ++k) xv[k] = STAGED ? xs[c[k] - lo] : x[c[k]];
+    for (int k = 0; k < kSplitK; ++k) xv[k] = STAGED ? xs[c[k]] : x[c[k]]; // STAGED: colidx holds LDS slots
 
     // 3. rows owned by this tile: zero the empty ones, mark the start of the others
     const int rf = tile_first[t];
@@ -157,65 +158,35 @@ __global__ __launch_bounds__(kBlock) void nnz_split_kernel(int m, int nnz, int n
     const int waves_total = gridDim.x * (kBlock / kWave);
     (void) m;
     for (int t = blockIdx.x * (kBlock / kWave) + wave; t < ntiles; t += waves_total)
-        nnz_tile<T, false>(t, lane, seg_lds[wave], nnz, rowptr, colidx, val, x, nullptr, 0, y, tile_first, carry);
+        nnz_tile<T, false>(t, lane, seg_lds[wave], nnz, rowptr, colidx, val, x, nullptr, y, tile_first, carry);
 }
 
-// ---- LDS-staged x tiles: a workgroup owns kSplitGroupTiles consecutive tiles and stages the column
-// span of their nnz range when it fits (same idea as csr5_group_kernel).
+// ---- LDS-staged x windows (xwindows.hpp): a workgroup owns kSplitGroupTiles consecutive tiles; the
+// columns of their nnz range are covered by up to 16 windows and `col_local` (a private copy of
+// ColIdx) holds LDS slots for staged groups, global columns otherwise.
 constexpr int kSplitGroupTiles = 16;
-
-__global__ __launch_bounds__(kBlock) void nnz_group_span_kernel(int nnz, int group_nnz, int max_span,
-                                                                const int *__restrict__ colidx,
-                                                                int *__restrict__ grp_lo, int *__restrict__ grp_span,
-                                                                int *__restrict__ staged /* [0] count, [1] max span */)
-{
-    __shared__ int smin[kBlock / kWave], smax[kBlock / kWave];
-    const long long b = (long long) blockIdx.x * group_nnz;
-    long long e = b + group_nnz;
-    if (e > nnz) e = nnz;
-    int mn = INT_MAX, mx = -1;
-    for (long long i = b + threadIdx.x; i < e; i += kBlock) {
-        const int c = colidx[i];
-        mn = min(mn, c);
-        mx = max(mx, c);
-    }
-#pragma unroll
-    for (int o = kWave / 2; o > 0; o >>= 1) {
-        mn = min(mn, __shfl_xor(mn, o, kWave));
-        mx = max(mx, __shfl_xor(mx, o, kWave));
-    }
-    if ((threadIdx.x & (kWave - 1)) == 0) { smin[threadIdx.x / kWave] = mn; smax[threadIdx.x / kWave] = mx; }
-    __syncthreads();
-    if (threadIdx.x == 0) {
-        for (int k = 1; k < kBlock / kWave; ++k) { mn = min(mn, smin[k]); mx = max(mx, smax[k]); }
-        const long long span = mx >= mn ? (long long) mx - mn + 1 : 0;
-        const bool ok = span > 0 && span <= max_span;
-        grp_lo[blockIdx.x] = ok ? mn : 0;
-        grp_span[blockIdx.x] = ok ? (int) span : 0;
-        if (ok) { atomicAdd(staged, 1); atomicMax(staged + 1, (int) span); }
-    }
-}
 
 template <typename T>
 __global__ __launch_bounds__(kBlock) void nnz_group_kernel(int nnz, int ntiles, const int *__restrict__ rowptr,
-                                                           const int *__restrict__ colidx, const T *__restrict__ val,
-                                                           const int *__restrict__ grp_lo, const int *__restrict__ grp_span,
+                                                           const int *__restrict__ col_local, const T *__restrict__ val,
+                                                           const TileWindows *__restrict__ wins,
                                                            const T *__restrict__ x, T *__restrict__ y,
                                                            const int *__restrict__ tile_first, T *__restrict__ carry)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char nnz_x_lds[];
     T *xs = reinterpret_cast<T *>(nnz_x_lds);
     __shared__ __attribute__((aligned(16))) int seg_lds[kBlock / kWave][SplitCfg<T>::Tile];
-    const int lo = grp_lo[blockIdx.x], span = grp_span[blockIdx.x];
-    for (int i = threadIdx.x; i < span; i += kBlock) xs[i] = x[lo + i];
-    if (span > 0) __syncthreads();
+    const TileWindows &tw = wins[blockIdx.x];
+    const bool staged = tw.nwin > 0;
+    stage_windows<kBlock, T>(tw, x, xs);
+    if (staged) __syncthreads();
     const int lane = threadIdx.x & (kWave - 1), wave = threadIdx.x / kWave;
     const int t0 = blockIdx.x * kSplitGroupTiles;
     for (int k = wave; k < kSplitGroupTiles; k += kBlock / kWave) {
         const int t = t0 + k;
         if (t >= ntiles) break;
-        if (span > 0) nnz_tile<T, true>(t, lane, seg_lds[wave], nnz, rowptr, colidx, val, x, xs, lo, y, tile_first, carry);
-        else nnz_tile<T, false>(t, lane, seg_lds[wave], nnz, rowptr, colidx, val, x, xs, lo, y, tile_first, carry);
+        if (staged) nnz_tile<T, true>(t, lane, seg_lds[wave], nnz, rowptr, col_local, val, x, xs, y, tile_first, carry);
+        else nnz_tile<T, false>(t, lane, seg_lds[wave], nnz, rowptr, col_local, val, x, xs, y, tile_first, carry);
     }
 }
 

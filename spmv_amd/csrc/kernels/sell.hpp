@@ -23,6 +23,7 @@
 #pragma once
 #include <climits>
 #include "common.hpp"
+#include "xwindows.hpp"
 
 namespace spmv {
 
@@ -174,43 +175,11 @@ __global__ __launch_bounds__(kBlock) void sell_kernel(int nchunks, const long lo
 // window as a whole only references x[lo, lo+span): when that span fits in LDS the workgroup stages
 // it once (coalesced) and every gather becomes an LDS read.
 //
-// Inspector: per window the min / max column over its slab entries.
-__global__ __launch_bounds__(kBlock) void sell_window_span_kernel(int chunks_per_win, int max_span,
-                                                                  const long long *__restrict__ chunk_ptr,
-                                                                  const int *__restrict__ scol,
-                                                                  int *__restrict__ win_lo, int *__restrict__ win_span,
-                                                                  int *__restrict__ staged_windows /* [0] count, [1] max span */)
-{
-    __shared__ int smin[kBlock / kWave], smax[kBlock / kWave];
-    const int w = blockIdx.x;
-    const long long b = chunk_ptr[(long long) w * chunks_per_win] * kSellC;
-    const long long e = chunk_ptr[(long long) (w + 1) * chunks_per_win] * kSellC;
-    int mn = INT_MAX, mx = -1;
-    for (long long i = b + threadIdx.x; i < e; i += kBlock) {
-        const int c = scol[i];
-        if (c >= 0) { mn = min(mn, c); mx = max(mx, c); }
-    }
-#pragma unroll
-    for (int o = kWave / 2; o > 0; o >>= 1) {
-        mn = min(mn, __shfl_xor(mn, o, kWave));
-        mx = max(mx, __shfl_xor(mx, o, kWave));
-    }
-    if ((threadIdx.x & (kWave - 1)) == 0) { smin[threadIdx.x / kWave] = mn; smax[threadIdx.x / kWave] = mx; }
-    __syncthreads();
-    if (threadIdx.x == 0) {
-        for (int k = 1; k < kBlock / kWave; ++k) { mn = min(mn, smin[k]); mx = max(mx, smax[k]); }
-        const long long span = mx >= mn ? (long long) mx - mn + 1 : 0;
-        const bool ok = span > 0 && span <= max_span;
-        win_lo[w] = ok ? mn : 0;
-        win_span[w] = ok ? (int) span : 0; // 0: gather from global memory
-        if (ok) { atomicAdd(staged_windows, 1); atomicMax(staged_windows + 1, (int) span); }
-    }
-}
-
+// Inspector: range_windows_kernel (xwindows.hpp) over each sigma window's slab entries, in place on scol.
 constexpr int kSellWinThreads = 512; // 8 wavefronts per sigma window
 
 template <typename T, bool STAGED>
-__device__ __forceinline__ void sell_chunk(const int *__restrict__ pc, const T *__restrict__ pv, int width, int lo,
+__device__ __forceinline__ void sell_chunk(const int *__restrict__ pc, const T *__restrict__ pv, int width,
                                            const T *__restrict__ xs, const T *__restrict__ x, T &sum)
 {
     constexpr int U = 8;
@@ -225,12 +194,12 @@ __device__ __forceinline__ void sell_chunk(const int *__restrict__ pc, const T *
         }
 #pragma unroll
         for (int u = 0; u < U; ++u)
-            if (cc[u] >= 0) sum = fmadd(vv[u], STAGED ? xs[cc[u] - lo] : x[cc[u]], sum);
+            if (cc[u] >= 0) sum = fmadd(vv[u], STAGED ? xs[cc[u]] : x[cc[u]], sum); // STAGED: scol holds LDS slots
     }
     for (; j < width; ++j) {
         const int cc = ld_stream(pc + (size_t) j * kSellC);
         const T vv = ld_stream(pv + (size_t) j * kSellC);
-        if (cc >= 0) sum = fmadd(vv, STAGED ? xs[cc - lo] : x[cc], sum);
+        if (cc >= 0) sum = fmadd(vv, STAGED ? xs[cc] : x[cc], sum);
     }
 }
 
@@ -241,16 +210,16 @@ __global__ __launch_bounds__(kSellWinThreads) void sell_window_kernel(int chunks
                                                                       const int *__restrict__ scol,
                                                                       const T *__restrict__ sval,
                                                                       const int *__restrict__ perm,
-                                                                      const int *__restrict__ win_lo,
-                                                                      const int *__restrict__ win_span,
+                                                                      const TileWindows *__restrict__ wins,
                                                                       const T *__restrict__ x, T *__restrict__ y)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char sell_x_lds[];
     T *xs = reinterpret_cast<T *>(sell_x_lds);
     const int w = blockIdx.x;
-    const int lo = win_lo[w], span = win_span[w];
-    for (int i = threadIdx.x; i < span; i += kSellWinThreads) xs[i] = x[lo + i];
-    if (span > 0) __syncthreads();
+    const TileWindows &tw = wins[w];
+    const bool staged = tw.nwin > 0;
+    stage_windows<kSellWinThreads, T>(tw, x, xs);
+    if (staged) __syncthreads();
     const int lane = threadIdx.x & (kWave - 1);
     for (int k = threadIdx.x / kWave; k < chunks_per_win; k += kSellWinThreads / kWave) {
         const long long c = (long long) w * chunks_per_win + k;
@@ -259,8 +228,8 @@ __global__ __launch_bounds__(kSellWinThreads) void sell_window_kernel(int chunks
         const int *pc = scol + (size_t) c0 * kSellC + lane;
         const T *pv = sval + (size_t) c0 * kSellC + lane;
         T sum = 0;
-        if (span > 0) sell_chunk<T, true>(pc, pv, width, lo, xs, x, sum);
-        else sell_chunk<T, false>(pc, pv, width, lo, xs, x, sum);
+        if (staged) sell_chunk<T, true>(pc, pv, width, xs, x, sum);
+        else sell_chunk<T, false>(pc, pv, width, xs, x, sum);
         const int row = perm[c * kSellC + lane];
         if (row >= 0) y[row] = sum;
     }

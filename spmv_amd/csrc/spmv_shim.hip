@@ -80,7 +80,8 @@ struct spmv_dev {
     int *tile_first = nullptr;
     void *carry = nullptr;
     int ns_groups = 0, ns_staged = 0, ns_maxspan = 0;
-    int *ns_lo = nullptr, *ns_span = nullptr;
+    int *ns_col = nullptr;          // private ColIdx copy (LDS slots for staged groups)
+    TileWindows *ns_wins = nullptr;
     // row blocks
     int nblocks = 0, rb_stride = 0;
     int *rb_split = nullptr;
@@ -97,13 +98,14 @@ struct spmv_dev {
     // sell
     int nchunks = 0;
     long long sell_cols = 0; // sum of chunk widths
-    int *perm = nullptr, *scol = nullptr, *win_lo = nullptr, *win_span = nullptr;
+    int *perm = nullptr, *scol = nullptr;
+    TileWindows *sell_wins = nullptr;
     int sell_nwin = 0, sell_staged = 0, sell_xcap = 0, sell_maxspan = 0; // windows, windows with x staged in LDS, LDS capacity in elements
     long long *chunk_ptr = nullptr;
     void *sval = nullptr;
     // csr5
     int c5_sigma = 0, c5_tiles = 0, c5_m2 = 0, c5_fixup = 0, c5_groups = 0, c5_staged = 0, c5_maxspan = 0;
-    int *c5_grp_lo = nullptr, *c5_grp_span = nullptr;
+    TileWindows *c5_wins = nullptr;
     int *c5_tile_ptr = nullptr, *c5_run_len = nullptr, *c5_row_map = nullptr, *c5_col = nullptr;
     unsigned *c5_desc = nullptr;
     void *c5_val = nullptr, *c5_carry = nullptr;
@@ -133,15 +135,15 @@ static void free_schedule(spmv_dev *d)
 {
     for (void *p : d->sched_allocs) (void) hipFree(p);
     d->sched_allocs.clear();
-    d->tile_first = nullptr; d->carry = nullptr; d->rb_split = nullptr; d->ns_lo = d->ns_span = nullptr; d->ns_groups = d->ns_staged = 0;
-    d->perm = d->scol = d->long_rows = d->lr_seg_lr = d->win_lo = d->win_span = nullptr; d->sell_staged = d->sell_nwin = 0; d->chunk_ptr = d->lr_seg_start = nullptr;
+    d->tile_first = nullptr; d->carry = nullptr; d->rb_split = nullptr; d->ns_col = nullptr; d->ns_wins = nullptr; d->ns_groups = d->ns_staged = 0;
+    d->perm = d->scol = d->long_rows = d->lr_seg_lr = nullptr; d->sell_wins = nullptr; d->sell_staged = d->sell_nwin = 0; d->chunk_ptr = d->lr_seg_start = nullptr;
     d->sval = d->lr_part = nullptr;
     d->ntiles = d->nblocks = d->nchunks = d->nlong = d->lr_segs = 0;
     d->long_thr = INT_MAX;
     d->vt_col = nullptr; d->vt_wins = nullptr; d->vt_tiles = d->vt_staged = d->vt_maxspan = 0;
     d->c5_tile_ptr = d->c5_run_len = d->c5_row_map = d->c5_col = nullptr; d->c5_desc = nullptr;
     d->c5_val = d->c5_carry = nullptr; d->c5_tiles = d->c5_m2 = d->c5_fixup = 0;
-    d->c5_grp_lo = d->c5_grp_span = nullptr; d->c5_groups = d->c5_staged = d->c5_maxspan = 0;
+    d->c5_wins = nullptr; d->c5_groups = d->c5_staged = d->c5_maxspan = 0;
     d->built = false;
 }
 
@@ -351,6 +353,34 @@ extern "C" void spmv_shim_matrix_destroy(spmv_dev *d)
 }
 
 // ------------------------------------------------------------------------------------ inspectors
+// x windows over contiguous ranges of a PRIVATE column array (xwindows.hpp).  Two passes: count the
+// groups whose columns fit LDS; only if at least half do (or in_place_ok is false and any does...)
+// rewrite the array into LDS slots.  Returns staged groups (0 = array untouched) and the LDS need.
+static int build_range_windows(spmv_dev *d, int groups, long long total, long long group_len, const long long *bounds, int bstride,
+                               int scale, int max_cols, int *cols, TileWindows *wins, int *staged_out, int *maxtotal_out)
+{
+    int *cnt = nullptr;
+    int host2[2] = {0, 0};
+    *staged_out = *maxtotal_out = 0;
+    if (groups <= 0) return SPMV_HIP_OK;
+    HIP_TRY(hipMalloc((void **) &cnt, 2 * sizeof(int)));
+    hipError_t e = hipMemsetAsync(cnt, 0, 2 * sizeof(int), d->stream);
+    range_windows_kernel<<<groups, kBlock, 0, d->stream>>>(total, group_len, bounds, bstride, scale, d->n, max_cols, cols, wins, cnt, 0);
+    if (e == hipSuccess) e = hipGetLastError();
+    if (e == hipSuccess) e = hipMemcpyAsync(host2, cnt, sizeof host2, hipMemcpyDeviceToHost, d->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(d->stream);
+    if (e == hipSuccess && host2[0] * 2 >= groups) { // worth it: rewrite the staged groups into LDS slots
+        range_windows_kernel<<<groups, kBlock, 0, d->stream>>>(total, group_len, bounds, bstride, scale, d->n, max_cols, cols, wins, cnt, 1);
+        e = hipGetLastError();
+        if (e == hipSuccess) e = hipStreamSynchronize(d->stream);
+        *staged_out = host2[0];
+        *maxtotal_out = host2[1];
+    }
+    (void) hipFree(cnt);
+    if (e != hipSuccess) return fail(SPMV_HIP_E_RUNTIME, "x-window inspector: %s", hipGetErrorString(e));
+    return SPMV_HIP_OK;
+}
+
 constexpr size_t kVecXTileBytes = 48 * 1024; // LDS budget of one row tile's x span (CSR-vector, Balanced)
 template <typename T> static int build_long_rows(spmv_dev *d, int thr);
 template <typename T> static int autotune_vector(spmv_dev *d);
@@ -374,22 +404,15 @@ static int build_nnz_split(spmv_dev *d)
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipMemcpyAsync(&d->need_fixup, flag, sizeof(int), hipMemcpyDeviceToHost, d->stream));
     HIP_TRY(hipStreamSynchronize(d->stream));
-    // column span of every group of kSplitGroupTiles tiles (LDS-staged x tiles)
+    // x windows of every group of kSplitGroupTiles tiles (xwindows.hpp) on a private ColIdx copy
     d->ns_groups = (d->ntiles + kSplitGroupTiles - 1) / kSplitGroupTiles;
+    ALLOC_TRY(d, &d->ns_col, sizeof(int) * ((size_t) d->nnz + kStreamPad), true);
+    ALLOC_TRY(d, &d->ns_wins, sizeof(TileWindows) * (size_t) d->ns_groups, true);
+    HIP_TRY(hipMemcpyAsync(d->ns_col, d->colidx, sizeof(int) * ((size_t) d->nnz + kStreamPad), hipMemcpyDeviceToDevice, d->stream));
     {
-        int *cnt = nullptr;
-        int host2[2] = {0, 0};
-        ALLOC_TRY(d, &cnt, 2 * sizeof(int), true);
-        ALLOC_TRY(d, &d->ns_lo, sizeof(int) * (size_t) d->ns_groups, true);
-        ALLOC_TRY(d, &d->ns_span, sizeof(int) * (size_t) d->ns_groups, true);
-        HIP_TRY(hipMemsetAsync(cnt, 0, 2 * sizeof(int), d->stream));
-        nnz_group_span_kernel<<<d->ns_groups, kBlock, 0, d->stream>>>((int) d->nnz, kSplitGroupTiles * tile, (int) (kSplitXTileBytes / sizeof(T)),
-                                                                      d->colidx, d->ns_lo, d->ns_span, cnt);
-        HIP_TRY(hipGetLastError());
-        HIP_TRY(hipMemcpyAsync(host2, cnt, 2 * sizeof(int), hipMemcpyDeviceToHost, d->stream));
-        HIP_TRY(hipStreamSynchronize(d->stream));
-        d->ns_staged = host2[0];
-        d->ns_maxspan = host2[1];
+        const int rc = build_range_windows(d, d->plan.variant == 3 ? 0 : d->ns_groups, d->nnz, (long long) kSplitGroupTiles * tile, nullptr, 1, 1,
+                                           (int) (kSplitXTileBytes / sizeof(T)), d->ns_col, d->ns_wins, &d->ns_staged, &d->ns_maxspan);
+        if (rc) return rc;
     }
     return SPMV_HIP_OK;
 }
@@ -540,20 +563,12 @@ static int build_sell(spmv_dev *d)
     HIP_TRY(hipGetLastError());
     d->sell_nwin = nwin;
     d->sell_staged = 0;
-    if (d->plan.sell_lds_x) { // x span of every window; windows that fit are staged in LDS by the executor
+    if (d->plan.sell_lds_x && d->plan.variant != 3) { // x windows of every sigma window, in place on scol (xwindows.hpp)
         d->sell_xcap = (int) (kSellXTileBytes / sizeof(T));
-        int *cnt = nullptr;
-        ALLOC_TRY(d, &cnt, 2 * sizeof(int), true);
-        ALLOC_TRY(d, &d->win_lo, sizeof(int) * (size_t) nwin, true);
-        ALLOC_TRY(d, &d->win_span, sizeof(int) * (size_t) nwin, true);
-        HIP_TRY(hipMemsetAsync(cnt, 0, 2 * sizeof(int), d->stream));
-        sell_window_span_kernel<<<nwin, kBlock, 0, d->stream>>>(sigma / kSellC, d->sell_xcap, d->chunk_ptr, d->scol, d->win_lo, d->win_span, cnt);
-        HIP_TRY(hipGetLastError());
-        int host2[2] = {0, 0};
-        HIP_TRY(hipMemcpyAsync(host2, cnt, 2 * sizeof(int), hipMemcpyDeviceToHost, d->stream));
-        HIP_TRY(hipStreamSynchronize(d->stream));
-        d->sell_staged = host2[0];
-        d->sell_maxspan = host2[1];
+        ALLOC_TRY(d, &d->sell_wins, sizeof(TileWindows) * (size_t) nwin, true);
+        const int rc = build_range_windows(d, nwin, (long long) slots, 0, d->chunk_ptr, sigma / kSellC, kSellC, d->sell_xcap, d->scol, d->sell_wins,
+                                           &d->sell_staged, &d->sell_maxspan);
+        if (rc) return rc;
         HIP_TRY(hipFuncSetAttribute((const void *) sell_window_kernel<T>, hipFuncAttributeMaxDynamicSharedMemorySize, (int) kSellXTileBytes));
     }
     HIP_TRY(hipStreamSynchronize(d->stream));
@@ -587,22 +602,13 @@ static int build_csr5_sigma(spmv_dev *d, const int *rp, int m2)
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipMemcpyAsync(&d->c5_fixup, flag, sizeof(int), hipMemcpyDeviceToHost, d->stream));
     HIP_TRY(hipStreamSynchronize(d->stream));
-    // x span of every group of kCsr5GroupTiles tiles (LDS-staged x tiles, csr5.hpp)
+    // x windows of every group of kCsr5GroupTiles tiles, in place on the transposed column copy (xwindows.hpp)
     d->c5_groups = (p + kCsr5GroupTiles - 1) / kCsr5GroupTiles;
+    ALLOC_TRY(d, &d->c5_wins, sizeof(TileWindows) * (size_t) d->c5_groups, true);
     {
-        int *cnt = nullptr;
-        int host2[2] = {0, 0};
-        ALLOC_TRY(d, &cnt, 2 * sizeof(int), true);
-        ALLOC_TRY(d, &d->c5_grp_lo, sizeof(int) * (size_t) d->c5_groups, true);
-        ALLOC_TRY(d, &d->c5_grp_span, sizeof(int) * (size_t) d->c5_groups, true);
-        HIP_TRY(hipMemsetAsync(cnt, 0, 2 * sizeof(int), d->stream));
-        csr5_group_span_kernel<<<d->c5_groups, kBlock, 0, d->stream>>>(p, TN, (int) (kCsr5XTileBytes / sizeof(T)), d->c5_col, d->c5_grp_lo,
-                                                                        d->c5_grp_span, cnt);
-        HIP_TRY(hipGetLastError());
-        HIP_TRY(hipMemcpyAsync(host2, cnt, 2 * sizeof(int), hipMemcpyDeviceToHost, d->stream));
-        HIP_TRY(hipStreamSynchronize(d->stream));
-        d->c5_staged = host2[0];
-        d->c5_maxspan = host2[1];
+        const int rc = build_range_windows(d, d->plan.variant == 3 ? 0 : d->c5_groups, (long long) p * TN, (long long) kCsr5GroupTiles * TN, nullptr, 1, 1,
+                                           (int) (kCsr5XTileBytes / sizeof(T)), d->c5_col, d->c5_wins, &d->c5_staged, &d->c5_maxspan);
+        if (rc) return rc;
     }
     return SPMV_HIP_OK;
 }
@@ -791,7 +797,7 @@ static int autotune_vector(spmv_dev *d)
 template <typename T, int SIGMA>
 static void launch_csr5(spmv_dev *d, const T *x, T *y)
 {
-    if (d->c5_staged * 2 >= d->c5_groups && d->plan.variant != 3) { // most groups fit their x span in LDS
+    if (d->c5_staged > 0) { // the inspector staged (at least half of) the groups: tcol holds LDS slots for them
         const size_t lds = (((size_t) d->c5_maxspan * sizeof(T)) + 1023) & ~(size_t) 1023;
         if (lds > 64 * 1024) { // above the default dynamic-LDS limit: raise it for this instantiation (idempotent, cheap)
             if (d->c5_row_map) (void) hipFuncSetAttribute((const void *) csr5_group_kernel<T, SIGMA, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int) lds);
@@ -799,10 +805,10 @@ static void launch_csr5(spmv_dev *d, const T *x, T *y)
         }
         if (d->c5_row_map)
             csr5_group_kernel<T, SIGMA, true><<<d->c5_groups, kBlock, lds, d->stream>>>(d->c5_tiles, d->c5_tile_ptr, d->c5_desc, d->c5_col,
-                (const T *) d->c5_val, d->c5_row_map, d->c5_grp_lo, d->c5_grp_span, x, y, (T *) d->c5_carry);
+                (const T *) d->c5_val, d->c5_row_map, d->c5_wins, x, y, (T *) d->c5_carry);
         else
             csr5_group_kernel<T, SIGMA, false><<<d->c5_groups, kBlock, lds, d->stream>>>(d->c5_tiles, d->c5_tile_ptr, d->c5_desc, d->c5_col,
-                (const T *) d->c5_val, nullptr, d->c5_grp_lo, d->c5_grp_span, x, y, (T *) d->c5_carry);
+                (const T *) d->c5_val, nullptr, d->c5_wins, x, y, (T *) d->c5_carry);
         return;
     }
     const int grid = grid_for(d->c5_tiles, kBlock / kWave, INT_MAX);
@@ -843,9 +849,9 @@ static int launch(spmv_dev *d, const T *x, T *y)
         if (d->plan.variant != 2) launch_long_rows<T>(d, x, y);
         break;
     case SPMV_SCHED_NNZ_SPLIT: {
-        if (d->ns_staged * 2 >= d->ns_groups && d->ns_groups > 0 && d->plan.variant != 3) {
+        if (d->ns_staged > 0) {
             const size_t lds = (((size_t) d->ns_maxspan * sizeof(T)) + 1023) & ~(size_t) 1023;
-            nnz_group_kernel<T><<<d->ns_groups, kBlock, lds, d->stream>>>((int) d->nnz, d->ntiles, d->rowptr, d->colidx, val, d->ns_lo, d->ns_span,
+            nnz_group_kernel<T><<<d->ns_groups, kBlock, lds, d->stream>>>((int) d->nnz, d->ntiles, d->rowptr, d->ns_col, val, d->ns_wins,
                                                                          x, y, d->tile_first, (T *) d->carry);
         } else {
             const int grid = grid_for(d->ntiles, kBlock / kWave, d->plan.variant == 1 ? d->cus * 8 : INT_MAX);
@@ -876,9 +882,9 @@ static int launch(spmv_dev *d, const T *x, T *y)
     case SPMV_SCHED_SELL:
         // staged path when at least half of the windows fit their x span in LDS; the LDS request is
         // sized by the largest staged span actually present (rounded to 16 KiB) to keep occupancy
-        if (d->plan.sell_lds_x && d->sell_staged * 2 >= d->sell_nwin && d->plan.variant != 3)
+        if (d->sell_staged > 0)
             sell_window_kernel<T><<<d->sell_nwin, kSellWinThreads, (((size_t) d->sell_maxspan * sizeof(T)) + 1023) & ~(size_t) 1023, d->stream>>>(
-                d->plan.sell_sigma / kSellC, d->chunk_ptr, d->scol, (const T *) d->sval, d->perm, d->win_lo, d->win_span, x, y);
+                d->plan.sell_sigma / kSellC, d->chunk_ptr, d->scol, (const T *) d->sval, d->perm, d->sell_wins, x, y);
         else
             sell_kernel<T><<<grid_for(d->nchunks, kBlock / kWave, d->plan.variant == 1 ? d->cus * 8 : INT_MAX), kBlock, 0, d->stream>>>(
                 d->nchunks, d->chunk_ptr, d->scol, (const T *) d->sval, d->perm, x, y);
@@ -1018,8 +1024,8 @@ extern "C" int spmv_shim_info(const spmv_dev *d, spmv_hip_info *o)
     if (d->plan.sched == SPMV_SCHED_CSR_VECTOR && d->vt_tiles > 0 && d->vec_choice != VEC_PIPE &&
         (d->vt_staged * 2 >= d->vt_tiles || d->vec_choice == VEC_TILE_D4 || d->vec_choice == VEC_TILE_D2))
         o->kernel_name = "csr_vector_tile_kernel";
-    if (d->plan.sched == SPMV_SCHED_NNZ_SPLIT && d->ns_groups > 0 && d->ns_staged * 2 >= d->ns_groups) o->kernel_name = "nnz_group_kernel";
-    if (d->plan.sched == SPMV_SCHED_CSR5 && d->c5_staged * 2 >= d->c5_groups && d->c5_groups > 0) o->kernel_name = "csr5_group_kernel";
-    if (d->plan.sched == SPMV_SCHED_SELL && d->plan.sell_lds_x && d->sell_staged * 2 >= d->sell_nwin && d->sell_nwin > 0) o->kernel_name = "sell_window_kernel";
+    if (d->plan.sched == SPMV_SCHED_NNZ_SPLIT && d->ns_staged > 0) o->kernel_name = "nnz_group_kernel";
+    if (d->plan.sched == SPMV_SCHED_CSR5 && d->c5_staged > 0) o->kernel_name = "csr5_group_kernel";
+    if (d->plan.sched == SPMV_SCHED_SELL && d->sell_staged > 0) o->kernel_name = "sell_window_kernel";
     return SPMV_HIP_OK;
 }
