@@ -79,7 +79,7 @@ typedef struct spmv_hip_info {
     double inspect_ms;          /* wall time of the inspector inside create */
     const char *schedule_name;
     const char *kernel_name;    /* symbol of the dominant kernel (as rocprofv3 shows it) */
-    int tuned_choice;           /* csr-vector autotune: 0 none, 10 tile/4-deep, 5 tile/2-deep, 4 pipe */
+    int tuned_choice;           /* csr-vector autotune: 0 none, 10/11 tile 4-deep, 5/12 tile 2-deep, 4 pipe */
     float tune_ms[3];           /* measured ms of {tile/4-deep, tile/2-deep, pipe} at create (0 if not tuned) */
 } spmv_hip_info;
 int spmv_hip_get_info(spmv_Handle_t handle, spmv_hip_info *out);

@@ -764,11 +764,13 @@ static int autotune_vector(spmv_dev *d)
     hipEvent_t e0, e1;
     (void) hipEventCreate(&e0);
     (void) hipEventCreate(&e1);
-    const int cand[3] = {VEC_TILE_D4, VEC_TILE_D2, VEC_PIPE};
-    float tmin[3] = {1e30f, 1e30f, 1e30f};
+    constexpr int kCand = 5;
+    const int cand[kCand] = {VEC_TILE_D4, VEC_TILE_D4_NOPRE, VEC_TILE_D2, VEC_TILE_D2_NOPRE, VEC_PIPE};
+    float tmin[kCand];
+    for (int k = 0; k < kCand; ++k) tmin[k] = 1e30f;
     for (int c : cand) { d->vec_choice = c; launch_vector_any<T>(d, x, y); } // warm every form once
     for (int round = 0; round < 4; ++round) // interleaved rounds (one process, same clocks): min per form
-        for (int k = 0; k < 3; ++k) {
+        for (int k = 0; k < kCand; ++k) {
             d->vec_choice = cand[k];
             (void) hipEventRecord(e0, d->stream);
             launch_vector_any<T>(d, x, y);
@@ -781,10 +783,12 @@ static int autotune_vector(spmv_dev *d)
         }
     float best = 1e30f;
     int best_c = VEC_AUTO;
-    for (int k = 0; k < 3; ++k) {
-        d->tune_ms[k] = tmin[k];
+    for (int k = 0; k < kCand; ++k) {
         if (tmin[k] < best) { best = tmin[k]; best_c = cand[k]; }
     }
+    d->tune_ms[0] = tmin[0] < tmin[1] ? tmin[0] : tmin[1]; // tile, 4 steps in flight (best of the two issue orders)
+    d->tune_ms[1] = tmin[2] < tmin[3] ? tmin[2] : tmin[3]; // tile, 2 steps in flight
+    d->tune_ms[2] = tmin[4];                               // pipe
     d->vec_choice = best_c;
     (void) hipEventDestroy(e0);
     (void) hipEventDestroy(e1);
@@ -1022,7 +1026,7 @@ extern "C" int spmv_shim_info(const spmv_dev *d, spmv_hip_info *o)
     o->schedule_name = kSchedNames[d->plan.sched];
     o->kernel_name = kKernelNames[d->plan.sched];
     if (d->plan.sched == SPMV_SCHED_CSR_VECTOR && d->vt_tiles > 0 && d->vec_choice != VEC_PIPE &&
-        (d->vt_staged * 2 >= d->vt_tiles || d->vec_choice == VEC_TILE_D4 || d->vec_choice == VEC_TILE_D2))
+        (d->vt_staged * 2 >= d->vt_tiles || (d->vec_choice != VEC_AUTO && d->vec_choice != VEC_PIPE)))
         o->kernel_name = "csr_vector_tile_kernel";
     if (d->plan.sched == SPMV_SCHED_NNZ_SPLIT && d->ns_staged > 0) o->kernel_name = "nnz_group_kernel";
     if (d->plan.sched == SPMV_SCHED_CSR5 && d->c5_staged > 0) o->kernel_name = "csr5_group_kernel";
