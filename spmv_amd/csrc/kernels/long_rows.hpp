@@ -49,17 +49,49 @@ __global__ __launch_bounds__(kBlock) void long_rows_segfill_kernel(int nlong, co
     for (long long s = seg_start[i]; s < seg_start[i + 1]; ++s) seg_lr[s] = i;
 }
 
+// Inspector: column range [lo, lo+span) of every segment, so the executor can start staging x at
+// once instead of first reducing min / max over the columns it has just loaded.
+__global__ __launch_bounds__(kBlock) void long_rows_segspan_kernel(const int *__restrict__ seg_lr,
+                                                                   const long long *__restrict__ seg_start,
+                                                                   const int *__restrict__ long_rows,
+                                                                   const int *__restrict__ rowptr,
+                                                                   const int *__restrict__ colidx,
+                                                                   int *__restrict__ seg_lo, int *__restrict__ seg_span)
+{
+    __shared__ int s_mn[kBlock / kWave], s_mx[kBlock / kWave];
+    const int s = blockIdx.x;
+    const int i = seg_lr[s];
+    const int row = long_rows[i];
+    const int p0 = rowptr[row] + (int) (s - seg_start[i]) * kLongSeg;
+    const int p1 = min(rowptr[row + 1], p0 + kLongSeg);
+    int mn = INT_MAX, mx = -1;
+    for (int p = p0 + threadIdx.x; p < p1; p += kBlock) { const int c = colidx[p]; mn = min(mn, c); mx = max(mx, c); }
+#pragma unroll
+    for (int o = kWave / 2; o > 0; o >>= 1) {
+        mn = min(mn, __shfl_xor(mn, o, kWave));
+        mx = max(mx, __shfl_xor(mx, o, kWave));
+    }
+    if ((threadIdx.x & (kWave - 1)) == 0) { s_mn[threadIdx.x / kWave] = mn; s_mx[threadIdx.x / kWave] = mx; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        mn = min(min(s_mn[0], s_mn[1]), min(s_mn[2], s_mn[3]));
+        mx = max(max(s_mx[0], s_mx[1]), max(s_mx[2], s_mx[3]));
+        seg_lo[s] = mn;
+        seg_span[s] = mx - mn + 1; // p1 > p0 for every segment
+    }
+}
+
 template <typename T>
 __global__ __launch_bounds__(kBlock) void long_rows_kernel(int nsegs, int xcap, const int *__restrict__ seg_lr,
                                                            const long long *__restrict__ seg_start,
                                                            const int *__restrict__ long_rows,
+                                                           const int *__restrict__ seg_lo, const int *__restrict__ seg_span,
                                                            const int *__restrict__ rowptr,
                                                            const int *__restrict__ colidx, const T *__restrict__ val,
                                                            const T *__restrict__ x, T *__restrict__ y, T *__restrict__ part)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char long_x_lds[]; // xcap elements of x
     T *xs = reinterpret_cast<T *>(long_x_lds);
-    __shared__ int s_mn[kBlock / kWave], s_mx[kBlock / kWave];
     __shared__ T s_sum[kBlock / kWave];
     const int lane = threadIdx.x & (kWave - 1), wave = threadIdx.x / kWave;
     const int s = blockIdx.x;
@@ -67,17 +99,22 @@ __global__ __launch_bounds__(kBlock) void long_rows_kernel(int nsegs, int xcap, 
     const long long s0 = seg_start[i];
     const bool single = seg_start[i + 1] - s0 == 1;
     const int row = long_rows[i];
+    const int mn = seg_lo[s];
+    const int span = seg_span[s];
+    const bool staged = span <= xcap;
     const int b = rowptr[row], e = rowptr[row + 1];
     const int p0 = b + (int) (s - s0) * kLongSeg;
     const int p1 = min(e, p0 + kLongSeg);
     const int a0 = (p0 & ~3) + threadIdx.x * 4;
     int c[4][4];
     T v[4][4];
-    int mn = INT_MAX, mx = -1;
 #pragma unroll
     for (int k = 0; k < 4; ++k) { // all 4 steps in flight; tail reads stay inside the padded allocation
         const int a = a0 + k * kBlock * 4;
         if (a < p1) { ld_stream4(colidx + a, c[k]); ld_stream4(val + a, v[k]); }
+    }
+    if (staged) { // x window of the segment, issued right behind the matrix stream
+        for (int t = threadIdx.x; t < span; t += kBlock) xs[t] = x[mn + t];
     }
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
@@ -86,24 +123,9 @@ __global__ __launch_bounds__(kBlock) void long_rows_kernel(int nsegs, int xcap, 
         for (int q = 0; q < 4; ++q) {
             const bool ok = a + q >= p0 && a + q < p1;
             c[k][q] = ok ? c[k][q] : -1;
-            if (ok) { mn = min(mn, c[k][q]); mx = max(mx, c[k][q]); }
         }
     }
-#pragma unroll
-    for (int o = kWave / 2; o > 0; o >>= 1) {
-        mn = min(mn, __shfl_xor(mn, o, kWave));
-        mx = max(mx, __shfl_xor(mx, o, kWave));
-    }
-    if (lane == 0) { s_mn[wave] = mn; s_mx[wave] = mx; }
-    __syncthreads();
-    mn = min(min(s_mn[0], s_mn[1]), min(s_mn[2], s_mn[3]));
-    mx = max(max(s_mx[0], s_mx[1]), max(s_mx[2], s_mx[3]));
-    const long long span = (long long) mx - mn + 1;
-    const bool staged = span <= xcap; // p1 > p0, so mx >= mn
-    if (staged) {
-        for (int t = threadIdx.x; t < (int) span; t += kBlock) xs[t] = x[mn + t];
-        __syncthreads();
-    }
+    if (staged) __syncthreads();
     T sum = 0;
 #pragma unroll
     for (int k = 0; k < 4; ++k) {

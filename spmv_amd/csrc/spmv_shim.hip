@@ -92,7 +92,7 @@ struct spmv_dev {
     TileWindows *vt_wins = nullptr; // x windows of every tile
     // long rows (csr-vector, sell)
     int nlong = 0, long_thr = INT_MAX, lr_segs = 0;
-    int *long_rows = nullptr, *lr_seg_lr = nullptr;
+    int *long_rows = nullptr, *lr_seg_lr = nullptr, *lr_seg_lo = nullptr, *lr_seg_span = nullptr;
     long long *lr_seg_start = nullptr;
     void *lr_part = nullptr;
     // sell
@@ -136,7 +136,7 @@ static void free_schedule(spmv_dev *d)
     for (void *p : d->sched_allocs) (void) hipFree(p);
     d->sched_allocs.clear();
     d->tile_first = nullptr; d->carry = nullptr; d->rb_split = nullptr; d->ns_col = nullptr; d->ns_wins = nullptr; d->ns_groups = d->ns_staged = 0;
-    d->perm = d->scol = d->long_rows = d->lr_seg_lr = nullptr; d->sell_wins = nullptr; d->sell_staged = d->sell_nwin = 0; d->chunk_ptr = d->lr_seg_start = nullptr;
+    d->perm = d->scol = d->long_rows = d->lr_seg_lr = d->lr_seg_lo = d->lr_seg_span = nullptr; d->sell_wins = nullptr; d->sell_staged = d->sell_nwin = 0; d->chunk_ptr = d->lr_seg_start = nullptr;
     d->sval = d->lr_part = nullptr;
     d->ntiles = d->nblocks = d->nchunks = d->nlong = d->lr_segs = 0;
     d->long_thr = INT_MAX;
@@ -498,7 +498,11 @@ static int build_long_rows(spmv_dev *d, int thr)
     d->lr_segs = (int) nsegs;
     ALLOC_TRY(d, &d->lr_seg_lr, sizeof(int) * (size_t) nsegs, true);
     ALLOC_TRY(d, &d->lr_part, sizeof(T) * (size_t) nsegs, true);
+    ALLOC_TRY(d, &d->lr_seg_lo, sizeof(int) * (size_t) nsegs, true);
+    ALLOC_TRY(d, &d->lr_seg_span, sizeof(int) * (size_t) nsegs, true);
     long_rows_segfill_kernel<<<grid_for(d->nlong, kBlock, INT_MAX), kBlock, 0, d->stream>>>(d->nlong, d->lr_seg_start, d->lr_seg_lr);
+    long_rows_segspan_kernel<<<(int) nsegs, kBlock, 0, d->stream>>>(d->lr_seg_lr, d->lr_seg_start, d->long_rows, d->rowptr, d->colidx,
+                                                                    d->lr_seg_lo, d->lr_seg_span);
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipStreamSynchronize(d->stream));
     return SPMV_HIP_OK;
@@ -521,7 +525,7 @@ static void launch_long_rows(spmv_dev *d, const T *x, T *y)
     if (d->nlong <= 0) return;
     constexpr size_t xbytes = 48 * 1024; // LDS x tile of one long-row segment
     long_rows_kernel<T><<<d->lr_segs, kBlock, xbytes, d->stream>>>(
-        d->lr_segs, (int) (xbytes / sizeof(T)), d->lr_seg_lr, d->lr_seg_start, d->long_rows, d->rowptr, d->colidx, (const T *) d->val, x, y, (T *) d->lr_part);
+        d->lr_segs, (int) (xbytes / sizeof(T)), d->lr_seg_lr, d->lr_seg_start, d->long_rows, d->lr_seg_lo, d->lr_seg_span, d->rowptr, d->colidx, (const T *) d->val, x, y, (T *) d->lr_part);
     if (d->lr_segs > d->nlong)
         long_rows_combine_kernel<T><<<grid_for(d->nlong, kBlock, INT_MAX), kBlock, 0, d->stream>>>(d->nlong, d->lr_seg_start, d->long_rows,
                                                                                                   (const T *) d->lr_part, y);

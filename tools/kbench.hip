@@ -121,7 +121,13 @@ int main(int argc, char **argv)
     vs.push_back({"stream_read nt x2blocks", [&] { stream_read<true><<<cus * 16, 256>>>(nnz, col, val, y); }});
     vs.push_back({"stream_read nt nonpersist", [&] { stream_read<true><<<(int) (nnz / 4 / 256), 256>>>(nnz, col, val, y); }});
 #define SS(M) vs.push_back({"stream_store mode" #M, [&] { stream_store<M><<<(int) (nnz / 4 / 256), 256>>>(nnz, col, val, y); }})
-    SS(0); SS(1); SS(11); SS(12); SS(13);
+    SS(0); SS(1);
+    double *y_unc = nullptr, *y_fine = nullptr;
+    if (hipExtMallocWithFlags((void **) &y_unc, sizeof(double) * m, hipDeviceMallocUncached) != hipSuccess) { y_unc = nullptr; (void) hipGetLastError(); }
+    if (hipExtMallocWithFlags((void **) &y_fine, sizeof(double) * m, hipDeviceMallocFinegrained) != hipSuccess) { y_fine = nullptr; (void) hipGetLastError(); }
+    if (y_unc) vs.push_back({"stream_store mode1 y=uncached", [&] { stream_store<1><<<(int) (nnz / 4 / 256), 256>>>(nnz, col, val, y_unc); }});
+    if (y_fine) vs.push_back({"stream_store mode1 y=finegrained", [&] { stream_store<1><<<(int) (nnz / 4 / 256), 256>>>(nnz, col, val, y_fine); }});
+    if (y_unc) vs.push_back({"stream_store mode3 y=uncached", [&] { stream_store<3><<<(int) (nnz / 4 / 256), 256>>>(nnz, col, val, y_unc); }});
     if (0) vs.push_back({"fill 2.56GB (as stream bytes)", [&] { fill_k<<<(int) (nnz / 2 / 256), 256>>>(nnz / 2, (f64x2 *) val); }});
     if (0) vs.push_back({"copy 1.28GB->1.28GB", [&] { copy_k<<<(int) (nnz / 4 / 256), 256>>>(nnz / 4, (const f64x2 *) val, (f64x2 *) val + nnz / 4); }});
     vs.push_back({"nnz_split nonpersist", [&] { nnz_split_kernel<double><<<(ntiles + 3) / 4, 256>>>(m, (int) nnz, ntiles, rowptr, col, val, x, y, tile_first, carry); }});
