@@ -56,7 +56,8 @@ __global__ __launch_bounds__(kBlock) void long_rows_segspan_kernel(const int *__
                                                                    const int *__restrict__ long_rows,
                                                                    const int *__restrict__ rowptr,
                                                                    const int *__restrict__ colidx,
-                                                                   int *__restrict__ seg_lo, int *__restrict__ seg_span)
+                                                                   int *__restrict__ seg_lo, int *__restrict__ seg_span,
+                                                                   int xcap, int *__restrict__ max_staged_span)
 {
     __shared__ int s_mn[kBlock / kWave], s_mx[kBlock / kWave];
     const int s = blockIdx.x;
@@ -78,6 +79,7 @@ __global__ __launch_bounds__(kBlock) void long_rows_segspan_kernel(const int *__
         mx = max(max(s_mx[0], s_mx[1]), max(s_mx[2], s_mx[3]));
         seg_lo[s] = mn;
         seg_span[s] = mx - mn + 1; // p1 > p0 for every segment
+        if (mx - mn + 1 <= xcap) atomicMax(max_staged_span, mx - mn + 1); // sizes the executor's LDS request
     }
 }
 

@@ -91,7 +91,7 @@ struct spmv_dev {
     int *vt_col = nullptr;          // tile-local ColIdx copy (LDS slots for staged tiles)
     TileWindows *vt_wins = nullptr; // x windows of every tile
     // long rows (csr-vector, sell)
-    int nlong = 0, long_thr = INT_MAX, lr_segs = 0;
+    int nlong = 0, long_thr = INT_MAX, lr_segs = 0, lr_maxspan = 0;
     int *long_rows = nullptr, *lr_seg_lr = nullptr, *lr_seg_lo = nullptr, *lr_seg_span = nullptr;
     long long *lr_seg_start = nullptr;
     void *lr_part = nullptr;
@@ -257,9 +257,12 @@ extern "C" int spmv_shim_matrix_create(spmv_dev **out, int m, int n, const int *
         return fail(SPMV_HIP_E_NODEVICE, "no HIP device visible (this library has no CPU path)");
     }
     spmv_dev *d = new spmv_dev();
-    HIP_TRY(hipGetDevice(&d->device));
     hipDeviceProp_t prop;
-    HIP_TRY(hipGetDeviceProperties(&prop, d->device));
+    if (hipGetDevice(&d->device) != hipSuccess || hipGetDeviceProperties(&prop, d->device) != hipSuccess) {
+        (void) hipGetLastError();
+        delete d;
+        return fail(SPMV_HIP_E_NODEVICE, "cannot query the current HIP device");
+    }
     d->cus = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
     d->m = m;
     d->n = n;
@@ -468,6 +471,8 @@ static int build_tile_windows(spmv_dev *d, int tiles, const int *split)
 // window; fp32 24576 columns, fp64 12288 columns).
 constexpr size_t kSellXTileBytes = 96 * 1024;
 
+constexpr size_t kLongXTileBytes = 48 * 1024; // LDS budget of one long-row segment's x span
+
 // Rows longer than thr -> long_rows[], cut into kLongSeg segments (kernels/long_rows.hpp).
 template <typename T>
 static int build_long_rows(spmv_dev *d, int thr)
@@ -501,9 +506,11 @@ static int build_long_rows(spmv_dev *d, int thr)
     ALLOC_TRY(d, &d->lr_seg_lo, sizeof(int) * (size_t) nsegs, true);
     ALLOC_TRY(d, &d->lr_seg_span, sizeof(int) * (size_t) nsegs, true);
     long_rows_segfill_kernel<<<grid_for(d->nlong, kBlock, INT_MAX), kBlock, 0, d->stream>>>(d->nlong, d->lr_seg_start, d->lr_seg_lr);
+    HIP_TRY(hipMemsetAsync(cnt, 0, sizeof(int), d->stream));
     long_rows_segspan_kernel<<<(int) nsegs, kBlock, 0, d->stream>>>(d->lr_seg_lr, d->lr_seg_start, d->long_rows, d->rowptr, d->colidx,
-                                                                    d->lr_seg_lo, d->lr_seg_span);
+                                                                    d->lr_seg_lo, d->lr_seg_span, (int) (kLongXTileBytes / sizeof(T)), cnt);
     HIP_TRY(hipGetLastError());
+    HIP_TRY(hipMemcpyAsync(&d->lr_maxspan, cnt, sizeof(int), hipMemcpyDeviceToHost, d->stream));
     HIP_TRY(hipStreamSynchronize(d->stream));
     return SPMV_HIP_OK;
 }
@@ -523,9 +530,10 @@ template <typename T>
 static void launch_long_rows(spmv_dev *d, const T *x, T *y)
 {
     if (d->nlong <= 0) return;
-    constexpr size_t xbytes = 48 * 1024; // LDS x tile of one long-row segment
+    // LDS request = the largest span that is actually staged (keeps several workgroups per CU)
+    const size_t xbytes = (((size_t) d->lr_maxspan * sizeof(T)) + 1023) & ~(size_t) 1023;
     long_rows_kernel<T><<<d->lr_segs, kBlock, xbytes, d->stream>>>(
-        d->lr_segs, (int) (xbytes / sizeof(T)), d->lr_seg_lr, d->lr_seg_start, d->long_rows, d->lr_seg_lo, d->lr_seg_span, d->rowptr, d->colidx, (const T *) d->val, x, y, (T *) d->lr_part);
+        d->lr_segs, (int) (kLongXTileBytes / sizeof(T)), d->lr_seg_lr, d->lr_seg_start, d->long_rows, d->lr_seg_lo, d->lr_seg_span, d->rowptr, d->colidx, (const T *) d->val, x, y, (T *) d->lr_part);
     if (d->lr_segs > d->nlong)
         long_rows_combine_kernel<T><<<grid_for(d->nlong, kBlock, INT_MAX), kBlock, 0, d->stream>>>(d->nlong, d->lr_seg_start, d->long_rows,
                                                                                                   (const T *) d->lr_part, y);
