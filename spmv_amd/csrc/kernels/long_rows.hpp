@@ -32,6 +32,47 @@ __global__ __launch_bounds__(kBlock) void long_rows_collect_kernel(int m, int th
         if (rowptr[r + 1] - rowptr[r] > thr) long_rows[atomicAdd(count, 1)] = (int) r;
 }
 
+// --- long rows as a CSR5 sub-matrix (default path) ------------------------------------------------
+// The segment kernel below gives a long row to whole workgroups, but a matrix whose long rows hold
+// half the non-zeros (config 4's power-law tail) then runs half its traffic through a kernel that
+// stages one row's x span at a time.  The default path instead gathers the long rows, in row order,
+// into a contiguous sub-CSR and runs the CSR5 inspector/executor over it (csr5.hpp, row_map = the
+// long-row list): perfectly balanced 64 x sigma tiles with grouped x windows.
+__global__ __launch_bounds__(kBlock) void long_rows_flag_kernel(int m, int thr, const int *__restrict__ rowptr, int *__restrict__ flags)
+{
+    const long long stride = (long long) gridDim.x * kBlock;
+    for (long long r = (long long) blockIdx.x * kBlock + threadIdx.x; r < m; r += stride)
+        flags[r] = rowptr[r + 1] - rowptr[r] > thr;
+}
+
+__global__ __launch_bounds__(kBlock) void long_rows_len_kernel(int nlong, const int *__restrict__ long_rows,
+                                                               const int *__restrict__ rowptr, int *__restrict__ lens)
+{
+    const int i = blockIdx.x * kBlock + threadIdx.x;
+    if (i < nlong) lens[i] = rowptr[long_rows[i] + 1] - rowptr[long_rows[i]];
+}
+
+__global__ __launch_bounds__(kBlock) void narrow_i64_kernel(int n, const long long *__restrict__ in, int *__restrict__ out)
+{
+    const int i = blockIdx.x * kBlock + threadIdx.x;
+    if (i < n) out[i] = (int) in[i];
+}
+
+// one workgroup per long row: copy its column indices and values to the sub-CSR
+template <typename T>
+__global__ __launch_bounds__(kBlock) void long_rows_gather_kernel(const int *__restrict__ long_rows, const int *__restrict__ rowptr,
+                                                                  const int *__restrict__ colidx, const T *__restrict__ val,
+                                                                  const int *__restrict__ sub_rowptr, int *__restrict__ sub_col,
+                                                                  T *__restrict__ sub_val)
+{
+    const int r = long_rows[blockIdx.x];
+    const int src = rowptr[r], len = rowptr[r + 1] - src, dst = sub_rowptr[blockIdx.x];
+    for (int k = threadIdx.x; k < len; k += kBlock) {
+        sub_col[dst + k] = colidx[src + k];
+        sub_val[dst + k] = val[src + k];
+    }
+}
+
 __global__ __launch_bounds__(kBlock) void long_rows_segcount_kernel(int nlong, const int *__restrict__ long_rows,
                                                                     const int *__restrict__ rowptr, int *__restrict__ seg_cnt)
 {

@@ -61,6 +61,19 @@ struct DevStats {
     int max_len, min_len, empty, bad, first, last;
 };
 
+// One CSR5 instance (kernels/csr5.hpp): the whole matrix for Method_CSR5SPMV, or the sub-matrix of
+// the long rows that CSR-vector / Balanced / SELL hand over (see build_long_rows).
+struct Csr5Plan {
+    int sigma = 0, tiles = 0, m2 = 0, fixup = 0, groups = 0, staged = 0, maxspan = 0;
+    long long nnz = 0;
+    bool zero_fill = false;       // rows outside row_map (empty rows) need y = 0 first
+    TileWindows *wins = nullptr;
+    int *tile_ptr = nullptr, *run_len = nullptr, *col = nullptr;
+    const int *row_map = nullptr; // CSR5 row -> y row (NULL: identity)
+    unsigned *desc = nullptr;
+    void *val = nullptr, *carry = nullptr;
+};
+
 struct spmv_dev {
     int device = 0;
     int cus = 256;
@@ -104,11 +117,11 @@ struct spmv_dev {
     long long *chunk_ptr = nullptr;
     void *sval = nullptr;
     // csr5
-    int c5_sigma = 0, c5_tiles = 0, c5_m2 = 0, c5_fixup = 0, c5_groups = 0, c5_staged = 0, c5_maxspan = 0;
-    TileWindows *c5_wins = nullptr;
-    int *c5_tile_ptr = nullptr, *c5_run_len = nullptr, *c5_row_map = nullptr, *c5_col = nullptr;
-    unsigned *c5_desc = nullptr;
-    void *c5_val = nullptr, *c5_carry = nullptr;
+    Csr5Plan c5, c5_long;
+    // long-row sub-matrix (rows longer than long_thr, in row order), the input of c5_long
+    int *lsub_rowptr = nullptr, *lsub_colidx = nullptr;
+    void *lsub_val = nullptr;
+    long long lsub_nnz = 0;
     // staging for host x / y
     void *x_stage = nullptr, *y_stage = nullptr;
     long long device_bytes = 0;
@@ -141,9 +154,9 @@ static void free_schedule(spmv_dev *d)
     d->ntiles = d->nblocks = d->nchunks = d->nlong = d->lr_segs = 0;
     d->long_thr = INT_MAX;
     d->vt_col = nullptr; d->vt_wins = nullptr; d->vt_tiles = d->vt_staged = d->vt_maxspan = 0;
-    d->c5_tile_ptr = d->c5_run_len = d->c5_row_map = d->c5_col = nullptr; d->c5_desc = nullptr;
-    d->c5_val = d->c5_carry = nullptr; d->c5_tiles = d->c5_m2 = d->c5_fixup = 0;
-    d->c5_wins = nullptr; d->c5_groups = d->c5_staged = d->c5_maxspan = 0;
+    d->c5 = Csr5Plan();
+    d->c5_long = Csr5Plan();
+    d->lsub_rowptr = d->lsub_colidx = nullptr; d->lsub_val = nullptr; d->lsub_nnz = 0;
     d->built = false;
 }
 
@@ -386,6 +399,9 @@ static int build_range_windows(spmv_dev *d, int groups, long long total, long lo
 
 constexpr size_t kVecXTileBytes = 48 * 1024; // LDS budget of one row tile's x span (CSR-vector, Balanced)
 template <typename T> static int build_long_rows(spmv_dev *d, int thr);
+template <typename T>
+static int build_csr5(spmv_dev *d, Csr5Plan &P, int m, long long nnz, const int *rowptr, const int *colidx, const T *val, int empty_rows,
+                      double mean_row_len, const int *out_rows);
 template <typename T> static int autotune_vector(spmv_dev *d);
 template <typename T> static int build_tile_windows(spmv_dev *d, int tiles, const int *split);
 
@@ -473,27 +489,61 @@ constexpr size_t kSellXTileBytes = 96 * 1024;
 
 constexpr size_t kLongXTileBytes = 48 * 1024; // LDS budget of one long-row segment's x span
 
-// Rows longer than thr -> long_rows[], cut into kLongSeg segments (kernels/long_rows.hpp).
+// Rows longer than thr -> long_rows[] (row order).  Default: gathered into a sub-CSR with its own CSR5
+// plan (d->c5_long); variant 13: cut into kLongSeg segments for long_rows_kernel (kernels/long_rows.hpp).
 template <typename T>
 static int build_long_rows(spmv_dev *d, int thr)
 {
     d->long_thr = thr;
     d->nlong = 0;
     d->lr_segs = 0;
+    d->c5_long = Csr5Plan();
     if (d->stats.max_row_len <= thr) return SPMV_HIP_OK;
-    int *cnt = nullptr, *seg_cnt = nullptr;
-    ALLOC_TRY(d, &cnt, sizeof(int), true);
-    HIP_TRY(hipMemsetAsync(cnt, 0, sizeof(int), d->stream));
-    count_longer_kernel<<<grid_for(d->m, kBlock, d->cus * 8), kBlock, 0, d->stream>>>(d->m, thr, d->rowptr, cnt);
-    HIP_TRY(hipGetLastError());
-    HIP_TRY(hipMemcpyAsync(&d->nlong, cnt, sizeof(int), hipMemcpyDeviceToHost, d->stream));
-    HIP_TRY(hipStreamSynchronize(d->stream));
-    if (d->nlong == 0) return SPMV_HIP_OK;
-    ALLOC_TRY(d, &d->long_rows, sizeof(int) * (size_t) d->nlong, true);
-    ALLOC_TRY(d, &seg_cnt, sizeof(int) * (size_t) d->nlong, true);
+    // deterministic compaction of the long rows (flags -> scan -> scatter), as csr5 does for non-empty rows
+    const int nb = (int) (((long long) d->m + kScanTile - 1) / kScanTile);
+    int *flags = nullptr, *sums = nullptr, *total = nullptr, *scratch = nullptr, *seg_cnt = nullptr;
+    ALLOC_TRY(d, &sums, sizeof(int) * (size_t) nb, true);
+    ALLOC_TRY(d, &total, sizeof(int), true);
+    HIP_TRY(hipMalloc((void **) &flags, sizeof(int) * (size_t) d->m));
+    long_rows_flag_kernel<<<grid_for(d->m, kBlock, d->cus * 8), kBlock, 0, d->stream>>>(d->m, thr, d->rowptr, flags);
+    scan_block_sums_kernel<<<nb, kBlock, 0, d->stream>>>(d->m, flags, sums);
+    scan_sums_inplace_kernel<<<1, kBlock, 0, d->stream>>>(nb, sums, total);
+    if (hipMemcpyAsync(&d->nlong, total, sizeof(int), hipMemcpyDeviceToHost, d->stream) != hipSuccess || hipStreamSynchronize(d->stream) != hipSuccess) {
+        (void) hipFree(flags);
+        d->nlong = 0;
+        return fail(SPMV_HIP_E_RUNTIME, "long-row scan failed");
+    }
+    if (d->nlong == 0) { (void) hipFree(flags); return SPMV_HIP_OK; }
+    int rc = dev_alloc(d, (void **) &d->long_rows, sizeof(int) * (size_t) d->nlong, true);
+    if (!rc) rc = dev_alloc(d, (void **) &scratch, sizeof(int) * (size_t) d->nlong, true);
+    if (rc) { (void) hipFree(flags); d->nlong = 0; return rc; }
+    csr5_compact_kernel<<<nb, kBlock, 0, d->stream>>>(d->m, flags, sums, d->rowptr, scratch, d->long_rows);
+    hipError_t e = hipStreamSynchronize(d->stream);
+    (void) hipFree(flags);
+    if (e != hipSuccess) { d->nlong = 0; return fail(SPMV_HIP_E_RUNTIME, "long-row compaction: %s", hipGetErrorString(e)); }
     ALLOC_TRY(d, &d->lr_seg_start, sizeof(long long) * ((size_t) d->nlong + 1), true);
-    HIP_TRY(hipMemsetAsync(cnt, 0, sizeof(int), d->stream));
-    long_rows_collect_kernel<<<grid_for(d->m, kBlock, d->cus * 8), kBlock, 0, d->stream>>>(d->m, thr, d->rowptr, d->long_rows, cnt);
+
+    if (d->plan.variant != 13) { // sub-CSR of the long rows + CSR5 over it
+        long long sub_nnz = 0;
+        long_rows_len_kernel<<<grid_for(d->nlong, kBlock, INT_MAX), kBlock, 0, d->stream>>>(d->nlong, d->long_rows, d->rowptr, scratch);
+        scan_i32_to_i64_kernel<<<1, kBlock, 0, d->stream>>>(d->nlong, scratch, d->lr_seg_start);
+        HIP_TRY(hipGetLastError());
+        HIP_TRY(hipMemcpyAsync(&sub_nnz, d->lr_seg_start + d->nlong, sizeof(long long), hipMemcpyDeviceToHost, d->stream));
+        HIP_TRY(hipStreamSynchronize(d->stream));
+        d->lsub_nnz = sub_nnz;
+        ALLOC_TRY(d, &d->lsub_rowptr, sizeof(int) * ((size_t) d->nlong + 1), true);
+        ALLOC_TRY(d, &d->lsub_colidx, sizeof(int) * (size_t) sub_nnz, true);
+        ALLOC_TRY(d, &d->lsub_val, sizeof(T) * (size_t) sub_nnz, true);
+        narrow_i64_kernel<<<grid_for((long long) d->nlong + 1, kBlock, INT_MAX), kBlock, 0, d->stream>>>(d->nlong + 1, d->lr_seg_start, d->lsub_rowptr);
+        long_rows_gather_kernel<T><<<d->nlong, kBlock, 0, d->stream>>>(d->long_rows, d->rowptr, d->colidx, (const T *) d->val, d->lsub_rowptr,
+                                                                      d->lsub_colidx, (T *) d->lsub_val);
+        HIP_TRY(hipGetLastError());
+        return build_csr5<T>(d, d->c5_long, d->nlong, sub_nnz, d->lsub_rowptr, d->lsub_colidx, (const T *) d->lsub_val, 0,
+                             (double) sub_nnz / (double) d->nlong, d->long_rows);
+    }
+
+    int *cnt = total;
+    ALLOC_TRY(d, &seg_cnt, sizeof(int) * (size_t) d->nlong, true);
     long_rows_segcount_kernel<<<grid_for(d->nlong, kBlock, INT_MAX), kBlock, 0, d->stream>>>(d->nlong, d->long_rows, d->rowptr, seg_cnt);
     scan_i32_to_i64_kernel<<<1, kBlock, 0, d->stream>>>(d->nlong, seg_cnt, d->lr_seg_start);
     HIP_TRY(hipGetLastError());
@@ -526,10 +576,13 @@ static int build_vector_tiles(spmv_dev *d)
     return build_tile_windows<T>(d, d->vt_tiles, nullptr);
 }
 
+template <typename T> static int launch_csr5(spmv_dev *d, const Csr5Plan &P, const T *x, T *y);
+
 template <typename T>
 static void launch_long_rows(spmv_dev *d, const T *x, T *y)
 {
     if (d->nlong <= 0) return;
+    if (d->c5_long.nnz > 0) { (void) launch_csr5<T>(d, d->c5_long, x, y); return; }
     // LDS request = the largest span that is actually staged (keeps several workgroups per CU)
     const size_t xbytes = (((size_t) d->lr_maxspan * sizeof(T)) + 1023) & ~(size_t) 1023;
     long_rows_kernel<T><<<d->lr_segs, kBlock, xbytes, d->stream>>>(
@@ -590,77 +643,80 @@ static int build_sell(spmv_dev *d)
 constexpr size_t kCsr5XTileBytes = 128 * 1024; // LDS budget of one tile group's x span (a CU has 160 KiB)
 
 template <typename T, int SIGMA>
-static int build_csr5_sigma(spmv_dev *d, const int *rp, int m2)
+static int build_csr5_sigma(spmv_dev *d, Csr5Plan &P, const int *rp, int m2, const int *colidx, const T *val)
 {
     constexpr int TN = kWave * SIGMA;
-    const int p = (int) ((d->nnz + TN - 1) / TN);
-    d->c5_tiles = p;
-    ALLOC_TRY(d, &d->c5_tile_ptr, sizeof(int) * ((size_t) p + 1), true);
-    ALLOC_TRY(d, &d->c5_desc, sizeof(unsigned) * (size_t) p * kWave, true);
-    ALLOC_TRY(d, &d->c5_run_len, sizeof(int) * (size_t) p, true);
-    ALLOC_TRY(d, &d->c5_carry, sizeof(T) * (size_t) p, true);
-    ALLOC_TRY(d, &d->c5_col, sizeof(int) * (size_t) p * TN, true);
-    ALLOC_TRY(d, &d->c5_val, sizeof(T) * (size_t) p * TN, true);
+    const int p = (int) ((P.nnz + TN - 1) / TN);
+    P.tiles = p;
+    ALLOC_TRY(d, &P.tile_ptr, sizeof(int) * ((size_t) p + 1), true);
+    ALLOC_TRY(d, &P.desc, sizeof(unsigned) * (size_t) p * kWave, true);
+    ALLOC_TRY(d, &P.run_len, sizeof(int) * (size_t) p, true);
+    ALLOC_TRY(d, &P.carry, sizeof(T) * (size_t) p, true);
+    ALLOC_TRY(d, &P.col, sizeof(int) * (size_t) p * TN, true);
+    ALLOC_TRY(d, &P.val, sizeof(T) * (size_t) p * TN, true);
     int *flag = nullptr;
     ALLOC_TRY(d, &flag, sizeof(int), true);
     HIP_TRY(hipMemsetAsync(flag, 0, sizeof(int), d->stream));
-    csr5_tile_ptr_kernel<<<grid_for((long long) p + 1, kBlock, INT_MAX), kBlock, 0, d->stream>>>(m2, (int) d->nnz, p, TN, rp, d->c5_tile_ptr);
+    csr5_tile_ptr_kernel<<<grid_for((long long) p + 1, kBlock, INT_MAX), kBlock, 0, d->stream>>>(m2, (int) P.nnz, p, TN, rp, P.tile_ptr);
     HIP_TRY(hipGetLastError());
-    csr5_desc_kernel<SIGMA><<<grid_for(p, kBlock / kWave, INT_MAX), kBlock, 0, d->stream>>>(m2, (int) d->nnz, p, rp, d->c5_tile_ptr, d->c5_desc,
-                                                                                           d->c5_run_len, flag);
+    csr5_desc_kernel<SIGMA><<<grid_for(p, kBlock / kWave, INT_MAX), kBlock, 0, d->stream>>>(m2, (int) P.nnz, p, rp, P.tile_ptr, P.desc, P.run_len, flag);
     HIP_TRY(hipGetLastError());
-    csr5_transpose_kernel<T, SIGMA><<<grid_for(p, kBlock / kWave, INT_MAX), kBlock, 0, d->stream>>>((int) d->nnz, p, d->colidx, (const T *) d->val,
-                                                                                                  d->c5_col, (T *) d->c5_val);
+    csr5_transpose_kernel<T, SIGMA><<<grid_for(p, kBlock / kWave, INT_MAX), kBlock, 0, d->stream>>>((int) P.nnz, p, colidx, val, P.col, (T *) P.val);
     HIP_TRY(hipGetLastError());
-    HIP_TRY(hipMemcpyAsync(&d->c5_fixup, flag, sizeof(int), hipMemcpyDeviceToHost, d->stream));
+    HIP_TRY(hipMemcpyAsync(&P.fixup, flag, sizeof(int), hipMemcpyDeviceToHost, d->stream));
     HIP_TRY(hipStreamSynchronize(d->stream));
     // x windows of every group of kCsr5GroupTiles tiles, in place on the transposed column copy (xwindows.hpp)
-    d->c5_groups = (p + kCsr5GroupTiles - 1) / kCsr5GroupTiles;
-    ALLOC_TRY(d, &d->c5_wins, sizeof(TileWindows) * (size_t) d->c5_groups, true);
-    {
-        const int rc = build_range_windows(d, d->plan.variant == 3 ? 0 : d->c5_groups, (long long) p * TN, (long long) kCsr5GroupTiles * TN, nullptr, 1, 1,
-                                           (int) (kCsr5XTileBytes / sizeof(T)), d->c5_col, d->c5_wins, &d->c5_staged, &d->c5_maxspan);
-        if (rc) return rc;
-    }
-    return SPMV_HIP_OK;
+    P.groups = (p + kCsr5GroupTiles - 1) / kCsr5GroupTiles;
+    ALLOC_TRY(d, &P.wins, sizeof(TileWindows) * (size_t) P.groups, true);
+    return build_range_windows(d, d->plan.variant == 3 ? 0 : P.groups, (long long) p * TN, (long long) kCsr5GroupTiles * TN, nullptr, 1, 1,
+                               (int) (kCsr5XTileBytes / sizeof(T)), P.col, P.wins, &P.staged, &P.maxspan);
 }
 
+// CSR5 over the CSR (m rows, nnz) given by rowptr / colidx / val.  out_rows (nullable, no empty rows
+// allowed then) names the y row of each CSR row -- used for the long-row sub-matrix.
 template <typename T>
-static int build_csr5(spmv_dev *d)
+static int build_csr5(spmv_dev *d, Csr5Plan &P, int m, long long nnz, const int *rowptr, const int *colidx, const T *val, int empty_rows,
+                      double mean_row_len, const int *out_rows)
 {
     int sigma = d->plan.csr5_sigma;
-    if (sigma == 0) sigma = d->stats.mean_row_len <= 4.0 ? 4 : (d->stats.mean_row_len <= 12.0 ? 8 : 16);
+    if (sigma == 0) sigma = mean_row_len <= 4.0 ? 4 : (mean_row_len <= 12.0 ? 8 : 16);
     if (sigma != 4 && sigma != 8 && sigma != 16) return fail(SPMV_HIP_E_ARG, "csr5_sigma must be 4, 8 or 16 (0 = auto), got %d", sigma);
-    d->c5_sigma = sigma;
-    if (d->nnz == 0) return SPMV_HIP_OK;
-    const int *rp = d->rowptr;
-    int m2 = d->m;
-    if (d->stats.empty_rows > 0) { // build over the compacted (non-empty) row space
-        const int nb = (int) (((long long) d->m + kScanTile - 1) / kScanTile);
-        int *flags = nullptr, *sums = nullptr, *total = nullptr, *rp2 = nullptr;
-        HIP_TRY(hipMalloc((void **) &flags, sizeof(int) * (size_t) d->m));
+    P = Csr5Plan();
+    P.sigma = sigma;
+    P.nnz = nnz;
+    P.row_map = out_rows;
+    if (nnz == 0) return SPMV_HIP_OK;
+    const int *rp = rowptr;
+    int m2 = m;
+    if (empty_rows > 0) { // build over the compacted (non-empty) row space
+        if (out_rows) return fail(SPMV_HIP_E_ARG, "csr5: a row map and empty rows cannot be combined");
+        const int nb = (int) (((long long) m + kScanTile - 1) / kScanTile);
+        int *flags = nullptr, *sums = nullptr, *total = nullptr, *rp2 = nullptr, *rmap = nullptr;
+        HIP_TRY(hipMalloc((void **) &flags, sizeof(int) * (size_t) m));
         auto cleanup = [&]() { (void) hipFree(flags); };
         if (dev_alloc(d, (void **) &sums, sizeof(int) * (size_t) nb, true) || dev_alloc(d, (void **) &total, sizeof(int), true)) { cleanup(); return SPMV_HIP_E_ALLOC; }
-        csr5_nonempty_kernel<<<grid_for(d->m, kBlock, d->cus * 8), kBlock, 0, d->stream>>>(d->m, d->rowptr, flags);
-        scan_block_sums_kernel<<<nb, kBlock, 0, d->stream>>>(d->m, flags, sums);
+        csr5_nonempty_kernel<<<grid_for(m, kBlock, d->cus * 8), kBlock, 0, d->stream>>>(m, rowptr, flags);
+        scan_block_sums_kernel<<<nb, kBlock, 0, d->stream>>>(m, flags, sums);
         scan_sums_inplace_kernel<<<1, kBlock, 0, d->stream>>>(nb, sums, total);
         if (hipMemcpyAsync(&m2, total, sizeof(int), hipMemcpyDeviceToHost, d->stream) != hipSuccess ||
             hipStreamSynchronize(d->stream) != hipSuccess) { cleanup(); return fail(SPMV_HIP_E_RUNTIME, "csr5 compaction scan failed"); }
         if (dev_alloc(d, (void **) &rp2, sizeof(int) * ((size_t) m2 + 1), true) ||
-            dev_alloc(d, (void **) &d->c5_row_map, sizeof(int) * (size_t) (m2 > 0 ? m2 : 1), true)) { cleanup(); return SPMV_HIP_E_ALLOC; }
-        csr5_compact_kernel<<<nb, kBlock, 0, d->stream>>>(d->m, flags, sums, d->rowptr, rp2, d->c5_row_map);
-        const int nnz32 = (int) d->nnz;
+            dev_alloc(d, (void **) &rmap, sizeof(int) * (size_t) (m2 > 0 ? m2 : 1), true)) { cleanup(); return SPMV_HIP_E_ALLOC; }
+        csr5_compact_kernel<<<nb, kBlock, 0, d->stream>>>(m, flags, sums, rowptr, rp2, rmap);
+        const int nnz32 = (int) nnz;
         hipError_t e = hipMemcpyAsync(rp2 + m2, &nnz32, sizeof(int), hipMemcpyHostToDevice, d->stream);
         if (e == hipSuccess) e = hipStreamSynchronize(d->stream);
         cleanup();
         if (e != hipSuccess) return fail(SPMV_HIP_E_RUNTIME, "csr5 compaction: %s", hipGetErrorString(e));
         rp = rp2;
+        P.row_map = rmap;
+        P.zero_fill = true;
     }
-    d->c5_m2 = m2;
+    P.m2 = m2;
     switch (sigma) {
-    case 4: return build_csr5_sigma<T, 4>(d, rp, m2);
-    case 8: return build_csr5_sigma<T, 8>(d, rp, m2);
-    default: return build_csr5_sigma<T, 16>(d, rp, m2);
+    case 4: return build_csr5_sigma<T, 4>(d, P, rp, m2, colidx, val);
+    case 8: return build_csr5_sigma<T, 8>(d, P, rp, m2, colidx, val);
+    default: return build_csr5_sigma<T, 16>(d, P, rp, m2, colidx, val);
     }
 }
 
@@ -692,7 +748,10 @@ extern "C" int spmv_shim_build(spmv_dev *d, const spmv_plan *plan)
         if (!rc) rc = f64 ? build_rowblock_tiles<double>(d) : build_rowblock_tiles<float>(d);
         break;
     case SPMV_SCHED_SELL: rc = f64 ? build_sell<double>(d) : build_sell<float>(d); break;
-    case SPMV_SCHED_CSR5: rc = f64 ? build_csr5<double>(d) : build_csr5<float>(d); break;
+    case SPMV_SCHED_CSR5:
+        rc = f64 ? build_csr5<double>(d, d->c5, d->m, d->nnz, d->rowptr, d->colidx, (const double *) d->val, d->stats.empty_rows, d->stats.mean_row_len, nullptr)
+                 : build_csr5<float>(d, d->c5, d->m, d->nnz, d->rowptr, d->colidx, (const float *) d->val, d->stats.empty_rows, d->stats.mean_row_len, nullptr);
+        break;
     }
     if (rc) { free_schedule(d); return rc; }
     d->inspect_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
@@ -708,7 +767,7 @@ constexpr int kVecNB = 4;
 // few percent, so create() times the applicable ones once on the resident matrix
 // (autotune_vector) and keeps the winner in d->vec_choice; plan.variant overrides for A/B runs.
 enum { VEC_AUTO = 0, VEC_STRIDED = 1, VEC_NO_LONG = 2, VEC_PIPE = 4, VEC_TILE_D2 = 5, VEC_TILE_D8 = 6, VEC_TILE_D4 = 10, VEC_TILE_D4_NOPRE = 11,
-       VEC_TILE_D2_NOPRE = 12 };
+       VEC_TILE_D2_NOPRE = 12, VEC_LONG_SEGMENTS = 13 /* long rows through long_rows_kernel instead of the CSR5 sub-matrix */ };
 
 template <typename T, int L, int DEPTH, bool PRE = true>
 static void launch_vector_tile(spmv_dev *d, const T *x, T *y, int long_thr)
@@ -811,29 +870,46 @@ static int autotune_vector(spmv_dev *d)
 }
 
 template <typename T, int SIGMA>
-static void launch_csr5(spmv_dev *d, const T *x, T *y)
+static void launch_csr5_sigma(spmv_dev *d, const Csr5Plan &P, const T *x, T *y)
 {
-    if (d->c5_staged > 0) { // the inspector staged (at least half of) the groups: tcol holds LDS slots for them
-        const size_t lds = (((size_t) d->c5_maxspan * sizeof(T)) + 1023) & ~(size_t) 1023;
+    if (P.staged > 0) { // the inspector staged (at least half of) the groups: the column copy holds LDS slots for them
+        const size_t lds = (((size_t) P.maxspan * sizeof(T)) + 1023) & ~(size_t) 1023;
         if (lds > 64 * 1024) { // above the default dynamic-LDS limit: raise it for this instantiation (idempotent, cheap)
-            if (d->c5_row_map) (void) hipFuncSetAttribute((const void *) csr5_group_kernel<T, SIGMA, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int) lds);
+            if (P.row_map) (void) hipFuncSetAttribute((const void *) csr5_group_kernel<T, SIGMA, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int) lds);
             else (void) hipFuncSetAttribute((const void *) csr5_group_kernel<T, SIGMA, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int) lds);
         }
-        if (d->c5_row_map)
-            csr5_group_kernel<T, SIGMA, true><<<d->c5_groups, kBlock, lds, d->stream>>>(d->c5_tiles, d->c5_tile_ptr, d->c5_desc, d->c5_col,
-                (const T *) d->c5_val, d->c5_row_map, d->c5_wins, x, y, (T *) d->c5_carry);
+        if (P.row_map)
+            csr5_group_kernel<T, SIGMA, true><<<P.groups, kBlock, lds, d->stream>>>(P.tiles, P.tile_ptr, P.desc, P.col, (const T *) P.val, P.row_map, P.wins,
+                                                                                   x, y, (T *) P.carry);
         else
-            csr5_group_kernel<T, SIGMA, false><<<d->c5_groups, kBlock, lds, d->stream>>>(d->c5_tiles, d->c5_tile_ptr, d->c5_desc, d->c5_col,
-                (const T *) d->c5_val, nullptr, d->c5_wins, x, y, (T *) d->c5_carry);
+            csr5_group_kernel<T, SIGMA, false><<<P.groups, kBlock, lds, d->stream>>>(P.tiles, P.tile_ptr, P.desc, P.col, (const T *) P.val, nullptr, P.wins,
+                                                                                    x, y, (T *) P.carry);
         return;
     }
-    const int grid = grid_for(d->c5_tiles, kBlock / kWave, INT_MAX);
-    if (d->c5_row_map)
-        csr5_kernel<T, SIGMA, true><<<grid, kBlock, 0, d->stream>>>(d->c5_tiles, d->c5_tile_ptr, d->c5_desc, d->c5_col, (const T *) d->c5_val,
-                                                                   d->c5_row_map, x, y, (T *) d->c5_carry);
+    const int grid = grid_for(P.tiles, kBlock / kWave, INT_MAX);
+    if (P.row_map)
+        csr5_kernel<T, SIGMA, true><<<grid, kBlock, 0, d->stream>>>(P.tiles, P.tile_ptr, P.desc, P.col, (const T *) P.val, P.row_map, x, y, (T *) P.carry);
     else
-        csr5_kernel<T, SIGMA, false><<<grid, kBlock, 0, d->stream>>>(d->c5_tiles, d->c5_tile_ptr, d->c5_desc, d->c5_col, (const T *) d->c5_val,
-                                                                    nullptr, x, y, (T *) d->c5_carry);
+        csr5_kernel<T, SIGMA, false><<<grid, kBlock, 0, d->stream>>>(P.tiles, P.tile_ptr, P.desc, P.col, (const T *) P.val, nullptr, x, y, (T *) P.carry);
+}
+
+// One CSR5 multiply: [y = 0 for the rows outside the plan] + tiles + carry fix-up.
+template <typename T>
+static int launch_csr5(spmv_dev *d, const Csr5Plan &P, const T *x, T *y)
+{
+    if (P.nnz == 0) return SPMV_HIP_OK;
+    if (P.zero_fill) HIP_TRY(hipMemsetAsync(y, 0, sizeof(T) * (size_t) d->m, d->stream)); // empty rows
+    switch (P.sigma) {
+    case 4: launch_csr5_sigma<T, 4>(d, P, x, y); break;
+    case 8: launch_csr5_sigma<T, 8>(d, P, x, y); break;
+    default: launch_csr5_sigma<T, 16>(d, P, x, y); break;
+    }
+    if (P.fixup && P.tiles > 1) {
+        const int g = grid_for(P.tiles - 1, kBlock, INT_MAX);
+        if (P.row_map) csr5_fixup_kernel<T, true><<<g, kBlock, 0, d->stream>>>(P.tiles, P.tile_ptr, P.run_len, P.row_map, (const T *) P.carry, y);
+        else csr5_fixup_kernel<T, false><<<g, kBlock, 0, d->stream>>>(P.tiles, P.tile_ptr, P.run_len, nullptr, (const T *) P.carry, y);
+    }
+    return SPMV_HIP_OK;
 }
 
 template <typename T, int L>
@@ -906,19 +982,11 @@ static int launch(spmv_dev *d, const T *x, T *y)
                 d->nchunks, d->chunk_ptr, d->scol, (const T *) d->sval, d->perm, x, y);
         launch_long_rows<T>(d, x, y);
         break;
-    case SPMV_SCHED_CSR5:
-        if (d->c5_row_map) HIP_TRY(hipMemsetAsync(y, 0, sizeof(T) * (size_t) d->m, d->stream)); // empty rows
-        switch (d->c5_sigma) {
-        case 4: launch_csr5<T, 4>(d, x, y); break;
-        case 8: launch_csr5<T, 8>(d, x, y); break;
-        default: launch_csr5<T, 16>(d, x, y); break;
-        }
-        if (d->c5_fixup && d->c5_tiles > 1) {
-            const int g = grid_for(d->c5_tiles - 1, kBlock, INT_MAX);
-            if (d->c5_row_map) csr5_fixup_kernel<T, true><<<g, kBlock, 0, d->stream>>>(d->c5_tiles, d->c5_tile_ptr, d->c5_run_len, d->c5_row_map, (const T *) d->c5_carry, y);
-            else csr5_fixup_kernel<T, false><<<g, kBlock, 0, d->stream>>>(d->c5_tiles, d->c5_tile_ptr, d->c5_run_len, nullptr, (const T *) d->c5_carry, y);
-        }
+    case SPMV_SCHED_CSR5: {
+        const int rc = launch_csr5<T>(d, d->c5, x, y);
+        if (rc) return rc;
         break;
+    }
     default: return fail(SPMV_HIP_E_ARG, "schedule %d has no executor", d->plan.sched);
     }
     HIP_TRY(hipGetLastError());
@@ -1020,11 +1088,11 @@ extern "C" int spmv_shim_info(const spmv_dev *d, spmv_hip_info *o)
     o->lanes_per_row = d->plan.sched == SPMV_SCHED_CSR_VECTOR ? d->plan.lanes_per_row : 0;
     o->sell_c = d->plan.sched == SPMV_SCHED_SELL ? kSellC : 0;
     o->sell_sigma = d->plan.sched == SPMV_SCHED_SELL ? d->plan.sell_sigma : 0;
-    o->tile_nnz = d->plan.sched == SPMV_SCHED_NNZ_SPLIT ? (d->vsize == 8 ? SplitCfg<double>::Tile : SplitCfg<float>::Tile) : (d->plan.sched == SPMV_SCHED_ROWBLOCK ? d->rb_stride : (d->plan.sched == SPMV_SCHED_CSR5 ? kWave * d->c5_sigma : 0));
+    o->tile_nnz = d->plan.sched == SPMV_SCHED_NNZ_SPLIT ? (d->vsize == 8 ? SplitCfg<double>::Tile : SplitCfg<float>::Tile) : (d->plan.sched == SPMV_SCHED_ROWBLOCK ? d->rb_stride : (d->plan.sched == SPMV_SCHED_CSR5 ? kWave * d->c5.sigma : 0));
     o->m = d->m;
     o->n = d->n;
     o->nnz = d->nnz;
-    o->stored_nnz = d->plan.sched == SPMV_SCHED_SELL ? d->sell_cols * kSellC : (d->plan.sched == SPMV_SCHED_CSR5 ? (long long) d->c5_tiles * kWave * d->c5_sigma : d->nnz);
+    o->stored_nnz = d->plan.sched == SPMV_SCHED_SELL ? d->sell_cols * kSellC : (d->plan.sched == SPMV_SCHED_CSR5 ? (long long) d->c5.tiles * kWave * d->c5.sigma : d->nnz);
     o->max_row_len = d->stats.max_row_len;
     o->min_row_len = d->stats.min_row_len;
     o->empty_rows = d->stats.empty_rows;
@@ -1041,7 +1109,7 @@ extern "C" int spmv_shim_info(const spmv_dev *d, spmv_hip_info *o)
         (d->vt_staged * 2 >= d->vt_tiles || (d->vec_choice != VEC_AUTO && d->vec_choice != VEC_PIPE)))
         o->kernel_name = "csr_vector_tile_kernel";
     if (d->plan.sched == SPMV_SCHED_NNZ_SPLIT && d->ns_staged > 0) o->kernel_name = "nnz_group_kernel";
-    if (d->plan.sched == SPMV_SCHED_CSR5 && d->c5_staged > 0) o->kernel_name = "csr5_group_kernel";
+    if (d->plan.sched == SPMV_SCHED_CSR5 && d->c5.staged > 0) o->kernel_name = "csr5_group_kernel";
     if (d->plan.sched == SPMV_SCHED_SELL && d->sell_staged > 0) o->kernel_name = "sell_window_kernel";
     return SPMV_HIP_OK;
 }
