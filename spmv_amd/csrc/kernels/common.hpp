@@ -27,6 +27,18 @@ __device__ __forceinline__ void ld_stream4(const int *p, int (&o)[4])
     const i32x4 v = __builtin_nontemporal_load(reinterpret_cast<const i32x4 *>(p));
     o[0] = v.x; o[1] = v.y; o[2] = v.z; o[3] = v.w;
 }
+// 4 consecutive 16-bit LDS slots (one 8-byte load), left PACKED in o[0], o[1]: the compressed
+// column stream of staged tiles (slot k = half k&1 of word k>>1, see lds_slot)
+__device__ __forceinline__ void ld_stream4(const unsigned short *p, int (&o)[4])
+{
+    const i32x2 v = __builtin_nontemporal_load(reinterpret_cast<const i32x2 *>(p));
+    o[0] = v.x; o[1] = v.y;
+}
+template <int K>
+__device__ __forceinline__ unsigned lds_slot(const int (&o)[4])
+{
+    return (K & 1) ? (unsigned) o[K >> 1] >> 16 : (unsigned) o[K >> 1] & 0xffffu;
+}
 __device__ __forceinline__ void ld_stream4(const float *p, float (&o)[4])
 {
     const f32x4 v = __builtin_nontemporal_load(reinterpret_cast<const f32x4 *>(p));

@@ -12,15 +12,17 @@
 //     its rows reference -- one window when the plain span [min, max] fits the LDS budget (banded
 //     matrices), several when the columns sit in a few far-apart bands (3-D stencils: 9 windows of
 //     ~260 columns for a 27-point stencil) -- and writes a tile-local copy of ColIdx in which each
-//     entry already IS the LDS slot of its column.  The executor stages the windows once per tile
-//     (coalesced) and every gather is xs[col_local], with no index arithmetic at all.  Tiles whose
-//     columns do not fit keep global indices in col_local and gather from L1/L2;
+//     entry already IS the LDS slot of its column, stored in 16 BITS (a slot is < 48 KiB / sizeof(T)):
+//     the staged tiles' column stream is 2 B/nnz instead of ColIdx's 4 B/nnz, i.e. 10 instead of
+//     12 B/nnz for fp64.  The executor stages the windows once per tile (coalesced) and every
+//     gather is xs[slot], with no index arithmetic at all.  Tiles whose columns do not fit read
+//     the original ColIdx and gather from L1/L2;
 //   - matrix stream: 16 B lane loads, DEPTH steps in flight per wave;
 //   - the 64 row sums of a wave are collected through LDS and written by ONE coalesced store.
 // Rows longer than long_thr are left to kernels/long_rows.hpp (which reads the ORIGINAL ColIdx) and
 // are excluded from the windows.
-// Extra HBM held: col_local int32[nnz] (read INSTEAD of ColIdx by this kernel: same traffic) and
-// 200 B of window table per tile.
+// Extra HBM held: col_local uint16[nnz] (read INSTEAD of ColIdx for staged tiles) and 200 B of window
+// table per tile.
 #pragma once
 #include <climits>
 #include "common.hpp"
@@ -38,14 +40,14 @@ __device__ __forceinline__ void tile_rows(int b, int m, const int *__restrict__ 
     else { r0 = (long long) b * kVecTileRows; r1 = r0 + kVecTileRows < m ? r0 + kVecTileRows : m; }
 }
 
-// Inspector: windows of one row tile + the tile-local column copy.  col_local must be pre-filled
-// with a copy of ColIdx (entries of unstaged tiles and of long rows keep their global value).
-__global__ __launch_bounds__(kBlock) void csr_tile_windows_kernel(int m, int n, int long_thr, int max_cols,
+// Inspector: windows of one row tile + the tile-local 16-bit column stream (written for staged tiles
+// only; unstaged tiles and long rows are computed from the original ColIdx).
+__global__ __launch_bounds__(kBlock) void csr_tile_windows_kernel(int m, int n, int long_thr, int max_cols, int slot_bytes,
                                                                   const int *__restrict__ split,
                                                                   const int *__restrict__ rowptr,
                                                                   const int *__restrict__ colidx,
                                                                   TileWindows *__restrict__ wins,
-                                                                  int *__restrict__ col_local,
+                                                                  unsigned short *__restrict__ col_local,
                                                                   int *__restrict__ staged /* [0] tiles staged, [1] max total */)
 {
     long long r0, r1;
@@ -58,35 +60,44 @@ __global__ __launch_bounds__(kBlock) void csr_tile_windows_kernel(int m, int n, 
             for (int p = p0 + l; p < p1; p += 16) body(colidx[p], (long long) p);
         }
     };
-    build_windows(n, max_cols, loop, col_local, wins[blockIdx.x], staged);
+    build_windows(n, max_cols, loop, col_local, wins[blockIdx.x], staged, true, slot_bytes);
 }
 
+// The wave program.  STAGED: c[][0..1] hold four packed 16-bit BYTE offsets into xs (the inspector
+// stores slot * sizeof(T)), so a gather is one extract + one ds_read with the LDS base as immediate;
+// zoff is the byte offset of a slot that holds 0 (masked entries read it: 0 * 0, never x's NaN/Inf).
+// A step whose lanes all hold four entries of their row, or none (regular matrices: every step),
+// takes the unmasked path.  The order of the fused multiply-adds is the same on both paths.
 template <typename T, int L, bool STAGED, int DEPTH, bool PRE = true>
 __device__ __forceinline__ void csr_vector_tile_wave(long long row_end, int long_thr, long long rw0, int lane,
                                                      const int *__restrict__ rp_lds, T *__restrict__ y_lds,
-                                                     const int *__restrict__ col_local, const T *__restrict__ val,
-                                                     const T *__restrict__ x, const T *__restrict__ xs,
+                                                     const int *__restrict__ colidx, const unsigned short *__restrict__ col_local,
+                                                     const T *__restrict__ val,
+                                                     const T *__restrict__ x, const T *__restrict__ xs, unsigned zoff,
                                                      T *__restrict__ y, const int (&c0)[4], const T (&v0)[4])
 {
     constexpr int RW = kWave / L; // rows per step
     constexpr int D = DEPTH < L ? DEPTH : L; // steps of matrix stream in flight per wave
     const int l = lane % L, sub = lane / L;
+    const unsigned char *xb = reinterpret_cast<const unsigned char *>(xs);
     int c[D][4];
     T v[D][4];
     int pp0[D], pp1[D];
 #pragma unroll
     for (int k = 0; k < 4; ++k) { c[0][k] = c0[k]; v[0][k] = v0[k]; } // PRE: step 0 was issued before the barrier
-    auto issue = [&](int s) { // RowPtr pair of step s from LDS, then its 16 B stream loads
+    auto issue = [&](int s) { // RowPtr pair of step s from LDS, then its stream loads
         const int slot = s % D;
         pp0[slot] = rp_lds[s * RW + sub];
         pp1[slot] = rp_lds[s * RW + sub + 1];
         if (pp1[slot] - pp0[slot] > long_thr) pp1[slot] = pp0[slot];
         if (s > 0 || !PRE) {
             const int an = (pp0[slot] & ~3) + l * 4;
-            ld_stream4(col_local + an, c[slot]);
+            if (STAGED) ld_stream4(col_local + an, c[slot]);
+            else ld_stream4(colidx + an, c[slot]);
             ld_stream4(val + an, v[slot]);
         }
     };
+    auto xat = [&](unsigned off) { return *reinterpret_cast<const T *>(xb + off); };
 #pragma unroll
     for (int s = 0; s < D && s < L; ++s) issue(s);
 #pragma unroll
@@ -95,23 +106,54 @@ __device__ __forceinline__ void csr_vector_tile_wave(long long row_end, int long
         const int p0 = pp0[cur], p1 = pp1[cur];
         const int a = (p0 & ~3) + l * 4;
         T sum = 0;
+        if (STAGED) {
+            const bool full = (a >= p0) & (a + 4 <= p1), none = a >= p1;
+            if (__all(full | none)) {
+                if (full) {
+                    const T x0 = xat(lds_slot<0>(c[cur])), x1 = xat(lds_slot<1>(c[cur])), x2 = xat(lds_slot<2>(c[cur])),
+                            x3 = xat(lds_slot<3>(c[cur]));
+                    sum = fmadd(v[cur][0], x0, sum);
+                    sum = fmadd(v[cur][1], x1, sum);
+                    sum = fmadd(v[cur][2], x2, sum);
+                    sum = fmadd(v[cur][3], x3, sum);
+                }
+            } else {
+                const unsigned t0 = (unsigned) (a - p0), len = (unsigned) (p1 - p0); // entry k is in the row iff t0 + k < len (unsigned)
+                const bool k0 = t0 < len, k1 = t0 + 1u < len, k2 = t0 + 2u < len, k3 = t0 + 3u < len;
+                const T x0 = xat(k0 ? lds_slot<0>(c[cur]) : zoff), x1 = xat(k1 ? lds_slot<1>(c[cur]) : zoff),
+                        x2 = xat(k2 ? lds_slot<2>(c[cur]) : zoff), x3 = xat(k3 ? lds_slot<3>(c[cur]) : zoff);
+                sum = fmadd(k0 ? v[cur][0] : T(0), x0, sum);
+                sum = fmadd(k1 ? v[cur][1] : T(0), x1, sum);
+                sum = fmadd(k2 ? v[cur][2] : T(0), x2, sum);
+                sum = fmadd(k3 ? v[cur][3] : T(0), x3, sum);
+            }
+        } else {
 #pragma unroll
-        for (int k = 0; k < 4; ++k) {
-            const bool ok = (a + k >= p0) & (a + k < p1);
-            const int ci = ok ? c[cur][k] : 0; // STAGED: an LDS slot; else a global column
-            const T xl = STAGED ? xs[ci] : x[ci];
-            sum = fmadd(ok ? v[cur][k] : T(0), ok ? xl : T(0), sum);
+            for (int k = 0; k < 4; ++k) {
+                const bool ok = (a + k >= p0) & (a + k < p1);
+                const int ci = ok ? c[cur][k] : 0;
+                const T xl = x[ci];
+                sum = fmadd(ok ? v[cur][k] : T(0), ok ? xl : T(0), sum);
+            }
         }
         if (__any(a + 4 * L < p1)) { // some row of this step is longer than 4L
             for (int aa = a + 4 * L; __any(aa < p1); aa += 4 * L) {
                 if (aa < p1) {
                     int cc[4];
                     T v2[4];
-                    ld_stream4(col_local + aa, cc);
+                    if (STAGED) ld_stream4(col_local + aa, cc);
+                    else ld_stream4(colidx + aa, cc);
                     ld_stream4(val + aa, v2);
+                    if (STAGED) {
+                        if (aa + 0 < p1) sum = fmadd(v2[0], xat(lds_slot<0>(cc)), sum);
+                        if (aa + 1 < p1) sum = fmadd(v2[1], xat(lds_slot<1>(cc)), sum);
+                        if (aa + 2 < p1) sum = fmadd(v2[2], xat(lds_slot<2>(cc)), sum);
+                        if (aa + 3 < p1) sum = fmadd(v2[3], xat(lds_slot<3>(cc)), sum);
+                    } else {
 #pragma unroll
-                    for (int k = 0; k < 4; ++k)
-                        if (aa + k < p1) sum = fmadd(v2[k], STAGED ? xs[cc[k]] : x[cc[k]], sum);
+                        for (int k = 0; k < 4; ++k)
+                            if (aa + k < p1) sum = fmadd(v2[k], x[cc[k]], sum);
+                    }
                 }
             }
         }
@@ -127,7 +169,8 @@ __device__ __forceinline__ void csr_vector_tile_wave(long long row_end, int long
 
 template <typename T, int L, int DEPTH = 4, bool PRE = true>
 __global__ __launch_bounds__(kVecTileThreads) void csr_vector_tile_kernel(int m, int long_thr, const int *__restrict__ rowptr,
-                                                                          const int *__restrict__ col_local,
+                                                                          const int *__restrict__ colidx,
+                                                                          const unsigned short *__restrict__ col_local,
                                                                           const T *__restrict__ val,
                                                                           const TileWindows *__restrict__ wins,
                                                                           const T *__restrict__ x, T *__restrict__ y)
@@ -145,6 +188,7 @@ __global__ __launch_bounds__(kVecTileThreads) void csr_vector_tile_kernel(int m,
     const int rp = rowptr[r];
     const int rpe = rowptr[re]; // wave-uniform
     const TileWindows &tw = wins[blockIdx.x];
+    const bool staged = tw.nwin > 0;
     // step 0 of the matrix stream is issued straight from registers (RowPtr handed over by
     // shuffles), BEFORE the x staging and the barrier, so neither sits in front of the first loads
     int c0[4] = {0, 0, 0, 0};
@@ -153,17 +197,19 @@ __global__ __launch_bounds__(kVecTileThreads) void csr_vector_tile_kernel(int m,
         const int sub = lane / L, l = lane % L;
         const int q0 = __shfl(rp, sub, kWave);
         const int a = (q0 & ~3) + l * 4;
-        ld_stream4(col_local + a, c0);
+        if (staged) ld_stream4(col_local + a, c0);
+        else ld_stream4(colidx + a, c0);
         ld_stream4(val + a, v0);
     }
     rp_lds[wave][lane] = rp;
     if (lane == 0) rp_lds[wave][kWave] = rpe;
-    const bool staged = tw.nwin > 0;
     stage_windows<kVecTileThreads, T>(tw, x, xs);
+    if (threadIdx.x == 0) xs[tw.total] = T(0); // the zero slot of masked entries
     __syncthreads();
     if (rw0 >= m) return;
-    if (staged) csr_vector_tile_wave<T, L, true, DEPTH, PRE>((long long) m, long_thr, rw0, lane, rp_lds[wave], y_lds[wave], col_local, val, x, xs, y, c0, v0);
-    else csr_vector_tile_wave<T, L, false, DEPTH, PRE>((long long) m, long_thr, rw0, lane, rp_lds[wave], y_lds[wave], col_local, val, x, xs, y, c0, v0);
+    const unsigned zoff = (unsigned) tw.total * (unsigned) sizeof(T);
+    if (staged) csr_vector_tile_wave<T, L, true, DEPTH, PRE>((long long) m, long_thr, rw0, lane, rp_lds[wave], y_lds[wave], colidx, col_local, val, x, xs, zoff, y, c0, v0);
+    else csr_vector_tile_wave<T, L, false, DEPTH, PRE>((long long) m, long_thr, rw0, lane, rp_lds[wave], y_lds[wave], colidx, col_local, val, x, xs, zoff, y, c0, v0);
 }
 
 // Balanced form (Method_Balanced): the same wave program over EQUAL-NNZ row blocks.  Block b owns
@@ -173,7 +219,8 @@ __global__ __launch_bounds__(kVecTileThreads) void csr_vector_tile_kernel(int m,
 template <typename T, int L, int DEPTH = 4>
 __global__ __launch_bounds__(kVecTileThreads) void csr_vector_rows_kernel(int long_thr, const int *__restrict__ split,
                                                                           const int *__restrict__ rowptr,
-                                                                          const int *__restrict__ col_local,
+                                                                          const int *__restrict__ colidx,
+                                                                          const unsigned short *__restrict__ col_local,
                                                                           const T *__restrict__ val,
                                                                           const TileWindows *__restrict__ wins,
                                                                           const T *__restrict__ x, T *__restrict__ y)
@@ -187,7 +234,9 @@ __global__ __launch_bounds__(kVecTileThreads) void csr_vector_rows_kernel(int lo
     const TileWindows &tw = wins[blockIdx.x];
     const bool staged = tw.nwin > 0;
     stage_windows<kVecTileThreads, T>(tw, x, xs);
+    if (threadIdx.x == 0) xs[tw.total] = T(0); // the zero slot of masked entries
     __syncthreads();
+    const unsigned zoff = (unsigned) tw.total * (unsigned) sizeof(T);
     const int c0[4] = {0, 0, 0, 0};
     const T v0[4] = {T(0), T(0), T(0), T(0)};
     for (long long rw0 = r_begin + (long long) wave * kWave; rw0 < r_end; rw0 += kVecTileRows) {
@@ -197,8 +246,8 @@ __global__ __launch_bounds__(kVecTileThreads) void csr_vector_rows_kernel(int lo
         rp_lds[wave][lane] = rowptr[r];
         if (lane == 0) rp_lds[wave][kWave] = rowptr[re];
         wave_lds_sync();
-        if (staged) csr_vector_tile_wave<T, L, true, DEPTH, false>(r_end, long_thr, rw0, lane, rp_lds[wave], y_lds[wave], col_local, val, x, xs, y, c0, v0);
-        else csr_vector_tile_wave<T, L, false, DEPTH, false>(r_end, long_thr, rw0, lane, rp_lds[wave], y_lds[wave], col_local, val, x, xs, y, c0, v0);
+        if (staged) csr_vector_tile_wave<T, L, true, DEPTH, false>(r_end, long_thr, rw0, lane, rp_lds[wave], y_lds[wave], colidx, col_local, val, x, xs, zoff, y, c0, v0);
+        else csr_vector_tile_wave<T, L, false, DEPTH, false>(r_end, long_thr, rw0, lane, rp_lds[wave], y_lds[wave], colidx, col_local, val, x, xs, zoff, y, c0, v0);
         wave_lds_sync(); // y_lds / rp_lds are reused by the next slab
     }
 }

@@ -47,10 +47,10 @@ __device__ __forceinline__ void stage_windows(const TileWindows &tw, const T *__
 // every (column, position) of the tile, distributing the entries over the workgroup's threads
 // (entries with c < 0 are padding and are skipped here).  On return `out` describes the windows
 // and, when the tile is staged, target[pos] has been overwritten with the LDS slot of each entry.
-template <typename Loop>
-__device__ __forceinline__ void build_windows(int n, int max_cols, Loop loop, int *__restrict__ target,
+template <typename Loop, typename Slot>
+__device__ __forceinline__ void build_windows(int n, int max_cols, Loop loop, Slot *__restrict__ target,
                                               TileWindows &out, int *__restrict__ staged /* [0] count, [1] max total */,
-                                              bool rewrite = true)
+                                              bool rewrite = true, int slot_scale = 1 /* target holds slot * slot_scale */)
 {
     __shared__ unsigned bitmap[kWinBitmapWords];
     __shared__ int smin[kBlock / kWave], smax[kBlock / kWave], wave_cnt[kBlock / kWave];
@@ -158,7 +158,7 @@ __device__ __forceinline__ void build_windows(int n, int max_cols, Loop loop, in
         if (c >= 0) {
             int w = 0;
             for (int k = 1; k < nwin; ++k) w = c >= s_start[k] ? k : w; // windows are sorted by start
-            target[pos] = s_base[w] + (c - s_start[w]);
+            target[pos] = (Slot) ((s_base[w] + (c - s_start[w])) * slot_scale);
         }
     });
 }

@@ -101,7 +101,7 @@ struct spmv_dev {
     // csr-vector x tiles
     int vt_tiles = 0, vt_staged = 0, vt_maxspan = 0, vec_choice = 0;
     float tune_ms[3] = {0, 0, 0}; // tile D4, tile D2, pipe (autotune_vector)
-    int *vt_col = nullptr;          // tile-local ColIdx copy (LDS slots for staged tiles)
+    unsigned short *vt_col = nullptr; // tile-local column stream: 16-bit LDS slots (staged tiles only)
     TileWindows *vt_wins = nullptr; // x windows of every tile
     // long rows (csr-vector, sell)
     int nlong = 0, long_thr = INT_MAX, lr_segs = 0, lr_maxspan = 0;
@@ -469,11 +469,12 @@ static int build_tile_windows(spmv_dev *d, int tiles, const int *split)
     int host2[2] = {0, 0};
     d->vt_tiles = tiles;
     ALLOC_TRY(d, &cnt, 2 * sizeof(int), true);
-    ALLOC_TRY(d, &d->vt_col, sizeof(int) * ((size_t) d->nnz + kStreamPad), true);
+    static_assert(kVecXTileBytes <= 65536, "LDS byte offsets must fit 16 bits");
+    ALLOC_TRY(d, &d->vt_col, sizeof(unsigned short) * ((size_t) d->nnz + kStreamPad), true);
     ALLOC_TRY(d, &d->vt_wins, sizeof(TileWindows) * (size_t) tiles, true);
-    HIP_TRY(hipMemcpyAsync(d->vt_col, d->colidx, sizeof(int) * ((size_t) d->nnz + kStreamPad), hipMemcpyDeviceToDevice, d->stream));
+    HIP_TRY(hipMemsetAsync(d->vt_col, 0, sizeof(unsigned short) * ((size_t) d->nnz + kStreamPad), d->stream));
     HIP_TRY(hipMemsetAsync(cnt, 0, 2 * sizeof(int), d->stream));
-    csr_tile_windows_kernel<<<tiles, kBlock, 0, d->stream>>>(d->m, d->n, d->long_thr, (int) (kVecXTileBytes / sizeof(T)), split, d->rowptr, d->colidx,
+    csr_tile_windows_kernel<<<tiles, kBlock, 0, d->stream>>>(d->m, d->n, d->long_thr, (int) (kVecXTileBytes / sizeof(T)) - 1, (int) sizeof(T), split, d->rowptr, d->colidx,
                                                              d->vt_wins, d->vt_col, cnt);
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipMemcpyAsync(host2, cnt, 2 * sizeof(int), hipMemcpyDeviceToHost, d->stream));
@@ -772,10 +773,10 @@ enum { VEC_AUTO = 0, VEC_STRIDED = 1, VEC_NO_LONG = 2, VEC_PIPE = 4, VEC_TILE_D2
 template <typename T, int L, int DEPTH, bool PRE = true>
 static void launch_vector_tile(spmv_dev *d, const T *x, T *y, int long_thr)
 {
-    const size_t lds = (((size_t) d->vt_maxspan * sizeof(T)) + 1023) & ~(size_t) 1023;
+    const size_t lds = ((((size_t) d->vt_maxspan + 1) * sizeof(T)) + 1023) & ~(size_t) 1023; // + the zero slot
     if (lds > 64 * 1024)
         (void) hipFuncSetAttribute((const void *) csr_vector_tile_kernel<T, L, DEPTH, PRE>, hipFuncAttributeMaxDynamicSharedMemorySize, (int) lds);
-    csr_vector_tile_kernel<T, L, DEPTH, PRE><<<d->vt_tiles, kVecTileThreads, lds, d->stream>>>(d->m, long_thr, d->rowptr, d->vt_col, (const T *) d->val,
+    csr_vector_tile_kernel<T, L, DEPTH, PRE><<<d->vt_tiles, kVecTileThreads, lds, d->stream>>>(d->m, long_thr, d->rowptr, d->colidx, d->vt_col, (const T *) d->val,
                                                                                            d->vt_wins, x, y);
 }
 
@@ -915,11 +916,11 @@ static int launch_csr5(spmv_dev *d, const Csr5Plan &P, const T *x, T *y)
 template <typename T, int L>
 static void launch_rows(spmv_dev *d, const T *x, T *y)
 {
-    const size_t lds = (((size_t) d->vt_maxspan * sizeof(T)) + 1023) & ~(size_t) 1023;
+    const size_t lds = ((((size_t) d->vt_maxspan + 1) * sizeof(T)) + 1023) & ~(size_t) 1023; // + the zero slot
     if (lds > 64 * 1024)
         (void) hipFuncSetAttribute((const void *) csr_vector_rows_kernel<T, L, (sizeof(T) == 8 ? 4 : 2)>, hipFuncAttributeMaxDynamicSharedMemorySize, (int) lds);
     csr_vector_rows_kernel<T, L, (sizeof(T) == 8 ? 4 : 2)><<<d->nblocks, kVecTileThreads, lds, d->stream>>>(
-        d->long_thr, d->rb_split, d->rowptr, d->vt_col, (const T *) d->val, d->vt_wins, x, y);
+        d->long_thr, d->rb_split, d->rowptr, d->colidx, d->vt_col, (const T *) d->val, d->vt_wins, x, y);
 }
 
 template <typename T>
