@@ -213,10 +213,13 @@ __global__ __launch_bounds__(kBlock) void csr5_transpose_kernel(int nnz, int p, 
 }
 
 // ---------------------------------------------------------------------------- executor
-// One tile by one wavefront.  STAGED: x[lo, lo+span) of the workgroup's tiles is in LDS (xs).
+// One tile by one wavefront.  STAGED: the x windows of the workgroup's tiles are in LDS (xs) and the
+// column stream is tcol16: 16-bit LDS slots, four per lane and 8-byte load (range_windows_kernel,
+// pack16 = SIGMA); padding entries point at the zero slot behind the windows, so no entry needs a test.
 template <typename T, int SIGMA, bool MAPPED, bool STAGED>
 __device__ __forceinline__ void csr5_tile(int t, int lane, const int *__restrict__ tile_ptr,
                                           const unsigned *__restrict__ desc, const int *__restrict__ tcol,
+                                          const unsigned short *__restrict__ tcol16,
                                           const T *__restrict__ tval, const int *__restrict__ row_map,
                                           const T *__restrict__ x, const T *__restrict__ xs,
                                           T *__restrict__ y, T *__restrict__ carry)
@@ -225,11 +228,22 @@ __device__ __forceinline__ void csr5_tile(int t, int lane, const int *__restrict
     const long long base = (long long) t * TN + lane;
     int c[SIGMA];
     T v[SIGMA];
+    if (STAGED) {
 #pragma unroll
-    for (int i = 0; i < SIGMA; ++i) {
-        c[i] = ld_stream(tcol + base + i * kWave);
-        v[i] = ld_stream(tval + base + i * kWave);
+        for (int q = 0; q < SIGMA / 4; ++q) {
+            int w[4];
+            ld_stream4(tcol16 + (long long) t * TN + q * (4 * kWave) + lane * 4, w);
+            c[4 * q + 0] = (int) lds_slot<0>(w);
+            c[4 * q + 1] = (int) lds_slot<1>(w);
+            c[4 * q + 2] = (int) lds_slot<2>(w);
+            c[4 * q + 3] = (int) lds_slot<3>(w);
+        }
+    } else {
+#pragma unroll
+        for (int i = 0; i < SIGMA; ++i) c[i] = ld_stream(tcol + base + i * kWave);
     }
+#pragma unroll
+    for (int i = 0; i < SIGMA; ++i) v[i] = ld_stream(tval + base + i * kWave);
     const unsigned d = desc[(long long) t * kWave + lane];
     const unsigned flags = d & kCsr5FlagMask;
     const int r0 = tile_ptr[t];
@@ -239,8 +253,8 @@ __device__ __forceinline__ void csr5_tile(int t, int lane, const int *__restrict
     T xv[SIGMA];
 #pragma unroll
     for (int i = 0; i < SIGMA; ++i) {
-        const int ci = c[i] >= 0 ? c[i] : 0; // STAGED: tcol holds LDS slots (xwindows.hpp), else global columns
-        xv[i] = STAGED ? xs[ci] : x[ci];
+        if (STAGED) xv[i] = xs[c[i]];
+        else xv[i] = x[c[i] >= 0 ? c[i] : 0];
     }
 
     T head = 0, acc = 0;
@@ -257,7 +271,7 @@ __device__ __forceinline__ void csr5_tile(int t, int lane, const int *__restrict
             }
             acc = 0;
         }
-        if (c[i] >= 0) acc = fmadd(v[i], xv[i], acc);
+        if (STAGED || c[i] >= 0) acc = fmadd(v[i], xv[i], acc); // STAGED: padding is 0 * xs[zero slot]
     }
     if (!started) { head = acc; acc = 0; }
 
@@ -286,20 +300,21 @@ __global__ __launch_bounds__(kBlock) void csr5_kernel(int p, const int *__restri
     const int lane = threadIdx.x & (kWave - 1);
     const int t = blockIdx.x * (kBlock / kWave) + threadIdx.x / kWave;
     if (t >= p) return;
-    csr5_tile<T, SIGMA, MAPPED, false>(t, lane, tile_ptr, desc, tcol, tval, row_map, x, nullptr, y, carry);
+    csr5_tile<T, SIGMA, MAPPED, false>(t, lane, tile_ptr, desc, tcol, nullptr, tval, row_map, x, nullptr, y, carry);
 }
 
 // ---- LDS-staged x windows (xwindows.hpp) --------------------------------------------------------
 // A workgroup owns kCsr5GroupTiles consecutive tiles.  range_windows_kernel covers the columns of
-// those tiles with up to 16 windows and rewrites the group's part of tcol into LDS slots; the
-// executor stages the windows once and all gathers of its tiles are LDS reads.  Groups whose
-// columns do not fit keep global columns in tcol and gather from L1/L2.
+// those tiles with up to 16 windows and writes the group's LDS slots to the 16-bit stream tcol16
+// (2 B/nnz instead of tcol's 4); the executor stages the windows once and all gathers of its tiles
+// are LDS reads.  Groups whose columns do not fit read the global columns in tcol and gather from L1/L2.
 constexpr int kCsr5GroupTiles = 16;
 
 template <typename T, int SIGMA, bool MAPPED>
 __global__ __launch_bounds__(kBlock) void csr5_group_kernel(int p, const int *__restrict__ tile_ptr,
                                                             const unsigned *__restrict__ desc,
-                                                            const int *__restrict__ tcol, const T *__restrict__ tval,
+                                                            const int *__restrict__ tcol, const unsigned short *__restrict__ tcol16,
+                                                            const T *__restrict__ tval,
                                                             const int *__restrict__ row_map,
                                                             const TileWindows *__restrict__ wins,
                                                             const T *__restrict__ x, T *__restrict__ y,
@@ -310,14 +325,17 @@ __global__ __launch_bounds__(kBlock) void csr5_group_kernel(int p, const int *__
     const TileWindows &tw = wins[blockIdx.x];
     const bool staged = tw.nwin > 0;
     stage_windows<kBlock, T>(tw, x, xs);
-    if (staged) __syncthreads();
+    if (staged) {
+        if (threadIdx.x == 0) xs[tw.total] = T(0); // the zero slot of padding entries
+        __syncthreads();
+    }
     const int lane = threadIdx.x & (kWave - 1);
     const int t0 = blockIdx.x * kCsr5GroupTiles;
     for (int k = threadIdx.x / kWave; k < kCsr5GroupTiles; k += kBlock / kWave) {
         const int t = t0 + k;
         if (t >= p) break;
-        if (staged) csr5_tile<T, SIGMA, MAPPED, true>(t, lane, tile_ptr, desc, tcol, tval, row_map, x, xs, y, carry);
-        else csr5_tile<T, SIGMA, MAPPED, false>(t, lane, tile_ptr, desc, tcol, tval, row_map, x, xs, y, carry);
+        if (staged) csr5_tile<T, SIGMA, MAPPED, true>(t, lane, tile_ptr, desc, tcol, tcol16, tval, row_map, x, xs, y, carry);
+        else csr5_tile<T, SIGMA, MAPPED, false>(t, lane, tile_ptr, desc, tcol, tcol16, tval, row_map, x, xs, y, carry);
     }
 }
 

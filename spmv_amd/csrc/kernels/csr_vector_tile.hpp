@@ -60,7 +60,8 @@ __global__ __launch_bounds__(kBlock) void csr_tile_windows_kernel(int m, int n, 
             for (int p = p0 + l; p < p1; p += 16) body(colidx[p], (long long) p);
         }
     };
-    build_windows(n, max_cols, loop, col_local, wins[blockIdx.x], staged, true, slot_bytes);
+    auto store = [&](long long pos, int slot, int) { col_local[pos] = (unsigned short) (slot * slot_bytes); };
+    build_windows(n, max_cols, loop, store, wins[blockIdx.x], staged, true);
 }
 
 // The wave program.  STAGED: c[][0..1] hold four packed 16-bit BYTE offsets into xs (the inspector

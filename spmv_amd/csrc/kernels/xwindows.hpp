@@ -45,12 +45,14 @@ __device__ __forceinline__ void stage_windows(const TileWindows &tw, const T *__
 
 // Inspector core, run by one 256-thread workgroup per tile.  `loop(body)` must call body(c, pos) for
 // every (column, position) of the tile, distributing the entries over the workgroup's threads
-// (entries with c < 0 are padding and are skipped here).  On return `out` describes the windows
-// and, when the tile is staged, target[pos] has been overwritten with the LDS slot of each entry.
-template <typename Loop, typename Slot>
-__device__ __forceinline__ void build_windows(int n, int max_cols, Loop loop, Slot *__restrict__ target,
+// (entries with c < 0 are padding and do not count).  On return `out` describes the windows and,
+// when the tile is staged and `rewrite` is set, store(pos, slot, total) has been called for every
+// entry with the LDS slot of its column (slot = -1 for padding; total = the tile's staged
+// elements, i.e. the first free slot -- executors keep a zero there for padding / masked entries).
+template <typename Loop, typename Store>
+__device__ __forceinline__ void build_windows(int n, int max_cols, Loop loop, Store store,
                                               TileWindows &out, int *__restrict__ staged /* [0] count, [1] max total */,
-                                              bool rewrite = true, int slot_scale = 1 /* target holds slot * slot_scale */)
+                                              bool rewrite = true)
 {
     __shared__ unsigned bitmap[kWinBitmapWords];
     __shared__ int smin[kBlock / kWave], smax[kBlock / kWave], wave_cnt[kBlock / kWave];
@@ -154,21 +156,30 @@ __device__ __forceinline__ void build_windows(int n, int max_cols, Loop loop, Sl
         if (nwin) { atomicAdd(staged, 1); atomicMax(staged + 1, s_total); }
     }
     if (nwin == 0 || !rewrite) return; // rewrite = false: count only (the caller decides, then runs again)
+    const int total = s_total;
     loop([&](int c, long long pos) { // the tile's private column copy now holds LDS slots
+        int slot = -1;
         if (c >= 0) {
             int w = 0;
             for (int k = 1; k < nwin; ++k) w = c >= s_start[k] ? k : w; // windows are sorted by start
-            target[pos] = (Slot) ((s_base[w] + (c - s_start[w])) * slot_scale);
+            slot = s_base[w] + (c - s_start[w]);
         }
+        store(pos, slot, total);
     });
 }
 
 // Inspector for tiles that are CONTIGUOUS RANGES of a private column array (CSR5 tile groups,
 // nnz-split tile groups, SELL sigma windows): group g covers cols[b, e) with
-// b = bounds ? bounds[g * bstride] * scale : g * group_len,  e likewise (clipped to total).  In place.
+// b = bounds ? bounds[g * bstride] * scale : g * group_len,  e likewise (clipped to total).
+// cols16 == NULL: in place (cols then holds int32 slots for staged groups).  Else cols is left
+// alone (unstaged groups keep reading global columns from it) and the staged groups' slots go to the
+// 16-bit stream cols16, padding entries to the zero slot; pack16 = 0: same positions, pack16 =
+// sigma (CSR5): position t*64*sigma + i*64 + lane -> t*64*sigma + (i/4)*256 + lane*4 + i%4, so a
+// lane fetches four slots with one 8-byte load.
 __global__ __launch_bounds__(kBlock) void range_windows_kernel(long long total, long long group_len,
                                                                const long long *__restrict__ bounds, int bstride, int scale,
                                                                int n, int max_cols, int *__restrict__ cols,
+                                                               unsigned short *__restrict__ cols16, int pack16,
                                                                TileWindows *__restrict__ wins, int *__restrict__ staged, int rewrite)
 {
     long long b, e;
@@ -178,7 +189,17 @@ __global__ __launch_bounds__(kBlock) void range_windows_kernel(long long total, 
     auto loop = [&](auto body) {
         for (long long i = b + threadIdx.x; i < e; i += kBlock) body(cols[i], i);
     };
-    build_windows(n, max_cols, loop, cols, wins[blockIdx.x], staged, rewrite != 0);
+    auto store = [&](long long pos, int slot, int tile_total) {
+        if (!cols16) { if (slot >= 0) cols[pos] = slot; return; }
+        long long q = pos;
+        if (pack16) {
+            const long long tn = (long long) kWave * pack16, t = pos / tn;
+            const int o = (int) (pos - t * tn), i = o / kWave, lane = o % kWave;
+            q = t * tn + (i / 4) * (4 * kWave) + lane * 4 + (i % 4);
+        }
+        cols16[q] = (unsigned short) (slot >= 0 ? slot : tile_total);
+    };
+    build_windows(n, max_cols, loop, store, wins[blockIdx.x], staged, rewrite != 0);
 }
 
 } // namespace spmv

@@ -68,7 +68,8 @@ struct Csr5Plan {
     long long nnz = 0;
     bool zero_fill = false;       // rows outside row_map (empty rows) need y = 0 first
     TileWindows *wins = nullptr;
-    int *tile_ptr = nullptr, *run_len = nullptr, *col = nullptr;
+    int *tile_ptr = nullptr, *run_len = nullptr, *col = nullptr; // col: transposed global columns (freed when every group is staged)
+    unsigned short *col16 = nullptr; // 16-bit LDS slots of the staged groups
     const int *row_map = nullptr; // CSR5 row -> y row (NULL: identity)
     unsigned *desc = nullptr;
     void *val = nullptr, *carry = nullptr;
@@ -143,6 +144,17 @@ static int dev_alloc(spmv_dev *d, void **p, size_t bytes, bool sched)
         int rc__ = dev_alloc((d), (void **) (p), (bytes), (sched));          \
         if (rc__) return rc__;                                               \
     } while (0)
+
+// release one schedule-owned allocation early
+static void sched_free(spmv_dev *d, void *p)
+{
+    for (size_t i = 0; i < d->sched_allocs.size(); ++i)
+        if (d->sched_allocs[i] == p) {
+            d->sched_allocs.erase(d->sched_allocs.begin() + (long) i);
+            (void) hipFree(p);
+            return;
+        }
+}
 
 static void free_schedule(spmv_dev *d)
 {
@@ -373,7 +385,8 @@ extern "C" void spmv_shim_matrix_destroy(spmv_dev *d)
 // groups whose columns fit LDS; only if at least half do (or in_place_ok is false and any does...)
 // rewrite the array into LDS slots.  Returns staged groups (0 = array untouched) and the LDS need.
 static int build_range_windows(spmv_dev *d, int groups, long long total, long long group_len, const long long *bounds, int bstride,
-                               int scale, int max_cols, int *cols, TileWindows *wins, int *staged_out, int *maxtotal_out)
+                               int scale, int max_cols, int *cols, TileWindows *wins, int *staged_out, int *maxtotal_out,
+                               unsigned short *cols16 = nullptr, int pack16 = 0)
 {
     int *cnt = nullptr;
     int host2[2] = {0, 0};
@@ -381,12 +394,12 @@ static int build_range_windows(spmv_dev *d, int groups, long long total, long lo
     if (groups <= 0) return SPMV_HIP_OK;
     HIP_TRY(hipMalloc((void **) &cnt, 2 * sizeof(int)));
     hipError_t e = hipMemsetAsync(cnt, 0, 2 * sizeof(int), d->stream);
-    range_windows_kernel<<<groups, kBlock, 0, d->stream>>>(total, group_len, bounds, bstride, scale, d->n, max_cols, cols, wins, cnt, 0);
+    range_windows_kernel<<<groups, kBlock, 0, d->stream>>>(total, group_len, bounds, bstride, scale, d->n, max_cols, cols, cols16, pack16, wins, cnt, 0);
     if (e == hipSuccess) e = hipGetLastError();
     if (e == hipSuccess) e = hipMemcpyAsync(host2, cnt, sizeof host2, hipMemcpyDeviceToHost, d->stream);
     if (e == hipSuccess) e = hipStreamSynchronize(d->stream);
     if (e == hipSuccess && host2[0] * 2 >= groups) { // worth it: rewrite the staged groups into LDS slots
-        range_windows_kernel<<<groups, kBlock, 0, d->stream>>>(total, group_len, bounds, bstride, scale, d->n, max_cols, cols, wins, cnt, 1);
+        range_windows_kernel<<<groups, kBlock, 0, d->stream>>>(total, group_len, bounds, bstride, scale, d->n, max_cols, cols, cols16, pack16, wins, cnt, 1);
         e = hipGetLastError();
         if (e == hipSuccess) e = hipStreamSynchronize(d->stream);
         *staged_out = host2[0];
@@ -669,8 +682,14 @@ static int build_csr5_sigma(spmv_dev *d, Csr5Plan &P, const int *rp, int m2, con
     // x windows of every group of kCsr5GroupTiles tiles, in place on the transposed column copy (xwindows.hpp)
     P.groups = (p + kCsr5GroupTiles - 1) / kCsr5GroupTiles;
     ALLOC_TRY(d, &P.wins, sizeof(TileWindows) * (size_t) P.groups, true);
-    return build_range_windows(d, d->plan.variant == 3 ? 0 : P.groups, (long long) p * TN, (long long) kCsr5GroupTiles * TN, nullptr, 1, 1,
-                               (int) (kCsr5XTileBytes / sizeof(T)), P.col, P.wins, &P.staged, &P.maxspan);
+    static_assert(kCsr5XTileBytes / sizeof(float) <= 65536, "LDS slots must fit 16 bits");
+    ALLOC_TRY(d, &P.col16, sizeof(unsigned short) * (size_t) p * TN, true);
+    const int rc = build_range_windows(d, d->plan.variant == 3 ? 0 : P.groups, (long long) p * TN, (long long) kCsr5GroupTiles * TN, nullptr, 1, 1,
+                                       (int) (kCsr5XTileBytes / sizeof(T)) - 1, P.col, P.wins, &P.staged, &P.maxspan, P.col16, SIGMA);
+    if (rc) return rc;
+    if (P.staged == P.groups) { sched_free(d, P.col); P.col = nullptr; }  // no group reads global columns
+    else if (P.staged == 0) { sched_free(d, P.col16); P.col16 = nullptr; }
+    return SPMV_HIP_OK;
 }
 
 // CSR5 over the CSR (m rows, nnz) given by rowptr / colidx / val.  out_rows (nullable, no empty rows
@@ -874,16 +893,16 @@ template <typename T, int SIGMA>
 static void launch_csr5_sigma(spmv_dev *d, const Csr5Plan &P, const T *x, T *y)
 {
     if (P.staged > 0) { // the inspector staged (at least half of) the groups: the column copy holds LDS slots for them
-        const size_t lds = (((size_t) P.maxspan * sizeof(T)) + 1023) & ~(size_t) 1023;
+        const size_t lds = ((((size_t) P.maxspan + 1) * sizeof(T)) + 1023) & ~(size_t) 1023; // + the zero slot
         if (lds > 64 * 1024) { // above the default dynamic-LDS limit: raise it for this instantiation (idempotent, cheap)
             if (P.row_map) (void) hipFuncSetAttribute((const void *) csr5_group_kernel<T, SIGMA, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int) lds);
             else (void) hipFuncSetAttribute((const void *) csr5_group_kernel<T, SIGMA, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int) lds);
         }
         if (P.row_map)
-            csr5_group_kernel<T, SIGMA, true><<<P.groups, kBlock, lds, d->stream>>>(P.tiles, P.tile_ptr, P.desc, P.col, (const T *) P.val, P.row_map, P.wins,
+            csr5_group_kernel<T, SIGMA, true><<<P.groups, kBlock, lds, d->stream>>>(P.tiles, P.tile_ptr, P.desc, P.col, P.col16, (const T *) P.val, P.row_map, P.wins,
                                                                                    x, y, (T *) P.carry);
         else
-            csr5_group_kernel<T, SIGMA, false><<<P.groups, kBlock, lds, d->stream>>>(P.tiles, P.tile_ptr, P.desc, P.col, (const T *) P.val, nullptr, P.wins,
+            csr5_group_kernel<T, SIGMA, false><<<P.groups, kBlock, lds, d->stream>>>(P.tiles, P.tile_ptr, P.desc, P.col, P.col16, (const T *) P.val, nullptr, P.wins,
                                                                                     x, y, (T *) P.carry);
         return;
     }
