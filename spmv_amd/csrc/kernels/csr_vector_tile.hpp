@@ -34,15 +34,15 @@ namespace spmv {
 constexpr int kVecTileThreads = 256;           // 4 wavefronts per workgroup (512 measured no better)
 constexpr int kVecTileRows = kVecTileThreads;  // rows per workgroup slab (64 per wave)
 // Row range of tile b: fixed 256-row tiles, or the equal-nnz blocks of `split` (Method_Balanced).
-__device__ __forceinline__ void tile_rows(int b, int m, const int *__restrict__ split, long long &r0, long long &r1)
+__device__ __forceinline__ void tile_rows(int b, int m, int rows_per_tile, const int *__restrict__ split, long long &r0, long long &r1)
 {
     if (split) { r0 = split[b]; r1 = split[b + 1]; }
-    else { r0 = (long long) b * kVecTileRows; r1 = r0 + kVecTileRows < m ? r0 + kVecTileRows : m; }
+    else { r0 = (long long) b * rows_per_tile; r1 = r0 + rows_per_tile < m ? r0 + rows_per_tile : m; }
 }
 
 // Inspector: windows of one row tile + the tile-local 16-bit column stream (written for staged tiles
 // only; unstaged tiles and long rows are computed from the original ColIdx).
-__global__ __launch_bounds__(kBlock) void csr_tile_windows_kernel(int m, int n, int long_thr, int max_cols, int slot_bytes,
+__global__ __launch_bounds__(kBlock) void csr_tile_windows_kernel(int m, int n, int rows_per_tile, int long_thr, int max_cols, int slot_bytes,
                                                                   const int *__restrict__ split,
                                                                   const int *__restrict__ rowptr,
                                                                   const int *__restrict__ colidx,
@@ -51,7 +51,7 @@ __global__ __launch_bounds__(kBlock) void csr_tile_windows_kernel(int m, int n, 
                                                                   int *__restrict__ staged /* [0] tiles staged, [1] max total */)
 {
     long long r0, r1;
-    tile_rows(blockIdx.x, m, split, r0, r1);
+    tile_rows(blockIdx.x, m, rows_per_tile, split, r0, r1);
     const int sub = threadIdx.x / 16, l = threadIdx.x % 16; // 16 lanes sweep a row
     auto loop = [&](auto body) {
         for (long long r = r0 + sub; r < r1; r += kBlock / 16) {
@@ -62,6 +62,118 @@ __global__ __launch_bounds__(kBlock) void csr_tile_windows_kernel(int m, int n, 
     };
     auto store = [&](long long pos, int slot, int) { col_local[pos] = (unsigned short) (slot * slot_bytes); };
     build_windows(n, max_cols, loop, store, wins[blockIdx.x], staged, true);
+}
+
+// Which four entries of a 4L-entry chunk a lane takes.  Every load instruction should cover one
+// contiguous run of memory over the wave (a lane stride of 32 B -- four consecutive doubles per
+// lane -- makes each 16-byte load touch twice the cache lines it uses).  So a lane takes 16 bytes of
+// values per load: fp32 four consecutive entries (one load), fp64 two pairs, entries 2l, 2l+1 and
+// 2L+2l, 2L+2l+1 (two loads, each contiguous over the L lanes of the row).
+template <typename T, int L>
+struct Lane4 {
+    static constexpr int EPL = 16 / (int) sizeof(T); // entries per 16-byte load
+    static __device__ __forceinline__ int pos(int l, int k) { return (k / EPL) * EPL * L + EPL * l + (k % EPL); }
+    // v[0..3] = val[base + pos(l, k)]
+    static __device__ __forceinline__ void load_val(const T *__restrict__ val, int base, int l, T (&v)[4])
+    {
+        if constexpr (EPL == 4) {
+            ld_stream4(val + base + 4 * l, v);
+        } else {
+            const f64x2 a = __builtin_nontemporal_load(reinterpret_cast<const f64x2 *>(val + base + 2 * l));
+            const f64x2 b = __builtin_nontemporal_load(reinterpret_cast<const f64x2 *>(val + base + 2 * L + 2 * l));
+            v[0] = a.x; v[1] = a.y; v[2] = b.x; v[3] = b.y;
+        }
+    }
+    // 16-bit slots, packed two per word in c[0], c[1] (see lds_slot)
+    static __device__ __forceinline__ void load_col16(const unsigned short *__restrict__ col, int base, int l, int (&c)[4])
+    {
+        if constexpr (EPL == 4) {
+            ld_stream4(col + base + 4 * l, c);
+        } else {
+            c[0] = __builtin_nontemporal_load(reinterpret_cast<const int *>(col + base + 2 * l));
+            c[1] = __builtin_nontemporal_load(reinterpret_cast<const int *>(col + base + 2 * L + 2 * l));
+        }
+    }
+    static __device__ __forceinline__ void load_col32(const int *__restrict__ col, int base, int l, int (&c)[4])
+    {
+        if constexpr (EPL == 4) {
+            ld_stream4(col + base + 4 * l, c);
+        } else {
+            const i32x2 a = __builtin_nontemporal_load(reinterpret_cast<const i32x2 *>(col + base + 2 * l));
+            const i32x2 b = __builtin_nontemporal_load(reinterpret_cast<const i32x2 *>(col + base + 2 * L + 2 * l));
+            c[0] = a.x; c[1] = a.y; c[2] = b.x; c[3] = b.y;
+        }
+    }
+};
+
+// One step of one lane group: lane l of the L lanes of row [p0, p1) multiplies its four entries
+// (c, v: already loaded by Lane4 from the chunk starting at the 16 B-aligned position p0 & ~3) and, for
+// rows longer than that chunk, walks on in chunks of 4L.  Returns the lane's partial sum (not yet reduced over the group).
+template <typename T, int L, bool STAGED>
+__device__ __forceinline__ T csr_vector_step(int p0, int p1, int l, const int (&cc0)[4], const T (&vv0)[4],
+                                             const int *__restrict__ colidx, const unsigned short *__restrict__ col_local,
+                                             const T *__restrict__ val, const T *__restrict__ x,
+                                             const unsigned char *__restrict__ xb, unsigned zoff)
+{
+    auto xat = [&](unsigned off) { return *reinterpret_cast<const T *>(xb + off); };
+    using LM = Lane4<T, L>;
+    const int base = p0 & ~3;
+    const int e0 = base + LM::pos(l, 0), e1 = base + LM::pos(l, 1), e2 = base + LM::pos(l, 2), e3 = base + LM::pos(l, 3); // ascending
+    T sum = 0;
+    if (STAGED) {
+        const bool full = (e0 >= p0) & (e3 < p1), none = e0 >= p1;
+        if (__all(full | none)) {
+            if (full) {
+                const T x0 = xat(lds_slot<0>(cc0)), x1 = xat(lds_slot<1>(cc0)), x2 = xat(lds_slot<2>(cc0)),
+                        x3 = xat(lds_slot<3>(cc0));
+                sum = fmadd(vv0[0], x0, sum);
+                sum = fmadd(vv0[1], x1, sum);
+                sum = fmadd(vv0[2], x2, sum);
+                sum = fmadd(vv0[3], x3, sum);
+            }
+        } else {
+            const unsigned len = (unsigned) (p1 - p0); // entry e is in the row iff e - p0 < len (unsigned)
+            const bool k0 = (unsigned) (e0 - p0) < len, k1 = (unsigned) (e1 - p0) < len, k2 = (unsigned) (e2 - p0) < len,
+                       k3 = (unsigned) (e3 - p0) < len;
+            const T x0 = xat(k0 ? lds_slot<0>(cc0) : zoff), x1 = xat(k1 ? lds_slot<1>(cc0) : zoff),
+                    x2 = xat(k2 ? lds_slot<2>(cc0) : zoff), x3 = xat(k3 ? lds_slot<3>(cc0) : zoff);
+            sum = fmadd(k0 ? vv0[0] : T(0), x0, sum);
+            sum = fmadd(k1 ? vv0[1] : T(0), x1, sum);
+            sum = fmadd(k2 ? vv0[2] : T(0), x2, sum);
+            sum = fmadd(k3 ? vv0[3] : T(0), x3, sum);
+        }
+    } else {
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const int e = base + LM::pos(l, k);
+            const bool ok = (e >= p0) & (e < p1);
+            const int ci = ok ? cc0[k] : 0;
+            const T xl = x[ci];
+            sum = fmadd(ok ? vv0[k] : T(0), ok ? xl : T(0), sum);
+        }
+    }
+    if (__any(base + 4 * L < p1)) { // some row of this step is longer than its first 4L-entry chunk
+        for (int bb = base + 4 * L; __any(bb < p1); bb += 4 * L) {
+            if (bb < p1) {
+                int cc[4];
+                T v2[4];
+                if (STAGED) LM::load_col16(col_local, bb, l, cc);
+                else LM::load_col32(colidx, bb, l, cc);
+                LM::load_val(val, bb, l, v2);
+                if (STAGED) {
+                    if (bb + LM::pos(l, 0) < p1) sum = fmadd(v2[0], xat(lds_slot<0>(cc)), sum);
+                    if (bb + LM::pos(l, 1) < p1) sum = fmadd(v2[1], xat(lds_slot<1>(cc)), sum);
+                    if (bb + LM::pos(l, 2) < p1) sum = fmadd(v2[2], xat(lds_slot<2>(cc)), sum);
+                    if (bb + LM::pos(l, 3) < p1) sum = fmadd(v2[3], xat(lds_slot<3>(cc)), sum);
+                } else {
+#pragma unroll
+                    for (int k = 0; k < 4; ++k)
+                        if (bb + LM::pos(l, k) < p1) sum = fmadd(v2[k], x[cc[k]], sum);
+                }
+            }
+        }
+    }
+    return sum;
 }
 
 // The wave program.  STAGED: c[][0..1] hold four packed 16-bit BYTE offsets into xs (the inspector
@@ -92,72 +204,19 @@ __device__ __forceinline__ void csr_vector_tile_wave(long long row_end, int long
         pp1[slot] = rp_lds[s * RW + sub + 1];
         if (pp1[slot] - pp0[slot] > long_thr) pp1[slot] = pp0[slot];
         if (s > 0 || !PRE) {
-            const int an = (pp0[slot] & ~3) + l * 4;
-            if (STAGED) ld_stream4(col_local + an, c[slot]);
-            else ld_stream4(colidx + an, c[slot]);
-            ld_stream4(val + an, v[slot]);
+            const int an = pp0[slot] & ~3;
+            if (STAGED) Lane4<T, L>::load_col16(col_local, an, l, c[slot]);
+            else Lane4<T, L>::load_col32(colidx, an, l, c[slot]);
+            Lane4<T, L>::load_val(val, an, l, v[slot]);
         }
     };
-    auto xat = [&](unsigned off) { return *reinterpret_cast<const T *>(xb + off); };
 #pragma unroll
     for (int s = 0; s < D && s < L; ++s) issue(s);
 #pragma unroll
     for (int s = 0; s < L; ++s) {
         const int cur = s % D;
         const int p0 = pp0[cur], p1 = pp1[cur];
-        const int a = (p0 & ~3) + l * 4;
-        T sum = 0;
-        if (STAGED) {
-            const bool full = (a >= p0) & (a + 4 <= p1), none = a >= p1;
-            if (__all(full | none)) {
-                if (full) {
-                    const T x0 = xat(lds_slot<0>(c[cur])), x1 = xat(lds_slot<1>(c[cur])), x2 = xat(lds_slot<2>(c[cur])),
-                            x3 = xat(lds_slot<3>(c[cur]));
-                    sum = fmadd(v[cur][0], x0, sum);
-                    sum = fmadd(v[cur][1], x1, sum);
-                    sum = fmadd(v[cur][2], x2, sum);
-                    sum = fmadd(v[cur][3], x3, sum);
-                }
-            } else {
-                const unsigned t0 = (unsigned) (a - p0), len = (unsigned) (p1 - p0); // entry k is in the row iff t0 + k < len (unsigned)
-                const bool k0 = t0 < len, k1 = t0 + 1u < len, k2 = t0 + 2u < len, k3 = t0 + 3u < len;
-                const T x0 = xat(k0 ? lds_slot<0>(c[cur]) : zoff), x1 = xat(k1 ? lds_slot<1>(c[cur]) : zoff),
-                        x2 = xat(k2 ? lds_slot<2>(c[cur]) : zoff), x3 = xat(k3 ? lds_slot<3>(c[cur]) : zoff);
-                sum = fmadd(k0 ? v[cur][0] : T(0), x0, sum);
-                sum = fmadd(k1 ? v[cur][1] : T(0), x1, sum);
-                sum = fmadd(k2 ? v[cur][2] : T(0), x2, sum);
-                sum = fmadd(k3 ? v[cur][3] : T(0), x3, sum);
-            }
-        } else {
-#pragma unroll
-            for (int k = 0; k < 4; ++k) {
-                const bool ok = (a + k >= p0) & (a + k < p1);
-                const int ci = ok ? c[cur][k] : 0;
-                const T xl = x[ci];
-                sum = fmadd(ok ? v[cur][k] : T(0), ok ? xl : T(0), sum);
-            }
-        }
-        if (__any(a + 4 * L < p1)) { // some row of this step is longer than 4L
-            for (int aa = a + 4 * L; __any(aa < p1); aa += 4 * L) {
-                if (aa < p1) {
-                    int cc[4];
-                    T v2[4];
-                    if (STAGED) ld_stream4(col_local + aa, cc);
-                    else ld_stream4(colidx + aa, cc);
-                    ld_stream4(val + aa, v2);
-                    if (STAGED) {
-                        if (aa + 0 < p1) sum = fmadd(v2[0], xat(lds_slot<0>(cc)), sum);
-                        if (aa + 1 < p1) sum = fmadd(v2[1], xat(lds_slot<1>(cc)), sum);
-                        if (aa + 2 < p1) sum = fmadd(v2[2], xat(lds_slot<2>(cc)), sum);
-                        if (aa + 3 < p1) sum = fmadd(v2[3], xat(lds_slot<3>(cc)), sum);
-                    } else {
-#pragma unroll
-                        for (int k = 0; k < 4; ++k)
-                            if (aa + k < p1) sum = fmadd(v2[k], x[cc[k]], sum);
-                    }
-                }
-            }
-        }
+        T sum = csr_vector_step<T, L, STAGED>(p0, p1, l, c[cur], v[cur], colidx, col_local, val, x, xb, zoff);
         sum = group_sum_dpp<L>(sum);
         if (l == 0) y_lds[s * RW + sub] = sum;
         if (s + D < L) issue(s + D); // refill the slot just consumed
@@ -197,10 +256,10 @@ __global__ __launch_bounds__(kVecTileThreads) void csr_vector_tile_kernel(int m,
     if (PRE) {
         const int sub = lane / L, l = lane % L;
         const int q0 = __shfl(rp, sub, kWave);
-        const int a = (q0 & ~3) + l * 4;
-        if (staged) ld_stream4(col_local + a, c0);
-        else ld_stream4(colidx + a, c0);
-        ld_stream4(val + a, v0);
+        const int a = q0 & ~3;
+        if (staged) Lane4<T, L>::load_col16(col_local, a, l, c0);
+        else Lane4<T, L>::load_col32(colidx, a, l, c0);
+        Lane4<T, L>::load_val(val, a, l, v0);
     }
     rp_lds[wave][lane] = rp;
     if (lane == 0) rp_lds[wave][kWave] = rpe;

@@ -416,7 +416,7 @@ template <typename T>
 static int build_csr5(spmv_dev *d, Csr5Plan &P, int m, long long nnz, const int *rowptr, const int *colidx, const T *val, int empty_rows,
                       double mean_row_len, const int *out_rows);
 template <typename T> static int autotune_vector(spmv_dev *d);
-template <typename T> static int build_tile_windows(spmv_dev *d, int tiles, const int *split);
+template <typename T> static int build_tile_windows(spmv_dev *d, int tiles, const int *split, int rows_per_tile = kVecTileRows);
 
 constexpr size_t kSplitXTileBytes = 48 * 1024; // LDS budget of one nnz-split tile group's x span
 
@@ -476,7 +476,7 @@ static int build_rowblock_tiles(spmv_dev *d)
 
 // Windows of every row tile + the tile-local ColIdx copy (kernels/csr_vector_tile.hpp).
 template <typename T>
-static int build_tile_windows(spmv_dev *d, int tiles, const int *split)
+static int build_tile_windows(spmv_dev *d, int tiles, const int *split, int rows_per_tile)
 {
     int *cnt = nullptr;
     int host2[2] = {0, 0};
@@ -487,7 +487,7 @@ static int build_tile_windows(spmv_dev *d, int tiles, const int *split)
     ALLOC_TRY(d, &d->vt_wins, sizeof(TileWindows) * (size_t) tiles, true);
     HIP_TRY(hipMemsetAsync(d->vt_col, 0, sizeof(unsigned short) * ((size_t) d->nnz + kStreamPad), d->stream));
     HIP_TRY(hipMemsetAsync(cnt, 0, 2 * sizeof(int), d->stream));
-    csr_tile_windows_kernel<<<tiles, kBlock, 0, d->stream>>>(d->m, d->n, d->long_thr, (int) (kVecXTileBytes / sizeof(T)) - 1, (int) sizeof(T), split, d->rowptr, d->colidx,
+    csr_tile_windows_kernel<<<tiles, kBlock, 0, d->stream>>>(d->m, d->n, rows_per_tile, d->long_thr, (int) (kVecXTileBytes / sizeof(T)) - 1, (int) sizeof(T), split, d->rowptr, d->colidx,
                                                              d->vt_wins, d->vt_col, cnt);
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipMemcpyAsync(host2, cnt, 2 * sizeof(int), hipMemcpyDeviceToHost, d->stream));
@@ -585,9 +585,10 @@ template <typename T>
 static int build_vector_tiles(spmv_dev *d)
 {
     d->vt_staged = d->vt_maxspan = 0;
-    d->vt_tiles = (int) (((long long) d->m + kVecTileRows - 1) / kVecTileRows);
+    const int rows = kVecTileRows;
+    d->vt_tiles = (int) (((long long) d->m + rows - 1) / rows);
     if (d->vt_tiles == 0 || d->nnz == 0) return SPMV_HIP_OK;
-    return build_tile_windows<T>(d, d->vt_tiles, nullptr);
+    return build_tile_windows<T>(d, d->vt_tiles, nullptr, rows);
 }
 
 template <typename T> static int launch_csr5(spmv_dev *d, const Csr5Plan &P, const T *x, T *y);
