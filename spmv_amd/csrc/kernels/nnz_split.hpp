@@ -55,6 +55,7 @@ __global__ __launch_bounds__(kBlock) void nnz_tile_first_kernel(int m, int ntile
 template <typename T, bool STAGED>
 __device__ __forceinline__ void nnz_tile(int t, int lane, int *__restrict__ seg, int nnz,
                                          const int *__restrict__ rowptr, const int *__restrict__ colidx,
+                                         const unsigned short *__restrict__ col16,
                                          const T *__restrict__ val, const T *__restrict__ x,
                                          const T *__restrict__ xs, T *__restrict__ y,
                                          const int *__restrict__ tile_first, T *__restrict__ carry)
@@ -70,14 +71,20 @@ __device__ __forceinline__ void nnz_tile(int t, int lane, int *__restrict__ seg,
     if (base + kSplitTile <= nnz) {
 #pragma unroll
         for (int q = 0; q < kSplitK; q += 4) {
-            ld_stream4(colidx + p + q, *reinterpret_cast<int(*)[4]>(&c[q]));
+            if (STAGED) { // 16-bit LDS slots, four per 8-byte load
+                int w[4];
+                ld_stream4(col16 + p + q, w);
+                c[q] = (int) lds_slot<0>(w); c[q + 1] = (int) lds_slot<1>(w); c[q + 2] = (int) lds_slot<2>(w); c[q + 3] = (int) lds_slot<3>(w);
+            } else {
+                ld_stream4(colidx + p + q, *reinterpret_cast<int(*)[4]>(&c[q]));
+            }
             ld_stream4(val + p + q, *reinterpret_cast<T(*)[4]>(&v[q]));
         }
     } else { // last, partial tile
 #pragma unroll
         for (int k = 0; k < kSplitK; ++k) {
             const bool in = p + k < nnz;
-            c[k] = in ? colidx[p + k] : 0;
+            c[k] = in ? (STAGED ? (int) col16[p + k] : colidx[p + k]) : 0;
             v[k] = in ? val[p + k] : T(0);
         }
     }
@@ -158,17 +165,18 @@ __global__ __launch_bounds__(kBlock) void nnz_split_kernel(int m, int nnz, int n
     const int waves_total = gridDim.x * (kBlock / kWave);
     (void) m;
     for (int t = blockIdx.x * (kBlock / kWave) + wave; t < ntiles; t += waves_total)
-        nnz_tile<T, false>(t, lane, seg_lds[wave], nnz, rowptr, colidx, val, x, nullptr, y, tile_first, carry);
+        nnz_tile<T, false>(t, lane, seg_lds[wave], nnz, rowptr, colidx, nullptr, val, x, nullptr, y, tile_first, carry);
 }
 
 // ---- LDS-staged x windows (xwindows.hpp): a workgroup owns kSplitGroupTiles consecutive tiles; the
-// columns of their nnz range are covered by up to 16 windows and `col_local` (a private copy of
-// ColIdx) holds LDS slots for staged groups, global columns otherwise.
+// columns of their nnz range are covered by up to 16 windows and `col16` holds the 16-bit LDS slots
+// of the staged groups' entries (2 B/nnz instead of ColIdx's 4); other groups read ColIdx.
 constexpr int kSplitGroupTiles = 16;
 
 template <typename T>
 __global__ __launch_bounds__(kBlock) void nnz_group_kernel(int nnz, int ntiles, const int *__restrict__ rowptr,
-                                                           const int *__restrict__ col_local, const T *__restrict__ val,
+                                                           const int *__restrict__ colidx, const unsigned short *__restrict__ col16,
+                                                           const T *__restrict__ val,
                                                            const TileWindows *__restrict__ wins,
                                                            const T *__restrict__ x, T *__restrict__ y,
                                                            const int *__restrict__ tile_first, T *__restrict__ carry)
@@ -185,8 +193,8 @@ __global__ __launch_bounds__(kBlock) void nnz_group_kernel(int nnz, int ntiles, 
     for (int k = wave; k < kSplitGroupTiles; k += kBlock / kWave) {
         const int t = t0 + k;
         if (t >= ntiles) break;
-        if (staged) nnz_tile<T, true>(t, lane, seg_lds[wave], nnz, rowptr, col_local, val, x, xs, y, tile_first, carry);
-        else nnz_tile<T, false>(t, lane, seg_lds[wave], nnz, rowptr, col_local, val, x, xs, y, tile_first, carry);
+        if (staged) nnz_tile<T, true>(t, lane, seg_lds[wave], nnz, rowptr, colidx, col16, val, x, xs, y, tile_first, carry);
+        else nnz_tile<T, false>(t, lane, seg_lds[wave], nnz, rowptr, colidx, col16, val, x, xs, y, tile_first, carry);
     }
 }
 

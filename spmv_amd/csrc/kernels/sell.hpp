@@ -179,9 +179,11 @@ __global__ __launch_bounds__(kBlock) void sell_kernel(int nchunks, const long lo
 constexpr int kSellWinThreads = 512; // 8 wavefronts per sigma window
 
 template <typename T, bool STAGED>
-__device__ __forceinline__ void sell_chunk(const int *__restrict__ pc, const T *__restrict__ pv, int width,
+__device__ __forceinline__ void sell_chunk(const int *__restrict__ pc, const unsigned short *__restrict__ pc16,
+                                           const T *__restrict__ pv, int width,
                                            const T *__restrict__ xs, const T *__restrict__ x, T &sum)
 {
+    // STAGED: the column stream is pc16, 16-bit LDS slots; padding points at the zero slot (0 * 0)
     constexpr int U = 8;
     int j = 0;
     for (; j + U <= width; j += U) {
@@ -189,17 +191,24 @@ __device__ __forceinline__ void sell_chunk(const int *__restrict__ pc, const T *
         T vv[U];
 #pragma unroll
         for (int u = 0; u < U; ++u) {
-            cc[u] = ld_stream(pc + (size_t) (j + u) * kSellC);
+            if (STAGED) cc[u] = ld_stream(pc16 + (size_t) (j + u) * kSellC);
+            else cc[u] = ld_stream(pc + (size_t) (j + u) * kSellC);
             vv[u] = ld_stream(pv + (size_t) (j + u) * kSellC);
         }
 #pragma unroll
-        for (int u = 0; u < U; ++u)
-            if (cc[u] >= 0) sum = fmadd(vv[u], STAGED ? xs[cc[u]] : x[cc[u]], sum); // STAGED: scol holds LDS slots
+        for (int u = 0; u < U; ++u) {
+            if (STAGED) sum = fmadd(vv[u], xs[cc[u]], sum);
+            else if (cc[u] >= 0) sum = fmadd(vv[u], x[cc[u]], sum);
+        }
     }
     for (; j < width; ++j) {
-        const int cc = ld_stream(pc + (size_t) j * kSellC);
         const T vv = ld_stream(pv + (size_t) j * kSellC);
-        if (cc >= 0) sum = fmadd(vv, STAGED ? xs[cc] : x[cc], sum);
+        if (STAGED) {
+            sum = fmadd(vv, xs[ld_stream(pc16 + (size_t) j * kSellC)], sum);
+        } else {
+            const int cc = ld_stream(pc + (size_t) j * kSellC);
+            if (cc >= 0) sum = fmadd(vv, x[cc], sum);
+        }
     }
 }
 
@@ -208,6 +217,7 @@ template <typename T>
 __global__ __launch_bounds__(kSellWinThreads) void sell_window_kernel(int chunks_per_win,
                                                                       const long long *__restrict__ chunk_ptr,
                                                                       const int *__restrict__ scol,
+                                                                      const unsigned short *__restrict__ scol16,
                                                                       const T *__restrict__ sval,
                                                                       const int *__restrict__ perm,
                                                                       const TileWindows *__restrict__ wins,
@@ -219,17 +229,21 @@ __global__ __launch_bounds__(kSellWinThreads) void sell_window_kernel(int chunks
     const TileWindows &tw = wins[w];
     const bool staged = tw.nwin > 0;
     stage_windows<kSellWinThreads, T>(tw, x, xs);
-    if (staged) __syncthreads();
+    if (staged) {
+        if (threadIdx.x == 0) xs[tw.total] = T(0); // the zero slot of padding entries
+        __syncthreads();
+    }
     const int lane = threadIdx.x & (kWave - 1);
     for (int k = threadIdx.x / kWave; k < chunks_per_win; k += kSellWinThreads / kWave) {
         const long long c = (long long) w * chunks_per_win + k;
         const long long c0 = chunk_ptr[c];
         const int width = (int) (chunk_ptr[c + 1] - c0);
         const int *pc = scol + (size_t) c0 * kSellC + lane;
+        const unsigned short *pc16 = scol16 + (size_t) c0 * kSellC + lane;
         const T *pv = sval + (size_t) c0 * kSellC + lane;
         T sum = 0;
-        if (staged) sell_chunk<T, true>(pc, pv, width, xs, x, sum);
-        else sell_chunk<T, false>(pc, pv, width, xs, x, sum);
+        if (staged) sell_chunk<T, true>(pc, pc16, pv, width, xs, x, sum);
+        else sell_chunk<T, false>(pc, pc16, pv, width, xs, x, sum);
         const int row = perm[c * kSellC + lane];
         if (row >= 0) y[row] = sum;
     }

@@ -94,7 +94,7 @@ struct spmv_dev {
     int *tile_first = nullptr;
     void *carry = nullptr;
     int ns_groups = 0, ns_staged = 0, ns_maxspan = 0;
-    int *ns_col = nullptr;          // private ColIdx copy (LDS slots for staged groups)
+    unsigned short *ns_col = nullptr; // 16-bit LDS slots of the staged groups' entries
     TileWindows *ns_wins = nullptr;
     // row blocks
     int nblocks = 0, rb_stride = 0;
@@ -114,6 +114,7 @@ struct spmv_dev {
     long long sell_cols = 0; // sum of chunk widths
     int *perm = nullptr, *scol = nullptr;
     TileWindows *sell_wins = nullptr;
+    unsigned short *scol16 = nullptr; // 16-bit LDS slots of the staged sigma windows
     int sell_nwin = 0, sell_staged = 0, sell_xcap = 0, sell_maxspan = 0; // windows, windows with x staged in LDS, LDS capacity in elements
     long long *chunk_ptr = nullptr;
     void *sval = nullptr;
@@ -161,7 +162,7 @@ static void free_schedule(spmv_dev *d)
     for (void *p : d->sched_allocs) (void) hipFree(p);
     d->sched_allocs.clear();
     d->tile_first = nullptr; d->carry = nullptr; d->rb_split = nullptr; d->ns_col = nullptr; d->ns_wins = nullptr; d->ns_groups = d->ns_staged = 0;
-    d->perm = d->scol = d->long_rows = d->lr_seg_lr = d->lr_seg_lo = d->lr_seg_span = nullptr; d->sell_wins = nullptr; d->sell_staged = d->sell_nwin = 0; d->chunk_ptr = d->lr_seg_start = nullptr;
+    d->perm = d->scol = d->long_rows = d->lr_seg_lr = d->lr_seg_lo = d->lr_seg_span = nullptr; d->sell_wins = nullptr; d->scol16 = nullptr; d->sell_staged = d->sell_nwin = 0; d->chunk_ptr = d->lr_seg_start = nullptr;
     d->sval = d->lr_part = nullptr;
     d->ntiles = d->nblocks = d->nchunks = d->nlong = d->lr_segs = 0;
     d->long_thr = INT_MAX;
@@ -438,12 +439,12 @@ static int build_nnz_split(spmv_dev *d)
     HIP_TRY(hipStreamSynchronize(d->stream));
     // x windows of every group of kSplitGroupTiles tiles (xwindows.hpp) on a private ColIdx copy
     d->ns_groups = (d->ntiles + kSplitGroupTiles - 1) / kSplitGroupTiles;
-    ALLOC_TRY(d, &d->ns_col, sizeof(int) * ((size_t) d->nnz + kStreamPad), true);
+    ALLOC_TRY(d, &d->ns_col, sizeof(unsigned short) * ((size_t) d->nnz + kStreamPad), true);
     ALLOC_TRY(d, &d->ns_wins, sizeof(TileWindows) * (size_t) d->ns_groups, true);
-    HIP_TRY(hipMemcpyAsync(d->ns_col, d->colidx, sizeof(int) * ((size_t) d->nnz + kStreamPad), hipMemcpyDeviceToDevice, d->stream));
+    HIP_TRY(hipMemsetAsync(d->ns_col, 0, sizeof(unsigned short) * ((size_t) d->nnz + kStreamPad), d->stream));
     {
         const int rc = build_range_windows(d, d->plan.variant == 3 ? 0 : d->ns_groups, d->nnz, (long long) kSplitGroupTiles * tile, nullptr, 1, 1,
-                                           (int) (kSplitXTileBytes / sizeof(T)), d->ns_col, d->ns_wins, &d->ns_staged, &d->ns_maxspan);
+                                           (int) (kSplitXTileBytes / sizeof(T)) - 1, d->colidx, d->ns_wins, &d->ns_staged, &d->ns_maxspan, d->ns_col, 0);
         if (rc) return rc;
     }
     return SPMV_HIP_OK;
@@ -644,11 +645,15 @@ static int build_sell(spmv_dev *d)
     d->sell_nwin = nwin;
     d->sell_staged = 0;
     if (d->plan.sell_lds_x && d->plan.variant != 3) { // x windows of every sigma window, in place on scol (xwindows.hpp)
-        d->sell_xcap = (int) (kSellXTileBytes / sizeof(T));
+        static_assert(kSellXTileBytes / sizeof(float) <= 65536, "LDS slots must fit 16 bits");
+        d->sell_xcap = (int) (kSellXTileBytes / sizeof(T)) - 1; // one slot stays free: the zero slot of padding entries
         ALLOC_TRY(d, &d->sell_wins, sizeof(TileWindows) * (size_t) nwin, true);
+        ALLOC_TRY(d, &d->scol16, sizeof(unsigned short) * (slots + 4), true);
         const int rc = build_range_windows(d, nwin, (long long) slots, 0, d->chunk_ptr, sigma / kSellC, kSellC, d->sell_xcap, d->scol, d->sell_wins,
-                                           &d->sell_staged, &d->sell_maxspan);
+                                           &d->sell_staged, &d->sell_maxspan, d->scol16, 0);
         if (rc) return rc;
+        if (d->sell_staged == nwin) { sched_free(d, d->scol); d->scol = nullptr; } // no window reads global columns
+        else if (d->sell_staged == 0) { sched_free(d, d->scol16); d->scol16 = nullptr; }
         HIP_TRY(hipFuncSetAttribute((const void *) sell_window_kernel<T>, hipFuncAttributeMaxDynamicSharedMemorySize, (int) kSellXTileBytes));
     }
     HIP_TRY(hipStreamSynchronize(d->stream));
@@ -963,8 +968,8 @@ static int launch(spmv_dev *d, const T *x, T *y)
         break;
     case SPMV_SCHED_NNZ_SPLIT: {
         if (d->ns_staged > 0) {
-            const size_t lds = (((size_t) d->ns_maxspan * sizeof(T)) + 1023) & ~(size_t) 1023;
-            nnz_group_kernel<T><<<d->ns_groups, kBlock, lds, d->stream>>>((int) d->nnz, d->ntiles, d->rowptr, d->ns_col, val, d->ns_wins,
+            const size_t lds = ((((size_t) d->ns_maxspan + 1) * sizeof(T)) + 1023) & ~(size_t) 1023;
+            nnz_group_kernel<T><<<d->ns_groups, kBlock, lds, d->stream>>>((int) d->nnz, d->ntiles, d->rowptr, d->colidx, d->ns_col, val, d->ns_wins,
                                                                          x, y, d->tile_first, (T *) d->carry);
         } else {
             const int grid = grid_for(d->ntiles, kBlock / kWave, d->plan.variant == 1 ? d->cus * 8 : INT_MAX);
@@ -996,8 +1001,8 @@ static int launch(spmv_dev *d, const T *x, T *y)
         // staged path when at least half of the windows fit their x span in LDS; the LDS request is
         // sized by the largest staged span actually present (rounded to 16 KiB) to keep occupancy
         if (d->sell_staged > 0)
-            sell_window_kernel<T><<<d->sell_nwin, kSellWinThreads, (((size_t) d->sell_maxspan * sizeof(T)) + 1023) & ~(size_t) 1023, d->stream>>>(
-                d->plan.sell_sigma / kSellC, d->chunk_ptr, d->scol, (const T *) d->sval, d->perm, d->sell_wins, x, y);
+            sell_window_kernel<T><<<d->sell_nwin, kSellWinThreads, ((((size_t) d->sell_maxspan + 1) * sizeof(T)) + 1023) & ~(size_t) 1023, d->stream>>>(
+                d->plan.sell_sigma / kSellC, d->chunk_ptr, d->scol, d->scol16, (const T *) d->sval, d->perm, d->sell_wins, x, y);
         else
             sell_kernel<T><<<grid_for(d->nchunks, kBlock / kWave, d->plan.variant == 1 ? d->cus * 8 : INT_MAX), kBlock, 0, d->stream>>>(
                 d->nchunks, d->chunk_ptr, d->scol, (const T *) d->sval, d->perm, x, y);
