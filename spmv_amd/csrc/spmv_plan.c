@@ -94,6 +94,70 @@ static int pow2_at_least(double v, int lo, int hi)
     return p;
 }
 
+/*
+ * CSR-vector shape -- L lanes per row and the long-row threshold -- from the row-length histogram.
+ * Cost model, in wave steps (64 lanes x 4 entries = 256 entry slots):
+ *   - a step serves R = 64/L rows and lasts as long as its longest row: ceil(len / 4L) iterations,
+ *     the first one costing 1, later ones 3 (the tail loop is not software-pipelined: each pass waits out a full memory latency).  With rows
+ *     taken as independent draws from the histogram, E[max] = sum_b cost(b) (F_b^R - F_(b-1)^R);
+ *   - rows above the threshold run on the CSR5 sub-matrix path at nnz / 256 steps x 1.1.
+ * Thresholds are tried at the histogram's bucket bounds (>= 64 and >= 4L) and at the historical
+ * rule max(64 L, 256).  A matrix of equal rows gets L = len/4 and no long rows; a skewed one gets a
+ * small L for its many short rows and hands the heavy tail to CSR5 (config 4: 1.11 -> 0.7 ms).
+ */
+static double pow_int(double f, int r) /* r = power of two */
+{
+    while (r > 1) { f *= f; r >>= 1; }
+    return f;
+}
+
+static void choose_vector_shape(const spmv_stats *st, int *lanes_out, int *thr_out)
+{
+    const int NB = SPMV_LEN_BUCKETS;
+    double best = -1.0;
+    int L, best_l = pow2_at_least(st->mean_row_len / 4.0, 1, 64), best_thr = 0;
+    long long rows_all = 0;
+    int b;
+    for (b = 0; b < NB; ++b) rows_all += st->hist_rows[b];
+    if (rows_all <= 0) { *lanes_out = best_l; *thr_out = 0; return; }
+    for (L = 1; L <= 64; L <<= 1) {
+        const int R = 64 / L;
+        const int def_thr = L * 64 > 256 ? L * 64 : 256;
+        int cand;
+        for (cand = -1; cand < NB - 1; ++cand) { /* -1: the default rule; else thr = 4 << cand */
+            const int thr = cand < 0 ? def_thr : (4 << cand);
+            long long rows_short = 0, cum = 0;
+            double nnz_long = 0.0, e_max = 0.0, f_prev = 0.0, cost;
+            int last_short = -1;
+            if (cand >= 0 && (thr < 64 || thr < 4 * L || thr >= def_thr)) continue;
+            for (b = 0; b < NB; ++b) {
+                const int upper_ok = b < NB - 1 ? (4 << b) <= thr : st->max_row_len <= thr;
+                if (upper_ok) { rows_short += st->hist_rows[b]; last_short = b; }
+                else nnz_long += (double) st->hist_nnz[b];
+            }
+            for (b = 0; b <= last_short && rows_short > 0; ++b) {
+                double mean_len, it, f;
+                if (st->hist_rows[b] == 0) continue;
+                cum += st->hist_rows[b];
+                mean_len = (double) st->hist_nnz[b] / (double) st->hist_rows[b];
+                it = (double) (long long) ((mean_len + 4.0 * L - 1.0) / (4.0 * L));
+                if (it < 1.0) it = 1.0;
+                f = pow_int((double) cum / (double) rows_short, R);
+                e_max += (1.0 + 3.0 * (it - 1.0)) * (f - f_prev);
+                f_prev = f;
+            }
+            cost = (double) rows_short / R * e_max + nnz_long / 256.0 * 1.1;
+            if (best < 0.0 || cost < best * 0.98 || (cost <= best && L > best_l)) { /* 2 % hysteresis towards fewer, simpler pieces */
+                best = cost;
+                best_l = L;
+                best_thr = cand < 0 ? 0 : thr;
+            }
+        }
+    }
+    *lanes_out = best_l;
+    *thr_out = best_thr;
+}
+
 void spmv_plan_choose(SPMV_METHODS requested, const spmv_stats *st, size_t value_size,
                       spmv_plan *plan, SPMV_METHODS *actual)
 {
@@ -109,9 +173,10 @@ void spmv_plan_choose(SPMV_METHODS requested, const spmv_stats *st, size_t value
     /* one workgroup's equal-nnz share (Method_Balanced): 8192 nnz ~ the 256 rows x 32 of a CSR-vector
      * tile; a row longer than the share flips the handle to Method_Balanced2 like the reference */
     plan->rowblock_nnz = rb > 0 ? (int) rb : 8192;
-    /* CSR-vector: every lane takes 4 consecutive elements per step (16 B loads), so L = power of
-     * two >= mean row length / 4 covers a mean-length row in one step; within [1, 64] */
-    plan->lanes_per_row = lanes > 0 ? (int) lanes : pow2_at_least(st->mean_row_len / 4.0, 1, 64);
+    /* CSR-vector: a lane group of L lanes takes 4L entries of its row per step (16 B loads); L and
+     * the long-row threshold come from the row-length histogram (choose_vector_shape) */
+    if (lanes > 0) plan->lanes_per_row = (int) lanes; /* forced: default long-row rule */
+    else choose_vector_shape(st, &plan->lanes_per_row, &plan->long_thr);
     (void) value_size;
     /* the reference's README ends on an empty "Matrix inspect and choose best
      * method to run" heading (README.md:222).  With auto_method = 1 the request is replaced by:

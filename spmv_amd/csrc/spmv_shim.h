@@ -26,16 +26,22 @@ enum spmv_sched {
     SPMV_SCHED_COUNT
 };
 
+#define SPMV_LEN_BUCKETS 11 /* <=4, 8, 16, ..., 2048, longer */
+
 typedef struct spmv_stats {
     int m, n;
     long long nnz;
     int max_row_len, min_row_len, empty_rows;
     double mean_row_len;
+    /* row-length histogram: bucket b counts the rows with 4*2^(b-1) < len <= 4*2^b (b = 0: len <= 4;
+     * the last bucket: everything longer), and the non-zeros those rows hold */
+    long long hist_rows[SPMV_LEN_BUCKETS], hist_nnz[SPMV_LEN_BUCKETS];
 } spmv_stats;
 
 typedef struct spmv_plan {
     int sched;          /* enum spmv_sched */
     int lanes_per_row;  /* csr-vector */
+    int long_thr;       /* csr-vector: rows longer than this go to the long-row (CSR5 sub-matrix) path; 0 = max(64 L, 256) */
     int sell_c, sell_sigma, sell_lds_x;
     int csr5_sigma;
     int rowblock_nnz;

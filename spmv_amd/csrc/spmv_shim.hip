@@ -59,6 +59,7 @@ extern "C" const char *spmv_shim_error_text(void) { return t_err; }
 // ------------------------------------------------------------------------------------ state
 struct DevStats {
     int max_len, min_len, empty, bad, first, last;
+    unsigned long long hist_rows[SPMV_LEN_BUCKETS], hist_nnz[SPMV_LEN_BUCKETS];
 };
 
 // One CSR5 instance (kernels/csr5.hpp): the whole matrix for Method_CSR5SPMV, or the sub-matrix of
@@ -196,6 +197,10 @@ extern "C" int spmv_shim_device_count(void)
 // ------------------------------------------------------------------------------------ stats
 __global__ __launch_bounds__(kBlock) void stats_kernel(int m, const int *__restrict__ rowptr, DevStats *s)
 {
+    __shared__ unsigned h_rows[SPMV_LEN_BUCKETS];
+    __shared__ unsigned long long h_nnz[SPMV_LEN_BUCKETS];
+    if (threadIdx.x < SPMV_LEN_BUCKETS) { h_rows[threadIdx.x] = 0; h_nnz[threadIdx.x] = 0; }
+    __syncthreads();
     int mx = 0, mn = INT_MAX, em = 0, bad = 0;
     const long long stride = (long long) gridDim.x * kBlock;
     for (long long r = (long long) blockIdx.x * kBlock + threadIdx.x; r < m; r += stride) {
@@ -204,6 +209,15 @@ __global__ __launch_bounds__(kBlock) void stats_kernel(int m, const int *__restr
         mn = min(mn, len);
         em += len == 0;
         bad |= len < 0;
+        int b = len <= 4 ? 0 : 32 - __clz((len - 1) >> 2); // smallest b with len <= 4 * 2^b
+        if (b > SPMV_LEN_BUCKETS - 1) b = SPMV_LEN_BUCKETS - 1;
+        atomicAdd(&h_rows[b], 1u);
+        atomicAdd(&h_nnz[b], (unsigned long long) (len > 0 ? len : 0));
+    }
+    __syncthreads();
+    if (threadIdx.x < SPMV_LEN_BUCKETS && h_rows[threadIdx.x]) {
+        atomicAdd(&s->hist_rows[threadIdx.x], (unsigned long long) h_rows[threadIdx.x]);
+        atomicAdd(&s->hist_nnz[threadIdx.x], h_nnz[threadIdx.x]);
     }
 #pragma unroll
     for (int o = kWave / 2; o > 0; o >>= 1) {
@@ -328,6 +342,10 @@ extern "C" int spmv_shim_matrix_create(spmv_dev **out, int m, int n, const int *
     d->stats.min_row_len = m > 0 ? hs.min_len : 0;
     d->stats.empty_rows = hs.empty;
     d->stats.mean_row_len = m > 0 ? (double) d->nnz / m : 0.0;
+    for (int b = 0; b < SPMV_LEN_BUCKETS; ++b) {
+        d->stats.hist_rows[b] = (long long) hs.hist_rows[b];
+        d->stats.hist_nnz[b] = (long long) hs.hist_nnz[b];
+    }
 
     // padded by kStreamPad elements: the 16 B-per-lane kernels round a row's tail read up
     if ((rc = dev_alloc(d, (void **) &d->colidx, sizeof(int) * ((size_t) d->nnz + kStreamPad), false))) return bail(rc);
@@ -760,8 +778,10 @@ extern "C" int spmv_shim_build(spmv_dev *d, const spmv_plan *plan)
     case SPMV_SCHED_CSR_VECTOR: {
         const int L = plan->lanes_per_row;
         if (L < 1 || L > 64 || (L & (L - 1))) return fail(SPMV_HIP_E_ARG, "lanes_per_row must be a power of two in [1, 64], got %d", L);
-        // a lane group takes 4L elements per step; beyond ~64 steps a whole wavefront per row segment wins
-        rc = f64 ? build_long_rows<double>(d, L * 64 > 256 ? L * 64 : 256) : build_long_rows<float>(d, L * 64 > 256 ? L * 64 : 256);
+        // a lane group takes 4L elements per step; rows longer than the planner's threshold (default: ~64
+        // steps) are handed to the long-row path
+        const int thr = plan->long_thr > 0 ? plan->long_thr : (L * 64 > 256 ? L * 64 : 256);
+        rc = f64 ? build_long_rows<double>(d, thr) : build_long_rows<float>(d, thr);
         if (!rc) rc = f64 ? build_vector_tiles<double>(d) : build_vector_tiles<float>(d);
         if (!rc && plan->autotune) rc = f64 ? autotune_vector<double>(d) : autotune_vector<float>(d);
         break;
