@@ -246,6 +246,9 @@ def main():
                 "frac": round(achieved / HBM_PEAK_GBPS, 4), "traffic": traffic_from_profiles(info["kernel_name"]),
                 "kernel": info["kernel_name"], "alg_bytes_per_launch": alg_bytes,
                 "launch_ms_mean": round(mean_launch, 5), "launch_ms_min": round(float(launch_ms.min()), 5),
+                "note": "achieved = SURVEY 8d algorithmic bytes (4 B ColIdx + value per nnz, RowPtr, x, y) / launch time; the kernel "
+                        "reads a 2 B/nnz column stream (16-bit LDS slots) instead of ColIdx, so traffic (rocprofv3 PMC, "
+                        "profiles/) is below alg_bytes_per_launch and traffic / launch time is the HBM rate actually sustained",
             },
         }
         if world == 1 and not args.no_cpu:

@@ -52,6 +52,20 @@ __global__ __launch_bounds__(256) void stream_read(long long nnz, const int *col
     if (acc == 1.2345 && iacc == 77) out[0] = acc;
 }
 
+// the tile kernel's stream after index compression: 16-bit column slots by 4 B/lane loads + doubles by
+// 16 B/lane loads (10 B per non-zero) -- the FETCH_SIZE calibration for that mix of load widths
+__global__ __launch_bounds__(256) void stream_read16(long long nnz, const unsigned short *col16, const double *val, double *out)
+{
+    double acc = 0; int iacc = 0;
+    const long long q = (long long) blockIdx.x * 256 + threadIdx.x; // one pair of entries per lane and load
+    if (q * 2 + 1 < nnz) {
+        const int c = __builtin_nontemporal_load((const int *) (col16 + q * 2));
+        const f64x2 a = __builtin_nontemporal_load((const f64x2 *) (val + q * 2));
+        acc += a.x + a.y; iacc ^= c;
+    }
+    if (acc == 1.2345 && iacc == 77) out[0] = acc;
+}
+
 // stream + store experiments: MODE 0 none, 1 = 8 lanes x 8 B per wave at the end, 2 = same at the START,
 // 3 = 64 lanes x 8 B from every 8th wave (same bytes, full lines), 4 = 8 lanes x 8 B nontemporal at end
 template <int MODE>
@@ -119,6 +133,7 @@ int main(int argc, char **argv)
 #define V4A(L, U, CAP, ABL) vs.push_back({"vec4 L" #L " U" #U " cap" #CAP " ABL" #ABL, [&] { csr_vector4_kernel<double, L, 1, U, ABL><<<grid_rows(256 / L * U, cus * CAP), 256>>>(m, rowptr, col, val, x, y); }})
     V4A(8, 1, 4096, 1); V4A(8, 1, 4096, 9); V4A(8, 1, 4096, 17); V4A(8, 1, 4096, 25); V4A(8, 1, 4096, 29); V4A(8, 1, 4096, 8); V4A(8, 1, 4096, 16); V4A(8, 2, 4096, 25);
     vs.push_back({"stream_read nt x2blocks", [&] { stream_read<true><<<cus * 16, 256>>>(nnz, col, val, y); }});
+    vs.push_back({"stream_read16 (10 B/nnz)", [&] { stream_read16<<<(int) ((nnz / 2 + 255) / 256), 256>>>(nnz, (const unsigned short *) col, val, y); }});
     vs.push_back({"stream_read nt nonpersist", [&] { stream_read<true><<<(int) (nnz / 4 / 256), 256>>>(nnz, col, val, y); }});
 #define SS(M) vs.push_back({"stream_store mode" #M, [&] { stream_store<M><<<(int) (nnz / 4 / 256), 256>>>(nnz, col, val, y); }})
     SS(0); SS(1);
