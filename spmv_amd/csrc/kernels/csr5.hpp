@@ -213,37 +213,17 @@ __global__ __launch_bounds__(kBlock) void csr5_transpose_kernel(int nnz, int p, 
 }
 
 // ---------------------------------------------------------------------------- executor
-// One tile by one wavefront.  STAGED: the x windows of the workgroup's tiles are in LDS (xs) and the
-// column stream is tcol16: 16-bit LDS slots, four per lane and 8-byte load (range_windows_kernel,
-// pack16 = SIGMA); padding entries point at the zero slot behind the windows, so no entry needs a test.
+// The arithmetic of one tile once the lane holds its SIGMA entries (c: LDS slots when STAGED, else
+// global columns with -1 = padding; v: values): gathers, per-lane segmented sums cut at the row-start
+// flags, cross-lane combine, y stores and the tile's carry.  Shared by the transposed (CSR5) and
+// the natural-layout (nnz-split) tile loaders.
 template <typename T, int SIGMA, bool MAPPED, bool STAGED>
-__device__ __forceinline__ void csr5_tile(int t, int lane, const int *__restrict__ tile_ptr,
-                                          const unsigned *__restrict__ desc, const int *__restrict__ tcol,
-                                          const unsigned short *__restrict__ tcol16,
-                                          const T *__restrict__ tval, const int *__restrict__ row_map,
-                                          const T *__restrict__ x, const T *__restrict__ xs,
-                                          T *__restrict__ y, T *__restrict__ carry)
+__device__ __forceinline__ void csr5_tile_compute(int t, int lane, const int (&c)[SIGMA], const T (&v)[SIGMA],
+                                                  const int *__restrict__ tile_ptr, const unsigned *__restrict__ desc,
+                                                  const int *__restrict__ row_map,
+                                                  const T *__restrict__ x, const T *__restrict__ xs,
+                                                  T *__restrict__ y, T *__restrict__ carry)
 {
-    constexpr int TN = kWave * SIGMA;
-    const long long base = (long long) t * TN + lane;
-    int c[SIGMA];
-    T v[SIGMA];
-    if (STAGED) {
-#pragma unroll
-        for (int q = 0; q < SIGMA / 4; ++q) {
-            int w[4];
-            ld_stream4(tcol16 + (long long) t * TN + q * (4 * kWave) + lane * 4, w);
-            c[4 * q + 0] = (int) lds_slot<0>(w);
-            c[4 * q + 1] = (int) lds_slot<1>(w);
-            c[4 * q + 2] = (int) lds_slot<2>(w);
-            c[4 * q + 3] = (int) lds_slot<3>(w);
-        }
-    } else {
-#pragma unroll
-        for (int i = 0; i < SIGMA; ++i) c[i] = ld_stream(tcol + base + i * kWave);
-    }
-#pragma unroll
-    for (int i = 0; i < SIGMA; ++i) v[i] = ld_stream(tval + base + i * kWave);
     const unsigned d = desc[(long long) t * kWave + lane];
     const unsigned flags = d & kCsr5FlagMask;
     const int r0 = tile_ptr[t];
@@ -287,6 +267,41 @@ __device__ __forceinline__ void csr5_tile(int t, int lane, const int *__restrict
     if (lane == kWave - 1) next = 0;
     if (started) y[MAPPED ? row_map[seg_row] : seg_row] = acc + next;
     if (lane == 0) carry[t] = B;
+}
+
+
+// One tile by one wavefront.  STAGED: the x windows of the workgroup's tiles are in LDS (xs) and the
+// column stream is tcol16: 16-bit LDS slots, four per lane and 8-byte load (range_windows_kernel,
+// pack16 = SIGMA); padding entries point at the zero slot behind the windows, so no entry needs a test.
+template <typename T, int SIGMA, bool MAPPED, bool STAGED>
+__device__ __forceinline__ void csr5_tile(int t, int lane, const int *__restrict__ tile_ptr,
+                                          const unsigned *__restrict__ desc, const int *__restrict__ tcol,
+                                          const unsigned short *__restrict__ tcol16,
+                                          const T *__restrict__ tval, const int *__restrict__ row_map,
+                                          const T *__restrict__ x, const T *__restrict__ xs,
+                                          T *__restrict__ y, T *__restrict__ carry)
+{
+    constexpr int TN = kWave * SIGMA;
+    const long long base = (long long) t * TN + lane;
+    int c[SIGMA];
+    T v[SIGMA];
+    if (STAGED) {
+#pragma unroll
+        for (int q = 0; q < SIGMA / 4; ++q) {
+            int w[4];
+            ld_stream4(tcol16 + (long long) t * TN + q * (4 * kWave) + lane * 4, w);
+            c[4 * q + 0] = (int) lds_slot<0>(w);
+            c[4 * q + 1] = (int) lds_slot<1>(w);
+            c[4 * q + 2] = (int) lds_slot<2>(w);
+            c[4 * q + 3] = (int) lds_slot<3>(w);
+        }
+    } else {
+#pragma unroll
+        for (int i = 0; i < SIGMA; ++i) c[i] = ld_stream(tcol + base + i * kWave);
+    }
+#pragma unroll
+    for (int i = 0; i < SIGMA; ++i) v[i] = ld_stream(tval + base + i * kWave);
+    csr5_tile_compute<T, SIGMA, MAPPED, STAGED>(t, lane, c, v, tile_ptr, desc, row_map, x, xs, y, carry);
 }
 
 template <typename T, int SIGMA, bool MAPPED>
@@ -336,6 +351,175 @@ __global__ __launch_bounds__(kBlock) void csr5_group_kernel(int p, const int *__
         if (t >= p) break;
         if (staged) csr5_tile<T, SIGMA, MAPPED, true>(t, lane, tile_ptr, desc, tcol, tcol16, tval, row_map, x, xs, y, carry);
         else csr5_tile<T, SIGMA, MAPPED, false>(t, lane, tile_ptr, desc, tcol, tcol16, tval, row_map, x, xs, y, carry);
+    }
+}
+
+// ---- natural-layout tiles (the nnz-split schedule: Method_Balanced2 / Method_Balanced_Yid) ------------
+// Same tiles, descriptors and carry fix-up, but NO transposed copies: the tile's 64*SIGMA entries are
+// read from the caller-ordered ColIdx / Val arrays (lane x owns entries x*SIGMA .. x*SIGMA+SIGMA-1, as
+// the reference's equal-nnz workers own consecutive nnz, parallel_balanced2_spmv.c:41-53).  A lane
+// reading its own SIGMA consecutive values directly would make every load instruction touch 64
+// different cache lines (measured: tiles wider than 4 entries per lane lost more than they won),
+// so the wave fetches the tile with fully coalesced 16-byte loads, parks it in LDS and each lane
+// reads its row back (row stride padded by 16 B / 4 B: conflict-free for ds_read_b128 / b32).
+// Extra HBM: none for values; a 2 B/nnz slot stream for staged groups.
+template <typename T, int SIGMA>
+struct NatLds {
+    static constexpr int kValRow = SIGMA * (int) sizeof(T) + 16; // bytes per lane row, padded
+    static constexpr int kColRow = SIGMA * 2 + 4;
+    static constexpr int kValBytes = kWave * kValRow;
+    static constexpr int kColBytes = (kWave * kColRow + 15) & ~15;
+    static constexpr int kBytes = kValBytes + kColBytes;         // per wavefront
+};
+
+template <typename T, int SIGMA, bool MAPPED, bool STAGED>
+__device__ __forceinline__ void nat_tile(int t, int lane, int nnz, unsigned zslot, unsigned char *__restrict__ wl,
+                                         const int *__restrict__ tile_ptr, const unsigned *__restrict__ desc,
+                                         const int *__restrict__ colidx, const unsigned short *__restrict__ col16,
+                                         const T *__restrict__ val, const int *__restrict__ row_map,
+                                         const T *__restrict__ x, const T *__restrict__ xs,
+                                         T *__restrict__ y, T *__restrict__ carry)
+{
+    using NL = NatLds<T, SIGMA>;
+    constexpr int TN = kWave * SIGMA;
+    constexpr int EPL = 16 / (int) sizeof(T);              // values per 16-byte load
+    constexpr int VL = SIGMA / EPL;                        // value loads per lane
+    constexpr int CB = SIGMA * 2 < 16 ? SIGMA * 2 : 16;    // bytes of slot stream per lane and load
+    constexpr int CS = CB / 2, CL = SIGMA * 2 / CB;        // slots per load, loads per lane
+    const long long tb = (long long) t * TN;
+    const int left = nnz - tb < TN ? (int) (nnz - tb) : TN; // entries of this tile that exist
+    unsigned char *lv = wl, *lc = wl + NL::kValBytes;
+    // 1. coalesced fetch -> LDS (entry p of the tile goes to row p / SIGMA, position p % SIGMA); all loads of
+    //    a whole tile are issued before the first LDS write, so they are in flight together
+    int c[SIGMA];
+    auto vdst = [&](int p) { return reinterpret_cast<T *>(lv + (p / SIGMA) * NL::kValRow + (p % SIGMA) * (int) sizeof(T)); };
+    auto cdst = [&](int p) { return reinterpret_cast<unsigned *>(lc + (p / SIGMA) * NL::kColRow + (p % SIGMA) * 2); };
+    if (left == TN) {
+        T tv[VL][EPL];
+        unsigned tw[CL][CS / 2]; // slot pairs
+#pragma unroll
+        for (int j = 0; j < VL; ++j) {
+            const int p = (j * kWave + lane) * EPL;
+            if constexpr (EPL == 4) {
+                const f32x4 q = __builtin_nontemporal_load(reinterpret_cast<const f32x4 *>(val + tb + p));
+                tv[j][0] = q.x; tv[j][1] = q.y; tv[j][2] = q.z; tv[j][3] = q.w;
+            } else {
+                const f64x2 q = __builtin_nontemporal_load(reinterpret_cast<const f64x2 *>(val + tb + p));
+                tv[j][0] = q.x; tv[j][1] = q.y;
+            }
+        }
+        if (STAGED) {
+#pragma unroll
+            for (int j = 0; j < CL; ++j) {
+                const int p = (j * kWave + lane) * CS;
+                if constexpr (CB == 16) {
+                    const i32x4 q = __builtin_nontemporal_load(reinterpret_cast<const i32x4 *>(col16 + tb + p));
+                    tw[j][0] = (unsigned) q.x; tw[j][1] = (unsigned) q.y; tw[j][2] = (unsigned) q.z; tw[j][3] = (unsigned) q.w;
+                } else {
+                    const i32x2 q = __builtin_nontemporal_load(reinterpret_cast<const i32x2 *>(col16 + tb + p));
+                    tw[j][0] = (unsigned) q.x; tw[j][1] = (unsigned) q.y;
+                }
+            }
+        } else { // global columns: straight from ColIdx (this path is gather-bound anyway)
+#pragma unroll
+            for (int q = 0; q < SIGMA; q += 4) ld_stream4(colidx + tb + lane * SIGMA + q, *reinterpret_cast<int(*)[4]>(&c[q]));
+        }
+#pragma unroll
+        for (int j = 0; j < VL; ++j) {
+            T *dst = vdst((j * kWave + lane) * EPL);
+#pragma unroll
+            for (int e = 0; e < EPL; ++e) dst[e] = tv[j][e];
+        }
+        if (STAGED) {
+#pragma unroll
+            for (int j = 0; j < CL; ++j) {
+                unsigned *dst = cdst((j * kWave + lane) * CS);
+#pragma unroll
+                for (int e = 0; e < CS / 2; ++e) dst[e] = tw[j][e];
+            }
+        }
+    } else { // the matrix's last tile: entry by entry, missing entries = 0 * zero slot
+        for (int j = 0; j < VL; ++j) {
+            const int p = (j * kWave + lane) * EPL;
+            T *dst = vdst(p);
+            for (int e = 0; e < EPL; ++e) dst[e] = p + e < left ? val[tb + p + e] : T(0);
+        }
+        if (STAGED) {
+            for (int j = 0; j < CL; ++j) {
+                const int p = (j * kWave + lane) * CS;
+                unsigned *dst = cdst(p);
+                for (int e = 0; e < CS; e += 2) {
+                    const unsigned lo = p + e < left ? col16[tb + p + e] : zslot, hi = p + e + 1 < left ? col16[tb + p + e + 1] : zslot;
+                    dst[e / 2] = lo | (hi << 16);
+                }
+            }
+        } else {
+#pragma unroll
+            for (int i = 0; i < SIGMA; ++i) c[i] = lane * SIGMA + i < left ? colidx[tb + lane * SIGMA + i] : -1;
+        }
+    }
+    wave_lds_sync();
+    // 2. each lane reads its row back
+    T v[SIGMA];
+    {
+        const T *src = reinterpret_cast<const T *>(lv + lane * NL::kValRow);
+#pragma unroll
+        for (int i = 0; i < SIGMA; ++i) v[i] = src[i];
+        if (STAGED) {
+            const unsigned *cs = reinterpret_cast<const unsigned *>(lc + lane * NL::kColRow);
+#pragma unroll
+            for (int i = 0; i < SIGMA; i += 2) {
+                const unsigned w = cs[i / 2];
+                c[i] = (int) (w & 0xffffu);
+                c[i + 1] = (int) (w >> 16);
+            }
+        }
+    }
+    wave_lds_sync(); // the buffer is free for the wave's next tile
+    csr5_tile_compute<T, SIGMA, MAPPED, STAGED>(t, lane, c, v, tile_ptr, desc, row_map, x, xs, y, carry);
+}
+
+template <typename T, int SIGMA, bool MAPPED>
+__global__ __launch_bounds__(kBlock) void nat_kernel(int p, int nnz, const int *__restrict__ tile_ptr,
+                                                     const unsigned *__restrict__ desc,
+                                                     const int *__restrict__ colidx, const T *__restrict__ val,
+                                                     const int *__restrict__ row_map,
+                                                     const T *__restrict__ x, T *__restrict__ y, T *__restrict__ carry)
+{
+    __shared__ __attribute__((aligned(16))) unsigned char nat_lds[kBlock / kWave][NatLds<T, SIGMA>::kBytes];
+    const int lane = threadIdx.x & (kWave - 1), wave = threadIdx.x / kWave;
+    const int t = blockIdx.x * (kBlock / kWave) + wave;
+    if (t >= p) return;
+    nat_tile<T, SIGMA, MAPPED, false>(t, lane, nnz, 0u, nat_lds[wave], tile_ptr, desc, colidx, nullptr, val, row_map, x, nullptr, y, carry);
+}
+
+template <typename T, int SIGMA, bool MAPPED>
+__global__ __launch_bounds__(kBlock) void nat_group_kernel(int p, int nnz, const int *__restrict__ tile_ptr,
+                                                           const unsigned *__restrict__ desc,
+                                                           const int *__restrict__ colidx, const unsigned short *__restrict__ col16,
+                                                           const T *__restrict__ val,
+                                                           const int *__restrict__ row_map,
+                                                           const TileWindows *__restrict__ wins,
+                                                           const T *__restrict__ x, T *__restrict__ y,
+                                                           T *__restrict__ carry)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char csr5_x_lds[];
+    __shared__ __attribute__((aligned(16))) unsigned char nat_lds[kBlock / kWave][NatLds<T, SIGMA>::kBytes];
+    T *xs = reinterpret_cast<T *>(csr5_x_lds);
+    const TileWindows &tw = wins[blockIdx.x];
+    const bool staged = tw.nwin > 0;
+    stage_windows<kBlock, T>(tw, x, xs);
+    if (staged) {
+        if (threadIdx.x == 0) xs[tw.total] = T(0); // the zero slot of the last tile's missing entries
+        __syncthreads();
+    }
+    const int lane = threadIdx.x & (kWave - 1), wave = threadIdx.x / kWave;
+    const int t0 = blockIdx.x * kCsr5GroupTiles;
+    for (int k = wave; k < kCsr5GroupTiles; k += kBlock / kWave) {
+        const int t = t0 + k;
+        if (t >= p) break;
+        if (staged) nat_tile<T, SIGMA, MAPPED, true>(t, lane, nnz, (unsigned) tw.total, nat_lds[wave], tile_ptr, desc, colidx, col16, val, row_map, x, xs, y, carry);
+        else nat_tile<T, SIGMA, MAPPED, false>(t, lane, nnz, 0u, nat_lds[wave], tile_ptr, desc, colidx, col16, val, row_map, x, xs, y, carry);
     }
 }
 

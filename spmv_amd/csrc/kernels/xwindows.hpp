@@ -39,7 +39,12 @@ __device__ __forceinline__ void stage_windows(const TileWindows &tw, const T *__
     const int nwin = tw.nwin;
     for (int w = 0; w < nwin; ++w) {
         const int st = tw.start[w], ln = tw.len[w], bs = tw.base[w];
-        for (int i = threadIdx.x; i < ln; i += NT) xs[bs + i] = x[st + i];
+        int i = threadIdx.x;
+        for (; i + 3 * NT < ln; i += 4 * NT) { // four loads in flight per thread (wide windows: thousands of columns)
+            const T a = x[st + i], b = x[st + i + NT], c = x[st + i + 2 * NT], d = x[st + i + 3 * NT];
+            xs[bs + i] = a; xs[bs + i + NT] = b; xs[bs + i + 2 * NT] = c; xs[bs + i + 3 * NT] = d;
+        }
+        for (; i < ln; i += NT) xs[bs + i] = x[st + i];
     }
 }
 

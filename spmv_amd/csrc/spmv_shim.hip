@@ -68,6 +68,7 @@ struct Csr5Plan {
     int sigma = 0, tiles = 0, m2 = 0, fixup = 0, groups = 0, staged = 0, maxspan = 0;
     long long nnz = 0;
     bool zero_fill = false;       // rows outside row_map (empty rows) need y = 0 first
+    bool natural = false;         // nnz-split: no transposed copies, col/val are the matrix's own arrays (kernels/csr5.hpp, nat_tile)
     TileWindows *wins = nullptr;
     int *tile_ptr = nullptr, *run_len = nullptr, *col = nullptr; // col: transposed global columns (freed when every group is staged)
     unsigned short *col16 = nullptr; // 16-bit LDS slots of the staged groups
@@ -120,7 +121,7 @@ struct spmv_dev {
     long long *chunk_ptr = nullptr;
     void *sval = nullptr;
     // csr5
-    Csr5Plan c5, c5_long;
+    Csr5Plan c5, c5_long, ns; // ns: the natural-layout plan of the nnz-split schedule
     // long-row sub-matrix (rows longer than long_thr, in row order), the input of c5_long
     int *lsub_rowptr = nullptr, *lsub_colidx = nullptr;
     void *lsub_val = nullptr;
@@ -170,6 +171,7 @@ static void free_schedule(spmv_dev *d)
     d->vt_col = nullptr; d->vt_wins = nullptr; d->vt_tiles = d->vt_staged = d->vt_maxspan = 0;
     d->c5 = Csr5Plan();
     d->c5_long = Csr5Plan();
+    d->ns = Csr5Plan();
     d->lsub_rowptr = d->lsub_colidx = nullptr; d->lsub_val = nullptr; d->lsub_nnz = 0;
     d->built = false;
 }
@@ -433,7 +435,7 @@ constexpr size_t kVecXTileBytes = 48 * 1024; // LDS budget of one row tile's x s
 template <typename T> static int build_long_rows(spmv_dev *d, int thr);
 template <typename T>
 static int build_csr5(spmv_dev *d, Csr5Plan &P, int m, long long nnz, const int *rowptr, const int *colidx, const T *val, int empty_rows,
-                      double mean_row_len, const int *out_rows);
+                      double mean_row_len, const int *out_rows, bool natural = false);
 template <typename T> static int autotune_vector(spmv_dev *d);
 template <typename T> static int build_tile_windows(spmv_dev *d, int tiles, const int *split, int rows_per_tile = kVecTileRows);
 
@@ -679,6 +681,7 @@ static int build_sell(spmv_dev *d)
 }
 
 constexpr size_t kCsr5XTileBytes = 128 * 1024; // LDS budget of one tile group's x span (a CU has 160 KiB)
+constexpr size_t kNatXTileBytes = 96 * 1024;   // same for natural-layout tiles, whose waves also park their tile in LDS (up to 46 KiB)
 
 template <typename T, int SIGMA>
 static int build_csr5_sigma(spmv_dev *d, Csr5Plan &P, const int *rp, int m2, const int *colidx, const T *val)
@@ -690,8 +693,13 @@ static int build_csr5_sigma(spmv_dev *d, Csr5Plan &P, const int *rp, int m2, con
     ALLOC_TRY(d, &P.desc, sizeof(unsigned) * (size_t) p * kWave, true);
     ALLOC_TRY(d, &P.run_len, sizeof(int) * (size_t) p, true);
     ALLOC_TRY(d, &P.carry, sizeof(T) * (size_t) p, true);
-    ALLOC_TRY(d, &P.col, sizeof(int) * (size_t) p * TN, true);
-    ALLOC_TRY(d, &P.val, sizeof(T) * (size_t) p * TN, true);
+    if (P.natural) { // the tiles read the matrix's own arrays
+        P.col = const_cast<int *>(colidx);
+        P.val = const_cast<T *>(val);
+    } else {
+        ALLOC_TRY(d, &P.col, sizeof(int) * (size_t) p * TN, true);
+        ALLOC_TRY(d, &P.val, sizeof(T) * (size_t) p * TN, true);
+    }
     int *flag = nullptr;
     ALLOC_TRY(d, &flag, sizeof(int), true);
     HIP_TRY(hipMemsetAsync(flag, 0, sizeof(int), d->stream));
@@ -699,14 +707,25 @@ static int build_csr5_sigma(spmv_dev *d, Csr5Plan &P, const int *rp, int m2, con
     HIP_TRY(hipGetLastError());
     csr5_desc_kernel<SIGMA><<<grid_for(p, kBlock / kWave, INT_MAX), kBlock, 0, d->stream>>>(m2, (int) P.nnz, p, rp, P.tile_ptr, P.desc, P.run_len, flag);
     HIP_TRY(hipGetLastError());
-    csr5_transpose_kernel<T, SIGMA><<<grid_for(p, kBlock / kWave, INT_MAX), kBlock, 0, d->stream>>>((int) P.nnz, p, colidx, val, P.col, (T *) P.val);
-    HIP_TRY(hipGetLastError());
+    if (!P.natural) {
+        csr5_transpose_kernel<T, SIGMA><<<grid_for(p, kBlock / kWave, INT_MAX), kBlock, 0, d->stream>>>((int) P.nnz, p, colidx, val, P.col, (T *) P.val);
+        HIP_TRY(hipGetLastError());
+    }
     HIP_TRY(hipMemcpyAsync(&P.fixup, flag, sizeof(int), hipMemcpyDeviceToHost, d->stream));
     HIP_TRY(hipStreamSynchronize(d->stream));
     // x windows of every group of kCsr5GroupTiles tiles, in place on the transposed column copy (xwindows.hpp)
     P.groups = (p + kCsr5GroupTiles - 1) / kCsr5GroupTiles;
     ALLOC_TRY(d, &P.wins, sizeof(TileWindows) * (size_t) P.groups, true);
     static_assert(kCsr5XTileBytes / sizeof(float) <= 65536, "LDS slots must fit 16 bits");
+    if (P.natural) { // slots in matrix order; the budget leaves room for the waves' tile buffers in LDS
+        ALLOC_TRY(d, &P.col16, sizeof(unsigned short) * ((size_t) P.nnz + kStreamPad), true);
+        HIP_TRY(hipMemsetAsync(P.col16, 0, sizeof(unsigned short) * ((size_t) P.nnz + kStreamPad), d->stream));
+        const int rc = build_range_windows(d, d->plan.variant == 3 ? 0 : P.groups, P.nnz, (long long) kCsr5GroupTiles * TN, nullptr, 1, 1,
+                                           (int) (kNatXTileBytes / sizeof(T)) - 1, P.col, P.wins, &P.staged, &P.maxspan, P.col16, 0);
+        if (rc) return rc;
+        if (P.staged == 0) { sched_free(d, P.col16); P.col16 = nullptr; }
+        return SPMV_HIP_OK;
+    }
     ALLOC_TRY(d, &P.col16, sizeof(unsigned short) * (size_t) p * TN, true);
     const int rc = build_range_windows(d, d->plan.variant == 3 ? 0 : P.groups, (long long) p * TN, (long long) kCsr5GroupTiles * TN, nullptr, 1, 1,
                                        (int) (kCsr5XTileBytes / sizeof(T)) - 1, P.col, P.wins, &P.staged, &P.maxspan, P.col16, SIGMA);
@@ -720,7 +739,7 @@ static int build_csr5_sigma(spmv_dev *d, Csr5Plan &P, const int *rp, int m2, con
 // allowed then) names the y row of each CSR row -- used for the long-row sub-matrix.
 template <typename T>
 static int build_csr5(spmv_dev *d, Csr5Plan &P, int m, long long nnz, const int *rowptr, const int *colidx, const T *val, int empty_rows,
-                      double mean_row_len, const int *out_rows)
+                      double mean_row_len, const int *out_rows, bool natural)
 {
     int sigma = d->plan.csr5_sigma;
     if (sigma == 0) sigma = mean_row_len <= 4.0 ? 4 : (mean_row_len <= 12.0 ? 8 : 16);
@@ -729,6 +748,7 @@ static int build_csr5(spmv_dev *d, Csr5Plan &P, int m, long long nnz, const int 
     P.sigma = sigma;
     P.nnz = nnz;
     P.row_map = out_rows;
+    P.natural = natural;
     if (nnz == 0) return SPMV_HIP_OK;
     const int *rp = rowptr;
     int m2 = m;
@@ -786,7 +806,15 @@ extern "C" int spmv_shim_build(spmv_dev *d, const spmv_plan *plan)
         if (!rc && plan->autotune) rc = f64 ? autotune_vector<double>(d) : autotune_vector<float>(d);
         break;
     }
-    case SPMV_SCHED_NNZ_SPLIT: rc = f64 ? build_nnz_split<double>(d) : build_nnz_split<float>(d); break;
+    case SPMV_SCHED_NNZ_SPLIT:
+        if (plan->variant == 8) { // A/B: the first-round 256-nnz tiles with LDS row marks (kernels/nnz_split.hpp)
+            rc = f64 ? build_nnz_split<double>(d) : build_nnz_split<float>(d);
+            break;
+        }
+        // equal-nnz tiles over the matrix's own arrays: CSR5 descriptors + carry fix-up, natural layout
+        rc = f64 ? build_csr5<double>(d, d->ns, d->m, d->nnz, d->rowptr, d->colidx, (const double *) d->val, d->stats.empty_rows, d->stats.mean_row_len, nullptr, true)
+                 : build_csr5<float>(d, d->ns, d->m, d->nnz, d->rowptr, d->colidx, (const float *) d->val, d->stats.empty_rows, d->stats.mean_row_len, nullptr, true);
+        break;
     case SPMV_SCHED_ROWBLOCK:
         if (plan->rowblock_nnz < 64) return fail(SPMV_HIP_E_ARG, "rowblock_nnz must be >= 64");
         if (d->stats.max_row_len > plan->rowblock_nnz) return fail(SPMV_HIP_E_ARG, "row-block schedule needs max_row_len <= rowblock_nnz");
@@ -915,28 +943,36 @@ static int autotune_vector(spmv_dev *d)
     return SPMV_HIP_OK;
 }
 
-template <typename T, int SIGMA>
-static void launch_csr5_sigma(spmv_dev *d, const Csr5Plan &P, const T *x, T *y)
+template <typename T, int SIGMA, bool MAPPED>
+static void launch_csr5_form(spmv_dev *d, const Csr5Plan &P, const T *x, T *y)
 {
-    if (P.staged > 0) { // the inspector staged (at least half of) the groups: the column copy holds LDS slots for them
+    if (P.staged > 0) { // the inspector staged (at least half of) the groups: their column stream is the 16-bit slot array
         const size_t lds = ((((size_t) P.maxspan + 1) * sizeof(T)) + 1023) & ~(size_t) 1023; // + the zero slot
-        if (lds > 64 * 1024) { // above the default dynamic-LDS limit: raise it for this instantiation (idempotent, cheap)
-            if (P.row_map) (void) hipFuncSetAttribute((const void *) csr5_group_kernel<T, SIGMA, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int) lds);
-            else (void) hipFuncSetAttribute((const void *) csr5_group_kernel<T, SIGMA, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int) lds);
+        if (P.natural) {
+            if (lds > 16 * 1024) // static tile buffers (up to 46 KiB) + this may pass the default 64 KiB limit
+                (void) hipFuncSetAttribute((const void *) nat_group_kernel<T, SIGMA, MAPPED>, hipFuncAttributeMaxDynamicSharedMemorySize, (int) lds);
+            nat_group_kernel<T, SIGMA, MAPPED><<<P.groups, kBlock, lds, d->stream>>>(P.tiles, (int) P.nnz, P.tile_ptr, P.desc, P.col, P.col16, (const T *) P.val,
+                                                                                    P.row_map, P.wins, x, y, (T *) P.carry);
+            return;
         }
-        if (P.row_map)
-            csr5_group_kernel<T, SIGMA, true><<<P.groups, kBlock, lds, d->stream>>>(P.tiles, P.tile_ptr, P.desc, P.col, P.col16, (const T *) P.val, P.row_map, P.wins,
-                                                                                   x, y, (T *) P.carry);
-        else
-            csr5_group_kernel<T, SIGMA, false><<<P.groups, kBlock, lds, d->stream>>>(P.tiles, P.tile_ptr, P.desc, P.col, P.col16, (const T *) P.val, nullptr, P.wins,
-                                                                                    x, y, (T *) P.carry);
+        if (lds > 64 * 1024) // above the default dynamic-LDS limit: raise it for this instantiation (idempotent, cheap)
+            (void) hipFuncSetAttribute((const void *) csr5_group_kernel<T, SIGMA, MAPPED>, hipFuncAttributeMaxDynamicSharedMemorySize, (int) lds);
+        csr5_group_kernel<T, SIGMA, MAPPED><<<P.groups, kBlock, lds, d->stream>>>(P.tiles, P.tile_ptr, P.desc, P.col, P.col16, (const T *) P.val, P.row_map, P.wins,
+                                                                                 x, y, (T *) P.carry);
         return;
     }
     const int grid = grid_for(P.tiles, kBlock / kWave, INT_MAX);
-    if (P.row_map)
-        csr5_kernel<T, SIGMA, true><<<grid, kBlock, 0, d->stream>>>(P.tiles, P.tile_ptr, P.desc, P.col, (const T *) P.val, P.row_map, x, y, (T *) P.carry);
+    if (P.natural)
+        nat_kernel<T, SIGMA, MAPPED><<<grid, kBlock, 0, d->stream>>>(P.tiles, (int) P.nnz, P.tile_ptr, P.desc, P.col, (const T *) P.val, P.row_map, x, y, (T *) P.carry);
     else
-        csr5_kernel<T, SIGMA, false><<<grid, kBlock, 0, d->stream>>>(P.tiles, P.tile_ptr, P.desc, P.col, (const T *) P.val, nullptr, x, y, (T *) P.carry);
+        csr5_kernel<T, SIGMA, MAPPED><<<grid, kBlock, 0, d->stream>>>(P.tiles, P.tile_ptr, P.desc, P.col, (const T *) P.val, P.row_map, x, y, (T *) P.carry);
+}
+
+template <typename T, int SIGMA>
+static void launch_csr5_sigma(spmv_dev *d, const Csr5Plan &P, const T *x, T *y)
+{
+    if (P.row_map) launch_csr5_form<T, SIGMA, true>(d, P, x, y);
+    else launch_csr5_form<T, SIGMA, false>(d, P, x, y);
 }
 
 // One CSR5 multiply: [y = 0 for the rows outside the plan] + tiles + carry fix-up.
@@ -987,6 +1023,11 @@ static int launch(spmv_dev *d, const T *x, T *y)
         if (d->plan.variant != 2) launch_long_rows<T>(d, x, y);
         break;
     case SPMV_SCHED_NNZ_SPLIT: {
+        if (d->plan.variant != 8) {
+            const int rc = launch_csr5<T>(d, d->ns, x, y);
+            if (rc) return rc;
+            break;
+        }
         if (d->ns_staged > 0) {
             const size_t lds = ((((size_t) d->ns_maxspan + 1) * sizeof(T)) + 1023) & ~(size_t) 1023;
             nnz_group_kernel<T><<<d->ns_groups, kBlock, lds, d->stream>>>((int) d->nnz, d->ntiles, d->rowptr, d->colidx, d->ns_col, val, d->ns_wins,
@@ -1134,7 +1175,7 @@ extern "C" int spmv_shim_info(const spmv_dev *d, spmv_hip_info *o)
     o->lanes_per_row = d->plan.sched == SPMV_SCHED_CSR_VECTOR ? d->plan.lanes_per_row : 0;
     o->sell_c = d->plan.sched == SPMV_SCHED_SELL ? kSellC : 0;
     o->sell_sigma = d->plan.sched == SPMV_SCHED_SELL ? d->plan.sell_sigma : 0;
-    o->tile_nnz = d->plan.sched == SPMV_SCHED_NNZ_SPLIT ? (d->vsize == 8 ? SplitCfg<double>::Tile : SplitCfg<float>::Tile) : (d->plan.sched == SPMV_SCHED_ROWBLOCK ? d->rb_stride : (d->plan.sched == SPMV_SCHED_CSR5 ? kWave * d->c5.sigma : 0));
+    o->tile_nnz = d->plan.sched == SPMV_SCHED_NNZ_SPLIT ? (d->plan.variant == 8 ? (d->vsize == 8 ? SplitCfg<double>::Tile : SplitCfg<float>::Tile) : kWave * d->ns.sigma) : (d->plan.sched == SPMV_SCHED_ROWBLOCK ? d->rb_stride : (d->plan.sched == SPMV_SCHED_CSR5 ? kWave * d->c5.sigma : 0));
     o->m = d->m;
     o->n = d->n;
     o->nnz = d->nnz;
@@ -1154,7 +1195,8 @@ extern "C" int spmv_shim_info(const spmv_dev *d, spmv_hip_info *o)
     if (d->plan.sched == SPMV_SCHED_CSR_VECTOR && d->vt_tiles > 0 && d->vec_choice != VEC_PIPE &&
         (d->vt_staged * 2 >= d->vt_tiles || (d->vec_choice != VEC_AUTO && d->vec_choice != VEC_PIPE)))
         o->kernel_name = "csr_vector_tile_kernel";
-    if (d->plan.sched == SPMV_SCHED_NNZ_SPLIT && d->ns_staged > 0) o->kernel_name = "nnz_group_kernel";
+    if (d->plan.sched == SPMV_SCHED_NNZ_SPLIT)
+        o->kernel_name = d->plan.variant == 8 ? (d->ns_staged > 0 ? "nnz_group_kernel" : "nnz_split_kernel") : (d->ns.staged > 0 ? "nat_group_kernel" : "nat_kernel");
     if (d->plan.sched == SPMV_SCHED_CSR5 && d->c5.staged > 0) o->kernel_name = "csr5_group_kernel";
     if (d->plan.sched == SPMV_SCHED_SELL && d->sell_staged > 0) o->kernel_name = "sell_window_kernel";
     return SPMV_HIP_OK;

@@ -201,6 +201,12 @@ def test_auto_method_picks_schedule_from_row_statistics():
     ("sell_lds_x", [0, 1], M.Method_SellCSigma),
     ("csr5_sigma", [4, 8, 16], M.Method_CSR5SPMV),
     ("rowblock_nnz", [64, 333, 4096, 100000], M.Method_Balanced),
+    ("csr5_sigma", [4, 8, 16], M.Method_Balanced_Yid),           # nnz-split = natural-layout tiles of 64 x sigma
+    ("variant", [8], M.Method_Balanced2),                        # A/B form: 256-nnz tiles with LDS row marks
+    ("variant", [3], M.Method_Balanced_Yid),                     # no x windows (global gathers)
+    ("variant", [1, 4, 5, 6, 10, 11, 12, 13], M.Method_Parallel),  # CSR-vector kernel forms / long-row segment kernel
+    ("variant", [3, 13], M.Method_SellCSigma),
+    ("variant", [3], M.Method_CSR5SPMV),
 ])
 @pytest.mark.parametrize("name", ["skewed_f64_eighths", "empty_mix_f32_eighths", "banded_wide_f64_eighths"])
 def test_tuning_options_do_not_change_results(key, values, method, name):
