@@ -27,8 +27,9 @@
 //   empty rows    the reference keeps per-tile offset tables for tiles whose row span contains
 //                 empty rows (format_avx2.h:256-326) and never writes y for empty rows
 //                 (SURVEY 4.3).  Here, if the matrix has empty rows, CSR5 is built over the
-//                 COMPACTED row space (row_map[k] = k-th non-empty row) and y is zero-filled
-//                 first; without empty rows row_map is not allocated and no indirection runs.
+//                 COMPACTED row space (row_map[k] = k-th non-empty row) and the tile kernel's
+//                 workgroups zero y for the listed empty rows on the side (empty_list); without
+//                 empty rows neither array is allocated and no indirection runs.
 // fp32 is native (the reference silently falls back to SELL for fp32, common.c:174-181).
 // Extra HBM traffic on top of B_alg per tile of 64*SIGMA nnz: 256 B desc + 4 B tile_ptr + s carry.
 #pragma once
@@ -101,7 +102,8 @@ __global__ __launch_bounds__(kBlock) void scan_sums_inplace_kernel(int nb, int *
 __global__ __launch_bounds__(kBlock) void csr5_compact_kernel(long long m, const int *__restrict__ flags,
                                                               const int *__restrict__ block_off,
                                                               const int *__restrict__ rowptr,
-                                                              int *__restrict__ rp2, int *__restrict__ row_map)
+                                                              int *__restrict__ rp2, int *__restrict__ row_map,
+                                                              int *__restrict__ empty_list = nullptr /* nullable: the other rows, in order */)
 {
     __shared__ int wave_tot[kBlock / kWave];
     __shared__ int slab_base;
@@ -125,6 +127,8 @@ __global__ __launch_bounds__(kBlock) void csr5_compact_kernel(long long m, const
             const int pos = off + inc - 1;
             rp2[pos] = rowptr[r];
             row_map[pos] = (int) r;
+        } else if (empty_list && r < m) {
+            empty_list[r - (off + inc)] = (int) r; // off + inc flagged rows lie in front of r
         }
         __syncthreads();
         if (threadIdx.x == kBlock - 1) slab_base = off + inc;
@@ -304,14 +308,24 @@ __device__ __forceinline__ void csr5_tile(int t, int lane, const int *__restrict
     csr5_tile_compute<T, SIGMA, MAPPED, STAGED>(t, lane, c, v, tile_ptr, desc, row_map, x, xs, y, carry);
 }
 
+// y = 0 for the matrix's empty rows (they are outside the compacted row space the tiles write), spread
+// over the workgroups of the tile kernel itself: no separate zero-fill launch, no 8·m-byte memset.
+template <typename T>
+__device__ __forceinline__ void zero_empty_rows(int n_empty, const int *__restrict__ empty_list, T *__restrict__ y)
+{
+    for (long long i = (long long) blockIdx.x * blockDim.x + threadIdx.x; i < n_empty; i += (long long) gridDim.x * blockDim.x)
+        y[empty_list[i]] = T(0);
+}
+
 template <typename T, int SIGMA, bool MAPPED>
 __global__ __launch_bounds__(kBlock) void csr5_kernel(int p, const int *__restrict__ tile_ptr,
                                                       const unsigned *__restrict__ desc,
                                                       const int *__restrict__ tcol, const T *__restrict__ tval,
                                                       const int *__restrict__ row_map,
                                                       const T *__restrict__ x, T *__restrict__ y,
-                                                      T *__restrict__ carry)
+                                                      T *__restrict__ carry, int n_empty, const int *__restrict__ empty_list)
 {
+    if (MAPPED) zero_empty_rows(n_empty, empty_list, y);
     const int lane = threadIdx.x & (kWave - 1);
     const int t = blockIdx.x * (kBlock / kWave) + threadIdx.x / kWave;
     if (t >= p) return;
@@ -333,8 +347,9 @@ __global__ __launch_bounds__(kBlock) void csr5_group_kernel(int p, const int *__
                                                             const int *__restrict__ row_map,
                                                             const TileWindows *__restrict__ wins,
                                                             const T *__restrict__ x, T *__restrict__ y,
-                                                            T *__restrict__ carry)
+                                                            T *__restrict__ carry, int n_empty, const int *__restrict__ empty_list)
 {
+    if (MAPPED) zero_empty_rows(n_empty, empty_list, y);
     extern __shared__ __attribute__((aligned(16))) unsigned char csr5_x_lds[];
     T *xs = reinterpret_cast<T *>(csr5_x_lds);
     const TileWindows &tw = wins[blockIdx.x];
@@ -484,8 +499,9 @@ __global__ __launch_bounds__(kBlock) void nat_kernel(int p, int nnz, const int *
                                                      const unsigned *__restrict__ desc,
                                                      const int *__restrict__ colidx, const T *__restrict__ val,
                                                      const int *__restrict__ row_map,
-                                                     const T *__restrict__ x, T *__restrict__ y, T *__restrict__ carry)
+                                                     const T *__restrict__ x, T *__restrict__ y, T *__restrict__ carry, int n_empty, const int *__restrict__ empty_list)
 {
+    if (MAPPED) zero_empty_rows(n_empty, empty_list, y);
     __shared__ __attribute__((aligned(16))) unsigned char nat_lds[kBlock / kWave][NatLds<T, SIGMA>::kBytes];
     const int lane = threadIdx.x & (kWave - 1), wave = threadIdx.x / kWave;
     const int t = blockIdx.x * (kBlock / kWave) + wave;
@@ -501,8 +517,9 @@ __global__ __launch_bounds__(kBlock) void nat_group_kernel(int p, int nnz, const
                                                            const int *__restrict__ row_map,
                                                            const TileWindows *__restrict__ wins,
                                                            const T *__restrict__ x, T *__restrict__ y,
-                                                           T *__restrict__ carry)
+                                                           T *__restrict__ carry, int n_empty, const int *__restrict__ empty_list)
 {
+    if (MAPPED) zero_empty_rows(n_empty, empty_list, y);
     extern __shared__ __attribute__((aligned(16))) unsigned char csr5_x_lds[];
     __shared__ __attribute__((aligned(16))) unsigned char nat_lds[kBlock / kWave][NatLds<T, SIGMA>::kBytes];
     T *xs = reinterpret_cast<T *>(csr5_x_lds);

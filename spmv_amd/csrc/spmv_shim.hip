@@ -67,7 +67,8 @@ struct DevStats {
 struct Csr5Plan {
     int sigma = 0, tiles = 0, m2 = 0, fixup = 0, groups = 0, staged = 0, maxspan = 0;
     long long nnz = 0;
-    bool zero_fill = false;       // rows outside row_map (empty rows) need y = 0 first
+    int n_empty = 0;              // empty rows (outside row_map): the tile kernel zeroes y for them
+    const int *empty_list = nullptr;
     bool natural = false;         // nnz-split: no transposed copies, col/val are the matrix's own arrays (kernels/csr5.hpp, nat_tile)
     TileWindows *wins = nullptr;
     int *tile_ptr = nullptr, *run_len = nullptr, *col = nullptr; // col: transposed global columns (freed when every group is staged)
@@ -755,7 +756,7 @@ static int build_csr5(spmv_dev *d, Csr5Plan &P, int m, long long nnz, const int 
     if (empty_rows > 0) { // build over the compacted (non-empty) row space
         if (out_rows) return fail(SPMV_HIP_E_ARG, "csr5: a row map and empty rows cannot be combined");
         const int nb = (int) (((long long) m + kScanTile - 1) / kScanTile);
-        int *flags = nullptr, *sums = nullptr, *total = nullptr, *rp2 = nullptr, *rmap = nullptr;
+        int *flags = nullptr, *sums = nullptr, *total = nullptr, *rp2 = nullptr, *rmap = nullptr, *elist = nullptr;
         HIP_TRY(hipMalloc((void **) &flags, sizeof(int) * (size_t) m));
         auto cleanup = [&]() { (void) hipFree(flags); };
         if (dev_alloc(d, (void **) &sums, sizeof(int) * (size_t) nb, true) || dev_alloc(d, (void **) &total, sizeof(int), true)) { cleanup(); return SPMV_HIP_E_ALLOC; }
@@ -765,8 +766,9 @@ static int build_csr5(spmv_dev *d, Csr5Plan &P, int m, long long nnz, const int 
         if (hipMemcpyAsync(&m2, total, sizeof(int), hipMemcpyDeviceToHost, d->stream) != hipSuccess ||
             hipStreamSynchronize(d->stream) != hipSuccess) { cleanup(); return fail(SPMV_HIP_E_RUNTIME, "csr5 compaction scan failed"); }
         if (dev_alloc(d, (void **) &rp2, sizeof(int) * ((size_t) m2 + 1), true) ||
-            dev_alloc(d, (void **) &rmap, sizeof(int) * (size_t) (m2 > 0 ? m2 : 1), true)) { cleanup(); return SPMV_HIP_E_ALLOC; }
-        csr5_compact_kernel<<<nb, kBlock, 0, d->stream>>>(m, flags, sums, rowptr, rp2, rmap);
+            dev_alloc(d, (void **) &rmap, sizeof(int) * (size_t) (m2 > 0 ? m2 : 1), true) ||
+            dev_alloc(d, (void **) &elist, sizeof(int) * (size_t) (m - m2 > 0 ? m - m2 : 1), true)) { cleanup(); return SPMV_HIP_E_ALLOC; }
+        csr5_compact_kernel<<<nb, kBlock, 0, d->stream>>>(m, flags, sums, rowptr, rp2, rmap, elist);
         const int nnz32 = (int) nnz;
         hipError_t e = hipMemcpyAsync(rp2 + m2, &nnz32, sizeof(int), hipMemcpyHostToDevice, d->stream);
         if (e == hipSuccess) e = hipStreamSynchronize(d->stream);
@@ -774,7 +776,8 @@ static int build_csr5(spmv_dev *d, Csr5Plan &P, int m, long long nnz, const int 
         if (e != hipSuccess) return fail(SPMV_HIP_E_RUNTIME, "csr5 compaction: %s", hipGetErrorString(e));
         rp = rp2;
         P.row_map = rmap;
-        P.zero_fill = true;
+        P.n_empty = m - m2;
+        P.empty_list = elist;
     }
     P.m2 = m2;
     switch (sigma) {
@@ -952,20 +955,20 @@ static void launch_csr5_form(spmv_dev *d, const Csr5Plan &P, const T *x, T *y)
             if (lds > 16 * 1024) // static tile buffers (up to 46 KiB) + this may pass the default 64 KiB limit
                 (void) hipFuncSetAttribute((const void *) nat_group_kernel<T, SIGMA, MAPPED>, hipFuncAttributeMaxDynamicSharedMemorySize, (int) lds);
             nat_group_kernel<T, SIGMA, MAPPED><<<P.groups, kBlock, lds, d->stream>>>(P.tiles, (int) P.nnz, P.tile_ptr, P.desc, P.col, P.col16, (const T *) P.val,
-                                                                                    P.row_map, P.wins, x, y, (T *) P.carry);
+                                                                                    P.row_map, P.wins, x, y, (T *) P.carry, P.n_empty, P.empty_list);
             return;
         }
         if (lds > 64 * 1024) // above the default dynamic-LDS limit: raise it for this instantiation (idempotent, cheap)
             (void) hipFuncSetAttribute((const void *) csr5_group_kernel<T, SIGMA, MAPPED>, hipFuncAttributeMaxDynamicSharedMemorySize, (int) lds);
         csr5_group_kernel<T, SIGMA, MAPPED><<<P.groups, kBlock, lds, d->stream>>>(P.tiles, P.tile_ptr, P.desc, P.col, P.col16, (const T *) P.val, P.row_map, P.wins,
-                                                                                 x, y, (T *) P.carry);
+                                                                                 x, y, (T *) P.carry, P.n_empty, P.empty_list);
         return;
     }
     const int grid = grid_for(P.tiles, kBlock / kWave, INT_MAX);
     if (P.natural)
-        nat_kernel<T, SIGMA, MAPPED><<<grid, kBlock, 0, d->stream>>>(P.tiles, (int) P.nnz, P.tile_ptr, P.desc, P.col, (const T *) P.val, P.row_map, x, y, (T *) P.carry);
+        nat_kernel<T, SIGMA, MAPPED><<<grid, kBlock, 0, d->stream>>>(P.tiles, (int) P.nnz, P.tile_ptr, P.desc, P.col, (const T *) P.val, P.row_map, x, y, (T *) P.carry, P.n_empty, P.empty_list);
     else
-        csr5_kernel<T, SIGMA, MAPPED><<<grid, kBlock, 0, d->stream>>>(P.tiles, P.tile_ptr, P.desc, P.col, (const T *) P.val, P.row_map, x, y, (T *) P.carry);
+        csr5_kernel<T, SIGMA, MAPPED><<<grid, kBlock, 0, d->stream>>>(P.tiles, P.tile_ptr, P.desc, P.col, (const T *) P.val, P.row_map, x, y, (T *) P.carry, P.n_empty, P.empty_list);
 }
 
 template <typename T, int SIGMA>
@@ -980,7 +983,6 @@ template <typename T>
 static int launch_csr5(spmv_dev *d, const Csr5Plan &P, const T *x, T *y)
 {
     if (P.nnz == 0) return SPMV_HIP_OK;
-    if (P.zero_fill) HIP_TRY(hipMemsetAsync(y, 0, sizeof(T) * (size_t) d->m, d->stream)); // empty rows
     switch (P.sigma) {
     case 4: launch_csr5_sigma<T, 4>(d, P, x, y); break;
     case 8: launch_csr5_sigma<T, 8>(d, P, x, y); break;
