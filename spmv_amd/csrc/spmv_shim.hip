@@ -931,9 +931,12 @@ static int autotune_vector(spmv_dev *d)
         }
     float best = 1e30f;
     int best_c = VEC_AUTO;
-    for (int k = 0; k < kCand; ++k) {
+    for (int k = 0; k < kCand - 1; ++k) {
         if (tmin[k] < best) { best = tmin[k]; best_c = cand[k]; }
     }
+    // the pipe form (int32 columns, global gathers) only on a clear win: a noisy sample -- e.g. another
+    // process on the device during create -- must not cost 30 % on every later launch
+    if (tmin[kCand - 1] < 0.95f * best) { best = tmin[kCand - 1]; best_c = VEC_PIPE; }
     d->tune_ms[0] = tmin[0] < tmin[1] ? tmin[0] : tmin[1]; // tile, 4 steps in flight (best of the two issue orders)
     d->tune_ms[1] = tmin[2] < tmin[3] ? tmin[2] : tmin[3]; // tile, 2 steps in flight
     d->tune_ms[2] = tmin[4];                               // pipe
