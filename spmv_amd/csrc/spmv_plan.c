@@ -32,6 +32,9 @@ static opt_t g_opts[] = {
     {"sell_c", 64, 64, 64, 1, 0},          /* one wavefront per chunk: C is the wave width */
     {"sell_sigma", 1024, 64, 1 << 20, 1, 0},
     {"sell_lds_x", 1, 0, 1, 0, 0},
+    {"slab_kib", 0, 0, 1 << 16, 1, 0},     /* row-block x column-slab executor: KiB of x per column slab (0 = 256) */
+    {"block_rows", 0, 0, 16384, 1, 0},     /* ... rows per block (0 = 64 KiB of y) */
+    {"cache_block", 1, 0, 2, 0, 0},        /* nnz-split family: 1 = row-block x column-slab executor when no x window can be staged (automatic), 2 = always, 0 = never */
     {"csr5_sigma", 0, 0, 16, 0, 0},
     {"rowblock_nnz", 0, 0, 1 << 20, 0, 0},
     {"variant", 0, 0, 1 << 20, 0, 0},
@@ -169,6 +172,9 @@ void spmv_plan_choose(SPMV_METHODS requested, const spmv_stats *st, size_t value
     plan->sell_c = (int) spmv_hip_get_option("sell_c");
     plan->sell_sigma = (int) spmv_hip_get_option("sell_sigma");
     plan->sell_lds_x = (int) spmv_hip_get_option("sell_lds_x");
+    plan->cache_block = (int) spmv_hip_get_option("cache_block");
+    plan->slab_kib = (int) spmv_hip_get_option("slab_kib");
+    plan->block_rows = (int) spmv_hip_get_option("block_rows");
     plan->csr5_sigma = (int) spmv_hip_get_option("csr5_sigma");
     /* one workgroup's equal-nnz share (Method_Balanced): 8192 nnz ~ the 256 rows x 32 of a CSR-vector
      * tile; a row longer than the share flips the handle to Method_Balanced2 like the reference */

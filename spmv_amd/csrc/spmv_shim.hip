@@ -28,6 +28,7 @@
 #include "kernels/sell.hpp"
 #include "kernels/csr5.hpp"
 #include "kernels/long_rows.hpp"
+#include "kernels/blocked.hpp"
 #include "kernels/csr_vector_tile.hpp"
 
 using namespace spmv;
@@ -123,6 +124,13 @@ struct spmv_dev {
     void *sval = nullptr;
     // csr5
     Csr5Plan c5, c5_long, ns; // ns: the natural-layout plan of the nnz-split schedule
+    // row blocks x column slabs (kernels/blocked.hpp): the nnz-split executor for columns without locality
+    bool blk_on = false;
+    int blk_R = 0, blk_K = 0, blk_B = 0;
+    long long *blk_start = nullptr, *blk_end = nullptr;
+    void *blk_val = nullptr;
+    int *blk_col = nullptr;
+    unsigned short *blk_row = nullptr;
     // long-row sub-matrix (rows longer than long_thr, in row order), the input of c5_long
     int *lsub_rowptr = nullptr, *lsub_colidx = nullptr;
     void *lsub_val = nullptr;
@@ -173,6 +181,7 @@ static void free_schedule(spmv_dev *d)
     d->c5 = Csr5Plan();
     d->c5_long = Csr5Plan();
     d->ns = Csr5Plan();
+    d->blk_on = false; d->blk_start = d->blk_end = nullptr; d->blk_val = nullptr; d->blk_col = nullptr; d->blk_row = nullptr;
     d->lsub_rowptr = d->lsub_colidx = nullptr; d->lsub_val = nullptr; d->lsub_nnz = 0;
     d->built = false;
 }
@@ -787,6 +796,56 @@ static int build_csr5(spmv_dev *d, Csr5Plan &P, int m, long long nnz, const int 
     }
 }
 
+// Row blocks x column slabs (kernels/blocked.hpp).  R rows per block: y of a block = 64 KiB of LDS;
+// W columns per slab: 256 KiB of x.
+template <typename T>
+static int build_blocked(spmv_dev *d)
+{
+    const int R = d->plan.block_rows > 0 ? d->plan.block_rows : (int) (64 * 1024 / sizeof(T));
+    const size_t slab_bytes = (size_t) (d->plan.slab_kib > 0 ? d->plan.slab_kib : 256) << 10;
+    int wshift = 0;
+    while ((sizeof(T) << wshift) < slab_bytes) ++wshift;
+    const int K = (int) ((((long long) d->n - 1) >> wshift) + 1);
+    const int B = (int) (((long long) d->m + R - 1) / R);
+    if ((long long) B * K > (1ll << 26)) return SPMV_HIP_OK; // cell table too large: keep the tile executor
+    int *cnt = nullptr, *tot = nullptr;
+    long long *cursor = nullptr;
+    const size_t cells = (size_t) B * K;
+    HIP_TRY(hipMalloc((void **) &cnt, sizeof(int) * cells));
+    auto cleanup = [&]() { (void) hipFree(cnt); if (tot) (void) hipFree(tot); if (cursor) (void) hipFree(cursor); };
+    if (hipMalloc((void **) &tot, sizeof(int) * (size_t) B) != hipSuccess || hipMalloc((void **) &cursor, sizeof(long long) * cells) != hipSuccess) {
+        cleanup();
+        return fail(SPMV_HIP_E_ALLOC, "hipMalloc(block cells)");
+    }
+    int rc = dev_alloc(d, (void **) &d->blk_start, sizeof(long long) * ((size_t) B + 1), true);
+    if (!rc) rc = dev_alloc(d, (void **) &d->blk_end, sizeof(long long) * (size_t) B, true);
+    if (rc) { cleanup(); return rc; }
+    hipError_t e = hipMemsetAsync(cnt, 0, sizeof(int) * cells, d->stream);
+    blk_count_kernel<<<grid_for(d->m, kBlock / 16, d->cus * 16), kBlock, 0, d->stream>>>(d->m, R, K, wshift, d->rowptr, d->colidx, cnt);
+    blk_totals_kernel<<<grid_for(B, kBlock, INT_MAX), kBlock, 0, d->stream>>>(B, K, cnt, tot);
+    scan_i32_to_i64_kernel<<<1, kBlock, 0, d->stream>>>(B, tot, d->blk_start);
+    blk_cells_kernel<<<grid_for(B, kBlock, INT_MAX), kBlock, 0, d->stream>>>(B, K, cnt, d->blk_start, cursor, d->blk_end);
+    long long total = 0;
+    if (e == hipSuccess) e = hipGetLastError();
+    if (e == hipSuccess) e = hipMemcpyAsync(&total, d->blk_start + B, sizeof(long long), hipMemcpyDeviceToHost, d->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(d->stream);
+    if (e != hipSuccess) { cleanup(); return fail(SPMV_HIP_E_RUNTIME, "block inspector: %s", hipGetErrorString(e)); }
+    const size_t slots = (size_t) total + 4096; // the last groups of a block read up to 3 load groups past its end
+    rc = dev_alloc(d, &d->blk_val, sizeof(T) * slots, true);
+    if (!rc) rc = dev_alloc(d, (void **) &d->blk_col, sizeof(int) * slots, true);
+    if (!rc) rc = dev_alloc(d, (void **) &d->blk_row, sizeof(unsigned short) * slots, true);
+    if (rc) { cleanup(); return rc; }
+    blk_fill_kernel<T><<<grid_for(d->m, kBlock / 16, d->cus * 16), kBlock, 0, d->stream>>>(d->m, R, K, wshift, d->rowptr, d->colidx, (const T *) d->val,
+                                                                                       (unsigned long long *) cursor, (T *) d->blk_val, d->blk_col, d->blk_row);
+    e = hipGetLastError();
+    if (e == hipSuccess) e = hipStreamSynchronize(d->stream);
+    cleanup();
+    if (e != hipSuccess) return fail(SPMV_HIP_E_RUNTIME, "block fill: %s", hipGetErrorString(e));
+    d->blk_R = R; d->blk_K = K; d->blk_B = B;
+    d->blk_on = true;
+    return SPMV_HIP_OK;
+}
+
 extern "C" int spmv_shim_build(spmv_dev *d, const spmv_plan *plan)
 {
     if (!d || !plan) return fail(SPMV_HIP_E_ARG, "build: NULL");
@@ -817,12 +876,21 @@ extern "C" int spmv_shim_build(spmv_dev *d, const spmv_plan *plan)
         // equal-nnz tiles over the matrix's own arrays: CSR5 descriptors + carry fix-up, natural layout
         rc = f64 ? build_csr5<double>(d, d->ns, d->m, d->nnz, d->rowptr, d->colidx, (const double *) d->val, d->stats.empty_rows, d->stats.mean_row_len, nullptr, true)
                  : build_csr5<float>(d, d->ns, d->m, d->nnz, d->rowptr, d->colidx, (const float *) d->val, d->stats.empty_rows, d->stats.mean_row_len, nullptr, true);
+        // columns without locality (no tile group's x windows fit LDS) and x far larger than an L2: gathers are
+        // fabric-bound -> row blocks x column slabs (kernels/blocked.hpp)
+        if (!rc && (plan->cache_block == 2 ||
+                    (plan->cache_block == 1 && d->ns.staged == 0 && d->nnz >= (1ll << 22) && (long long) d->n * (long long) d->vsize >= (16ll << 20))))
+            rc = f64 ? build_blocked<double>(d) : build_blocked<float>(d);
         break;
     case SPMV_SCHED_ROWBLOCK:
         if (plan->rowblock_nnz < 64) return fail(SPMV_HIP_E_ARG, "rowblock_nnz must be >= 64");
         if (d->stats.max_row_len > plan->rowblock_nnz) return fail(SPMV_HIP_E_ARG, "row-block schedule needs max_row_len <= rowblock_nnz");
         rc = build_rowblock(d);
         if (!rc) rc = f64 ? build_rowblock_tiles<double>(d) : build_rowblock_tiles<float>(d);
+        // same fall-back as nnz-split for columns without locality (Method_Balanced and Method_Balanced2 are one family)
+        if (!rc && (plan->cache_block == 2 ||
+                    (plan->cache_block == 1 && d->vt_staged == 0 && d->nnz >= (1ll << 22) && (long long) d->n * (long long) d->vsize >= (16ll << 20))))
+            rc = f64 ? build_blocked<double>(d) : build_blocked<float>(d);
         break;
     case SPMV_SCHED_SELL: rc = f64 ? build_sell<double>(d) : build_sell<float>(d); break;
     case SPMV_SCHED_CSR5:
@@ -949,6 +1017,14 @@ static int autotune_vector(spmv_dev *d)
     return SPMV_HIP_OK;
 }
 
+template <typename T>
+static void launch_blocked(spmv_dev *d, const T *x, T *y)
+{
+    const size_t lds = (size_t) d->blk_R * sizeof(T);
+    if (lds > 64 * 1024) (void) hipFuncSetAttribute((const void *) blk_kernel<T>, hipFuncAttributeMaxDynamicSharedMemorySize, (int) lds);
+    blk_kernel<T><<<d->blk_B, kBlkThreads, lds, d->stream>>>(d->m, d->blk_R, d->blk_start, d->blk_end, (const T *) d->blk_val, d->blk_col, d->blk_row, x, y);
+}
+
 template <typename T, int SIGMA, bool MAPPED>
 static void launch_csr5_form(spmv_dev *d, const Csr5Plan &P, const T *x, T *y)
 {
@@ -1028,6 +1104,7 @@ static int launch(spmv_dev *d, const T *x, T *y)
         if (d->plan.variant != 2) launch_long_rows<T>(d, x, y);
         break;
     case SPMV_SCHED_NNZ_SPLIT: {
+        if (d->blk_on) { launch_blocked<T>(d, x, y); break; }
         if (d->plan.variant != 8) {
             const int rc = launch_csr5<T>(d, d->ns, x, y);
             if (rc) return rc;
@@ -1048,6 +1125,7 @@ static int launch(spmv_dev *d, const T *x, T *y)
         break;
     }
     case SPMV_SCHED_ROWBLOCK:
+        if (d->blk_on) { launch_blocked<T>(d, x, y); break; }
         if (d->plan.variant == 7 && d->rb_stride <= 4096) { // A/B: the first-round LDS-products kernel
             rowblock_kernel<T><<<d->nblocks, kBlock, 2 * (size_t) d->rb_stride * sizeof(T), d->stream>>>(d->rb_split, d->rowptr, d->colidx, val, x, y);
             break;
@@ -1200,7 +1278,8 @@ extern "C" int spmv_shim_info(const spmv_dev *d, spmv_hip_info *o)
     if (d->plan.sched == SPMV_SCHED_CSR_VECTOR && d->vt_tiles > 0 && d->vec_choice != VEC_PIPE &&
         (d->vt_staged * 2 >= d->vt_tiles || (d->vec_choice != VEC_AUTO && d->vec_choice != VEC_PIPE)))
         o->kernel_name = "csr_vector_tile_kernel";
-    if (d->plan.sched == SPMV_SCHED_NNZ_SPLIT)
+    if (d->blk_on) o->kernel_name = "blk_kernel";
+    else if (d->plan.sched == SPMV_SCHED_NNZ_SPLIT)
         o->kernel_name = d->plan.variant == 8 ? (d->ns_staged > 0 ? "nnz_group_kernel" : "nnz_split_kernel") : (d->ns.staged > 0 ? "nat_group_kernel" : "nat_kernel");
     if (d->plan.sched == SPMV_SCHED_CSR5 && d->c5.staged > 0) o->kernel_name = "csr5_group_kernel";
     if (d->plan.sched == SPMV_SCHED_SELL && d->sell_staged > 0) o->kernel_name = "sell_window_kernel";

@@ -82,6 +82,24 @@ def test_golden_device_pointers(name, method):
     check(yd.cpu().numpy(), csr, x, y_ref, exact=name.endswith("eighths"))
 
 
+@pytest.mark.parametrize("method", [M.Method_Balanced, M.Method_Balanced2, M.Method_Balanced_Yid], ids=lambda m: m.name)
+@pytest.mark.parametrize("name", NAMES)
+def test_golden_row_block_column_slab_executor(name, method):
+    """Option cache_block = 2 forces the executor that big matrices without column locality get
+    automatically (kernels/blocked.hpp): y of a row block accumulates in LDS by floating-point atomics, so
+    the bar is bit-exact on exact-arithmetic inputs and the north_star tolerance otherwise."""
+    csr, x, y_ref = load_golden(name)
+    api.set_option("cache_block", 2)
+    try:
+        y, actual = run_host(csr, x, method)
+        y2, _ = run_host(csr, x, method)
+    finally:
+        api.set_option("cache_block", 1)
+    assert actual in (M.Method_Balanced2, M.Method_Balanced_Yid, M.Method_Balanced)
+    check(y, csr, x, y_ref, exact=name.endswith("eighths"))
+    check(y2, csr, x, y_ref, exact=name.endswith("eighths"))
+
+
 @pytest.mark.parametrize("way", list(api.VECTORIZED_WAY)[:4], ids=lambda w: w.name)
 def test_every_vectorized_way_runs_the_hip_backend(way):
     """The reference stores vectorizedWay and never reads it (common.c:80); here all four values
