@@ -81,6 +81,9 @@ typedef struct spmv_hip_info {
     const char *kernel_name;    /* symbol of the dominant kernel (as rocprofv3 shows it) */
     int tuned_choice;           /* csr-vector autotune: 0 none, 10/11 tile 4-deep, 5/12 tile 2-deep, 4 pipe */
     float tune_ms[3];           /* measured ms of {tile/4-deep, tile/2-deep, pipe} at create (0 if not tuned) */
+    int x_groups;               /* tiles / tile groups / sigma windows the inspector analysed for x windows */
+    int x_groups_staged;        /* ... of which have their x windows staged in LDS (0: every gather goes to L1/L2) */
+    int cache_blocked;          /* 1: the row-block x column-slab executor runs (option "cache_block") */
 } spmv_hip_info;
 int spmv_hip_get_info(spmv_Handle_t handle, spmv_hip_info *out);
 

@@ -64,7 +64,8 @@ class spmv_hip_info(C.Structure):
                 ("mean_row_len", C.c_double), ("device_bytes", C.c_longlong),
                 ("alg_bytes", C.c_longlong), ("inspect_ms", C.c_double),
                 ("schedule_name", C.c_char_p), ("kernel_name", C.c_char_p),
-                ("tuned_choice", C.c_int), ("tune_ms", C.c_float * 3)]
+                ("tuned_choice", C.c_int), ("tune_ms", C.c_float * 3),
+                ("x_groups", C.c_int), ("x_groups_staged", C.c_int), ("cache_blocked", C.c_int)]
 
 
 # Every symbol include/*.h declares: functions with their prototypes, then data symbols.

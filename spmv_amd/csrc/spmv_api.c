@@ -160,6 +160,32 @@ static int state_build(spmv_Handle_t h, spmv_hip_state *st, int m, int n, const 
         st->dev = NULL;
         return rc;
     }
+    /* automatic choice, second stage: the row statistics cannot see whether the COLUMNS have locality.  If
+     * the schedule just built could not stage a single x window on a matrix whose x is far larger than an
+     * L2, every gather crosses the fabric -- rebuild as nnz-split, whose executor for that case keeps y of
+     * a row block in LDS and walks the entries column slab by column slab (kernels/blocked.hpp). */
+    if (spmv_hip_get_option("auto_method") == 1 && spmv_hip_get_option("cache_block") != 0 &&
+        (st->plan.sched == SPMV_SCHED_CSR_VECTOR || st->plan.sched == SPMV_SCHED_CSR5)) {
+        spmv_hip_info info;
+        if (spmv_shim_info(st->dev, &info) == SPMV_HIP_OK && info.x_groups > 0 && info.x_groups_staged == 0 &&
+            info.nnz >= (1ll << 22) && (long long) n * (long long) h->data_size >= (16ll << 20)) {
+            spmv_plan second;
+            SPMV_METHODS second_actual = Method_Balanced_Yid;
+            spmv_plan_choose_ex(Method_Balanced_Yid, &stats, (size_t) h->data_size, &second, &second_actual, 0);
+            if (spmv_shim_build(st->dev, &second) == SPMV_HIP_OK) {
+                st->plan = second;
+                actual = second_actual;
+            } else { /* keep the first choice */
+                rc = spmv_shim_build(st->dev, &st->plan);
+                if (rc) {
+                    spmv_set_error(rc, "create/inspect", spmv_shim_error_text());
+                    spmv_shim_matrix_destroy(st->dev);
+                    st->dev = NULL;
+                    return rc;
+                }
+            }
+        }
+    }
     if (st->stream_set) spmv_shim_set_stream(st->dev, st->stream);
     spmv_shim_set_async(st->dev, st->async);
     st->m = m;

@@ -24,5 +24,8 @@ void spmv_set_error(int code, const char *where, const char *what);
  * parallel_balanced2_spmv.c:87-92). */
 void spmv_plan_choose(SPMV_METHODS requested, const spmv_stats *stats, size_t value_size,
                       spmv_plan *plan, SPMV_METHODS *actual);
+/* allow_auto = 0: ignore option "auto_method" (second stage of the automatic choice, spmv_api.c) */
+void spmv_plan_choose_ex(SPMV_METHODS requested, const spmv_stats *st, size_t value_size,
+                         spmv_plan *plan, SPMV_METHODS *actual, int allow_auto);
 
 #endif

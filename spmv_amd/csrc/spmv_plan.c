@@ -164,6 +164,12 @@ static void choose_vector_shape(const spmv_stats *st, int *lanes_out, int *thr_o
 void spmv_plan_choose(SPMV_METHODS requested, const spmv_stats *st, size_t value_size,
                       spmv_plan *plan, SPMV_METHODS *actual)
 {
+    spmv_plan_choose_ex(requested, st, value_size, plan, actual, 1);
+}
+
+void spmv_plan_choose_ex(SPMV_METHODS requested, const spmv_stats *st, size_t value_size,
+                         spmv_plan *plan, SPMV_METHODS *actual, int allow_auto)
+{
     long lanes = spmv_hip_get_option("lanes_per_row");
     long rb = spmv_hip_get_option("rowblock_nnz");
     memset(plan, 0, sizeof *plan);
@@ -190,7 +196,7 @@ void spmv_plan_choose(SPMV_METHODS requested, const spmv_stats *st, size_t value
      *   everything else (skewed, very short or many empty rows)              -> CSR5
      * (measured: CSR-vector leads on regular shapes without inspector cost, CSR5 on skewed and
      * power-law shapes -- DESIGN.md section 3).  The handle reports the method actually used. */
-    if (spmv_hip_get_option("auto_method") == 1 && st->m > 0) {
+    if (allow_auto && spmv_hip_get_option("auto_method") == 1 && st->m > 0) {
         const int regular = st->mean_row_len >= 4.0 && (double) st->max_row_len <= 4.0 * st->mean_row_len &&
                             (double) st->empty_rows <= 0.01 * (double) st->m;
         requested = regular ? Method_Parallel : Method_CSR5SPMV;

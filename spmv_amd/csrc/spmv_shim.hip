@@ -1278,6 +1278,15 @@ extern "C" int spmv_shim_info(const spmv_dev *d, spmv_hip_info *o)
     if (d->plan.sched == SPMV_SCHED_CSR_VECTOR && d->vt_tiles > 0 && d->vec_choice != VEC_PIPE &&
         (d->vt_staged * 2 >= d->vt_tiles || (d->vec_choice != VEC_AUTO && d->vec_choice != VEC_PIPE)))
         o->kernel_name = "csr_vector_tile_kernel";
+    o->cache_blocked = d->blk_on ? 1 : 0;
+    switch (d->plan.sched) {
+    case SPMV_SCHED_CSR_VECTOR:
+    case SPMV_SCHED_ROWBLOCK: o->x_groups = d->vt_tiles; o->x_groups_staged = d->vt_staged; break;
+    case SPMV_SCHED_NNZ_SPLIT: o->x_groups = d->plan.variant == 8 ? d->ns_groups : d->ns.groups; o->x_groups_staged = d->plan.variant == 8 ? d->ns_staged : d->ns.staged; break;
+    case SPMV_SCHED_SELL: o->x_groups = d->sell_nwin; o->x_groups_staged = d->sell_staged; break;
+    case SPMV_SCHED_CSR5: o->x_groups = d->c5.groups; o->x_groups_staged = d->c5.staged; break;
+    default: o->x_groups = o->x_groups_staged = 0; break;
+    }
     if (d->blk_on) o->kernel_name = "blk_kernel";
     else if (d->plan.sched == SPMV_SCHED_NNZ_SPLIT)
         o->kernel_name = d->plan.variant == 8 ? (d->ns_staged > 0 ? "nnz_group_kernel" : "nnz_split_kernel") : (d->ns.staged > 0 ? "nat_group_kernel" : "nat_kernel");

@@ -99,6 +99,54 @@ def test_config2_random_columns_and_linearity():
     assert float((yx - want).abs().max()) <= 64 * 2.3e-16 * k
 
 
+def test_random_columns_balanced_family_runs_cache_blocked_and_auto_finds_it():
+    """Config 2 with uniformly random columns: no x window can be staged, x (80 MB) dwarfs an L2 -> the
+    Balanced family runs the row-block x column-slab executor (kernels/blocked.hpp); with auto_method the
+    second stage of the automatic choice (spmv_api.c) lands there too.  Exact inputs -> exact bits; random
+    inputs -> the north_star tolerance (LDS atomics: the order of a row's additions is not fixed)."""
+    m = n = 10_000_000
+    k = 32
+    _, _, rp, ci, va = synth.uniform_k_device(m, n, k, "eighths", torch.float64, DEV, seed=13)
+    g = torch.Generator(device=DEV); g.manual_seed(15)
+    x = torch.randint(0, 8, (n,), generator=g, device=DEV).double() * 0.125
+    want = _definition_regular(m, k, ci, va, x)
+    for method in (M.Method_Balanced, M.Method_Balanced_Yid):
+        y = torch.full((m,), float("nan"), dtype=torch.float64, device=DEV)
+        with api.Handle(m, n, rp, ci, va, method) as h:
+            h.spmv(x, y)
+            info = h.info()
+        torch.cuda.synchronize()
+        assert info["cache_blocked"] == 1 and info["kernel_name"] == "blk_kernel" and info["x_groups_staged"] == 0
+        assert torch.equal(y, want)
+    api.set_option("auto_method", 1)
+    try:
+        y = torch.full((m,), float("nan"), dtype=torch.float64, device=DEV)
+        with api.Handle(m, n, rp, ci, va, M.Method_Serial) as h:
+            h.spmv(x, y)
+            info = h.info()
+            chosen = h.method
+    finally:
+        api.set_option("auto_method", 0)
+    torch.cuda.synchronize()
+    assert chosen == M.Method_Balanced_Yid and info["cache_blocked"] == 1
+    assert torch.equal(y, want)
+    # random values: tolerance
+    _, _, rp, ci, va = synth.uniform_k_device(m, n, k, "uniform", torch.float64, DEV, seed=17)
+    xr = torch.rand(n, generator=g, device=DEV, dtype=torch.float64) * 2 - 1
+    y = torch.empty(m, dtype=torch.float64, device=DEV)
+    with api.Handle(m, n, rp, ci, va, M.Method_Balanced_Yid) as h:
+        h.spmv(xr, y)
+    torch.cuda.synchronize()
+    assert float((y - _definition_regular(m, k, ci, va, xr)).abs().max()) <= 64 * 2.3e-16 * k
+    # option 0 switches it off
+    api.set_option("cache_block", 0)
+    try:
+        with api.Handle(m, n, rp, ci, va, M.Method_Balanced_Yid) as h:
+            assert h.info()["cache_blocked"] == 0
+    finally:
+        api.set_option("cache_block", 1)
+
+
 def test_config4_skewed_fp32_schedules_bit_identical():
     m = n = 10_000_000
     lens = synth.skewed_lengths_device(m, DEV, seed=2)
