@@ -56,7 +56,15 @@ int spmv_hip_synchronize(spmv_Handle_t handle);
  *                  XX[i] = X[index[i]] and scatters Y[index[i]] = YY[i] exactly as the reference's harness
  *                  does for its OPT_LEVEL 3 path, test_spmv.c:95-101, 130-137)
  *       "auto_method" (0/1: create() replaces the requested method by the one its row statistics
- *                      favour -- CSR-vector for regular rows, CSR5 otherwise; the handle reports it)
+ *                      favour -- CSR-vector for regular rows, CSR5 otherwise -- and, if that schedule cannot
+ *                      stage a single x window on a matrix whose x is far larger than an L2, by
+ *                      Method_Balanced_Yid with the cache-blocked executor; the handle reports it)
+ *       "cache_block" (0 never / 1 automatic (default) / 2 always: the Balanced family -- Method_Balanced,
+ *                      _Balanced2, _Balanced_Yid -- runs a row-block x column-slab executor when no x window
+ *                      fits LDS, nnz >= 2^22 and n * size >= 16 MiB: ~3x faster on columns without locality;
+ *                      y of a row block is accumulated by LDS floating-point atomics, so results are
+ *                      bit-reproducible only for exactly representable data)
+ *       "slab_kib" (KiB of x per column slab, 0 = 256)  "block_rows" (rows per block, 0 = 64 KiB of y)
  * Each key can also be preset with the environment variable SPMV_HIP_<KEY IN CAPS>.
  * Returns 0, or SPMV_HIP_E_ARG for an unknown key / illegal value. */
 int spmv_hip_set_option(const char *key, long value);
