@@ -226,6 +226,7 @@ def main():
         alg_bytes = 4 * (m_loc + 1) + nnz_k * (4 + s) + s * (sh.n_local if sh.split else sh.n_x) + s * m_loc
         mean_launch = float(launch_ms.mean())
         achieved = alg_bytes / (mean_launch * 1e-3) / 1e9
+        traffic = traffic_from_profiles(info["kernel_name"])
         out = {
             "metric": "SpMV GFLOP/s (fp64 CSR, y = A x through spmv())" if s == 8 else "SpMV GFLOP/s (fp32 CSR)",
             "value": round(gflops, 2), "unit": "GFLOP/s", "n_gpus": world, "steps": K, "warmup": args.warmup,
@@ -243,12 +244,14 @@ def main():
             "hbm_gbps_alg": round(achieved, 1),
             "roofline": {
                 "bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
-                "frac": round(achieved / HBM_PEAK_GBPS, 4), "traffic": traffic_from_profiles(info["kernel_name"]),
+                "frac": round(achieved / HBM_PEAK_GBPS, 4), "traffic": traffic,
+                "sustained": None if traffic is None else round(traffic / 1e9 / (mean_launch / 1e3), 1),
+                "frac_sustained": None if traffic is None else round(traffic / 1e9 / (mean_launch / 1e3) / HBM_PEAK_GBPS, 4),
                 "kernel": info["kernel_name"], "alg_bytes_per_launch": alg_bytes,
                 "launch_ms_mean": round(mean_launch, 5), "launch_ms_min": round(float(launch_ms.min()), 5),
                 "note": "achieved = SURVEY 8d algorithmic bytes (4 B ColIdx + value per nnz, RowPtr, x, y) / launch time; the kernel "
                         "reads a 2 B/nnz column stream (16-bit LDS slots) instead of ColIdx, so traffic (rocprofv3 PMC, "
-                        "profiles/) is below alg_bytes_per_launch and traffic / launch time is the HBM rate actually sustained",
+                        "profiles/) is below alg_bytes_per_launch; sustained = traffic / launch time is the HBM rate actually moved",
             },
         }
         if world == 1 and not args.no_cpu:

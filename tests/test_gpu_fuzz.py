@@ -1,0 +1,99 @@
+"""GPU differential fuzz: random shapes x every schedule x random tuning options, exact arithmetic.
+
+Values and x are multiples of 1/8 with small magnitude, so every partial sum is exactly representable
+and EVERY summation order gives the same bits: any difference from the numpy evaluation of the
+definition is an indexing / masking / carry bug, not rounding.  The shapes aim at the edges of the tile
+machinery: rows that straddle tile and lane-group boundaries, empty rows in every position, one row
+holding most of the matrix, m or n of 1, columns with and without locality (x windows staged or not),
+matrices of exactly one tile, and so on.  The reference has no such test (one RMSE check)."""
+import numpy as np
+import pytest
+
+from spmv_amd import api, build, synth
+
+pytestmark = pytest.mark.gpu
+M = api.SPMV_METHODS
+METHODS = [M.Method_Serial, M.Method_Parallel, M.Method_Balanced, M.Method_Balanced2,
+           M.Method_Balanced_Yid, M.Method_SellCSigma, M.Method_CSR5SPMV]
+
+
+@pytest.fixture(scope="module", autouse=True)
+def _lib():
+    build.build()
+    api.load()
+
+
+def _lengths(rng, m, n):
+    kind = rng.integers(0, 8)
+    if kind == 0:
+        lens = rng.integers(0, 9, m)
+    elif kind == 1:
+        lens = np.full(m, rng.integers(1, 70))
+    elif kind == 2:                                    # power law with empties
+        lens = np.floor(rng.pareto(1.3, m) * 2).astype(np.int64)
+    elif kind == 3:                                    # one row holds most of the matrix
+        lens = rng.integers(0, 4, m)
+        lens[rng.integers(0, m)] = rng.integers(1000, 20000)
+    elif kind == 4:                                    # blocks of empty rows
+        lens = rng.integers(1, 40, m)
+        for _ in range(4):
+            a = rng.integers(0, m)
+            lens[a:a + rng.integers(1, max(2, m // 3))] = 0
+        lens[0] = 0
+        lens[-1] = 0
+    elif kind == 5:                                    # lengths around the lane-group / tile sizes
+        lens = rng.choice([0, 1, 3, 4, 5, 15, 16, 17, 31, 32, 33, 63, 64, 65, 255, 256, 257, 1023, 1024, 1025], m)
+    elif kind == 6:                                    # a few very long rows among short ones
+        lens = rng.integers(2, 12, m)
+        idx = rng.integers(0, m, max(1, m // 50))
+        lens[idx] = rng.integers(300, 5000, idx.shape[0])
+    else:
+        lens = rng.integers(0, 2, m) * rng.integers(1, 200, m)
+    return np.minimum(lens, n).astype(np.int64)
+
+
+def _case(seed):
+    rng = np.random.default_rng(1000 + seed)
+    m = int(rng.choice([1, 2, 63, 64, 65, 255, 256, 257, 1000, 2500, 4097, 9000]))
+    n = int(rng.choice([1, 7, 64, 300, 1024, 5000, 70000]))
+    lens = _lengths(rng, m, n)
+    local = int(rng.choice([0, 0, 8, 200])) if n > 400 else 0
+    dtype = np.float64 if rng.integers(0, 2) else np.float32
+    csr = synth.from_row_lengths(lens, n, "eighths", dtype, seed=seed, local=local)
+    x = (rng.integers(-8, 9, n) * 0.125).astype(dtype)
+    return csr, x, rng
+
+
+def _definition(csr, x):
+    prod = csr.val.astype(np.float64) * x.astype(np.float64)[csr.colidx]
+    cs = np.concatenate([[0.0], np.cumsum(prod)])      # exact: multiples of 1/64, |sum| << 2^53 / 64
+    rp = csr.rowptr.astype(np.int64)
+    return (cs[rp[1:]] - cs[rp[:-1]]).astype(csr.val.dtype)
+
+
+OPTIONS = {"csr5_sigma": [0, 4, 8, 16], "sell_sigma": [64, 1024], "rowblock_nnz": [0, 64, 700], "lanes_per_row": [0, 1, 4, 64],
+           "cache_block": [1, 2], "variant": [0, 0, 0, 3, 13]}
+
+
+@pytest.mark.parametrize("seed", range(48))
+def test_fuzz_every_schedule_matches_the_definition(seed):
+    csr, x, rng = _case(seed)
+    want = _definition(csr, x)
+    # the exactness argument needs fp32 row sums below 2^24 / 64: true by construction (|v|,|x| <= 1, rows <= 20000)
+    chosen = {k: int(rng.choice(v)) for k, v in OPTIONS.items()}
+    defaults = {k: api.get_option(k) for k in chosen}
+    try:
+        for k, v in chosen.items():
+            api.set_option(k, v)
+        for method in METHODS:
+            y = np.full(csr.m, np.nan, dtype=csr.val.dtype)
+            h = api.spmv_create_handle_all_in_one(csr.m, csr.n, csr.rowptr, csr.colidx, csr.val, 1, method,
+                                                  csr.val.dtype.itemsize, api.VECTORIZED_WAY.VECTOR_HIP, "fuzz")
+            api.spmv(h, csr.m, csr.rowptr, csr.colidx, csr.val, x, y)
+            api.spmv_destory_handle(h)
+            assert not np.isnan(y).any(), (seed, method, chosen)
+            bad = np.nonzero(y != want)[0]
+            assert bad.size == 0, (seed, method.name, chosen, csr.m, csr.n, int(bad[0]), float(y[bad[0]]), float(want[bad[0]]))
+    finally:
+        for k, v in defaults.items():
+            api.set_option(k, v)
