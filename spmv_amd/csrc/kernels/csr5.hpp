@@ -340,7 +340,7 @@ __global__ __launch_bounds__(kBlock) void csr5_kernel(int p, const int *__restri
 constexpr int kCsr5GroupTiles = 16;
 
 template <typename T, int SIGMA, bool MAPPED>
-__global__ __launch_bounds__(kBlock) void csr5_group_kernel(int p, const int *__restrict__ tile_ptr,
+__global__ __launch_bounds__(kBlock) void csr5_group_kernel(int group_tiles, int p, const int *__restrict__ tile_ptr,
                                                             const unsigned *__restrict__ desc,
                                                             const int *__restrict__ tcol, const unsigned short *__restrict__ tcol16,
                                                             const T *__restrict__ tval,
@@ -360,8 +360,8 @@ __global__ __launch_bounds__(kBlock) void csr5_group_kernel(int p, const int *__
         __syncthreads();
     }
     const int lane = threadIdx.x & (kWave - 1);
-    const int t0 = blockIdx.x * kCsr5GroupTiles;
-    for (int k = threadIdx.x / kWave; k < kCsr5GroupTiles; k += kBlock / kWave) {
+    const int t0 = blockIdx.x * group_tiles;
+    for (int k = threadIdx.x / kWave; k < group_tiles; k += kBlock / kWave) {
         const int t = t0 + k;
         if (t >= p) break;
         if (staged) csr5_tile<T, SIGMA, MAPPED, true>(t, lane, tile_ptr, desc, tcol, tcol16, tval, row_map, x, xs, y, carry);
@@ -510,7 +510,7 @@ __global__ __launch_bounds__(kBlock) void nat_kernel(int p, int nnz, const int *
 }
 
 template <typename T, int SIGMA, bool MAPPED>
-__global__ __launch_bounds__(kBlock) void nat_group_kernel(int p, int nnz, const int *__restrict__ tile_ptr,
+__global__ __launch_bounds__(kBlock) void nat_group_kernel(int group_tiles, int p, int nnz, const int *__restrict__ tile_ptr,
                                                            const unsigned *__restrict__ desc,
                                                            const int *__restrict__ colidx, const unsigned short *__restrict__ col16,
                                                            const T *__restrict__ val,
@@ -531,8 +531,8 @@ __global__ __launch_bounds__(kBlock) void nat_group_kernel(int p, int nnz, const
         __syncthreads();
     }
     const int lane = threadIdx.x & (kWave - 1), wave = threadIdx.x / kWave;
-    const int t0 = blockIdx.x * kCsr5GroupTiles;
-    for (int k = wave; k < kCsr5GroupTiles; k += kBlock / kWave) {
+    const int t0 = blockIdx.x * group_tiles;
+    for (int k = wave; k < group_tiles; k += kBlock / kWave) {
         const int t = t0 + k;
         if (t >= p) break;
         if (staged) nat_tile<T, SIGMA, MAPPED, true>(t, lane, nnz, (unsigned) tw.total, nat_lds[wave], tile_ptr, desc, colidx, col16, val, row_map, x, xs, y, carry);

@@ -66,7 +66,7 @@ struct DevStats {
 // One CSR5 instance (kernels/csr5.hpp): the whole matrix for Method_CSR5SPMV, or the sub-matrix of
 // the long rows that CSR-vector / Balanced / SELL hand over (see build_long_rows).
 struct Csr5Plan {
-    int sigma = 0, tiles = 0, m2 = 0, fixup = 0, groups = 0, staged = 0, maxspan = 0;
+    int sigma = 0, tiles = 0, m2 = 0, fixup = 0, groups = 0, staged = 0, maxspan = 0, group_tiles = kCsr5GroupTiles;
     long long nnz = 0;
     int n_empty = 0;              // empty rows (outside row_map): the tile kernel zeroes y for them
     const int *empty_list = nullptr;
@@ -723,25 +723,44 @@ static int build_csr5_sigma(spmv_dev *d, Csr5Plan &P, const int *rp, int m2, con
     }
     HIP_TRY(hipMemcpyAsync(&P.fixup, flag, sizeof(int), hipMemcpyDeviceToHost, d->stream));
     HIP_TRY(hipStreamSynchronize(d->stream));
-    // x windows of every group of kCsr5GroupTiles tiles, in place on the transposed column copy (xwindows.hpp)
-    P.groups = (p + kCsr5GroupTiles - 1) / kCsr5GroupTiles;
-    ALLOC_TRY(d, &P.wins, sizeof(TileWindows) * (size_t) P.groups, true);
+    // x windows of every group of consecutive tiles -> the 16-bit slot stream (xwindows.hpp).  Group size:
+    // 16 tiles (natural layout: 32) unless staging the windows costs more than 15 % of the bytes the group
+    // streams -- wide windows, e.g. columns scattered +-4096 around the diagonal -- then 32 and 64 tiles are
+    // tried as long as the groups still fit LDS (config 4: CSR5 0.64 -> 0.58 ms fp32, 1.22 -> 1.05 ms fp64;
+    // narrow windows lose 3-7 % with larger groups, so they keep 16).
     static_assert(kCsr5XTileBytes / sizeof(float) <= 65536, "LDS slots must fit 16 bits");
-    if (P.natural) { // slots in matrix order; the budget leaves room for the waves' tile buffers in LDS
+    const int base_gt = P.natural ? 2 * kCsr5GroupTiles : kCsr5GroupTiles;
+    const int forced_gt = d->plan.variant == 40 ? 32 : (d->plan.variant == 41 ? 64 : (d->plan.variant == 42 ? 8 : 0)); // A/B
+    const long long total = P.natural ? P.nnz : (long long) p * TN;
+    const int max_cols = (int) ((P.natural ? kNatXTileBytes : kCsr5XTileBytes) / sizeof(T)) - 1;
+    ALLOC_TRY(d, &P.wins, sizeof(TileWindows) * (size_t) ((p + 7) / 8), true);
+    if (P.natural) {
         ALLOC_TRY(d, &P.col16, sizeof(unsigned short) * ((size_t) P.nnz + kStreamPad), true);
         HIP_TRY(hipMemsetAsync(P.col16, 0, sizeof(unsigned short) * ((size_t) P.nnz + kStreamPad), d->stream));
-        const int rc = build_range_windows(d, d->plan.variant == 3 ? 0 : P.groups, P.nnz, (long long) kCsr5GroupTiles * TN, nullptr, 1, 1,
-                                           (int) (kNatXTileBytes / sizeof(T)) - 1, P.col, P.wins, &P.staged, &P.maxspan, P.col16, 0);
-        if (rc) return rc;
-        if (P.staged == 0) { sched_free(d, P.col16); P.col16 = nullptr; }
-        return SPMV_HIP_OK;
+    } else {
+        ALLOC_TRY(d, &P.col16, sizeof(unsigned short) * (size_t) p * TN, true);
     }
-    ALLOC_TRY(d, &P.col16, sizeof(unsigned short) * (size_t) p * TN, true);
-    const int rc = build_range_windows(d, d->plan.variant == 3 ? 0 : P.groups, (long long) p * TN, (long long) kCsr5GroupTiles * TN, nullptr, 1, 1,
-                                       (int) (kCsr5XTileBytes / sizeof(T)) - 1, P.col, P.wins, &P.staged, &P.maxspan, P.col16, SIGMA);
+    auto inspect = [&](int gt) -> int {
+        P.group_tiles = gt;
+        P.groups = (p + gt - 1) / gt;
+        return build_range_windows(d, d->plan.variant == 3 ? 0 : P.groups, total, (long long) gt * TN, nullptr, 1, 1, max_cols, P.col, P.wins,
+                                   &P.staged, &P.maxspan, P.col16, P.natural ? 0 : SIGMA);
+    };
+    int rc = inspect(forced_gt ? forced_gt : base_gt);
     if (rc) return rc;
-    if (P.staged == P.groups) { sched_free(d, P.col); P.col = nullptr; }  // no group reads global columns
-    else if (P.staged == 0) { sched_free(d, P.col16); P.col16 = nullptr; }
+    while (!forced_gt && P.staged > 0 && P.group_tiles < 64 &&
+           (double) P.maxspan * sizeof(T) > 0.15 * (double) P.group_tiles * TN * (sizeof(T) + 2)) {
+        const int prev = P.group_tiles;
+        rc = inspect(prev * 2);
+        if (rc) return rc;
+        if (P.staged == 0) { // the larger groups no longer fit: back to the last size that did
+            rc = inspect(prev);
+            if (rc) return rc;
+            break;
+        }
+    }
+    if (P.staged == 0) { sched_free(d, P.col16); P.col16 = nullptr; }
+    else if (!P.natural && P.staged == P.groups) { sched_free(d, P.col); P.col = nullptr; } // no group reads global columns
     return SPMV_HIP_OK;
 }
 
@@ -1033,13 +1052,13 @@ static void launch_csr5_form(spmv_dev *d, const Csr5Plan &P, const T *x, T *y)
         if (P.natural) {
             if (lds > 16 * 1024) // static tile buffers (up to 46 KiB) + this may pass the default 64 KiB limit
                 (void) hipFuncSetAttribute((const void *) nat_group_kernel<T, SIGMA, MAPPED>, hipFuncAttributeMaxDynamicSharedMemorySize, (int) lds);
-            nat_group_kernel<T, SIGMA, MAPPED><<<P.groups, kBlock, lds, d->stream>>>(P.tiles, (int) P.nnz, P.tile_ptr, P.desc, P.col, P.col16, (const T *) P.val,
+            nat_group_kernel<T, SIGMA, MAPPED><<<P.groups, kBlock, lds, d->stream>>>(P.group_tiles, P.tiles, (int) P.nnz, P.tile_ptr, P.desc, P.col, P.col16, (const T *) P.val,
                                                                                     P.row_map, P.wins, x, y, (T *) P.carry, P.n_empty, P.empty_list);
             return;
         }
         if (lds > 64 * 1024) // above the default dynamic-LDS limit: raise it for this instantiation (idempotent, cheap)
             (void) hipFuncSetAttribute((const void *) csr5_group_kernel<T, SIGMA, MAPPED>, hipFuncAttributeMaxDynamicSharedMemorySize, (int) lds);
-        csr5_group_kernel<T, SIGMA, MAPPED><<<P.groups, kBlock, lds, d->stream>>>(P.tiles, P.tile_ptr, P.desc, P.col, P.col16, (const T *) P.val, P.row_map, P.wins,
+        csr5_group_kernel<T, SIGMA, MAPPED><<<P.groups, kBlock, lds, d->stream>>>(P.group_tiles, P.tiles, P.tile_ptr, P.desc, P.col, P.col16, (const T *) P.val, P.row_map, P.wins,
                                                                                  x, y, (T *) P.carry, P.n_empty, P.empty_list);
         return;
     }
