@@ -212,9 +212,11 @@ __device__ __forceinline__ void sell_chunk(const int *__restrict__ pc, const uns
     }
 }
 
-// One workgroup per sigma window; the window's x span is staged in LDS when it fits.
+// One workgroup per GROUP of consecutive sigma windows (chunks_per_win chunks); the group's x windows are
+// staged in LDS when they fit.  A group is one sigma window unless staging is expensive next to the
+// group's own stream (build_sell widens it then).
 template <typename T>
-__global__ __launch_bounds__(kSellWinThreads) void sell_window_kernel(int chunks_per_win,
+__global__ __launch_bounds__(kSellWinThreads) void sell_window_kernel(int chunks_per_win, long long nchunks,
                                                                       const long long *__restrict__ chunk_ptr,
                                                                       const int *__restrict__ scol,
                                                                       const unsigned short *__restrict__ scol16,
@@ -236,6 +238,7 @@ __global__ __launch_bounds__(kSellWinThreads) void sell_window_kernel(int chunks
     const int lane = threadIdx.x & (kWave - 1);
     for (int k = threadIdx.x / kWave; k < chunks_per_win; k += kSellWinThreads / kWave) {
         const long long c = (long long) w * chunks_per_win + k;
+        if (c >= nchunks) break;
         const long long c0 = chunk_ptr[c];
         const int width = (int) (chunk_ptr[c + 1] - c0);
         const int *pc = scol + (size_t) c0 * kSellC + lane;

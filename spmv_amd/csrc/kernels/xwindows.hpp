@@ -183,12 +183,19 @@ __device__ __forceinline__ void build_windows(int n, int max_cols, Loop loop, St
 // lane fetches four slots with one 8-byte load.
 __global__ __launch_bounds__(kBlock) void range_windows_kernel(long long total, long long group_len,
                                                                const long long *__restrict__ bounds, int bstride, int scale,
+                                                               long long nbounds /* bounds has nbounds + 1 entries */,
                                                                int n, int max_cols, int *__restrict__ cols,
                                                                unsigned short *__restrict__ cols16, int pack16,
                                                                TileWindows *__restrict__ wins, int *__restrict__ staged, int rewrite)
 {
     long long b, e;
-    if (bounds) { b = bounds[(long long) blockIdx.x * bstride] * scale; e = bounds[((long long) blockIdx.x + 1) * bstride] * scale; }
+    if (bounds) {
+        long long i0 = (long long) blockIdx.x * bstride, i1 = i0 + bstride;
+        if (i0 > nbounds) i0 = nbounds;
+        if (i1 > nbounds) i1 = nbounds;
+        b = bounds[i0] * scale;
+        e = bounds[i1] * scale;
+    }
     else { b = (long long) blockIdx.x * group_len; e = b + group_len; }
     if (e > total) e = total;
     auto loop = [&](auto body) {

@@ -119,7 +119,7 @@ struct spmv_dev {
     int *perm = nullptr, *scol = nullptr;
     TileWindows *sell_wins = nullptr;
     unsigned short *scol16 = nullptr; // 16-bit LDS slots of the staged sigma windows
-    int sell_nwin = 0, sell_staged = 0, sell_xcap = 0, sell_maxspan = 0; // windows, windows with x staged in LDS, LDS capacity in elements
+    int sell_nwin = 0, sell_staged = 0, sell_xcap = 0, sell_maxspan = 0, sell_group = 1; // windows, windows with x staged in LDS, LDS capacity in elements
     long long *chunk_ptr = nullptr;
     void *sval = nullptr;
     // csr5
@@ -417,7 +417,7 @@ extern "C" void spmv_shim_matrix_destroy(spmv_dev *d)
 // rewrite the array into LDS slots.  Returns staged groups (0 = array untouched) and the LDS need.
 static int build_range_windows(spmv_dev *d, int groups, long long total, long long group_len, const long long *bounds, int bstride,
                                int scale, int max_cols, int *cols, TileWindows *wins, int *staged_out, int *maxtotal_out,
-                               unsigned short *cols16 = nullptr, int pack16 = 0)
+                               unsigned short *cols16 = nullptr, int pack16 = 0, long long nbounds = 0)
 {
     int *cnt = nullptr;
     int host2[2] = {0, 0};
@@ -425,12 +425,12 @@ static int build_range_windows(spmv_dev *d, int groups, long long total, long lo
     if (groups <= 0) return SPMV_HIP_OK;
     HIP_TRY(hipMalloc((void **) &cnt, 2 * sizeof(int)));
     hipError_t e = hipMemsetAsync(cnt, 0, 2 * sizeof(int), d->stream);
-    range_windows_kernel<<<groups, kBlock, 0, d->stream>>>(total, group_len, bounds, bstride, scale, d->n, max_cols, cols, cols16, pack16, wins, cnt, 0);
+    range_windows_kernel<<<groups, kBlock, 0, d->stream>>>(total, group_len, bounds, bstride, scale, nbounds, d->n, max_cols, cols, cols16, pack16, wins, cnt, 0);
     if (e == hipSuccess) e = hipGetLastError();
     if (e == hipSuccess) e = hipMemcpyAsync(host2, cnt, sizeof host2, hipMemcpyDeviceToHost, d->stream);
     if (e == hipSuccess) e = hipStreamSynchronize(d->stream);
     if (e == hipSuccess && host2[0] * 2 >= groups) { // worth it: rewrite the staged groups into LDS slots
-        range_windows_kernel<<<groups, kBlock, 0, d->stream>>>(total, group_len, bounds, bstride, scale, d->n, max_cols, cols, cols16, pack16, wins, cnt, 1);
+        range_windows_kernel<<<groups, kBlock, 0, d->stream>>>(total, group_len, bounds, bstride, scale, nbounds, d->n, max_cols, cols, cols16, pack16, wins, cnt, 1);
         e = hipGetLastError();
         if (e == hipSuccess) e = hipStreamSynchronize(d->stream);
         *staged_out = host2[0];
@@ -674,15 +674,30 @@ static int build_sell(spmv_dev *d)
     HIP_TRY(hipGetLastError());
     d->sell_nwin = nwin;
     d->sell_staged = 0;
+    d->sell_group = 1;
     if (d->plan.sell_lds_x && d->plan.variant != 3) { // x windows of every sigma window, in place on scol (xwindows.hpp)
         static_assert(kSellXTileBytes / sizeof(float) <= 65536, "LDS slots must fit 16 bits");
         d->sell_xcap = (int) (kSellXTileBytes / sizeof(T)) - 1; // one slot stays free: the zero slot of padding entries
         ALLOC_TRY(d, &d->sell_wins, sizeof(TileWindows) * (size_t) nwin, true);
         ALLOC_TRY(d, &d->scol16, sizeof(unsigned short) * (slots + 4), true);
-        const int rc = build_range_windows(d, nwin, (long long) slots, 0, d->chunk_ptr, sigma / kSellC, kSellC, d->sell_xcap, d->scol, d->sell_wins,
-                                           &d->sell_staged, &d->sell_maxspan, d->scol16, 0);
+        // one sigma window per workgroup, or 2 / 4 / 8 consecutive ones while staging the x windows costs more
+        // than 15 % of the bytes the group streams (short rows + scattered columns: config 4)
+        auto inspect = [&](int g) -> int {
+            d->sell_group = g;
+            d->sell_nwin = (nwin + g - 1) / g;
+            return build_range_windows(d, d->sell_nwin, (long long) slots, 0, d->chunk_ptr, g * (sigma / kSellC), kSellC, d->sell_xcap, d->scol, d->sell_wins,
+                                       &d->sell_staged, &d->sell_maxspan, d->scol16, 0, d->nchunks);
+        };
+        int rc = inspect(1);
         if (rc) return rc;
-        if (d->sell_staged == nwin) { sched_free(d, d->scol); d->scol = nullptr; } // no window reads global columns
+        while (d->sell_staged > 0 && d->sell_group < 8 &&
+               (double) d->sell_maxspan * sizeof(T) > 0.15 * (double) slots * (sizeof(T) + 2) / (double) d->sell_nwin) {
+            const int prev = d->sell_group;
+            rc = inspect(prev * 2);
+            if (rc) return rc;
+            if (d->sell_staged == 0) { rc = inspect(prev); if (rc) return rc; break; }
+        }
+        if (d->sell_staged == d->sell_nwin) { sched_free(d, d->scol); d->scol = nullptr; } // no window reads global columns
         else if (d->sell_staged == 0) { sched_free(d, d->scol16); d->scol16 = nullptr; }
         HIP_TRY(hipFuncSetAttribute((const void *) sell_window_kernel<T>, hipFuncAttributeMaxDynamicSharedMemorySize, (int) kSellXTileBytes));
     }
@@ -1165,7 +1180,7 @@ static int launch(spmv_dev *d, const T *x, T *y)
         // sized by the largest staged span actually present (rounded to 16 KiB) to keep occupancy
         if (d->sell_staged > 0)
             sell_window_kernel<T><<<d->sell_nwin, kSellWinThreads, ((((size_t) d->sell_maxspan + 1) * sizeof(T)) + 1023) & ~(size_t) 1023, d->stream>>>(
-                d->plan.sell_sigma / kSellC, d->chunk_ptr, d->scol, d->scol16, (const T *) d->sval, d->perm, d->sell_wins, x, y);
+                d->sell_group * (d->plan.sell_sigma / kSellC), (long long) d->nchunks, d->chunk_ptr, d->scol, d->scol16, (const T *) d->sval, d->perm, d->sell_wins, x, y);
         else
             sell_kernel<T><<<grid_for(d->nchunks, kBlock / kWave, d->plan.variant == 1 ? d->cus * 8 : INT_MAX), kBlock, 0, d->stream>>>(
                 d->nchunks, d->chunk_ptr, d->scol, (const T *) d->sval, d->perm, x, y);
