@@ -1,0 +1,474 @@
+// shim/inspect.hpp -- part of the single translation unit spmv_shim.hip: the device-side INSPECTORS, one
+// build_* per schedule (x windows, CSR-vector tiles, long rows, row blocks, SELL, CSR5 / natural tiles,
+// row blocks x column slabs).  They run once at create (spmv_shim_build) and only launch kernels from
+// kernels/*.hpp; nothing here touches host copies of the matrix.
+#pragma once
+
+// ------------------------------------------------------------------------------------ inspectors
+// x windows over contiguous ranges of a PRIVATE column array (xwindows.hpp).  Two passes: count the
+// groups whose columns fit LDS; only if at least half do (or in_place_ok is false and any does...)
+// rewrite the array into LDS slots.  Returns staged groups (0 = array untouched) and the LDS need.
+static int build_range_windows(spmv_dev *d, int groups, long long total, long long group_len, const long long *bounds, int bstride,
+                               int scale, int max_cols, int *cols, TileWindows *wins, int *staged_out, int *maxtotal_out,
+                               unsigned short *cols16 = nullptr, int pack16 = 0, long long nbounds = 0)
+{
+    int *cnt = nullptr;
+    int host2[2] = {0, 0};
+    *staged_out = *maxtotal_out = 0;
+    if (groups <= 0) return SPMV_HIP_OK;
+    HIP_TRY(hipMalloc((void **) &cnt, 2 * sizeof(int)));
+    hipError_t e = hipMemsetAsync(cnt, 0, 2 * sizeof(int), d->stream);
+    range_windows_kernel<<<groups, kBlock, 0, d->stream>>>(total, group_len, bounds, bstride, scale, nbounds, d->n, max_cols, cols, cols16, pack16, wins, cnt, 0);
+    if (e == hipSuccess) e = hipGetLastError();
+    if (e == hipSuccess) e = hipMemcpyAsync(host2, cnt, sizeof host2, hipMemcpyDeviceToHost, d->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(d->stream);
+    if (e == hipSuccess && host2[0] * 2 >= groups) { // worth it: rewrite the staged groups into LDS slots
+        range_windows_kernel<<<groups, kBlock, 0, d->stream>>>(total, group_len, bounds, bstride, scale, nbounds, d->n, max_cols, cols, cols16, pack16, wins, cnt, 1);
+        e = hipGetLastError();
+        if (e == hipSuccess) e = hipStreamSynchronize(d->stream);
+        *staged_out = host2[0];
+        *maxtotal_out = host2[1];
+    }
+    (void) hipFree(cnt);
+    if (e != hipSuccess) return fail(SPMV_HIP_E_RUNTIME, "x-window inspector: %s", hipGetErrorString(e));
+    return SPMV_HIP_OK;
+}
+
+constexpr size_t kVecXTileBytes = 48 * 1024; // LDS budget of one row tile's x span (CSR-vector, Balanced)
+template <typename T> static int build_long_rows(spmv_dev *d, int thr);
+template <typename T>
+static int build_csr5(spmv_dev *d, Csr5Plan &P, int m, long long nnz, const int *rowptr, const int *colidx, const T *val, int empty_rows,
+                      double mean_row_len, const int *out_rows, bool natural = false);
+template <typename T> static int autotune_vector(spmv_dev *d);
+template <typename T> static int build_tile_windows(spmv_dev *d, int tiles, const int *split, int rows_per_tile = kVecTileRows);
+
+constexpr size_t kSplitXTileBytes = 48 * 1024; // LDS budget of one nnz-split tile group's x span
+
+template <typename T>
+static int build_nnz_split(spmv_dev *d)
+{
+    constexpr int tile = SplitCfg<T>::Tile;
+    d->ntiles = (int) ((d->nnz + tile - 1) / tile);
+    if (d->ntiles == 0) return SPMV_HIP_OK;
+    ALLOC_TRY(d, &d->tile_first, sizeof(int) * ((size_t) d->ntiles + 1), true);
+    ALLOC_TRY(d, &d->carry, sizeof(T) * (size_t) d->ntiles, true);
+    int *flag = nullptr;
+    ALLOC_TRY(d, &flag, sizeof(int), true);
+    HIP_TRY(hipMemsetAsync(flag, 0, sizeof(int), d->stream));
+    nnz_tile_first_kernel<<<grid_for((long long) d->ntiles + 1, kBlock, INT_MAX), kBlock, 0, d->stream>>>(
+        d->m, d->ntiles, tile, d->rowptr, d->tile_first, flag);
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipMemcpyAsync(&d->need_fixup, flag, sizeof(int), hipMemcpyDeviceToHost, d->stream));
+    HIP_TRY(hipStreamSynchronize(d->stream));
+    // x windows of every group of kSplitGroupTiles tiles (xwindows.hpp) on a private ColIdx copy
+    d->ns_groups = (d->ntiles + kSplitGroupTiles - 1) / kSplitGroupTiles;
+    ALLOC_TRY(d, &d->ns_col, sizeof(unsigned short) * ((size_t) d->nnz + kStreamPad), true);
+    ALLOC_TRY(d, &d->ns_wins, sizeof(TileWindows) * (size_t) d->ns_groups, true);
+    HIP_TRY(hipMemsetAsync(d->ns_col, 0, sizeof(unsigned short) * ((size_t) d->nnz + kStreamPad), d->stream));
+    {
+        const int rc = build_range_windows(d, d->plan.variant == 3 ? 0 : d->ns_groups, d->nnz, (long long) kSplitGroupTiles * tile, nullptr, 1, 1,
+                                           (int) (kSplitXTileBytes / sizeof(T)) - 1, d->colidx, d->ns_wins, &d->ns_staged, &d->ns_maxspan, d->ns_col, 0);
+        if (rc) return rc;
+    }
+    return SPMV_HIP_OK;
+}
+
+static int build_rowblock(spmv_dev *d)
+{
+    d->rb_stride = d->plan.rowblock_nnz;
+    d->nblocks = (int) ((d->nnz + d->rb_stride - 1) / d->rb_stride);
+    if (d->nblocks < 1) d->nblocks = 1;
+    ALLOC_TRY(d, &d->rb_split, sizeof(int) * ((size_t) d->nblocks + 1), true);
+    rowblock_split_kernel<<<grid_for((long long) d->nblocks + 1, kBlock, INT_MAX), kBlock, 0, d->stream>>>(
+        d->m, (int) d->nnz, d->nblocks, d->rb_stride, d->rowptr, d->rb_split);
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipStreamSynchronize(d->stream));
+    return SPMV_HIP_OK;
+}
+
+// Balanced executor = the CSR-vector wave program over the equal-nnz row blocks: long rows + x spans
+template <typename T>
+static int build_rowblock_tiles(spmv_dev *d)
+{
+    const int L = d->plan.lanes_per_row;
+    int rc = build_long_rows<T>(d, L * 64 > 256 ? L * 64 : 256);
+    if (rc) return rc;
+    rc = build_tile_windows<T>(d, d->nblocks, d->rb_split);
+    if (rc) return rc;
+    return SPMV_HIP_OK;
+}
+
+// Windows of every row tile + the tile-local ColIdx copy (kernels/csr_vector_tile.hpp).
+template <typename T>
+static int build_tile_windows(spmv_dev *d, int tiles, const int *split, int rows_per_tile)
+{
+    int *cnt = nullptr;
+    int host2[2] = {0, 0};
+    d->vt_tiles = tiles;
+    ALLOC_TRY(d, &cnt, 2 * sizeof(int), true);
+    static_assert(kVecXTileBytes <= 65536, "LDS byte offsets must fit 16 bits");
+    ALLOC_TRY(d, &d->vt_col, sizeof(unsigned short) * ((size_t) d->nnz + kStreamPad), true);
+    ALLOC_TRY(d, &d->vt_wins, sizeof(TileWindows) * (size_t) tiles, true);
+    HIP_TRY(hipMemsetAsync(d->vt_col, 0, sizeof(unsigned short) * ((size_t) d->nnz + kStreamPad), d->stream));
+    HIP_TRY(hipMemsetAsync(cnt, 0, 2 * sizeof(int), d->stream));
+    csr_tile_windows_kernel<<<tiles, kBlock, 0, d->stream>>>(d->m, d->n, rows_per_tile, d->long_thr, (int) (kVecXTileBytes / sizeof(T)) - 1, (int) sizeof(T), split, d->rowptr, d->colidx,
+                                                             d->vt_wins, d->vt_col, cnt);
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipMemcpyAsync(host2, cnt, 2 * sizeof(int), hipMemcpyDeviceToHost, d->stream));
+    HIP_TRY(hipStreamSynchronize(d->stream));
+    d->vt_staged = host2[0];
+    d->vt_maxspan = host2[1];
+    return SPMV_HIP_OK;
+}
+
+// LDS budget of one SELL window's x tile: 96 KiB of the CU's 160 KiB (one 512-thread workgroup per
+// window; fp32 24576 columns, fp64 12288 columns).
+constexpr size_t kSellXTileBytes = 96 * 1024;
+
+constexpr size_t kLongXTileBytes = 48 * 1024; // LDS budget of one long-row segment's x span
+
+// Rows longer than thr -> long_rows[] (row order).  Default: gathered into a sub-CSR with its own CSR5
+// plan (d->c5_long); variant 13: cut into kLongSeg segments for long_rows_kernel (kernels/long_rows.hpp).
+template <typename T>
+static int build_long_rows(spmv_dev *d, int thr)
+{
+    d->long_thr = thr;
+    d->nlong = 0;
+    d->lr_segs = 0;
+    d->c5_long = Csr5Plan();
+    if (d->stats.max_row_len <= thr) return SPMV_HIP_OK;
+    // deterministic compaction of the long rows (flags -> scan -> scatter), as csr5 does for non-empty rows
+    const int nb = (int) (((long long) d->m + kScanTile - 1) / kScanTile);
+    int *flags = nullptr, *sums = nullptr, *total = nullptr, *scratch = nullptr, *seg_cnt = nullptr;
+    ALLOC_TRY(d, &sums, sizeof(int) * (size_t) nb, true);
+    ALLOC_TRY(d, &total, sizeof(int), true);
+    HIP_TRY(hipMalloc((void **) &flags, sizeof(int) * (size_t) d->m));
+    long_rows_flag_kernel<<<grid_for(d->m, kBlock, d->cus * 8), kBlock, 0, d->stream>>>(d->m, thr, d->rowptr, flags);
+    scan_block_sums_kernel<<<nb, kBlock, 0, d->stream>>>(d->m, flags, sums);
+    scan_sums_inplace_kernel<<<1, kBlock, 0, d->stream>>>(nb, sums, total);
+    if (hipMemcpyAsync(&d->nlong, total, sizeof(int), hipMemcpyDeviceToHost, d->stream) != hipSuccess || hipStreamSynchronize(d->stream) != hipSuccess) {
+        (void) hipFree(flags);
+        d->nlong = 0;
+        return fail(SPMV_HIP_E_RUNTIME, "long-row scan failed");
+    }
+    if (d->nlong == 0) { (void) hipFree(flags); return SPMV_HIP_OK; }
+    int rc = dev_alloc(d, (void **) &d->long_rows, sizeof(int) * (size_t) d->nlong, true);
+    if (!rc) rc = dev_alloc(d, (void **) &scratch, sizeof(int) * (size_t) d->nlong, true);
+    if (rc) { (void) hipFree(flags); d->nlong = 0; return rc; }
+    csr5_compact_kernel<<<nb, kBlock, 0, d->stream>>>(d->m, flags, sums, d->rowptr, scratch, d->long_rows);
+    hipError_t e = hipStreamSynchronize(d->stream);
+    (void) hipFree(flags);
+    if (e != hipSuccess) { d->nlong = 0; return fail(SPMV_HIP_E_RUNTIME, "long-row compaction: %s", hipGetErrorString(e)); }
+    ALLOC_TRY(d, &d->lr_seg_start, sizeof(long long) * ((size_t) d->nlong + 1), true);
+
+    if (d->plan.variant != 13) { // sub-CSR of the long rows + CSR5 over it
+        long long sub_nnz = 0;
+        long_rows_len_kernel<<<grid_for(d->nlong, kBlock, INT_MAX), kBlock, 0, d->stream>>>(d->nlong, d->long_rows, d->rowptr, scratch);
+        scan_i32_to_i64_kernel<<<1, kBlock, 0, d->stream>>>(d->nlong, scratch, d->lr_seg_start);
+        HIP_TRY(hipGetLastError());
+        HIP_TRY(hipMemcpyAsync(&sub_nnz, d->lr_seg_start + d->nlong, sizeof(long long), hipMemcpyDeviceToHost, d->stream));
+        HIP_TRY(hipStreamSynchronize(d->stream));
+        d->lsub_nnz = sub_nnz;
+        ALLOC_TRY(d, &d->lsub_rowptr, sizeof(int) * ((size_t) d->nlong + 1), true);
+        ALLOC_TRY(d, &d->lsub_colidx, sizeof(int) * (size_t) sub_nnz, true);
+        ALLOC_TRY(d, &d->lsub_val, sizeof(T) * (size_t) sub_nnz, true);
+        narrow_i64_kernel<<<grid_for((long long) d->nlong + 1, kBlock, INT_MAX), kBlock, 0, d->stream>>>(d->nlong + 1, d->lr_seg_start, d->lsub_rowptr);
+        long_rows_gather_kernel<T><<<d->nlong, kBlock, 0, d->stream>>>(d->long_rows, d->rowptr, d->colidx, (const T *) d->val, d->lsub_rowptr,
+                                                                      d->lsub_colidx, (T *) d->lsub_val);
+        HIP_TRY(hipGetLastError());
+        return build_csr5<T>(d, d->c5_long, d->nlong, sub_nnz, d->lsub_rowptr, d->lsub_colidx, (const T *) d->lsub_val, 0,
+                             (double) sub_nnz / (double) d->nlong, d->long_rows);
+    }
+
+    int *cnt = total;
+    ALLOC_TRY(d, &seg_cnt, sizeof(int) * (size_t) d->nlong, true);
+    long_rows_segcount_kernel<<<grid_for(d->nlong, kBlock, INT_MAX), kBlock, 0, d->stream>>>(d->nlong, d->long_rows, d->rowptr, seg_cnt);
+    scan_i32_to_i64_kernel<<<1, kBlock, 0, d->stream>>>(d->nlong, seg_cnt, d->lr_seg_start);
+    HIP_TRY(hipGetLastError());
+    long long nsegs = 0;
+    HIP_TRY(hipMemcpyAsync(&nsegs, d->lr_seg_start + d->nlong, sizeof(long long), hipMemcpyDeviceToHost, d->stream));
+    HIP_TRY(hipStreamSynchronize(d->stream));
+    d->lr_segs = (int) nsegs;
+    ALLOC_TRY(d, &d->lr_seg_lr, sizeof(int) * (size_t) nsegs, true);
+    ALLOC_TRY(d, &d->lr_part, sizeof(T) * (size_t) nsegs, true);
+    ALLOC_TRY(d, &d->lr_seg_lo, sizeof(int) * (size_t) nsegs, true);
+    ALLOC_TRY(d, &d->lr_seg_span, sizeof(int) * (size_t) nsegs, true);
+    long_rows_segfill_kernel<<<grid_for(d->nlong, kBlock, INT_MAX), kBlock, 0, d->stream>>>(d->nlong, d->lr_seg_start, d->lr_seg_lr);
+    HIP_TRY(hipMemsetAsync(cnt, 0, sizeof(int), d->stream));
+    long_rows_segspan_kernel<<<(int) nsegs, kBlock, 0, d->stream>>>(d->lr_seg_lr, d->lr_seg_start, d->long_rows, d->rowptr, d->colidx,
+                                                                    d->lr_seg_lo, d->lr_seg_span, (int) (kLongXTileBytes / sizeof(T)), cnt);
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipMemcpyAsync(&d->lr_maxspan, cnt, sizeof(int), hipMemcpyDeviceToHost, d->stream));
+    HIP_TRY(hipStreamSynchronize(d->stream));
+    return SPMV_HIP_OK;
+}
+
+
+// x windows of every 256-row tile (kernels/csr_vector_tile.hpp)
+template <typename T>
+static int build_vector_tiles(spmv_dev *d)
+{
+    d->vt_staged = d->vt_maxspan = 0;
+    const int rows = kVecTileRows;
+    d->vt_tiles = (int) (((long long) d->m + rows - 1) / rows);
+    if (d->vt_tiles == 0 || d->nnz == 0) return SPMV_HIP_OK;
+    return build_tile_windows<T>(d, d->vt_tiles, nullptr, rows);
+}
+
+template <typename T> static int launch_csr5(spmv_dev *d, const Csr5Plan &P, const T *x, T *y);
+
+template <typename T>
+static void launch_long_rows(spmv_dev *d, const T *x, T *y)
+{
+    if (d->nlong <= 0) return;
+    if (d->c5_long.nnz > 0) { (void) launch_csr5<T>(d, d->c5_long, x, y); return; }
+    // LDS request = the largest span that is actually staged (keeps several workgroups per CU)
+    const size_t xbytes = (((size_t) d->lr_maxspan * sizeof(T)) + 1023) & ~(size_t) 1023;
+    long_rows_kernel<T><<<d->lr_segs, kBlock, xbytes, d->stream>>>(
+        d->lr_segs, (int) (kLongXTileBytes / sizeof(T)), d->lr_seg_lr, d->lr_seg_start, d->long_rows, d->lr_seg_lo, d->lr_seg_span, d->rowptr, d->colidx, (const T *) d->val, x, y, (T *) d->lr_part);
+    if (d->lr_segs > d->nlong)
+        long_rows_combine_kernel<T><<<grid_for(d->nlong, kBlock, INT_MAX), kBlock, 0, d->stream>>>(d->nlong, d->lr_seg_start, d->long_rows,
+                                                                                                  (const T *) d->lr_part, y);
+}
+
+template <typename T>
+static int build_sell(spmv_dev *d)
+{
+    const int sigma = d->plan.sell_sigma;
+    if (d->plan.sell_c != kSellC) return fail(SPMV_HIP_E_ARG, "sell_c must be 64 (one wavefront per chunk)");
+    if (sigma < kSellC || sigma > 4096 || (sigma & (sigma - 1)))
+        return fail(SPMV_HIP_E_ARG, "sell_sigma must be a power of two in [64, 4096], got %d", sigma);
+    if (d->m == 0) return SPMV_HIP_OK;
+    const int nwin = (int) (((long long) d->m + sigma - 1) / sigma);
+    d->nchunks = nwin * (sigma / kSellC);
+    // rows that would pad a whole chunk to their length are kept in CSR (see sell.hpp)
+    double thr = 8.0 * d->stats.mean_row_len;
+    if (thr < 64.0) thr = 64.0;
+    {
+        const int rc = build_long_rows<T>(d, thr > (double) INT_MAX ? INT_MAX : (int) thr);
+        if (rc) return rc;
+    }
+    int *width = nullptr;
+    ALLOC_TRY(d, &d->perm, sizeof(int) * (size_t) nwin * sigma, true);
+    ALLOC_TRY(d, &width, sizeof(int) * (size_t) d->nchunks, true);
+    ALLOC_TRY(d, &d->chunk_ptr, sizeof(long long) * ((size_t) d->nchunks + 1), true);
+    sell_sort_kernel<<<nwin, kBlock, sizeof(unsigned long long) * (size_t) sigma, d->stream>>>(
+        d->m, sigma, d->long_thr, d->rowptr, d->perm, width);
+    HIP_TRY(hipGetLastError());
+    scan_i32_to_i64_kernel<<<1, kBlock, 0, d->stream>>>(d->nchunks, width, d->chunk_ptr);
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipMemcpyAsync(&d->sell_cols, d->chunk_ptr + d->nchunks, sizeof(long long), hipMemcpyDeviceToHost, d->stream));
+    HIP_TRY(hipStreamSynchronize(d->stream));
+    const size_t slots = (size_t) d->sell_cols * kSellC;
+    ALLOC_TRY(d, &d->scol, sizeof(int) * slots, true);
+    ALLOC_TRY(d, &d->sval, sizeof(T) * slots, true);
+    sell_fill_kernel<T><<<grid_for(d->nchunks, kBlock / kWave, INT_MAX), kBlock, 0, d->stream>>>(
+        d->nchunks, d->rowptr, d->colidx, (const T *) d->val, d->perm, d->chunk_ptr, d->scol, (T *) d->sval);
+    HIP_TRY(hipGetLastError());
+    d->sell_nwin = nwin;
+    d->sell_staged = 0;
+    d->sell_group = 1;
+    if (d->plan.sell_lds_x && d->plan.variant != 3) { // x windows of every sigma window, in place on scol (xwindows.hpp)
+        static_assert(kSellXTileBytes / sizeof(float) <= 65536, "LDS slots must fit 16 bits");
+        d->sell_xcap = (int) (kSellXTileBytes / sizeof(T)) - 1; // one slot stays free: the zero slot of padding entries
+        ALLOC_TRY(d, &d->sell_wins, sizeof(TileWindows) * (size_t) nwin, true);
+        ALLOC_TRY(d, &d->scol16, sizeof(unsigned short) * (slots + 4), true);
+        // one sigma window per workgroup, or 2 / 4 / 8 consecutive ones while staging the x windows costs more
+        // than 15 % of the bytes the group streams (short rows + scattered columns: config 4)
+        auto inspect = [&](int g) -> int {
+            d->sell_group = g;
+            d->sell_nwin = (nwin + g - 1) / g;
+            return build_range_windows(d, d->sell_nwin, (long long) slots, 0, d->chunk_ptr, g * (sigma / kSellC), kSellC, d->sell_xcap, d->scol, d->sell_wins,
+                                       &d->sell_staged, &d->sell_maxspan, d->scol16, 0, d->nchunks);
+        };
+        int rc = inspect(1);
+        if (rc) return rc;
+        while (d->sell_staged > 0 && d->sell_group < 8 &&
+               (double) d->sell_maxspan * sizeof(T) > 0.15 * (double) slots * (sizeof(T) + 2) / (double) d->sell_nwin) {
+            const int prev = d->sell_group;
+            rc = inspect(prev * 2);
+            if (rc) return rc;
+            if (d->sell_staged == 0) { rc = inspect(prev); if (rc) return rc; break; }
+        }
+        if (d->sell_staged == d->sell_nwin) { sched_free(d, d->scol); d->scol = nullptr; } // no window reads global columns
+        else if (d->sell_staged == 0) { sched_free(d, d->scol16); d->scol16 = nullptr; }
+        HIP_TRY(hipFuncSetAttribute((const void *) sell_window_kernel<T>, hipFuncAttributeMaxDynamicSharedMemorySize, (int) kSellXTileBytes));
+    }
+    HIP_TRY(hipStreamSynchronize(d->stream));
+    return SPMV_HIP_OK;
+}
+
+constexpr size_t kCsr5XTileBytes = 128 * 1024; // LDS budget of one tile group's x span (a CU has 160 KiB)
+constexpr size_t kNatXTileBytes = 96 * 1024;   // same for natural-layout tiles, whose waves also park their tile in LDS (up to 46 KiB)
+
+template <typename T, int SIGMA>
+static int build_csr5_sigma(spmv_dev *d, Csr5Plan &P, const int *rp, int m2, const int *colidx, const T *val)
+{
+    constexpr int TN = kWave * SIGMA;
+    const int p = (int) ((P.nnz + TN - 1) / TN);
+    P.tiles = p;
+    ALLOC_TRY(d, &P.tile_ptr, sizeof(int) * ((size_t) p + 1), true);
+    ALLOC_TRY(d, &P.desc, sizeof(unsigned) * (size_t) p * kWave, true);
+    ALLOC_TRY(d, &P.run_len, sizeof(int) * (size_t) p, true);
+    ALLOC_TRY(d, &P.carry, sizeof(T) * (size_t) p, true);
+    if (P.natural) { // the tiles read the matrix's own arrays
+        P.col = const_cast<int *>(colidx);
+        P.val = const_cast<T *>(val);
+    } else {
+        ALLOC_TRY(d, &P.col, sizeof(int) * (size_t) p * TN, true);
+        ALLOC_TRY(d, &P.val, sizeof(T) * (size_t) p * TN, true);
+    }
+    int *flag = nullptr;
+    ALLOC_TRY(d, &flag, sizeof(int), true);
+    HIP_TRY(hipMemsetAsync(flag, 0, sizeof(int), d->stream));
+    csr5_tile_ptr_kernel<<<grid_for((long long) p + 1, kBlock, INT_MAX), kBlock, 0, d->stream>>>(m2, (int) P.nnz, p, TN, rp, P.tile_ptr);
+    HIP_TRY(hipGetLastError());
+    csr5_desc_kernel<SIGMA><<<grid_for(p, kBlock / kWave, INT_MAX), kBlock, 0, d->stream>>>(m2, (int) P.nnz, p, rp, P.tile_ptr, P.desc, P.run_len, flag);
+    HIP_TRY(hipGetLastError());
+    if (!P.natural) {
+        csr5_transpose_kernel<T, SIGMA><<<grid_for(p, kBlock / kWave, INT_MAX), kBlock, 0, d->stream>>>((int) P.nnz, p, colidx, val, P.col, (T *) P.val);
+        HIP_TRY(hipGetLastError());
+    }
+    HIP_TRY(hipMemcpyAsync(&P.fixup, flag, sizeof(int), hipMemcpyDeviceToHost, d->stream));
+    HIP_TRY(hipStreamSynchronize(d->stream));
+    // x windows of every group of consecutive tiles -> the 16-bit slot stream (xwindows.hpp).  Group size:
+    // 16 tiles (natural layout: 32) unless staging the windows costs more than 15 % of the bytes the group
+    // streams -- wide windows, e.g. columns scattered +-4096 around the diagonal -- then 32 and 64 tiles are
+    // tried as long as the groups still fit LDS (config 4: CSR5 0.64 -> 0.58 ms fp32, 1.22 -> 1.05 ms fp64;
+    // narrow windows lose 3-7 % with larger groups, so they keep 16).
+    static_assert(kCsr5XTileBytes / sizeof(float) <= 65536, "LDS slots must fit 16 bits");
+    const int base_gt = P.natural ? 2 * kCsr5GroupTiles : kCsr5GroupTiles;
+    const int forced_gt = d->plan.variant == 40 ? 32 : (d->plan.variant == 41 ? 64 : (d->plan.variant == 42 ? 8 : 0)); // A/B
+    const long long total = P.natural ? P.nnz : (long long) p * TN;
+    const int max_cols = (int) ((P.natural ? kNatXTileBytes : kCsr5XTileBytes) / sizeof(T)) - 1;
+    ALLOC_TRY(d, &P.wins, sizeof(TileWindows) * (size_t) ((p + 7) / 8), true);
+    if (P.natural) {
+        ALLOC_TRY(d, &P.col16, sizeof(unsigned short) * ((size_t) P.nnz + kStreamPad), true);
+        HIP_TRY(hipMemsetAsync(P.col16, 0, sizeof(unsigned short) * ((size_t) P.nnz + kStreamPad), d->stream));
+    } else {
+        ALLOC_TRY(d, &P.col16, sizeof(unsigned short) * (size_t) p * TN, true);
+    }
+    auto inspect = [&](int gt) -> int {
+        P.group_tiles = gt;
+        P.groups = (p + gt - 1) / gt;
+        return build_range_windows(d, d->plan.variant == 3 ? 0 : P.groups, total, (long long) gt * TN, nullptr, 1, 1, max_cols, P.col, P.wins,
+                                   &P.staged, &P.maxspan, P.col16, P.natural ? 0 : SIGMA);
+    };
+    int rc = inspect(forced_gt ? forced_gt : base_gt);
+    if (rc) return rc;
+    while (!forced_gt && P.staged > 0 && P.group_tiles < 64 &&
+           (double) P.maxspan * sizeof(T) > 0.15 * (double) P.group_tiles * TN * (sizeof(T) + 2)) {
+        const int prev = P.group_tiles;
+        rc = inspect(prev * 2);
+        if (rc) return rc;
+        if (P.staged == 0) { // the larger groups no longer fit: back to the last size that did
+            rc = inspect(prev);
+            if (rc) return rc;
+            break;
+        }
+    }
+    if (P.staged == 0) { sched_free(d, P.col16); P.col16 = nullptr; }
+    else if (!P.natural && P.staged == P.groups) { sched_free(d, P.col); P.col = nullptr; } // no group reads global columns
+    return SPMV_HIP_OK;
+}
+
+// CSR5 over the CSR (m rows, nnz) given by rowptr / colidx / val.  out_rows (nullable, no empty rows
+// allowed then) names the y row of each CSR row -- used for the long-row sub-matrix.
+template <typename T>
+static int build_csr5(spmv_dev *d, Csr5Plan &P, int m, long long nnz, const int *rowptr, const int *colidx, const T *val, int empty_rows,
+                      double mean_row_len, const int *out_rows, bool natural)
+{
+    int sigma = d->plan.csr5_sigma;
+    if (sigma == 0) sigma = mean_row_len <= 4.0 ? 4 : (mean_row_len <= 12.0 ? 8 : 16);
+    if (sigma != 4 && sigma != 8 && sigma != 16) return fail(SPMV_HIP_E_ARG, "csr5_sigma must be 4, 8 or 16 (0 = auto), got %d", sigma);
+    P = Csr5Plan();
+    P.sigma = sigma;
+    P.nnz = nnz;
+    P.row_map = out_rows;
+    P.natural = natural;
+    if (nnz == 0) return SPMV_HIP_OK;
+    const int *rp = rowptr;
+    int m2 = m;
+    if (empty_rows > 0) { // build over the compacted (non-empty) row space
+        if (out_rows) return fail(SPMV_HIP_E_ARG, "csr5: a row map and empty rows cannot be combined");
+        const int nb = (int) (((long long) m + kScanTile - 1) / kScanTile);
+        int *flags = nullptr, *sums = nullptr, *total = nullptr, *rp2 = nullptr, *rmap = nullptr, *elist = nullptr;
+        HIP_TRY(hipMalloc((void **) &flags, sizeof(int) * (size_t) m));
+        auto cleanup = [&]() { (void) hipFree(flags); };
+        if (dev_alloc(d, (void **) &sums, sizeof(int) * (size_t) nb, true) || dev_alloc(d, (void **) &total, sizeof(int), true)) { cleanup(); return SPMV_HIP_E_ALLOC; }
+        csr5_nonempty_kernel<<<grid_for(m, kBlock, d->cus * 8), kBlock, 0, d->stream>>>(m, rowptr, flags);
+        scan_block_sums_kernel<<<nb, kBlock, 0, d->stream>>>(m, flags, sums);
+        scan_sums_inplace_kernel<<<1, kBlock, 0, d->stream>>>(nb, sums, total);
+        if (hipMemcpyAsync(&m2, total, sizeof(int), hipMemcpyDeviceToHost, d->stream) != hipSuccess ||
+            hipStreamSynchronize(d->stream) != hipSuccess) { cleanup(); return fail(SPMV_HIP_E_RUNTIME, "csr5 compaction scan failed"); }
+        if (dev_alloc(d, (void **) &rp2, sizeof(int) * ((size_t) m2 + 1), true) ||
+            dev_alloc(d, (void **) &rmap, sizeof(int) * (size_t) (m2 > 0 ? m2 : 1), true) ||
+            dev_alloc(d, (void **) &elist, sizeof(int) * (size_t) (m - m2 > 0 ? m - m2 : 1), true)) { cleanup(); return SPMV_HIP_E_ALLOC; }
+        csr5_compact_kernel<<<nb, kBlock, 0, d->stream>>>(m, flags, sums, rowptr, rp2, rmap, elist);
+        const int nnz32 = (int) nnz;
+        hipError_t e = hipMemcpyAsync(rp2 + m2, &nnz32, sizeof(int), hipMemcpyHostToDevice, d->stream);
+        if (e == hipSuccess) e = hipStreamSynchronize(d->stream);
+        cleanup();
+        if (e != hipSuccess) return fail(SPMV_HIP_E_RUNTIME, "csr5 compaction: %s", hipGetErrorString(e));
+        rp = rp2;
+        P.row_map = rmap;
+        P.n_empty = m - m2;
+        P.empty_list = elist;
+    }
+    P.m2 = m2;
+    switch (sigma) {
+    case 4: return build_csr5_sigma<T, 4>(d, P, rp, m2, colidx, val);
+    case 8: return build_csr5_sigma<T, 8>(d, P, rp, m2, colidx, val);
+    default: return build_csr5_sigma<T, 16>(d, P, rp, m2, colidx, val);
+    }
+}
+
+// Row blocks x column slabs (kernels/blocked.hpp).  R rows per block: y of a block = 64 KiB of LDS;
+// W columns per slab: 256 KiB of x.
+template <typename T>
+static int build_blocked(spmv_dev *d)
+{
+    const int R = d->plan.block_rows > 0 ? d->plan.block_rows : (int) (64 * 1024 / sizeof(T));
+    const size_t slab_bytes = (size_t) (d->plan.slab_kib > 0 ? d->plan.slab_kib : 256) << 10;
+    int wshift = 0;
+    while ((sizeof(T) << wshift) < slab_bytes) ++wshift;
+    const int K = (int) ((((long long) d->n - 1) >> wshift) + 1);
+    const int B = (int) (((long long) d->m + R - 1) / R);
+    if ((long long) B * K > (1ll << 26)) return SPMV_HIP_OK; // cell table too large: keep the tile executor
+    int *cnt = nullptr, *tot = nullptr;
+    long long *cursor = nullptr;
+    const size_t cells = (size_t) B * K;
+    HIP_TRY(hipMalloc((void **) &cnt, sizeof(int) * cells));
+    auto cleanup = [&]() { (void) hipFree(cnt); if (tot) (void) hipFree(tot); if (cursor) (void) hipFree(cursor); };
+    if (hipMalloc((void **) &tot, sizeof(int) * (size_t) B) != hipSuccess || hipMalloc((void **) &cursor, sizeof(long long) * cells) != hipSuccess) {
+        cleanup();
+        return fail(SPMV_HIP_E_ALLOC, "hipMalloc(block cells)");
+    }
+    int rc = dev_alloc(d, (void **) &d->blk_start, sizeof(long long) * ((size_t) B + 1), true);
+    if (!rc) rc = dev_alloc(d, (void **) &d->blk_end, sizeof(long long) * (size_t) B, true);
+    if (rc) { cleanup(); return rc; }
+    hipError_t e = hipMemsetAsync(cnt, 0, sizeof(int) * cells, d->stream);
+    blk_count_kernel<<<grid_for(d->m, kBlock / 16, d->cus * 16), kBlock, 0, d->stream>>>(d->m, R, K, wshift, d->rowptr, d->colidx, cnt);
+    blk_totals_kernel<<<grid_for(B, kBlock, INT_MAX), kBlock, 0, d->stream>>>(B, K, cnt, tot);
+    scan_i32_to_i64_kernel<<<1, kBlock, 0, d->stream>>>(B, tot, d->blk_start);
+    blk_cells_kernel<<<grid_for(B, kBlock, INT_MAX), kBlock, 0, d->stream>>>(B, K, cnt, d->blk_start, cursor, d->blk_end);
+    long long total = 0;
+    if (e == hipSuccess) e = hipGetLastError();
+    if (e == hipSuccess) e = hipMemcpyAsync(&total, d->blk_start + B, sizeof(long long), hipMemcpyDeviceToHost, d->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(d->stream);
+    if (e != hipSuccess) { cleanup(); return fail(SPMV_HIP_E_RUNTIME, "block inspector: %s", hipGetErrorString(e)); }
+    const size_t slots = (size_t) total + 4096; // the last groups of a block read up to 3 load groups past its end
+    rc = dev_alloc(d, &d->blk_val, sizeof(T) * slots, true);
+    if (!rc) rc = dev_alloc(d, (void **) &d->blk_col, sizeof(int) * slots, true);
+    if (!rc) rc = dev_alloc(d, (void **) &d->blk_row, sizeof(unsigned short) * slots, true);
+    if (rc) { cleanup(); return rc; }
+    blk_fill_kernel<T><<<grid_for(d->m, kBlock / 16, d->cus * 16), kBlock, 0, d->stream>>>(d->m, R, K, wshift, d->rowptr, d->colidx, (const T *) d->val,
+                                                                                       (unsigned long long *) cursor, (T *) d->blk_val, d->blk_col, d->blk_row);
+    e = hipGetLastError();
+    if (e == hipSuccess) e = hipStreamSynchronize(d->stream);
+    cleanup();
+    if (e != hipSuccess) return fail(SPMV_HIP_E_RUNTIME, "block fill: %s", hipGetErrorString(e));
+    d->blk_R = R; d->blk_K = K; d->blk_B = B;
+    d->blk_on = true;
+    return SPMV_HIP_OK;
+}

@@ -1,0 +1,263 @@
+// shim/launch.hpp -- part of the single translation unit spmv_shim.hip: the EXECUTORS' launchers (which
+// kernel form, which template arguments, grid and LDS size per schedule), the create-time autotune of the
+// CSR-vector forms, and launch<T>() = one y = A x on the handle's stream.
+#pragma once
+
+// ------------------------------------------------------------------------------------ executors
+// One workgroup per kVecNB * (256/L) consecutive rows, dispatched in row order: measured on the
+// config-2 shape a plain in-order grid beats a persistent grid-stride loop by ~10 %.
+constexpr int kVecNB = 4;
+// Kernel forms of the CSR-vector schedule.  Which one is fastest differs between MI355X boxes by a
+// few percent, so create() times the applicable ones once on the resident matrix
+// (autotune_vector) and keeps the winner in d->vec_choice; plan.variant overrides for A/B runs.
+enum { VEC_AUTO = 0, VEC_STRIDED = 1, VEC_NO_LONG = 2, VEC_PIPE = 4, VEC_TILE_D2 = 5, VEC_TILE_D8 = 6, VEC_TILE_D4 = 10, VEC_TILE_D4_NOPRE = 11,
+       VEC_TILE_D2_NOPRE = 12, VEC_LONG_SEGMENTS = 13 /* long rows through long_rows_kernel instead of the CSR5 sub-matrix */ };
+
+template <typename T, int L, int DEPTH, bool PRE = true>
+static void launch_vector_tile(spmv_dev *d, const T *x, T *y, int long_thr)
+{
+    const size_t lds = ((((size_t) d->vt_maxspan + 1) * sizeof(T)) + 1023) & ~(size_t) 1023; // + the zero slot
+    if (lds > 64 * 1024)
+        (void) hipFuncSetAttribute((const void *) csr_vector_tile_kernel<T, L, DEPTH, PRE>, hipFuncAttributeMaxDynamicSharedMemorySize, (int) lds);
+    csr_vector_tile_kernel<T, L, DEPTH, PRE><<<d->vt_tiles, kVecTileThreads, lds, d->stream>>>(d->m, long_thr, d->rowptr, d->colidx, d->vt_col, (const T *) d->val,
+                                                                                           d->vt_wins, x, y);
+}
+
+template <typename T, int L>
+static void launch_vector(spmv_dev *d, const T *x, T *y)
+{
+    const int v = d->plan.variant ? d->plan.variant : d->vec_choice;
+    const int long_thr = v == VEC_NO_LONG ? INT_MAX : d->long_thr;
+    if (v == VEC_STRIDED) { // A/B: the first-round strided kernel
+        csr_vector_kernel<T, (L < 2 ? 2 : L)><<<grid_for(d->m, kBlock / (L < 2 ? 2 : L), d->cus * 32), kBlock, 0, d->stream>>>(
+            d->m, d->rowptr, d->colidx, (const T *) d->val, x, y);
+        return;
+    }
+    const bool tile_default = d->vt_staged * 2 >= d->vt_tiles; // most x tiles fit LDS
+    const bool tile_forced = v == VEC_TILE_D2 || v == VEC_TILE_D4 || v == VEC_TILE_D8 || v == VEC_TILE_D4_NOPRE || v == VEC_TILE_D2_NOPRE;
+    if (d->vt_tiles > 0 && v != VEC_PIPE && (tile_default || tile_forced)) { // tile kernel (unstaged tiles gather from L1/L2)
+        if (v == VEC_TILE_D2) launch_vector_tile<T, L, 2>(d, x, y, long_thr);
+        else if (v == VEC_TILE_D8) launch_vector_tile<T, L, 8>(d, x, y, long_thr);
+        else if (v == VEC_TILE_D4) launch_vector_tile<T, L, 4>(d, x, y, long_thr);
+        else if (v == VEC_TILE_D4_NOPRE) launch_vector_tile<T, L, 4, false>(d, x, y, long_thr);
+        else if (v == VEC_TILE_D2_NOPRE) launch_vector_tile<T, L, 2, false>(d, x, y, long_thr);
+        else launch_vector_tile<T, L, (sizeof(T) == 8 ? 4 : 2)>(d, x, y, long_thr); // measured default
+        return;
+    }
+    constexpr int rows = kBlock / L * kVecNB;
+    const int grid = grid_for(d->m, rows, INT_MAX);
+    csr_vector_pipe_kernel<T, L, kVecNB><<<grid, kBlock, 0, d->stream>>>(d->m, long_thr, d->rowptr, d->colidx, (const T *) d->val, x, y);
+}
+
+template <typename T>
+static void launch_vector_any(spmv_dev *d, const T *x, T *y)
+{
+    switch (d->plan.lanes_per_row) {
+    case 1: launch_vector<T, 1>(d, x, y); break;
+    case 2: launch_vector<T, 2>(d, x, y); break;
+    case 4: launch_vector<T, 4>(d, x, y); break;
+    case 8: launch_vector<T, 8>(d, x, y); break;
+    case 16: launch_vector<T, 16>(d, x, y); break;
+    case 32: launch_vector<T, 32>(d, x, y); break;
+    default: launch_vector<T, 64>(d, x, y); break;
+    }
+}
+
+// Time the applicable CSR-vector forms on the resident matrix (x = 1) and keep the fastest.
+template <typename T>
+static int autotune_vector(spmv_dev *d)
+{
+    d->vec_choice = VEC_AUTO;
+    if (d->nnz < (1ll << 24) || d->plan.variant != 0 || d->vt_tiles <= 0) return SPMV_HIP_OK;
+    T *x = nullptr, *y = nullptr;
+    if (hipMalloc((void **) &x, sizeof(T) * (size_t) d->n) != hipSuccess || hipMalloc((void **) &y, sizeof(T) * (size_t) d->m) != hipSuccess) {
+        (void) hipGetLastError();
+        if (x) (void) hipFree(x);
+        return SPMV_HIP_OK; // no room to tune: keep the default
+    }
+    fill_value_kernel<T><<<grid_for(d->n, kBlock, d->cus * 8), kBlock, 0, d->stream>>>(d->n, x, T(1));
+    hipEvent_t e0, e1;
+    (void) hipEventCreate(&e0);
+    (void) hipEventCreate(&e1);
+    constexpr int kCand = 5;
+    const int cand[kCand] = {VEC_TILE_D4, VEC_TILE_D4_NOPRE, VEC_TILE_D2, VEC_TILE_D2_NOPRE, VEC_PIPE};
+    float tmin[kCand];
+    for (int k = 0; k < kCand; ++k) tmin[k] = 1e30f;
+    for (int c : cand) { d->vec_choice = c; launch_vector_any<T>(d, x, y); } // warm every form once
+    for (int round = 0; round < 4; ++round) // interleaved rounds (one process, same clocks): min per form
+        for (int k = 0; k < kCand; ++k) {
+            d->vec_choice = cand[k];
+            (void) hipEventRecord(e0, d->stream);
+            launch_vector_any<T>(d, x, y);
+            launch_vector_any<T>(d, x, y);
+            (void) hipEventRecord(e1, d->stream);
+            (void) hipEventSynchronize(e1);
+            float ms = 0;
+            (void) hipEventElapsedTime(&ms, e0, e1);
+            if (ms * 0.5f < tmin[k]) tmin[k] = ms * 0.5f;
+        }
+    float best = 1e30f;
+    int best_c = VEC_AUTO;
+    for (int k = 0; k < kCand - 1; ++k) {
+        if (tmin[k] < best) { best = tmin[k]; best_c = cand[k]; }
+    }
+    // the pipe form (int32 columns, global gathers) only on a clear win: a noisy sample -- e.g. another
+    // process on the device during create -- must not cost 30 % on every later launch
+    if (tmin[kCand - 1] < 0.95f * best) { best = tmin[kCand - 1]; best_c = VEC_PIPE; }
+    d->tune_ms[0] = tmin[0] < tmin[1] ? tmin[0] : tmin[1]; // tile, 4 steps in flight (best of the two issue orders)
+    d->tune_ms[1] = tmin[2] < tmin[3] ? tmin[2] : tmin[3]; // tile, 2 steps in flight
+    d->tune_ms[2] = tmin[4];                               // pipe
+    d->vec_choice = best_c;
+    (void) hipEventDestroy(e0);
+    (void) hipEventDestroy(e1);
+    (void) hipFree(x);
+    (void) hipFree(y);
+    if (hipGetLastError() != hipSuccess) d->vec_choice = VEC_AUTO;
+    return SPMV_HIP_OK;
+}
+
+template <typename T>
+static void launch_blocked(spmv_dev *d, const T *x, T *y)
+{
+    const size_t lds = (size_t) d->blk_R * sizeof(T);
+    if (lds > 64 * 1024) (void) hipFuncSetAttribute((const void *) blk_kernel<T>, hipFuncAttributeMaxDynamicSharedMemorySize, (int) lds);
+    blk_kernel<T><<<d->blk_B, kBlkThreads, lds, d->stream>>>(d->m, d->blk_R, d->blk_start, d->blk_end, (const T *) d->blk_val, d->blk_col, d->blk_row, x, y);
+}
+
+template <typename T, int SIGMA, bool MAPPED>
+static void launch_csr5_form(spmv_dev *d, const Csr5Plan &P, const T *x, T *y)
+{
+    if (P.staged > 0) { // the inspector staged (at least half of) the groups: their column stream is the 16-bit slot array
+        const size_t lds = ((((size_t) P.maxspan + 1) * sizeof(T)) + 1023) & ~(size_t) 1023; // + the zero slot
+        if (P.natural) {
+            if (lds > 16 * 1024) // static tile buffers (up to 46 KiB) + this may pass the default 64 KiB limit
+                (void) hipFuncSetAttribute((const void *) nat_group_kernel<T, SIGMA, MAPPED>, hipFuncAttributeMaxDynamicSharedMemorySize, (int) lds);
+            nat_group_kernel<T, SIGMA, MAPPED><<<P.groups, kBlock, lds, d->stream>>>(P.group_tiles, P.tiles, (int) P.nnz, P.tile_ptr, P.desc, P.col, P.col16, (const T *) P.val,
+                                                                                    P.row_map, P.wins, x, y, (T *) P.carry, P.n_empty, P.empty_list);
+            return;
+        }
+        if (lds > 64 * 1024) // above the default dynamic-LDS limit: raise it for this instantiation (idempotent, cheap)
+            (void) hipFuncSetAttribute((const void *) csr5_group_kernel<T, SIGMA, MAPPED>, hipFuncAttributeMaxDynamicSharedMemorySize, (int) lds);
+        csr5_group_kernel<T, SIGMA, MAPPED><<<P.groups, kBlock, lds, d->stream>>>(P.group_tiles, P.tiles, P.tile_ptr, P.desc, P.col, P.col16, (const T *) P.val, P.row_map, P.wins,
+                                                                                 x, y, (T *) P.carry, P.n_empty, P.empty_list);
+        return;
+    }
+    const int grid = grid_for(P.tiles, kBlock / kWave, INT_MAX);
+    if (P.natural)
+        nat_kernel<T, SIGMA, MAPPED><<<grid, kBlock, 0, d->stream>>>(P.tiles, (int) P.nnz, P.tile_ptr, P.desc, P.col, (const T *) P.val, P.row_map, x, y, (T *) P.carry, P.n_empty, P.empty_list);
+    else
+        csr5_kernel<T, SIGMA, MAPPED><<<grid, kBlock, 0, d->stream>>>(P.tiles, P.tile_ptr, P.desc, P.col, (const T *) P.val, P.row_map, x, y, (T *) P.carry, P.n_empty, P.empty_list);
+}
+
+template <typename T, int SIGMA>
+static void launch_csr5_sigma(spmv_dev *d, const Csr5Plan &P, const T *x, T *y)
+{
+    if (P.row_map) launch_csr5_form<T, SIGMA, true>(d, P, x, y);
+    else launch_csr5_form<T, SIGMA, false>(d, P, x, y);
+}
+
+// One CSR5 multiply: [y = 0 for the rows outside the plan] + tiles + carry fix-up.
+template <typename T>
+static int launch_csr5(spmv_dev *d, const Csr5Plan &P, const T *x, T *y)
+{
+    if (P.nnz == 0) return SPMV_HIP_OK;
+    switch (P.sigma) {
+    case 4: launch_csr5_sigma<T, 4>(d, P, x, y); break;
+    case 8: launch_csr5_sigma<T, 8>(d, P, x, y); break;
+    default: launch_csr5_sigma<T, 16>(d, P, x, y); break;
+    }
+    if (P.fixup && P.tiles > 1) {
+        const int g = grid_for(P.tiles - 1, kBlock, INT_MAX);
+        if (P.row_map) csr5_fixup_kernel<T, true><<<g, kBlock, 0, d->stream>>>(P.tiles, P.tile_ptr, P.run_len, P.row_map, (const T *) P.carry, y);
+        else csr5_fixup_kernel<T, false><<<g, kBlock, 0, d->stream>>>(P.tiles, P.tile_ptr, P.run_len, nullptr, (const T *) P.carry, y);
+    }
+    return SPMV_HIP_OK;
+}
+
+template <typename T, int L>
+static void launch_rows(spmv_dev *d, const T *x, T *y)
+{
+    const size_t lds = ((((size_t) d->vt_maxspan + 1) * sizeof(T)) + 1023) & ~(size_t) 1023; // + the zero slot
+    if (lds > 64 * 1024)
+        (void) hipFuncSetAttribute((const void *) csr_vector_rows_kernel<T, L, (sizeof(T) == 8 ? 4 : 2)>, hipFuncAttributeMaxDynamicSharedMemorySize, (int) lds);
+    csr_vector_rows_kernel<T, L, (sizeof(T) == 8 ? 4 : 2)><<<d->nblocks, kVecTileThreads, lds, d->stream>>>(
+        d->long_thr, d->rb_split, d->rowptr, d->colidx, d->vt_col, (const T *) d->val, d->vt_wins, x, y);
+}
+
+template <typename T>
+static int launch(spmv_dev *d, const T *x, T *y)
+{
+    if (d->m == 0) return SPMV_HIP_OK;
+    if (d->nnz == 0) { // nothing to multiply: y = 0
+        fill_zero_kernel<T><<<grid_for(d->m, kBlock, d->cus * 8), kBlock, 0, d->stream>>>(d->m, y);
+        HIP_TRY(hipGetLastError());
+        return SPMV_HIP_OK;
+    }
+    const T *val = (const T *) d->val;
+    switch (d->plan.sched) {
+    case SPMV_SCHED_CSR_SCALAR:
+        csr_scalar_kernel<T><<<grid_for(d->m, kBlock, d->cus * 8), kBlock, 0, d->stream>>>(d->m, d->rowptr, d->colidx, val, x, y);
+        break;
+    case SPMV_SCHED_CSR_VECTOR:
+        launch_vector_any<T>(d, x, y);
+        if (d->plan.variant != 2) launch_long_rows<T>(d, x, y);
+        break;
+    case SPMV_SCHED_NNZ_SPLIT: {
+        if (d->blk_on) { launch_blocked<T>(d, x, y); break; }
+        if (d->plan.variant != 8) {
+            const int rc = launch_csr5<T>(d, d->ns, x, y);
+            if (rc) return rc;
+            break;
+        }
+        if (d->ns_staged > 0) {
+            const size_t lds = ((((size_t) d->ns_maxspan + 1) * sizeof(T)) + 1023) & ~(size_t) 1023;
+            nnz_group_kernel<T><<<d->ns_groups, kBlock, lds, d->stream>>>((int) d->nnz, d->ntiles, d->rowptr, d->colidx, d->ns_col, val, d->ns_wins,
+                                                                         x, y, d->tile_first, (T *) d->carry);
+        } else {
+            const int grid = grid_for(d->ntiles, kBlock / kWave, d->plan.variant == 1 ? d->cus * 8 : INT_MAX);
+            nnz_split_kernel<T><<<grid, kBlock, 0, d->stream>>>(d->m, (int) d->nnz, d->ntiles, d->rowptr, d->colidx, val, x, y,
+                                                                 d->tile_first, (T *) d->carry);
+        }
+        if (d->need_fixup && d->ntiles > 1)
+            nnz_fixup_kernel<T><<<grid_for(d->ntiles - 1, kBlock, INT_MAX), kBlock, 0, d->stream>>>(
+                d->ntiles, d->rowptr, d->tile_first, (const T *) d->carry, y);
+        break;
+    }
+    case SPMV_SCHED_ROWBLOCK:
+        if (d->blk_on) { launch_blocked<T>(d, x, y); break; }
+        if (d->plan.variant == 7 && d->rb_stride <= 4096) { // A/B: the first-round LDS-products kernel
+            rowblock_kernel<T><<<d->nblocks, kBlock, 2 * (size_t) d->rb_stride * sizeof(T), d->stream>>>(d->rb_split, d->rowptr, d->colidx, val, x, y);
+            break;
+        }
+        switch (d->plan.lanes_per_row) {
+        case 1: launch_rows<T, 1>(d, x, y); break;
+        case 2: launch_rows<T, 2>(d, x, y); break;
+        case 4: launch_rows<T, 4>(d, x, y); break;
+        case 8: launch_rows<T, 8>(d, x, y); break;
+        case 16: launch_rows<T, 16>(d, x, y); break;
+        case 32: launch_rows<T, 32>(d, x, y); break;
+        default: launch_rows<T, 64>(d, x, y); break;
+        }
+        launch_long_rows<T>(d, x, y);
+        break;
+    case SPMV_SCHED_SELL:
+        // staged path when at least half of the windows fit their x span in LDS; the LDS request is
+        // sized by the largest staged span actually present (rounded to 16 KiB) to keep occupancy
+        if (d->sell_staged > 0)
+            sell_window_kernel<T><<<d->sell_nwin, kSellWinThreads, ((((size_t) d->sell_maxspan + 1) * sizeof(T)) + 1023) & ~(size_t) 1023, d->stream>>>(
+                d->sell_group * (d->plan.sell_sigma / kSellC), (long long) d->nchunks, d->chunk_ptr, d->scol, d->scol16, (const T *) d->sval, d->perm, d->sell_wins, x, y);
+        else
+            sell_kernel<T><<<grid_for(d->nchunks, kBlock / kWave, d->plan.variant == 1 ? d->cus * 8 : INT_MAX), kBlock, 0, d->stream>>>(
+                d->nchunks, d->chunk_ptr, d->scol, (const T *) d->sval, d->perm, x, y);
+        launch_long_rows<T>(d, x, y);
+        break;
+    case SPMV_SCHED_CSR5: {
+        const int rc = launch_csr5<T>(d, d->c5, x, y);
+        if (rc) return rc;
+        break;
+    }
+    default: return fail(SPMV_HIP_E_ARG, "schedule %d has no executor", d->plan.sched);
+    }
+    HIP_TRY(hipGetLastError());
+    return SPMV_HIP_OK;
+}

@@ -1,0 +1,269 @@
+// shim/state.hpp -- part of the single translation unit spmv_shim.hip (included there, in order):
+// error channel, the device-side state of a handle (spmv_dev), allocation bookkeeping and the small
+// utility kernels (row statistics, ColIdx validation, fills).
+#pragma once
+
+// ------------------------------------------------------------------------------------ errors
+static thread_local char t_err[400] = "";
+
+static int fail(int code, const char *fmt, ...)
+{
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(t_err, sizeof t_err, fmt, ap);
+    va_end(ap);
+    return code;
+}
+
+extern "C" const char *spmv_shim_error_text(void) { return t_err; }
+
+#define HIP_TRY(expr)                                                                              \
+    do {                                                                                           \
+        hipError_t e__ = (expr);                                                                   \
+        if (e__ != hipSuccess) {                                                                   \
+            (void) hipGetLastError();                                                              \
+            return fail(e__ == hipErrorOutOfMemory ? SPMV_HIP_E_ALLOC : SPMV_HIP_E_RUNTIME,        \
+                        "%s -> %s", #expr, hipGetErrorString(e__));                                \
+        }                                                                                          \
+    } while (0)
+
+// ------------------------------------------------------------------------------------ state
+struct DevStats {
+    int max_len, min_len, empty, bad, first, last;
+    unsigned long long hist_rows[SPMV_LEN_BUCKETS], hist_nnz[SPMV_LEN_BUCKETS];
+};
+
+// One CSR5 instance (kernels/csr5.hpp): the whole matrix for Method_CSR5SPMV, or the sub-matrix of
+// the long rows that CSR-vector / Balanced / SELL hand over (see build_long_rows).
+struct Csr5Plan {
+    int sigma = 0, tiles = 0, m2 = 0, fixup = 0, groups = 0, staged = 0, maxspan = 0, group_tiles = kCsr5GroupTiles;
+    long long nnz = 0;
+    int n_empty = 0;              // empty rows (outside row_map): the tile kernel zeroes y for them
+    const int *empty_list = nullptr;
+    bool natural = false;         // nnz-split: no transposed copies, col/val are the matrix's own arrays (kernels/csr5.hpp, nat_tile)
+    TileWindows *wins = nullptr;
+    int *tile_ptr = nullptr, *run_len = nullptr, *col = nullptr; // col: transposed global columns (freed when every group is staged)
+    unsigned short *col16 = nullptr; // 16-bit LDS slots of the staged groups
+    const int *row_map = nullptr; // CSR5 row -> y row (NULL: identity)
+    unsigned *desc = nullptr;
+    void *val = nullptr, *carry = nullptr;
+};
+
+struct spmv_dev {
+    int device = 0;
+    int cus = 256;
+    hipStream_t stream = nullptr;
+    int async = 0;
+    int m = 0, n = 0;
+    long long nnz = 0;
+    size_t vsize = 8;
+    // resident CSR
+    int *rowptr = nullptr, *colidx = nullptr;
+    void *val = nullptr;
+    spmv_stats stats{};
+    spmv_plan plan{};
+    bool built = false;
+    // nnz-split
+    int ntiles = 0, need_fixup = 0;
+    int *tile_first = nullptr;
+    void *carry = nullptr;
+    int ns_groups = 0, ns_staged = 0, ns_maxspan = 0;
+    unsigned short *ns_col = nullptr; // 16-bit LDS slots of the staged groups' entries
+    TileWindows *ns_wins = nullptr;
+    // row blocks
+    int nblocks = 0, rb_stride = 0;
+    int *rb_split = nullptr;
+    // csr-vector x tiles
+    int vt_tiles = 0, vt_staged = 0, vt_maxspan = 0, vec_choice = 0;
+    float tune_ms[3] = {0, 0, 0}; // tile D4, tile D2, pipe (autotune_vector)
+    unsigned short *vt_col = nullptr; // tile-local column stream: 16-bit LDS slots (staged tiles only)
+    TileWindows *vt_wins = nullptr; // x windows of every tile
+    // long rows (csr-vector, sell)
+    int nlong = 0, long_thr = INT_MAX, lr_segs = 0, lr_maxspan = 0;
+    int *long_rows = nullptr, *lr_seg_lr = nullptr, *lr_seg_lo = nullptr, *lr_seg_span = nullptr;
+    long long *lr_seg_start = nullptr;
+    void *lr_part = nullptr;
+    // sell
+    int nchunks = 0;
+    long long sell_cols = 0; // sum of chunk widths
+    int *perm = nullptr, *scol = nullptr;
+    TileWindows *sell_wins = nullptr;
+    unsigned short *scol16 = nullptr; // 16-bit LDS slots of the staged sigma windows
+    int sell_nwin = 0, sell_staged = 0, sell_xcap = 0, sell_maxspan = 0, sell_group = 1; // windows, windows with x staged in LDS, LDS capacity in elements
+    long long *chunk_ptr = nullptr;
+    void *sval = nullptr;
+    // csr5
+    Csr5Plan c5, c5_long, ns; // ns: the natural-layout plan of the nnz-split schedule
+    // row blocks x column slabs (kernels/blocked.hpp): the nnz-split executor for columns without locality
+    bool blk_on = false;
+    int blk_R = 0, blk_K = 0, blk_B = 0;
+    long long *blk_start = nullptr, *blk_end = nullptr;
+    void *blk_val = nullptr;
+    int *blk_col = nullptr;
+    unsigned short *blk_row = nullptr;
+    // long-row sub-matrix (rows longer than long_thr, in row order), the input of c5_long
+    int *lsub_rowptr = nullptr, *lsub_colidx = nullptr;
+    void *lsub_val = nullptr;
+    long long lsub_nnz = 0;
+    // staging for host x / y
+    void *x_stage = nullptr, *y_stage = nullptr;
+    long long device_bytes = 0;
+    double inspect_ms = 0;
+    std::vector<void *> sched_allocs; // freed when the schedule is rebuilt
+};
+
+static int dev_alloc(spmv_dev *d, void **p, size_t bytes, bool sched)
+{
+    *p = nullptr;
+    if (bytes == 0) bytes = 16;
+    HIP_TRY(hipMalloc(p, bytes));
+    d->device_bytes += (long long) bytes;
+    if (sched) d->sched_allocs.push_back(*p);
+    return SPMV_HIP_OK;
+}
+#define ALLOC_TRY(d, p, bytes, sched)                                        \
+    do {                                                                     \
+        int rc__ = dev_alloc((d), (void **) (p), (bytes), (sched));          \
+        if (rc__) return rc__;                                               \
+    } while (0)
+
+// release one schedule-owned allocation early
+static void sched_free(spmv_dev *d, void *p)
+{
+    for (size_t i = 0; i < d->sched_allocs.size(); ++i)
+        if (d->sched_allocs[i] == p) {
+            d->sched_allocs.erase(d->sched_allocs.begin() + (long) i);
+            (void) hipFree(p);
+            return;
+        }
+}
+
+static void free_schedule(spmv_dev *d)
+{
+    for (void *p : d->sched_allocs) (void) hipFree(p);
+    d->sched_allocs.clear();
+    d->tile_first = nullptr; d->carry = nullptr; d->rb_split = nullptr; d->ns_col = nullptr; d->ns_wins = nullptr; d->ns_groups = d->ns_staged = 0;
+    d->perm = d->scol = d->long_rows = d->lr_seg_lr = d->lr_seg_lo = d->lr_seg_span = nullptr; d->sell_wins = nullptr; d->scol16 = nullptr; d->sell_staged = d->sell_nwin = 0; d->chunk_ptr = d->lr_seg_start = nullptr;
+    d->sval = d->lr_part = nullptr;
+    d->ntiles = d->nblocks = d->nchunks = d->nlong = d->lr_segs = 0;
+    d->long_thr = INT_MAX;
+    d->vt_col = nullptr; d->vt_wins = nullptr; d->vt_tiles = d->vt_staged = d->vt_maxspan = 0;
+    d->c5 = Csr5Plan();
+    d->c5_long = Csr5Plan();
+    d->ns = Csr5Plan();
+    d->blk_on = false; d->blk_start = d->blk_end = nullptr; d->blk_val = nullptr; d->blk_col = nullptr; d->blk_row = nullptr;
+    d->lsub_rowptr = d->lsub_colidx = nullptr; d->lsub_val = nullptr; d->lsub_nnz = 0;
+    d->built = false;
+}
+
+// true if the pointer is usable by a kernel as is (device or managed memory)
+static bool is_device_ptr(const void *p)
+{
+    if (!p) return false;
+    hipPointerAttribute_t a;
+    memset(&a, 0, sizeof a);
+    if (hipPointerGetAttributes(&a, p) != hipSuccess) {
+        (void) hipGetLastError(); // plain malloc memory: "invalid value", not an error for us
+        return false;
+    }
+    return a.type == hipMemoryTypeDevice || a.type == hipMemoryTypeManaged;
+}
+
+extern "C" int spmv_shim_device_count(void)
+{
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) { (void) hipGetLastError(); return 0; }
+    return n;
+}
+
+// ------------------------------------------------------------------------------------ stats
+__global__ __launch_bounds__(kBlock) void stats_kernel(int m, const int *__restrict__ rowptr, DevStats *s)
+{
+    __shared__ unsigned h_rows[SPMV_LEN_BUCKETS];
+    __shared__ unsigned long long h_nnz[SPMV_LEN_BUCKETS];
+    if (threadIdx.x < SPMV_LEN_BUCKETS) { h_rows[threadIdx.x] = 0; h_nnz[threadIdx.x] = 0; }
+    __syncthreads();
+    int mx = 0, mn = INT_MAX, em = 0, bad = 0;
+    const long long stride = (long long) gridDim.x * kBlock;
+    for (long long r = (long long) blockIdx.x * kBlock + threadIdx.x; r < m; r += stride) {
+        const int len = rowptr[r + 1] - rowptr[r];
+        mx = max(mx, len);
+        mn = min(mn, len);
+        em += len == 0;
+        bad |= len < 0;
+        int b = len <= 4 ? 0 : 32 - __clz((len - 1) >> 2); // smallest b with len <= 4 * 2^b
+        if (b > SPMV_LEN_BUCKETS - 1) b = SPMV_LEN_BUCKETS - 1;
+        atomicAdd(&h_rows[b], 1u);
+        atomicAdd(&h_nnz[b], (unsigned long long) (len > 0 ? len : 0));
+    }
+    __syncthreads();
+    if (threadIdx.x < SPMV_LEN_BUCKETS && h_rows[threadIdx.x]) {
+        atomicAdd(&s->hist_rows[threadIdx.x], (unsigned long long) h_rows[threadIdx.x]);
+        atomicAdd(&s->hist_nnz[threadIdx.x], h_nnz[threadIdx.x]);
+    }
+#pragma unroll
+    for (int o = kWave / 2; o > 0; o >>= 1) {
+        mx = max(mx, __shfl_xor(mx, o, kWave));
+        mn = min(mn, __shfl_xor(mn, o, kWave));
+        em += __shfl_xor(em, o, kWave);
+        bad |= __shfl_xor(bad, o, kWave);
+    }
+    if ((threadIdx.x & (kWave - 1)) == 0) {
+        atomicMax(&s->max_len, mx);
+        atomicMin(&s->min_len, mn);
+        atomicAdd(&s->empty, em);
+        if (bad) atomicOr(&s->bad, 1);
+    }
+    if (blockIdx.x == 0 && threadIdx.x == 0) { s->first = rowptr[0]; s->last = rowptr[m]; }
+}
+
+__global__ __launch_bounds__(kBlock) void count_longer_kernel(int m, int thr, const int *__restrict__ rowptr, int *count)
+{
+    int c = 0;
+    const long long stride = (long long) gridDim.x * kBlock;
+    for (long long r = (long long) blockIdx.x * kBlock + threadIdx.x; r < m; r += stride)
+        c += (rowptr[r + 1] - rowptr[r]) > thr;
+#pragma unroll
+    for (int o = kWave / 2; o > 0; o >>= 1) c += __shfl_xor(c, o, kWave);
+    if ((threadIdx.x & (kWave - 1)) == 0 && c) atomicAdd(count, c);
+}
+
+// min / max of ColIdx (create-time validation: an index outside [0, n) would make a gather fault)
+__global__ __launch_bounds__(kBlock) void colidx_range_kernel(long long nnz, const int *__restrict__ colidx, int *__restrict__ mnmx)
+{
+    int mn = INT_MAX, mx = INT_MIN;
+    const long long stride = (long long) gridDim.x * kBlock;
+    for (long long i = (long long) blockIdx.x * kBlock + threadIdx.x; i < nnz; i += stride) {
+        const int c = ld_stream(colidx + i);
+        mn = min(mn, c);
+        mx = max(mx, c);
+    }
+#pragma unroll
+    for (int o = kWave / 2; o > 0; o >>= 1) {
+        mn = min(mn, __shfl_xor(mn, o, kWave));
+        mx = max(mx, __shfl_xor(mx, o, kWave));
+    }
+    if ((threadIdx.x & (kWave - 1)) == 0) { atomicMin(mnmx, mn); atomicMax(mnmx + 1, mx); }
+}
+
+template <typename T>
+__global__ __launch_bounds__(kBlock) void fill_value_kernel(long long n, T *y, T v)
+{
+    const long long stride = (long long) gridDim.x * kBlock;
+    for (long long i = (long long) blockIdx.x * kBlock + threadIdx.x; i < n; i += stride) y[i] = v;
+}
+
+template <typename T>
+__global__ __launch_bounds__(kBlock) void fill_zero_kernel(long long n, T *y)
+{
+    const long long stride = (long long) gridDim.x * kBlock;
+    for (long long i = (long long) blockIdx.x * kBlock + threadIdx.x; i < n; i += stride) y[i] = T(0);
+}
+
+static int grid_for(long long work_items, int per_block, int cap)
+{
+    long long g = (work_items + per_block - 1) / per_block;
+    if (g < 1) g = 1;
+    if (g > cap) g = cap;
+    return (int) g;
+}
