@@ -45,7 +45,7 @@ ALL = [M.Method_Parallel, M.Method_Balanced, M.Method_Balanced_Yid, M.Method_Sel
 _, _, rp, ci, va = synth.banded_device(10_000_000, 10_000_000, 32, "uniform", torch.float64, dev, 1)
 run("config 2: 1e7 x 1e7, 32 nnz/row banded, fp64 (named schedule: CSR-vector)", 10_000_000, 10_000_000, rp, ci, va, ALL)
 _, _, rp, ci, va = synth.uniform_k_device(10_000_000, 10_000_000, 32, "uniform", torch.float64, dev, 1)
-run("config 2 variant (ii): uniformly random columns", 10_000_000, 10_000_000, rp, ci, va, [M.Method_Parallel, M.Method_CSR5SPMV], 5)
+run("config 2 variant (ii): uniformly random columns", 10_000_000, 10_000_000, rp, ci, va, [M.Method_Balanced_Yid, M.Method_Balanced, M.Method_Parallel, M.Method_CSR5SPMV], 5)
 lens = synth.powerlaw_lengths_device(1_000_000, 3.1, 4700, 1.6, dev, 1)
 _, _, rp, ci, va = synth.from_row_lengths_device(lens, 1_000_000, "uniform", torch.float64, dev, 1)
 run("config 3 stand-in webbase-1M-style (named schedule: Balanced2 nnz-split)", 1_000_000, 1_000_000, rp, ci, va,
