@@ -9,8 +9,10 @@
 // (parallel_balanced2_spmv.c:41-53) and gather x wherever the columns point.
 //
 // Here, for that case only:
-//   inspector   rows are cut into blocks of R rows, columns into slabs of W columns (W * sizeof(T) =
-//               256 KiB: a few slabs fit an XCD's 4 MiB L2 next to the matrix stream).  The entries of a
+//   inspector   rows are cut into blocks of R rows, columns into slabs of W columns -- as narrow as a
+//               table of 2^25 (block, slab) cells allows, down to 32 columns: the sweep over x is what
+//               keeps x in L2, and narrow slabs additionally put gathers from one cache line into
+//               neighbouring lanes, which merge into one L2 request.  The entries of a
 //               row block are stored sorted by SLAB (counting sort on the device: histogram of
 //               (block, slab) cells, scans, scatter), as three streams: value, global column, and
 //               the 16-bit row number inside the block.  Block regions start at multiples of 8
@@ -26,7 +28,7 @@
 //               partial sums, no carries, no read-modify-write of y in HBM.
 //
 // Measured (config 2 with uniformly random columns, fp64): 84 % of the L2 requests hit (5 % for the tile
-// executors), 5.9 -> 2.1 ms.  What bounds it now is the L2's rate of random requests (~1.4e11/s over
+// executors), 5.9 -> 2.0 ms; Orkut-style stand-in (74 nnz/row, 3e6 columns): 3.5 -> 1.13 ms.  What bounds it now is the L2's rate of random requests (~1.4e11/s over
 // the chip; the LDS atomics are free: removing them changes nothing).
 //
 // The order in which the atomics of one row arrive is not fixed, so results are reproducible
