@@ -3,12 +3,15 @@
  *   host_c_check rcm                 RCM on a scrambled band matrix: permutation valid, band recovered
  *   host_c_check mtx <file> [...]    run the Matrix Market reader over files, print rc and sizes
  *   host_c_check bin <file>          write + re-read a cache file
+ *   host_c_check plan                the planner (spmv_plan.c): method -> schedule, CSR-vector shape from histograms
  */
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
 #include "spmv_io.h"
 #include "reorder/rcm.h"
+#include "spmv_hip.h"
+#include "spmv_internal.h"
 
 static int check_rcm(void)
 {
@@ -44,10 +47,85 @@ static int check_rcm(void)
     return rc;
 }
 
+/* spmv_plan.c reports illegal option values through the API's error channel */
+void spmv_set_error(int code, const char *where, const char *what) { (void) code; (void) where; (void) what; }
+
+static void hist_put(spmv_stats *st, int len, long long rows)
+{
+    int b = 0;
+    while (b < SPMV_LEN_BUCKETS - 1 && len > (4 << b)) ++b;
+    st->hist_rows[b] += rows;
+    st->hist_nnz[b] += rows * len;
+    st->m += (int) rows;
+    st->nnz += rows * len;
+    if (len > st->max_row_len) st->max_row_len = len;
+    if (len < st->min_row_len) st->min_row_len = len;
+    if (len == 0) st->empty_rows += (int) rows;
+}
+
+static int check_plan(void)
+{
+    spmv_stats st;
+    spmv_plan pl;
+    SPMV_METHODS act;
+    int rc = 0;
+    /* equal rows of 32 (config 2): one pass per row with 8 lanes, nothing handed to the long-row path */
+    memset(&st, 0, sizeof st); st.min_row_len = 1 << 30; st.n = 10000000;
+    hist_put(&st, 32, 10000000); st.mean_row_len = 32.0;
+    spmv_plan_choose(Method_Parallel, &st, 8, &pl, &act);
+    printf("equal32: sched=%d L=%d thr=%d act=%d\n", pl.sched, pl.lanes_per_row, pl.long_thr, act);
+    if (pl.sched != SPMV_SCHED_CSR_VECTOR || pl.lanes_per_row != 8 || pl.long_thr != 0 || act != Method_Parallel) rc = 1;
+    /* config 4's shape: 90 % rows of ~16, 9 % of ~160, 1 % of ~2500 -> small L, the heavy classes to CSR5 */
+    memset(&st, 0, sizeof st); st.min_row_len = 1 << 30; st.n = 10000000;
+    hist_put(&st, 8, 3000000); hist_put(&st, 14, 3000000); hist_put(&st, 22, 3000000);
+    hist_put(&st, 100, 450000); hist_put(&st, 220, 450000); hist_put(&st, 2500, 100000);
+    st.mean_row_len = (double) st.nnz / st.m;
+    spmv_plan_choose(Method_Parallel, &st, 4, &pl, &act);
+    printf("skewed: L=%d thr=%d\n", pl.lanes_per_row, pl.long_thr);
+    if (pl.lanes_per_row < 4 || pl.lanes_per_row > 8 || pl.long_thr != 64) rc = 2;
+    /* Balanced: a row longer than a worker's share flips the handle to Balanced2 (parallel_balanced2_spmv.c:72-92) */
+    spmv_plan_choose(Method_Balanced, &st, 4, &pl, &act);
+    if (act != Method_Balanced2 || pl.sched != SPMV_SCHED_NNZ_SPLIT) rc = 3;
+    memset(&st, 0, sizeof st); st.min_row_len = 1 << 30; hist_put(&st, 32, 1000); st.mean_row_len = 32.0;
+    spmv_plan_choose(Method_Balanced2, &st, 8, &pl, &act);
+    if (act != Method_Balanced || pl.sched != SPMV_SCHED_ROWBLOCK) rc = 4;
+    /* no histogram (m = 0): the mean rule, no crash */
+    memset(&st, 0, sizeof st);
+    spmv_plan_choose(Method_Parallel, &st, 8, &pl, &act);
+    if (pl.lanes_per_row != 1 || pl.long_thr != 0) rc = 5;
+    /* very long equal rows: 64 lanes */
+    memset(&st, 0, sizeof st); st.min_row_len = 1 << 30; hist_put(&st, 5000, 1000); st.mean_row_len = 5000.0;
+    spmv_plan_choose(Method_Parallel, &st, 8, &pl, &act);
+    printf("long5000: L=%d thr=%d\n", pl.lanes_per_row, pl.long_thr);
+    if (pl.lanes_per_row != 64) rc = 6;
+    /* out-of-range method -> serial (common.c:136); SELL / CSR5 map 1:1 */
+    spmv_plan_choose((SPMV_METHODS) 99, &st, 8, &pl, &act);
+    if (act != Method_Serial || pl.sched != SPMV_SCHED_CSR_SCALAR) rc = 7;
+    spmv_plan_choose(Method_SellCSigma, &st, 8, &pl, &act);
+    if (pl.sched != SPMV_SCHED_SELL || pl.sell_c != 64 || pl.sell_sigma != 1024) rc = 8;
+    spmv_plan_choose(Method_CSR5SPMV, &st, 4, &pl, &act);
+    if (pl.sched != SPMV_SCHED_CSR5 || act != Method_CSR5SPMV) rc = 9;
+    /* auto_method: regular -> CSR-vector, skewed -> CSR5; spmv_plan_choose_ex(…, 0) ignores the option */
+    if (spmv_hip_set_option("auto_method", 1) != 0) rc = 10;
+    spmv_plan_choose(Method_Serial, &st, 8, &pl, &act);
+    if (act != Method_Parallel) rc = 11;
+    st.max_row_len = 100000;
+    spmv_plan_choose(Method_Serial, &st, 8, &pl, &act);
+    if (act != Method_CSR5SPMV) rc = 12;
+    spmv_plan_choose_ex(Method_Serial, &st, 8, &pl, &act, 0);
+    if (act != Method_Serial) rc = 13;
+    spmv_hip_set_option("auto_method", 0);
+    /* illegal option values are refused */
+    if (spmv_hip_set_option("lanes_per_row", 3) == 0 || spmv_hip_set_option("nope", 1) == 0 || spmv_hip_set_option("cache_block", 3) == 0) rc = 14;
+    printf("plan rc=%d\n", rc);
+    return rc;
+}
+
 int main(int argc, char **argv)
 {
     int i;
     if (argc >= 2 && strcmp(argv[1], "rcm") == 0) return check_rcm();
+    if (argc >= 2 && strcmp(argv[1], "plan") == 0) return check_plan();
     if (argc >= 3 && strcmp(argv[1], "mtx") == 0) {
         for (i = 2; i < argc; ++i) {
             int m = -1, n = -1, nnz = -1, sym = -1, *rp = NULL, *ci = NULL;

@@ -16,7 +16,7 @@ def exe(tmp_path_factory):
     out = str(tmp_path_factory.mktemp("hostc") / "host_c_check")
     cmd = ["gcc", "-std=c11", "-O1", "-g", "-Wall", "-Wextra", "-fsanitize=address,undefined", "-fno-sanitize-recover=undefined",
            f"-I{os.path.join(ROOT, 'include')}", f"-I{CSRC}", os.path.join(ROOT, "tests", "c", "host_c_check.c"),
-           os.path.join(CSRC, "io", "mtx_io.c"), os.path.join(CSRC, "reorder", "rcm.c"), "-o", out]
+           os.path.join(CSRC, "io", "mtx_io.c"), os.path.join(CSRC, "reorder", "rcm.c"), os.path.join(CSRC, "spmv_plan.c"), "-o", out]
     r = subprocess.run(cmd, capture_output=True, text=True)
     assert r.returncode == 0, r.stderr
     return out
@@ -25,6 +25,14 @@ def exe(tmp_path_factory):
 def _run(exe, *args):
     env = dict(os.environ, ASAN_OPTIONS="detect_leaks=1:abort_on_error=0", UBSAN_OPTIONS="print_stacktrace=1")
     return subprocess.run([exe, *args], capture_output=True, text=True, env=env, timeout=120)
+
+
+def test_planner_maps_methods_and_shapes_csr_vector_from_histograms(exe):
+    """spmv_plan.c under ASan/UBSan: method -> schedule map, the Balanced/Balanced2 rewrite of the reference
+    (parallel_balanced2_spmv.c:72-92), the histogram cost model for CSR-vector (L, long-row threshold), auto_method."""
+    r = _run(exe, "plan")
+    assert r.returncode == 0, r.stdout + r.stderr
+    assert "equal32: sched=1 L=8 thr=0" in r.stdout and "plan rc=0" in r.stdout
 
 
 def test_rcm_recovers_a_scrambled_band_without_sanitizer_findings(exe):
