@@ -108,8 +108,8 @@ __device__ __forceinline__ void lds_add(float *p, float v) { (void) unsafeAtomic
 __device__ __forceinline__ void lds_add(double *p, double v) { (void) unsafeAtomicAdd(p, v); }
 
 // Executor.  Dynamic LDS: R * sizeof(T) bytes (the block's y).
-template <typename T>
-__global__ __launch_bounds__(kBlkThreads) void blk_kernel(int m, int R, const long long *__restrict__ start, const long long *__restrict__ end,
+template <typename T, int NT = kBlkThreads>
+__global__ __launch_bounds__(NT) void blk_kernel(int m, int R, const long long *__restrict__ start, const long long *__restrict__ end,
                                                           const T *__restrict__ bval, const int *__restrict__ bcol,
                                                           const unsigned short *__restrict__ brow, const T *__restrict__ x, T *__restrict__ y)
 {
@@ -117,16 +117,16 @@ __global__ __launch_bounds__(kBlkThreads) void blk_kernel(int m, int R, const lo
     T *ys = reinterpret_cast<T *>(blk_y_lds);
     constexpr int EPL = 16 / (int) sizeof(T); // entries per 16-byte value load
     constexpr int UN = 4;                     // load groups in flight per thread (2, 8, 16 measured no better)
-    for (int i = threadIdx.x; i < R; i += kBlkThreads) ys[i] = T(0);
+    for (int i = threadIdx.x; i < R; i += NT) ys[i] = T(0);
     __syncthreads();
     const long long s = start[blockIdx.x], e = end[blockIdx.x];
-    for (long long base = s + (long long) threadIdx.x * EPL; base < e; base += (long long) kBlkThreads * EPL * UN) {
+    for (long long base = s + (long long) threadIdx.x * EPL; base < e; base += (long long) NT * EPL * UN) {
         T v[UN][EPL];
         int c[UN][EPL];
         unsigned rw[UN][EPL];
 #pragma unroll
         for (int u = 0; u < UN; ++u) { // every instruction reads one contiguous run over the wave
-            const long long p = base + (long long) u * kBlkThreads * EPL;
+            const long long p = base + (long long) u * NT * EPL;
             if (p < e) {
                 if constexpr (EPL == 2) {
                     const f64x2 q = __builtin_nontemporal_load(reinterpret_cast<const f64x2 *>(bval + p));
@@ -146,13 +146,13 @@ __global__ __launch_bounds__(kBlkThreads) void blk_kernel(int m, int R, const lo
         T xv[UN][EPL];
 #pragma unroll
         for (int u = 0; u < UN; ++u) {
-            const long long p = base + (long long) u * kBlkThreads * EPL;
+            const long long p = base + (long long) u * NT * EPL;
 #pragma unroll
             for (int j = 0; j < EPL; ++j) xv[u][j] = p + j < e ? x[c[u][j]] : T(0); // cached loads: the slab stays in L2
         }
 #pragma unroll
         for (int u = 0; u < UN; ++u) {
-            const long long p = base + (long long) u * kBlkThreads * EPL;
+            const long long p = base + (long long) u * NT * EPL;
 #pragma unroll
             for (int j = 0; j < EPL; ++j)
                 if (p + j < e) lds_add(&ys[rw[u][j]], v[u][j] * xv[u][j]);
@@ -160,7 +160,7 @@ __global__ __launch_bounds__(kBlkThreads) void blk_kernel(int m, int R, const lo
     }
     __syncthreads();
     const long long r0 = (long long) blockIdx.x * R;
-    for (int i = threadIdx.x; i < R; i += kBlkThreads)
+    for (int i = threadIdx.x; i < R; i += NT)
         if (r0 + i < m) y[r0 + i] = ys[i];
 }
 

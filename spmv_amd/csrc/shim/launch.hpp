@@ -120,8 +120,12 @@ template <typename T>
 static void launch_blocked(spmv_dev *d, const T *x, T *y)
 {
     const size_t lds = (size_t) d->blk_R * sizeof(T);
-    if (lds > 64 * 1024) (void) hipFuncSetAttribute((const void *) blk_kernel<T>, hipFuncAttributeMaxDynamicSharedMemorySize, (int) lds);
-    blk_kernel<T><<<d->blk_B, kBlkThreads, lds, d->stream>>>(d->m, d->blk_R, d->blk_start, d->blk_end, (const T *) d->blk_val, d->blk_col, d->blk_row, x, y);
+    if (lds > 64 * 1024) { // one 512-thread workgroup per CU: same 8 waves as two 256-thread ones
+        (void) hipFuncSetAttribute((const void *) blk_kernel<T, 512>, hipFuncAttributeMaxDynamicSharedMemorySize, (int) lds);
+        blk_kernel<T, 512><<<d->blk_B, 512, lds, d->stream>>>(d->m, d->blk_R, d->blk_start, d->blk_end, (const T *) d->blk_val, d->blk_col, d->blk_row, x, y);
+    } else {
+        blk_kernel<T, kBlkThreads><<<d->blk_B, kBlkThreads, lds, d->stream>>>(d->m, d->blk_R, d->blk_start, d->blk_end, (const T *) d->blk_val, d->blk_col, d->blk_row, x, y);
+    }
 }
 
 template <typename T, int SIGMA, bool MAPPED>

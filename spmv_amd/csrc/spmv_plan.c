@@ -33,7 +33,7 @@ static opt_t g_opts[] = {
     {"sell_sigma", 1024, 64, 1 << 20, 1, 0},
     {"sell_lds_x", 1, 0, 1, 0, 0},
     {"slab_kib", 0, 0, 1 << 16, 1, 0},     /* row-block x column-slab executor: KiB of x per column slab (0 = 256) */
-    {"block_rows", 0, 0, 16384, 1, 0},     /* ... rows per block (0 = 64 KiB of y) */
+    {"block_rows", 0, 0, 32768, 1, 0},     /* ... rows per block (0 = 64 KiB of y) */
     {"cache_block", 1, 0, 2, 0, 0},        /* nnz-split family: 1 = row-block x column-slab executor when no x window can be staged (automatic), 2 = always, 0 = never */
     {"csr5_sigma", 0, 0, 16, 0, 0},
     {"rowblock_nnz", 0, 0, 1 << 20, 0, 0},
