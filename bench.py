@@ -59,7 +59,7 @@ def parse():
     ap.add_argument("--method", type=int, default=1, help="SPMV_METHODS id (1 = Method_Parallel = CSR-vector)")
     ap.add_argument("--xchg", default="halo", choices=["halo", "allgather", "bcast", "none"])
     ap.add_argument("--cpu-rows", type=int, default=1_000_000)
-    ap.add_argument("--cpu-seconds", type=float, default=15.0)
+    ap.add_argument("--cpu-seconds", type=float, default=10.0, help="CPU baseline: keep timing calls for about this long (at least 100 calls)")
     ap.add_argument("--no-cpu", action="store_true")
     ap.add_argument("--no-overlap", action="store_true", help="halo mode: do not split interior / boundary rows")
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
@@ -104,7 +104,7 @@ def cpu_baseline(args, rp, ci, va, x, y_gpu, n_cols):
         run()
     times = []
     t_end = time.perf_counter() + args.cpu_seconds
-    while len(times) < 100 and (time.perf_counter() < t_end or len(times) < 5):
+    while len(times) < 4000 and (time.perf_counter() < t_end or len(times) < 100):   # >= the harness' 100 calls, ~cpu_seconds of work
         t0 = time.perf_counter()
         run()
         times.append(time.perf_counter() - t0)
