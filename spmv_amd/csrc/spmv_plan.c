@@ -182,9 +182,18 @@ void spmv_plan_choose_ex(SPMV_METHODS requested, const spmv_stats *st, size_t va
     plan->slab_kib = (int) spmv_hip_get_option("slab_kib");
     plan->block_rows = (int) spmv_hip_get_option("block_rows");
     plan->csr5_sigma = (int) spmv_hip_get_option("csr5_sigma");
-    /* one workgroup's equal-nnz share (Method_Balanced): 8192 nnz ~ the 256 rows x 32 of a CSR-vector
-     * tile; a row longer than the share flips the handle to Method_Balanced2 like the reference */
-    plan->rowblock_nnz = rb > 0 ? (int) rb : 8192;
+    /* one workgroup's equal-nnz share (Method_Balanced): the non-zeros of 256 mean-length rows, so that a
+     * block is about one 256-row slab of the CSR-vector wave program (8192 for config 2; a share that is
+     * not a multiple of the slab leaves three of the four waves idle in the block's last slab: on the
+     * 27-point stencil Balanced went from 1.18x to 1.04x of CSR-vector's time); a row longer than the share flips the handle to Method_Balanced2 like
+     * the reference */
+    if (rb > 0) plan->rowblock_nnz = (int) rb;
+    else {
+        double share = 256.0 * st->mean_row_len;
+        if (share < 2048.0) share = 2048.0;
+        if (share > 65536.0) share = 65536.0;
+        plan->rowblock_nnz = (int) share;
+    }
     /* CSR-vector: a lane group of L lanes takes 4L entries of its row per step (16 B loads); L and
      * the long-row threshold come from the row-length histogram (choose_vector_shape) */
     if (lanes > 0) plan->lanes_per_row = (int) lanes; /* forced: default long-row rule */
