@@ -28,19 +28,20 @@
 /* ---------------------------------------------------------------- options */
 typedef struct { const char *key; long value; long lo, hi; int pow2; int env_read; } opt_t;
 static opt_t g_opts[] = {
-    {"lanes_per_row", 0, 0, 64, 1, 0},
+    {"lanes_per_row", 0, 0, 64, 1, 0},     /* CSR-vector: 0 = from the row-length histogram */
     {"sell_c", 64, 64, 64, 1, 0},          /* one wavefront per chunk: C is the wave width */
     {"sell_sigma", 1024, 64, 1 << 20, 1, 0},
-    {"sell_lds_x", 1, 0, 1, 0, 0},
-    {"slab_kib", 0, 0, 1 << 16, 1, 0},     /* row-block x column-slab executor: KiB of x per column slab (0 = 256) */
+    {"sell_lds_x", 1, 0, 1, 0, 0},         /* SELL: stage the x windows of the sigma windows in LDS */
+    {"csr5_sigma", 0, 0, 16, 0, 0},        /* CSR5 / nnz-split tiles of 64 x sigma entries: 0 = auto, else 4, 8, 16 */
+    {"rowblock_nnz", 0, 0, 1 << 20, 0, 0}, /* Balanced: equal-nnz share of one row block, 0 = 256 mean-length rows */
+    {"cache_block", 1, 0, 2, 0, 0},        /* Balanced family: row-block x column-slab executor when no x window can
+                                            * be staged: 1 = automatic, 2 = always, 0 = never */
+    {"slab_kib", 0, 0, 1 << 16, 1, 0},     /* ... KiB of x per column slab (0 = as narrow as the cell table allows) */
     {"block_rows", 0, 0, 32768, 1, 0},     /* ... rows per block (0 = 64 KiB of y) */
-    {"cache_block", 1, 0, 2, 0, 0},        /* nnz-split family: 1 = row-block x column-slab executor when no x window can be staged (automatic), 2 = always, 0 = never */
-    {"csr5_sigma", 0, 0, 16, 0, 0},
-    {"rowblock_nnz", 0, 0, 1 << 20, 0, 0},
-    {"variant", 0, 0, 1 << 20, 0, 0},
-    {"auto_method", 0, 0, 1, 0, 0},
-    {"autotune", 1, 0, 1, 0, 0},
-    {"reorder", 0, 0, 1, 0, 0},            /* 1: square matrices are RCM-reordered at create; handle->index = permutation */           /* 1: create() times the CSR-vector kernel forms on big matrices */        /* 1: create() picks the schedule from the row statistics */
+    {"variant", 0, 0, 1 << 20, 0, 0},      /* kernel-form selector of the A/B harness and the variant tests, 0 = default */
+    {"auto_method", 0, 0, 1, 0, 0},        /* 1: create() picks the schedule from the matrix (two stages, spmv_api.c) */
+    {"autotune", 1, 0, 1, 0, 0},           /* 1: create() times the CSR-vector kernel forms on matrices >= 2^24 nnz */
+    {"reorder", 0, 0, 1, 0, 0},            /* 1: square matrices are RCM-reordered at create; handle->index = permutation */
 };
 #define N_OPTS ((int) (sizeof g_opts / sizeof g_opts[0]))
 
