@@ -202,14 +202,29 @@ void spmv_plan_choose_ex(SPMV_METHODS requested, const spmv_stats *st, size_t va
     (void) value_size;
     /* the reference's README ends on an empty "Matrix inspect and choose best
      * method to run" heading (README.md:222).  With auto_method = 1 the request is replaced by:
-     *   regular rows (longest row <= 4 x mean, mean >= 4, < 1 % empty rows)  -> CSR-vector
-     *   everything else (skewed, very short or many empty rows)              -> CSR5
-     * (measured: CSR-vector leads on regular shapes without inspector cost, CSR5 on skewed and
-     * power-law shapes -- DESIGN.md section 3).  The handle reports the method actually used. */
+     *   regular rows (longest row <= 4 x mean, mean >= 4, < 1 % empty rows) that fill the lane groups'
+     *   4L-entry chunks to >= 90 %                                            -> CSR-vector
+     *   everything else (skewed, very short or many empty rows, or rows that leave the chunks
+     *   emptier -- 27-entry stencil rows in 32-entry chunks: 84 %)            -> CSR5
+     * (measured: CSR-vector leads on regular shapes that fill its chunks, CSR5 elsewhere -- DESIGN.md
+     * section 3).  spmv_api.c adds a second stage for matrices without column locality.  The handle reports
+     * the method actually used. */
     if (allow_auto && spmv_hip_get_option("auto_method") == 1 && st->m > 0) {
         const int regular = st->mean_row_len >= 4.0 && (double) st->max_row_len <= 4.0 * st->mean_row_len &&
                             (double) st->empty_rows <= 0.01 * (double) st->m;
-        requested = regular ? Method_Parallel : Method_CSR5SPMV;
+        /* chunk fill of CSR-vector with the L just chosen: nnz / sum over rows of ceil(len / 4L) * 4L, rows
+         * taken at their bucket's mean length (exact when all rows are equal) */
+        double slots = 0.0;
+        const double chunk = 4.0 * plan->lanes_per_row;
+        int b;
+        for (b = 0; b < SPMV_LEN_BUCKETS; ++b)
+            if (st->hist_rows[b] > 0) {
+                const double mean_len = (double) st->hist_nnz[b] / (double) st->hist_rows[b];
+                double passes = (double) (long long) ((mean_len + chunk - 1.0) / chunk);
+                if (passes < 1.0) passes = 1.0;
+                slots += (double) st->hist_rows[b] * passes * chunk;
+            }
+        requested = regular && (slots <= 0.0 || (double) st->nnz >= 0.9 * slots) ? Method_Parallel : Method_CSR5SPMV;
     }
     *actual = requested;
     switch (requested) {

@@ -201,12 +201,15 @@ def test_handle_info_and_alg_bytes():
 
 def test_auto_method_picks_schedule_from_row_statistics():
     """SURVEY 8f f-3 (the reference only has an empty README heading for it, README.md:222)."""
-    reg, xr, yr = load_golden("banded_wide_f64_eighths")
+    reg, xr, yr = load_golden("banded_f64_eighths")              # 16 entries per row: fills 4-lane chunks
+    odd, xo, yo = load_golden("banded_wide_f64_eighths")         # 78 per row: 61 % of a 128-entry chunk
     skw, xs, ys = load_golden("powerlaw_f64_eighths")
     api.set_option("auto_method", 1)
     try:
         y, actual = run_host(reg, xr, M.Method_Serial)
         assert actual == M.Method_Parallel and np.array_equal(y, yr)
+        y, actual = run_host(odd, xo, M.Method_Serial)
+        assert actual == M.Method_CSR5SPMV and np.array_equal(y, yo)
         y, actual = run_host(skw, xs, M.Method_Serial)
         assert actual == M.Method_CSR5SPMV and np.array_equal(y, ys)
     finally:
