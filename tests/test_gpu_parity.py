@@ -369,3 +369,37 @@ def test_multi_window_x_tiles_on_stencil_structure(method, dtype):
         name = h.info()["kernel_name"]
     assert np.array_equal(y, want)
     assert name in ("csr_vector_tile_kernel", "csr_vector_rows_kernel")
+
+
+def test_create_destroy_cycles_return_all_device_memory():
+    """Every schedule's inspector products (incl. early-freed column copies, long-row sub-matrices, the
+    cache-blocked streams and the autotune / inspector scratch) are released by spmv_destory_handle and by
+    spmv_clear_handle: free HBM after 3 cycles over all methods equals free HBM after the first."""
+    import torch
+    csr, x, _ = load_golden("skewed_f64_eighths")
+    big = synth.from_row_lengths(np.full(40000, 24), 40000, "eighths", np.float64, seed=3)      # no locality: global gathers
+    xb = np.ones(big.n)
+
+    def cycle():
+        for mat, xv in ((csr, x), (big, xb)):
+            for method in ALL_METHODS:
+                for cb in (1, 2):
+                    api.set_option("cache_block", cb)
+                    y = np.empty(mat.m, dtype=mat.val.dtype)
+                    h = api.spmv_create_handle_all_in_one(mat.m, mat.n, mat.rowptr, mat.colidx, mat.val, 1, method,
+                                                          mat.val.dtype.itemsize, api.VECTORIZED_WAY.VECTOR_HIP, "leak")
+                    api.spmv(h, mat.m, mat.rowptr, mat.colidx, mat.val, xv, y)
+                    if method == M.Method_CSR5SPMV:
+                        api.spmv_clear_handle(h)          # releases the device state, keeps the handle shell
+                    api.spmv_destory_handle(h)
+        api.set_option("cache_block", 1)
+        torch.cuda.synchronize()
+        return torch.cuda.mem_get_info()[0]
+
+    try:
+        first = cycle()
+        for _ in range(2):
+            last = cycle()
+    finally:
+        api.set_option("cache_block", 1)
+    assert last >= first - (1 << 20), (first, last)      # nothing accumulates (1 MiB slack for the runtime)
