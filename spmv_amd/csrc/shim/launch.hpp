@@ -69,6 +69,7 @@ static int autotune_vector(spmv_dev *d)
 {
     d->vec_choice = VEC_AUTO;
     if (d->nnz < (1ll << 24) || d->plan.variant != 0 || d->vt_tiles <= 0) return SPMV_HIP_OK;
+    if (d->vt_staged * 2 < d->vt_tiles) return SPMV_HIP_OK; // x windows not staged: the pipe form runs, nothing to choose (and 45 gather-bound launches would cost ~0.3 s)
     T *x = nullptr, *y = nullptr;
     if (hipMalloc((void **) &x, sizeof(T) * (size_t) d->n) != hipSuccess || hipMalloc((void **) &y, sizeof(T) * (size_t) d->m) != hipSuccess) {
         (void) hipGetLastError();
