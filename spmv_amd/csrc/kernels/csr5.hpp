@@ -376,18 +376,20 @@ __global__ __launch_bounds__(kBlock) void csr5_group_kernel(int group_tiles, int
 // reading its own SIGMA consecutive values directly would make every load instruction touch 64
 // different cache lines (measured: tiles wider than 4 entries per lane lost more than they won),
 // so the wave fetches the tile with fully coalesced 16-byte loads, parks it in LDS and each lane
-// reads its row back (row stride padded by 16 B / 4 B: conflict-free for ds_read_b128 / b32).
+// reads its row back (row stride padded by 16 B / 4 B: conflict-free for ds_read_b128 / b32) -- in two
+// halves of 32 lane rows, which halves the buffer (LDS is what limits the resident workgroups here).
 // Extra HBM: none for values; a 2 B/nnz slot stream for staged groups.
-template <typename T, int SIGMA>
+template <typename T, int SIGMA, bool HALF>
 struct NatLds {
+    static constexpr int kRows = HALF ? kWave / 2 : kWave;       // HALF: the tile is handed over in two halves of 32 lane rows
     static constexpr int kValRow = SIGMA * (int) sizeof(T) + 16; // bytes per lane row, padded
     static constexpr int kColRow = SIGMA * 2 + 4;
-    static constexpr int kValBytes = kWave * kValRow;
-    static constexpr int kColBytes = (kWave * kColRow + 15) & ~15;
-    static constexpr int kBytes = kValBytes + kColBytes;         // per wavefront
+    static constexpr int kValBytes = kRows * kValRow;
+    static constexpr int kColBytes = (kRows * kColRow + 15) & ~15;
+    static constexpr int kBytes = kValBytes + kColBytes;         // per wavefront: 11.5 KiB (5.8 KiB HALF) for fp64, sigma = 16
 };
 
-template <typename T, int SIGMA, bool MAPPED, bool STAGED>
+template <typename T, int SIGMA, bool MAPPED, bool STAGED, bool HALF>
 __device__ __forceinline__ void nat_tile(int t, int lane, int nnz, unsigned zslot, unsigned char *__restrict__ wl,
                                          const int *__restrict__ tile_ptr, const unsigned *__restrict__ desc,
                                          const int *__restrict__ colidx, const unsigned short *__restrict__ col16,
@@ -395,7 +397,7 @@ __device__ __forceinline__ void nat_tile(int t, int lane, int nnz, unsigned zslo
                                          const T *__restrict__ x, const T *__restrict__ xs,
                                          T *__restrict__ y, T *__restrict__ carry)
 {
-    using NL = NatLds<T, SIGMA>;
+    using NL = NatLds<T, SIGMA, HALF>;
     constexpr int TN = kWave * SIGMA;
     constexpr int EPL = 16 / (int) sizeof(T);              // values per 16-byte load
     constexpr int VL = SIGMA / EPL;                        // value loads per lane
@@ -404,14 +406,12 @@ __device__ __forceinline__ void nat_tile(int t, int lane, int nnz, unsigned zslo
     const long long tb = (long long) t * TN;
     const int left = nnz - tb < TN ? (int) (nnz - tb) : TN; // entries of this tile that exist
     unsigned char *lv = wl, *lc = wl + NL::kValBytes;
-    // 1. coalesced fetch -> LDS (entry p of the tile goes to row p / SIGMA, position p % SIGMA); all loads of
-    //    a whole tile are issued before the first LDS write, so they are in flight together
+    // 1. coalesced fetch into registers: load group j of a lane holds entries (j*64 + lane) * EPL ... of the tile;
+    //    every load of a whole tile is issued before the first LDS write, so they are in flight together
     int c[SIGMA];
-    auto vdst = [&](int p) { return reinterpret_cast<T *>(lv + (p / SIGMA) * NL::kValRow + (p % SIGMA) * (int) sizeof(T)); };
-    auto cdst = [&](int p) { return reinterpret_cast<unsigned *>(lc + (p / SIGMA) * NL::kColRow + (p % SIGMA) * 2); };
+    T tv[VL][EPL];
+    unsigned tw[CL][CS / 2]; // slot pairs
     if (left == TN) {
-        T tv[VL][EPL];
-        unsigned tw[CL][CS / 2]; // slot pairs
 #pragma unroll
         for (int j = 0; j < VL; ++j) {
             const int p = (j * kWave + lane) * EPL;
@@ -439,33 +439,21 @@ __device__ __forceinline__ void nat_tile(int t, int lane, int nnz, unsigned zslo
 #pragma unroll
             for (int q = 0; q < SIGMA; q += 4) ld_stream4(colidx + tb + lane * SIGMA + q, *reinterpret_cast<int(*)[4]>(&c[q]));
         }
-#pragma unroll
-        for (int j = 0; j < VL; ++j) {
-            T *dst = vdst((j * kWave + lane) * EPL);
-#pragma unroll
-            for (int e = 0; e < EPL; ++e) dst[e] = tv[j][e];
-        }
-        if (STAGED) {
-#pragma unroll
-            for (int j = 0; j < CL; ++j) {
-                unsigned *dst = cdst((j * kWave + lane) * CS);
-#pragma unroll
-                for (int e = 0; e < CS / 2; ++e) dst[e] = tw[j][e];
-            }
-        }
     } else { // the matrix's last tile: entry by entry, missing entries = 0 * zero slot
+#pragma unroll
         for (int j = 0; j < VL; ++j) {
             const int p = (j * kWave + lane) * EPL;
-            T *dst = vdst(p);
-            for (int e = 0; e < EPL; ++e) dst[e] = p + e < left ? val[tb + p + e] : T(0);
+#pragma unroll
+            for (int e = 0; e < EPL; ++e) tv[j][e] = p + e < left ? val[tb + p + e] : T(0);
         }
         if (STAGED) {
+#pragma unroll
             for (int j = 0; j < CL; ++j) {
                 const int p = (j * kWave + lane) * CS;
-                unsigned *dst = cdst(p);
+#pragma unroll
                 for (int e = 0; e < CS; e += 2) {
                     const unsigned lo = p + e < left ? col16[tb + p + e] : zslot, hi = p + e + 1 < left ? col16[tb + p + e + 1] : zslot;
-                    dst[e / 2] = lo | (hi << 16);
+                    tw[j][e / 2] = lo | (hi << 16);
                 }
             }
         } else {
@@ -473,24 +461,50 @@ __device__ __forceinline__ void nat_tile(int t, int lane, int nnz, unsigned zslo
             for (int i = 0; i < SIGMA; ++i) c[i] = lane * SIGMA + i < left ? colidx[tb + lane * SIGMA + i] : -1;
         }
     }
-    wave_lds_sync();
-    // 2. each lane reads its row back
+    // 2. hand-over through LDS in two halves (lane rows 0..31, then 32..63: half the buffer, twice the syncs):
+    //    entry p of the tile belongs to lane row p / SIGMA, position p % SIGMA
     T v[SIGMA];
-    {
-        const T *src = reinterpret_cast<const T *>(lv + lane * NL::kValRow);
 #pragma unroll
-        for (int i = 0; i < SIGMA; ++i) v[i] = src[i];
-        if (STAGED) {
-            const unsigned *cs = reinterpret_cast<const unsigned *>(lc + lane * NL::kColRow);
+    for (int half = 0; half < (HALF ? 2 : 1); ++half) {
+        const int r0 = half * NL::kRows;
 #pragma unroll
-            for (int i = 0; i < SIGMA; i += 2) {
-                const unsigned w = cs[i / 2];
-                c[i] = (int) (w & 0xffffu);
-                c[i + 1] = (int) (w >> 16);
+        for (int j = 0; j < VL; ++j) {
+            const int p = (j * kWave + lane) * EPL, row = p / SIGMA - r0;
+            if (row >= 0 && row < NL::kRows) {
+                T *dst = reinterpret_cast<T *>(lv + row * NL::kValRow + (p % SIGMA) * (int) sizeof(T));
+#pragma unroll
+                for (int e = 0; e < EPL; ++e) dst[e] = tv[j][e];
             }
         }
+        if (STAGED) {
+#pragma unroll
+            for (int j = 0; j < CL; ++j) {
+                const int p = (j * kWave + lane) * CS, row = p / SIGMA - r0;
+                if (row >= 0 && row < NL::kRows) {
+                    unsigned *dst = reinterpret_cast<unsigned *>(lc + row * NL::kColRow + (p % SIGMA) * 2);
+#pragma unroll
+                    for (int e = 0; e < CS / 2; ++e) dst[e] = tw[j][e];
+                }
+            }
+        }
+        wave_lds_sync();
+        const int mine = lane - r0;
+        if (mine >= 0 && mine < NL::kRows) {
+            const T *src = reinterpret_cast<const T *>(lv + mine * NL::kValRow);
+#pragma unroll
+            for (int i = 0; i < SIGMA; ++i) v[i] = src[i];
+            if (STAGED) {
+                const unsigned *cs = reinterpret_cast<const unsigned *>(lc + mine * NL::kColRow);
+#pragma unroll
+                for (int i = 0; i < SIGMA; i += 2) {
+                    const unsigned w = cs[i / 2];
+                    c[i] = (int) (w & 0xffffu);
+                    c[i + 1] = (int) (w >> 16);
+                }
+            }
+        }
+        wave_lds_sync(); // the buffer is free for the other half / the wave's next tile
     }
-    wave_lds_sync(); // the buffer is free for the wave's next tile
     csr5_tile_compute<T, SIGMA, MAPPED, STAGED>(t, lane, c, v, tile_ptr, desc, row_map, x, xs, y, carry);
 }
 
@@ -502,14 +516,16 @@ __global__ __launch_bounds__(kBlock) void nat_kernel(int p, int nnz, const int *
                                                      const T *__restrict__ x, T *__restrict__ y, T *__restrict__ carry, int n_empty, const int *__restrict__ empty_list)
 {
     if (MAPPED) zero_empty_rows(n_empty, empty_list, y);
-    __shared__ __attribute__((aligned(16))) unsigned char nat_lds[kBlock / kWave][NatLds<T, SIGMA>::kBytes];
+    __shared__ __attribute__((aligned(16))) unsigned char nat_lds[kBlock / kWave][NatLds<T, SIGMA, false>::kBytes];
     const int lane = threadIdx.x & (kWave - 1), wave = threadIdx.x / kWave;
     const int t = blockIdx.x * (kBlock / kWave) + wave;
     if (t >= p) return;
-    nat_tile<T, SIGMA, MAPPED, false>(t, lane, nnz, 0u, nat_lds[wave], tile_ptr, desc, colidx, nullptr, val, row_map, x, nullptr, y, carry);
+    nat_tile<T, SIGMA, MAPPED, false, false>(t, lane, nnz, 0u, nat_lds[wave], tile_ptr, desc, colidx, nullptr, val, row_map, x, nullptr, y, carry);
 }
 
-template <typename T, int SIGMA, bool MAPPED>
+// HALF: two-half hand-over (half the tile buffers, twice the wave syncs: ~8 % slower per tile) -- chosen by
+// the launcher when the x windows are so large that the full buffers would leave one workgroup per CU.
+template <typename T, int SIGMA, bool MAPPED, bool HALF>
 __global__ __launch_bounds__(kBlock) void nat_group_kernel(int group_tiles, int p, int nnz, const int *__restrict__ tile_ptr,
                                                            const unsigned *__restrict__ desc,
                                                            const int *__restrict__ colidx, const unsigned short *__restrict__ col16,
@@ -521,7 +537,7 @@ __global__ __launch_bounds__(kBlock) void nat_group_kernel(int group_tiles, int 
 {
     if (MAPPED) zero_empty_rows(n_empty, empty_list, y);
     extern __shared__ __attribute__((aligned(16))) unsigned char csr5_x_lds[];
-    __shared__ __attribute__((aligned(16))) unsigned char nat_lds[kBlock / kWave][NatLds<T, SIGMA>::kBytes];
+    __shared__ __attribute__((aligned(16))) unsigned char nat_lds[kBlock / kWave][NatLds<T, SIGMA, HALF>::kBytes];
     T *xs = reinterpret_cast<T *>(csr5_x_lds);
     const TileWindows &tw = wins[blockIdx.x];
     const bool staged = tw.nwin > 0;
@@ -535,8 +551,8 @@ __global__ __launch_bounds__(kBlock) void nat_group_kernel(int group_tiles, int 
     for (int k = wave; k < group_tiles; k += kBlock / kWave) {
         const int t = t0 + k;
         if (t >= p) break;
-        if (staged) nat_tile<T, SIGMA, MAPPED, true>(t, lane, nnz, (unsigned) tw.total, nat_lds[wave], tile_ptr, desc, colidx, col16, val, row_map, x, xs, y, carry);
-        else nat_tile<T, SIGMA, MAPPED, false>(t, lane, nnz, 0u, nat_lds[wave], tile_ptr, desc, colidx, col16, val, row_map, x, xs, y, carry);
+        if (staged) nat_tile<T, SIGMA, MAPPED, true, HALF>(t, lane, nnz, (unsigned) tw.total, nat_lds[wave], tile_ptr, desc, colidx, col16, val, row_map, x, xs, y, carry);
+        else nat_tile<T, SIGMA, MAPPED, false, HALF>(t, lane, nnz, 0u, nat_lds[wave], tile_ptr, desc, colidx, col16, val, row_map, x, xs, y, carry);
     }
 }
 

@@ -135,10 +135,19 @@ static void launch_csr5_form(spmv_dev *d, const Csr5Plan &P, const T *x, T *y)
     if (P.staged > 0) { // the inspector staged (at least half of) the groups: their column stream is the 16-bit slot array
         const size_t lds = ((((size_t) P.maxspan + 1) * sizeof(T)) + 1023) & ~(size_t) 1023; // + the zero slot
         if (P.natural) {
-            if (lds > 16 * 1024) // static tile buffers (up to 46 KiB) + this may pass the default 64 KiB limit
-                (void) hipFuncSetAttribute((const void *) nat_group_kernel<T, SIGMA, MAPPED>, hipFuncAttributeMaxDynamicSharedMemorySize, (int) lds);
-            nat_group_kernel<T, SIGMA, MAPPED><<<P.groups, kBlock, lds, d->stream>>>(P.group_tiles, P.tiles, (int) P.nnz, P.tile_ptr, P.desc, P.col, P.col16, (const T *) P.val,
-                                                                                    P.row_map, P.wins, x, y, (T *) P.carry, P.n_empty, P.empty_list);
+            // the waves' tile buffers are static LDS next to the x windows: if the full-size buffers would leave
+            // one workgroup per CU, hand the tiles over in two halves (half the buffers)
+            constexpr size_t full = (size_t) (kBlock / kWave) * NatLds<T, SIGMA, false>::kBytes;
+            const bool half = lds + full > 76 * 1024; // two workgroups no longer fit a CU's 160 KiB
+            if (half) {
+                if (lds > 16 * 1024) (void) hipFuncSetAttribute((const void *) nat_group_kernel<T, SIGMA, MAPPED, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int) lds);
+                nat_group_kernel<T, SIGMA, MAPPED, true><<<P.groups, kBlock, lds, d->stream>>>(P.group_tiles, P.tiles, (int) P.nnz, P.tile_ptr, P.desc, P.col, P.col16,
+                                                                                              (const T *) P.val, P.row_map, P.wins, x, y, (T *) P.carry, P.n_empty, P.empty_list);
+            } else {
+                if (lds > 16 * 1024) (void) hipFuncSetAttribute((const void *) nat_group_kernel<T, SIGMA, MAPPED, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int) lds);
+                nat_group_kernel<T, SIGMA, MAPPED, false><<<P.groups, kBlock, lds, d->stream>>>(P.group_tiles, P.tiles, (int) P.nnz, P.tile_ptr, P.desc, P.col, P.col16,
+                                                                                               (const T *) P.val, P.row_map, P.wins, x, y, (T *) P.carry, P.n_empty, P.empty_list);
+            }
             return;
         }
         if (lds > 64 * 1024) // above the default dynamic-LDS limit: raise it for this instantiation (idempotent, cheap)
