@@ -109,13 +109,14 @@ struct Lane4 {
 // One step of one lane group: lane l of the L lanes of row [p0, p1) multiplies its four entries
 // (c, v: already loaded by Lane4 from the chunk starting at the 16 B-aligned position p0 & ~3) and, for
 // rows longer than that chunk, walks on in chunks of 4L.  Returns the lane's partial sum (not yet reduced over the group).
-template <typename T, int L, bool STAGED>
+template <typename T, int L, bool STAGED, int SHIFT = 0>
 __device__ __forceinline__ T csr_vector_step(int p0, int p1, int l, const int (&cc0)[4], const T (&vv0)[4],
                                              const int *__restrict__ colidx, const unsigned short *__restrict__ col_local,
                                              const T *__restrict__ val, const T *__restrict__ x,
                                              const unsigned char *__restrict__ xb, unsigned zoff)
 {
-    auto xat = [&](unsigned off) { return *reinterpret_cast<const T *>(xb + off); };
+    // SHIFT = 0: the stream holds LDS byte offsets; SHIFT = log2(sizeof(T)): slot indices (windows above 64 KiB)
+    auto xat = [&](unsigned off) { return *reinterpret_cast<const T *>(xb + ((size_t) off << SHIFT)); };
     using LM = Lane4<T, L>;
     const int base = p0 & ~3;
     const int e0 = base + LM::pos(l, 0), e1 = base + LM::pos(l, 1), e2 = base + LM::pos(l, 2), e3 = base + LM::pos(l, 3); // ascending
@@ -181,7 +182,7 @@ __device__ __forceinline__ T csr_vector_step(int p0, int p1, int l, const int (&
 // zoff is the byte offset of a slot that holds 0 (masked entries read it: 0 * 0, never x's NaN/Inf).
 // A step whose lanes all hold four entries of their row, or none (regular matrices: every step),
 // takes the unmasked path.  The order of the fused multiply-adds is the same on both paths.
-template <typename T, int L, bool STAGED, int DEPTH, bool PRE = true>
+template <typename T, int L, bool STAGED, int DEPTH, bool PRE = true, int SHIFT = 0>
 __device__ __forceinline__ void csr_vector_tile_wave(long long row_end, int long_thr, long long rw0, int lane,
                                                      const int *__restrict__ rp_lds, T *__restrict__ y_lds,
                                                      const int *__restrict__ colidx, const unsigned short *__restrict__ col_local,
@@ -216,7 +217,7 @@ __device__ __forceinline__ void csr_vector_tile_wave(long long row_end, int long
     for (int s = 0; s < L; ++s) {
         const int cur = s % D;
         const int p0 = pp0[cur], p1 = pp1[cur];
-        T sum = csr_vector_step<T, L, STAGED>(p0, p1, l, c[cur], v[cur], colidx, col_local, val, x, xb, zoff);
+        T sum = csr_vector_step<T, L, STAGED, SHIFT>(p0, p1, l, c[cur], v[cur], colidx, col_local, val, x, xb, zoff);
         sum = group_sum_dpp<L>(sum);
         if (l == 0) y_lds[s * RW + sub] = sum;
         if (s + D < L) issue(s + D); // refill the slot just consumed
@@ -276,8 +277,9 @@ __global__ __launch_bounds__(kVecTileThreads) void csr_vector_tile_kernel(int m,
 // rows [split[b], split[b+1]) (init_csrSplitter_balanced2 semantics, parallel_balanced2_spmv.c:41-53,
 // built by rowblock_split_kernel) and walks them in 256-row slabs, 64 rows per wave; the x windows
 // of the whole block are staged once.
-template <typename T, int L, int DEPTH = 4>
+template <typename T, int L, int DEPTH = 4, bool WIDE = false>
 __global__ __launch_bounds__(kVecTileThreads) void csr_vector_rows_kernel(int long_thr, const int *__restrict__ split,
+                                                                          int rows_per_block, int m,
                                                                           const int *__restrict__ rowptr,
                                                                           const int *__restrict__ colidx,
                                                                           const unsigned short *__restrict__ col_local,
@@ -285,18 +287,23 @@ __global__ __launch_bounds__(kVecTileThreads) void csr_vector_rows_kernel(int lo
                                                                           const TileWindows *__restrict__ wins,
                                                                           const T *__restrict__ x, T *__restrict__ y)
 {
+    // WIDE: x windows above 64 KiB (fp64 rows whose columns scatter over thousands of columns): the column
+    // stream holds slot INDICES instead of byte offsets; blocks are `rows_per_block` consecutive rows
+    // (split == NULL) so that one staging serves more rows.
+    constexpr int SHIFT = WIDE ? (sizeof(T) == 8 ? 3 : 2) : 0;
     extern __shared__ __attribute__((aligned(16))) unsigned char vec_x_lds[];
     T *xs = reinterpret_cast<T *>(vec_x_lds);
     __shared__ int rp_lds[kVecTileThreads / kWave][kWave + 2];
     __shared__ T y_lds[kVecTileThreads / kWave][kWave];
     const int lane = threadIdx.x & (kWave - 1), wave = threadIdx.x / kWave;
-    const long long r_begin = split[blockIdx.x], r_end = split[blockIdx.x + 1];
+    long long r_begin, r_end;
+    tile_rows(blockIdx.x, m, rows_per_block, split, r_begin, r_end);
     const TileWindows &tw = wins[blockIdx.x];
     const bool staged = tw.nwin > 0;
     stage_windows<kVecTileThreads, T>(tw, x, xs);
     if (threadIdx.x == 0) xs[tw.total] = T(0); // the zero slot of masked entries
     __syncthreads();
-    const unsigned zoff = (unsigned) tw.total * (unsigned) sizeof(T);
+    const unsigned zoff = WIDE ? (unsigned) tw.total : (unsigned) tw.total * (unsigned) sizeof(T);
     const int c0[4] = {0, 0, 0, 0};
     const T v0[4] = {T(0), T(0), T(0), T(0)};
     for (long long rw0 = r_begin + (long long) wave * kWave; rw0 < r_end; rw0 += kVecTileRows) {
@@ -306,8 +313,8 @@ __global__ __launch_bounds__(kVecTileThreads) void csr_vector_rows_kernel(int lo
         rp_lds[wave][lane] = rowptr[r];
         if (lane == 0) rp_lds[wave][kWave] = rowptr[re];
         wave_lds_sync();
-        if (staged) csr_vector_tile_wave<T, L, true, DEPTH, false>(r_end, long_thr, rw0, lane, rp_lds[wave], y_lds[wave], colidx, col_local, val, x, xs, zoff, y, c0, v0);
-        else csr_vector_tile_wave<T, L, false, DEPTH, false>(r_end, long_thr, rw0, lane, rp_lds[wave], y_lds[wave], colidx, col_local, val, x, xs, zoff, y, c0, v0);
+        if (staged) csr_vector_tile_wave<T, L, true, DEPTH, false, SHIFT>(r_end, long_thr, rw0, lane, rp_lds[wave], y_lds[wave], colidx, col_local, val, x, xs, zoff, y, c0, v0);
+        else csr_vector_tile_wave<T, L, false, DEPTH, false, SHIFT>(r_end, long_thr, rw0, lane, rp_lds[wave], y_lds[wave], colidx, col_local, val, x, xs, zoff, y, c0, v0);
         wave_lds_sync(); // y_lds / rp_lds are reused by the next slab
     }
 }

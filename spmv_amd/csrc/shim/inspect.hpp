@@ -40,7 +40,8 @@ template <typename T>
 static int build_csr5(spmv_dev *d, Csr5Plan &P, int m, long long nnz, const int *rowptr, const int *colidx, const T *val, int empty_rows,
                       double mean_row_len, const int *out_rows, bool natural = false);
 template <typename T> static int autotune_vector(spmv_dev *d);
-template <typename T> static int build_tile_windows(spmv_dev *d, int tiles, const int *split, int rows_per_tile = kVecTileRows);
+template <typename T> static int build_tile_windows(spmv_dev *d, int tiles, const int *split, int rows_per_tile = kVecTileRows, bool wide = false);
+constexpr size_t kVecWideXTileBytes = 96 * 1024; // budget of the wide form (slot indices; two workgroups per CU)
 
 constexpr size_t kSplitXTileBytes = 48 * 1024; // LDS budget of one nnz-split tile group's x span
 
@@ -95,29 +96,43 @@ static int build_rowblock_tiles(spmv_dev *d)
     if (rc) return rc;
     rc = build_tile_windows<T>(d, d->nblocks, d->rb_split);
     if (rc) return rc;
-    return SPMV_HIP_OK;
+    if (d->vt_staged * 2 < d->vt_tiles && d->plan.variant == 0) { // wide windows: slot indices, 96 KiB budget (same blocks)
+        rc = build_tile_windows<T>(d, d->nblocks, d->rb_split, kVecTileRows, true);
+        if (rc) return rc;
+        if (d->vt_staged * 2 < d->vt_tiles) rc = build_tile_windows<T>(d, d->nblocks, d->rb_split);
+    }
+    return rc;
 }
 
 // Windows of every row tile + the tile-local ColIdx copy (kernels/csr_vector_tile.hpp).
 template <typename T>
-static int build_tile_windows(spmv_dev *d, int tiles, const int *split, int rows_per_tile)
+static int build_tile_windows(spmv_dev *d, int tiles, const int *split, int rows_per_tile, bool wide)
 {
     int *cnt = nullptr;
     int host2[2] = {0, 0};
     d->vt_tiles = tiles;
     ALLOC_TRY(d, &cnt, 2 * sizeof(int), true);
     static_assert(kVecXTileBytes <= 65536, "LDS byte offsets must fit 16 bits");
-    ALLOC_TRY(d, &d->vt_col, sizeof(unsigned short) * ((size_t) d->nnz + kStreamPad), true);
+    static_assert(kVecWideXTileBytes / sizeof(float) <= 65536, "LDS slot indices must fit 16 bits");
+    if (!d->vt_col) {
+        ALLOC_TRY(d, &d->vt_col, sizeof(unsigned short) * ((size_t) d->nnz + kStreamPad), true);
+        HIP_TRY(hipMemsetAsync(d->vt_col, 0, sizeof(unsigned short) * ((size_t) d->nnz + kStreamPad), d->stream));
+    }
+    if (d->vt_wins) sched_free(d, d->vt_wins);
     ALLOC_TRY(d, &d->vt_wins, sizeof(TileWindows) * (size_t) tiles, true);
-    HIP_TRY(hipMemsetAsync(d->vt_col, 0, sizeof(unsigned short) * ((size_t) d->nnz + kStreamPad), d->stream));
     HIP_TRY(hipMemsetAsync(cnt, 0, 2 * sizeof(int), d->stream));
-    csr_tile_windows_kernel<<<tiles, kBlock, 0, d->stream>>>(d->m, d->n, rows_per_tile, d->long_thr, (int) (kVecXTileBytes / sizeof(T)) - 1, (int) sizeof(T), split, d->rowptr, d->colidx,
+    // narrow form: the stream holds LDS byte offsets (budget 48 KiB); wide form: slot indices (budget 96 KiB)
+    csr_tile_windows_kernel<<<tiles, kBlock, 0, d->stream>>>(d->m, d->n, rows_per_tile, d->long_thr,
+                                                             (int) ((wide ? kVecWideXTileBytes : kVecXTileBytes) / sizeof(T)) - 1, wide ? 1 : (int) sizeof(T),
+                                                             split, d->rowptr, d->colidx,
                                                              d->vt_wins, d->vt_col, cnt);
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipMemcpyAsync(host2, cnt, 2 * sizeof(int), hipMemcpyDeviceToHost, d->stream));
     HIP_TRY(hipStreamSynchronize(d->stream));
     d->vt_staged = host2[0];
     d->vt_maxspan = host2[1];
+    d->vt_wide = wide;
+    d->vt_rows = rows_per_tile;
     return SPMV_HIP_OK;
 }
 
@@ -212,7 +227,17 @@ static int build_vector_tiles(spmv_dev *d)
     const int rows = kVecTileRows;
     d->vt_tiles = (int) (((long long) d->m + rows - 1) / rows);
     if (d->vt_tiles == 0 || d->nnz == 0) return SPMV_HIP_OK;
-    return build_tile_windows<T>(d, d->vt_tiles, nullptr, rows);
+    int rc = build_tile_windows<T>(d, d->vt_tiles, nullptr, rows);
+    if (rc || d->vt_staged * 2 >= d->vt_tiles || d->plan.variant != 0) return rc;
+    // fewer than half of the 256-row tiles fit the 48 KiB budget.  Before settling for global gathers (pipe
+    // form), try the WIDE form: 1024-row blocks walked by the rows kernel, 96 KiB budget, slot indices in the
+    // stream (windows above 64 KiB: fp64 rows scattered over +-4096 columns, config 4 in fp64: 2.04 -> 1.52 ms)
+    const int wide_rows = 4 * kVecTileRows;
+    const int wide_tiles = (int) (((long long) d->m + wide_rows - 1) / wide_rows);
+    rc = build_tile_windows<T>(d, wide_tiles, nullptr, wide_rows, true);
+    if (rc) return rc;
+    if (d->vt_staged * 2 >= d->vt_tiles) return SPMV_HIP_OK;
+    return build_tile_windows<T>(d, (int) (((long long) d->m + rows - 1) / rows), nullptr, rows); // no: back to the narrow tiles (unstaged -> pipe form)
 }
 
 template <typename T> static int launch_csr5(spmv_dev *d, const Csr5Plan &P, const T *x, T *y);

@@ -69,7 +69,7 @@ static int autotune_vector(spmv_dev *d)
 {
     d->vec_choice = VEC_AUTO;
     if (d->nnz < (1ll << 24) || d->plan.variant != 0 || d->vt_tiles <= 0) return SPMV_HIP_OK;
-    if (d->vt_staged * 2 < d->vt_tiles) return SPMV_HIP_OK; // x windows not staged: the pipe form runs, nothing to choose (and 45 gather-bound launches would cost ~0.3 s)
+    if (d->vt_wide || d->vt_staged * 2 < d->vt_tiles) return SPMV_HIP_OK; // wide form: one kernel form; x windows not staged: the pipe form runs, nothing to choose (and 45 gather-bound launches would cost ~0.3 s)
     T *x = nullptr, *y = nullptr;
     if (hipMalloc((void **) &x, sizeof(T) * (size_t) d->n) != hipSuccess || hipMalloc((void **) &y, sizeof(T) * (size_t) d->m) != hipSuccess) {
         (void) hipGetLastError();
@@ -188,14 +188,35 @@ static int launch_csr5(spmv_dev *d, const Csr5Plan &P, const T *x, T *y)
     return SPMV_HIP_OK;
 }
 
+// The rows kernel: Balanced's equal-nnz row blocks (split), or CSR-vector's wide form (uniform blocks).
 template <typename T, int L>
-static void launch_rows(spmv_dev *d, const T *x, T *y)
+static void launch_rows(spmv_dev *d, const T *x, T *y, const int *split)
 {
+    constexpr int DEPTH = sizeof(T) == 8 ? 4 : 2;
     const size_t lds = ((((size_t) d->vt_maxspan + 1) * sizeof(T)) + 1023) & ~(size_t) 1023; // + the zero slot
-    if (lds > 64 * 1024)
-        (void) hipFuncSetAttribute((const void *) csr_vector_rows_kernel<T, L, (sizeof(T) == 8 ? 4 : 2)>, hipFuncAttributeMaxDynamicSharedMemorySize, (int) lds);
-    csr_vector_rows_kernel<T, L, (sizeof(T) == 8 ? 4 : 2)><<<d->nblocks, kVecTileThreads, lds, d->stream>>>(
-        d->long_thr, d->rb_split, d->rowptr, d->colidx, d->vt_col, (const T *) d->val, d->vt_wins, x, y);
+    if (d->vt_wide) {
+        if (lds > 64 * 1024) (void) hipFuncSetAttribute((const void *) csr_vector_rows_kernel<T, L, DEPTH, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int) lds);
+        csr_vector_rows_kernel<T, L, DEPTH, true><<<d->vt_tiles, kVecTileThreads, lds, d->stream>>>(
+            d->long_thr, split, d->vt_rows, d->m, d->rowptr, d->colidx, d->vt_col, (const T *) d->val, d->vt_wins, x, y);
+        return;
+    }
+    if (lds > 64 * 1024) (void) hipFuncSetAttribute((const void *) csr_vector_rows_kernel<T, L, DEPTH>, hipFuncAttributeMaxDynamicSharedMemorySize, (int) lds);
+    csr_vector_rows_kernel<T, L, DEPTH><<<d->vt_tiles, kVecTileThreads, lds, d->stream>>>(
+        d->long_thr, split, d->vt_rows, d->m, d->rowptr, d->colidx, d->vt_col, (const T *) d->val, d->vt_wins, x, y);
+}
+
+template <typename T>
+static void launch_rows_any(spmv_dev *d, const T *x, T *y, const int *split)
+{
+    switch (d->plan.lanes_per_row) {
+    case 1: launch_rows<T, 1>(d, x, y, split); break;
+    case 2: launch_rows<T, 2>(d, x, y, split); break;
+    case 4: launch_rows<T, 4>(d, x, y, split); break;
+    case 8: launch_rows<T, 8>(d, x, y, split); break;
+    case 16: launch_rows<T, 16>(d, x, y, split); break;
+    case 32: launch_rows<T, 32>(d, x, y, split); break;
+    default: launch_rows<T, 64>(d, x, y, split); break;
+    }
 }
 
 template <typename T>
@@ -213,7 +234,8 @@ static int launch(spmv_dev *d, const T *x, T *y)
         csr_scalar_kernel<T><<<grid_for(d->m, kBlock, d->cus * 8), kBlock, 0, d->stream>>>(d->m, d->rowptr, d->colidx, val, x, y);
         break;
     case SPMV_SCHED_CSR_VECTOR:
-        launch_vector_any<T>(d, x, y);
+        if (d->vt_wide) launch_rows_any<T>(d, x, y, nullptr); // wide x windows: uniform 1024-row blocks, slot-index stream
+        else launch_vector_any<T>(d, x, y);
         if (d->plan.variant != 2) launch_long_rows<T>(d, x, y);
         break;
     case SPMV_SCHED_NNZ_SPLIT: {
@@ -243,15 +265,7 @@ static int launch(spmv_dev *d, const T *x, T *y)
             rowblock_kernel<T><<<d->nblocks, kBlock, 2 * (size_t) d->rb_stride * sizeof(T), d->stream>>>(d->rb_split, d->rowptr, d->colidx, val, x, y);
             break;
         }
-        switch (d->plan.lanes_per_row) {
-        case 1: launch_rows<T, 1>(d, x, y); break;
-        case 2: launch_rows<T, 2>(d, x, y); break;
-        case 4: launch_rows<T, 4>(d, x, y); break;
-        case 8: launch_rows<T, 8>(d, x, y); break;
-        case 16: launch_rows<T, 16>(d, x, y); break;
-        case 32: launch_rows<T, 32>(d, x, y); break;
-        default: launch_rows<T, 64>(d, x, y); break;
-        }
+        launch_rows_any<T>(d, x, y, d->rb_split);
         launch_long_rows<T>(d, x, y);
         break;
     case SPMV_SCHED_SELL:

@@ -75,6 +75,8 @@ struct spmv_dev {
     int *rb_split = nullptr;
     // csr-vector x tiles
     int vt_tiles = 0, vt_staged = 0, vt_maxspan = 0, vec_choice = 0;
+    bool vt_wide = false;           // windows above 64 KiB: slot-index stream, blocks of vt_rows rows, rows kernel
+    int vt_rows = 256;
     float tune_ms[3] = {0, 0, 0}; // tile D4, tile D2, pipe (autotune_vector)
     unsigned short *vt_col = nullptr; // tile-local column stream: 16-bit LDS slots (staged tiles only)
     TileWindows *vt_wins = nullptr; // x windows of every tile
@@ -147,7 +149,7 @@ static void free_schedule(spmv_dev *d)
     d->sval = d->lr_part = nullptr;
     d->ntiles = d->nblocks = d->nchunks = d->nlong = d->lr_segs = 0;
     d->long_thr = INT_MAX;
-    d->vt_col = nullptr; d->vt_wins = nullptr; d->vt_tiles = d->vt_staged = d->vt_maxspan = 0;
+    d->vt_col = nullptr; d->vt_wins = nullptr; d->vt_tiles = d->vt_staged = d->vt_maxspan = 0; d->vt_wide = false; d->vt_rows = 256;
     d->c5 = Csr5Plan();
     d->c5_long = Csr5Plan();
     d->ns = Csr5Plan();

@@ -325,6 +325,7 @@ extern "C" int spmv_shim_info(const spmv_dev *d, spmv_hip_info *o)
     if (d->plan.sched == SPMV_SCHED_CSR_VECTOR && d->vt_tiles > 0 && d->vec_choice != VEC_PIPE &&
         (d->vt_staged * 2 >= d->vt_tiles || (d->vec_choice != VEC_AUTO && d->vec_choice != VEC_PIPE)))
         o->kernel_name = "csr_vector_tile_kernel";
+    if (d->plan.sched == SPMV_SCHED_CSR_VECTOR && d->vt_wide) o->kernel_name = "csr_vector_rows_kernel";
     o->cache_blocked = d->blk_on ? 1 : 0;
     switch (d->plan.sched) {
     case SPMV_SCHED_CSR_VECTOR:
