@@ -403,3 +403,32 @@ def test_create_destroy_cycles_return_all_device_memory():
     finally:
         api.set_option("cache_block", 1)
     assert last >= first - (1 << 20), (first, last)      # nothing accumulates (1 MiB slack for the runtime)
+
+
+def test_wide_x_windows_use_the_slot_index_form():
+    """fp64 rows whose columns scatter over ~9000 columns: a 256-row tile's window (72 KB) exceeds the 48 KiB
+    budget of the byte-offset stream, so CSR-vector and Balanced run the wide form (1024-row blocks / the
+    row blocks, 96 KiB budget, slot indices) instead of falling back to global gathers.  Exact inputs -> exact bits."""
+    m = n = 40000
+    csr = synth.from_row_lengths(np.full(m, 12), n, "eighths", np.float64, seed=21, local=4500)
+    rng = np.random.default_rng(5)
+    x = (rng.integers(-8, 9, n) * 0.125)
+    prod = csr.val * x[csr.colidx]
+    cs = np.concatenate([[0.0], np.cumsum(prod)])
+    want = cs[csr.rowptr[1:].astype(np.int64)] - cs[csr.rowptr[:-1].astype(np.int64)]
+    import torch
+    dev = torch.device("cuda:0")
+    rp, ci = torch.from_numpy(csr.rowptr).to(dev), torch.from_numpy(csr.colidx).to(dev)
+    va, xd = torch.from_numpy(csr.val).to(dev), torch.from_numpy(x).to(dev)
+    for method in (M.Method_Parallel, M.Method_Balanced):
+        yd = torch.full((m,), float("nan"), dtype=torch.float64, device=dev)
+        with api.Handle(m, n, rp, ci, va, method) as h:
+            h.spmv(xd, yd)
+            info = h.info()
+        torch.cuda.synchronize()
+        assert info["kernel_name"] == "csr_vector_rows_kernel" and info["x_groups_staged"] * 2 >= info["x_groups"], info
+        assert np.array_equal(yd.cpu().numpy(), want), method
+    # fp32 of the same matrix fits the narrow budget: the tile kernel
+    csr32 = synth.CSR(m, n, csr.rowptr, csr.colidx, csr.val.astype(np.float32))
+    y, _ = run_host(csr32, x.astype(np.float32), M.Method_Parallel)
+    assert np.array_equal(y, want.astype(np.float32))
