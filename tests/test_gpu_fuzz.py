@@ -6,6 +6,8 @@ definition is an indexing / masking / carry bug, not rounding.  The shapes aim a
 machinery: rows that straddle tile and lane-group boundaries, empty rows in every position, one row
 holding most of the matrix, m or n of 1, columns with and without locality (x windows staged or not),
 matrices of exactly one tile, and so on.  The reference has no such test (one RMSE check)."""
+import os
+
 import numpy as np
 import pytest
 
@@ -75,7 +77,11 @@ OPTIONS = {"csr5_sigma": [0, 4, 8, 16], "sell_sigma": [64, 1024], "rowblock_nnz"
            "cache_block": [1, 2], "variant": [0, 0, 0, 3, 13]}
 
 
-@pytest.mark.parametrize("seed", range(48))
+# SPMV_FUZZ_FIRST / SPMV_FUZZ_SEEDS widen the sweep (348 seeds were run once on the final kernels)
+_FIRST, _COUNT = int(os.environ.get("SPMV_FUZZ_FIRST", "0")), int(os.environ.get("SPMV_FUZZ_SEEDS", "48"))
+
+
+@pytest.mark.parametrize("seed", range(_FIRST, _FIRST + _COUNT))
 def test_fuzz_every_schedule_matches_the_definition(seed):
     csr, x, rng = _case(seed)
     want = _definition(csr, x)
