@@ -269,6 +269,7 @@ static int build_sell(spmv_dev *d)
     // rows that would pad a whole chunk to their length are kept in CSR (see sell.hpp)
     double thr = 8.0 * d->stats.mean_row_len;
     if (thr < 64.0) thr = 64.0;
+    if (d->plan.sell_long_thr > 0) thr = (double) d->plan.sell_long_thr;
     {
         const int rc = build_long_rows<T>(d, thr > (double) INT_MAX ? INT_MAX : (int) thr);
         if (rc) return rc;

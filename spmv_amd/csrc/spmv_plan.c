@@ -32,6 +32,7 @@ static opt_t g_opts[] = {
     {"sell_c", 64, 64, 64, 1, 0},          /* one wavefront per chunk: C is the wave width */
     {"sell_sigma", 1024, 64, 1 << 20, 1, 0},
     {"sell_lds_x", 1, 0, 1, 0, 0},         /* SELL: stage the x windows of the sigma windows in LDS */
+    {"sell_long_thr", 0, 0, 1 << 20, 0, 0},/* SELL: rows longer than this leave the slabs for the long-row path (0 = max(64, 8 x mean)) */
     {"csr5_sigma", 0, 0, 16, 0, 0},        /* CSR5 / nnz-split tiles of 64 x sigma entries: 0 = auto, else 4, 8, 16 */
     {"rowblock_nnz", 0, 0, 1 << 20, 0, 0}, /* Balanced: equal-nnz share of one row block, 0 = 256 mean-length rows */
     {"cache_block", 1, 0, 2, 0, 0},        /* Balanced family: row-block x column-slab executor when no x window can
@@ -179,6 +180,7 @@ void spmv_plan_choose_ex(SPMV_METHODS requested, const spmv_stats *st, size_t va
     plan->sell_c = (int) spmv_hip_get_option("sell_c");
     plan->sell_sigma = (int) spmv_hip_get_option("sell_sigma");
     plan->sell_lds_x = (int) spmv_hip_get_option("sell_lds_x");
+    plan->sell_long_thr = (int) spmv_hip_get_option("sell_long_thr");
     plan->cache_block = (int) spmv_hip_get_option("cache_block");
     plan->slab_kib = (int) spmv_hip_get_option("slab_kib");
     plan->block_rows = (int) spmv_hip_get_option("block_rows");

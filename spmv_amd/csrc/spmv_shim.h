@@ -42,7 +42,7 @@ typedef struct spmv_plan {
     int sched;          /* enum spmv_sched */
     int lanes_per_row;  /* csr-vector */
     int long_thr;       /* csr-vector: rows longer than this go to the long-row (CSR5 sub-matrix) path; 0 = max(64 L, 256) */
-    int sell_c, sell_sigma, sell_lds_x;
+    int sell_c, sell_sigma, sell_lds_x, sell_long_thr;
     int csr5_sigma;
     int slab_kib, block_rows; /* row-block x column-slab executor shape (0 = defaults) */
     int cache_block;    /* nnz-split family: 0 never, 1 automatic, 2 always use the row-block x column-slab executor */
