@@ -19,7 +19,7 @@
 //     the original ColIdx and gather from L1/L2;
 //   - matrix stream: 16 B lane loads, DEPTH steps in flight per wave;
 //   - the 64 row sums of a wave are collected through LDS and written by ONE coalesced store.
-// Rows longer than long_thr are left to kernels/long_rows.hpp (which reads the ORIGINAL ColIdx) and
+// Rows longer than long_thr are left to the long-row path (a CSR5 plan over their sub-matrix, long_rows.hpp) and
 // are excluded from the windows.
 // Extra HBM held: col_local uint16[nnz] (read INSTEAD of ColIdx for staged tiles) and 200 B of window
 // table per tile.

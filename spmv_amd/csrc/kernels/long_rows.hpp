@@ -1,4 +1,6 @@
-// long_rows.hpp -- rows far longer than the schedule's lane group, computed by whole wavefronts.
+// long_rows.hpp -- rows far longer than the schedule's lane group: the sub-matrix gather of the default
+// long-row path (a CSR5 plan over the long rows, see the section further down) and the first-round segment
+// kernel kept as A/B variant 13.
 //
 // Used by CSR-vector (Method_Parallel) and SELL-C-sigma (Method_SellCSigma): a row much longer than
 // L*4 would keep one lane group looping (CSR-vector) or pad a whole 64-row chunk to its length

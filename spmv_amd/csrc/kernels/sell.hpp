@@ -9,13 +9,13 @@
 //
 // HBM layout (global arrays instead of the reference's per-window mallocs):
 //   perm      int32[nchunks*64]   original row of each sorted slot, -1 = no row (padding slot,
-//                                 or a LONG row handled by kernels/long_rows.hpp)
+//                                 or a LONG row handled by the long-row path, kernels/long_rows.hpp)
 //   chunk_ptr int64[nchunks+1]    prefix sum of chunk widths (in columns; element offset = *64)
 //   col / val [chunk_ptr[nchunks]*64]  column-major inside a chunk: (row slot l, j) at
 //                                 (chunk_ptr[c] + j)*64 + l;  padding: col = -1, val = 0
 //   long rows                     rows longer than `long_thr` are excluded from the slabs (they would
-//                                 pad their whole chunk to their length) and computed by whole
-//                                 wavefronts straight from CSR (kernels/long_rows.hpp) -- the
+//                                 pad their whole chunk to their length) and computed by
+//                                 the long-row path (their CSR5 sub-matrix, kernels/long_rows.hpp) -- the
 //                                 analogue of the reference's CSR remainder loop
 //                                 (sell_C_Sigma_spmv.c:289-298).
 // Rows are sorted DESCENDING by length inside a window (the reference sorts ascending; either is
