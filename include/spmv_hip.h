@@ -56,7 +56,8 @@ int spmv_hip_synchronize(spmv_Handle_t handle);
  *                  resident, and handle->index holds the permutation -- the caller gathers
  *                  XX[i] = X[index[i]] and scatters Y[index[i]] = YY[i] exactly as the reference's harness
  *                  does for its OPT_LEVEL 3 path, test_spmv.c:95-101, 130-137)
- *       "auto_method" (0/1: create() replaces the requested method by the one its row statistics
+ *       "auto_method" (0/1/2; 2 = like 1, then every candidate schedule is built and timed on scratch vectors at
+ *                      create and the fastest kept, +0.1..0.3 s for 3e8 nnz.  1: create() replaces the requested method by the one its row statistics
  *                      favour -- CSR-vector for regular rows, CSR5 otherwise -- and, if that schedule cannot
  *                      stage a single x window on a matrix whose x is far larger than an L2, by
  *                      Method_Balanced_Yid with the cache-blocked executor; the handle reports it)

@@ -164,7 +164,7 @@ static int state_build(spmv_Handle_t h, spmv_hip_state *st, int m, int n, const 
      * the schedule just built could not stage a single x window on a matrix whose x is far larger than an
      * L2, every gather crosses the fabric -- rebuild as nnz-split, whose executor for that case keeps y of
      * a row block in LDS and walks the entries column slab by column slab (kernels/blocked.hpp). */
-    if (spmv_hip_get_option("auto_method") == 1 && spmv_hip_get_option("cache_block") != 0 &&
+    if (spmv_hip_get_option("auto_method") >= 1 && spmv_hip_get_option("cache_block") != 0 &&
         (st->plan.sched == SPMV_SCHED_CSR_VECTOR || st->plan.sched == SPMV_SCHED_CSR5)) {
         spmv_hip_info info;
         if (spmv_shim_info(st->dev, &info) == SPMV_HIP_OK && info.x_groups > 0 && info.x_groups_staged == 0 &&
@@ -185,6 +185,41 @@ static int state_build(spmv_Handle_t h, spmv_hip_state *st, int m, int n, const 
                 }
             }
         }
+    }
+    /* automatic choice, measured (auto_method = 2): the rules above pick from row statistics; which schedule is
+     * fastest also depends on the columns and, by a few percent, on the device.  For matrices
+     * large enough to be worth it, every candidate schedule is built and timed on scratch vectors and the
+     * fastest is kept (the rule-based choice stays on a tie within 2 %). */
+    if (spmv_hip_get_option("auto_method") == 2 && stats.nnz >= (1ll << 20)) {
+        static const SPMV_METHODS cand[] = {Method_Parallel, Method_CSR5SPMV, Method_SellCSigma, Method_Balanced_Yid, Method_Balanced};
+        spmv_plan best_plan = st->plan;
+        SPMV_METHODS best_method = actual;
+        double best_ms = spmv_shim_time_self(st->dev, 5);
+        unsigned k;
+        int current_is_best = best_ms >= 0.0;
+        for (k = 0; k < sizeof cand / sizeof cand[0] && best_ms >= 0.0; ++k) {
+            spmv_plan p;
+            SPMV_METHODS a = cand[k];
+            double ms;
+            spmv_plan_choose_ex(cand[k], &stats, (size_t) h->data_size, &p, &a, 0);
+            if (a == actual && p.sched == st->plan.sched) continue; /* the one already built and timed */
+            if (a == best_method && p.sched == best_plan.sched) continue;
+            if (spmv_shim_build(st->dev, &p) != SPMV_HIP_OK) { current_is_best = 0; continue; }
+            current_is_best = 0;
+            ms = spmv_shim_time_self(st->dev, 5);
+            if (ms >= 0.0 && ms < 0.98 * best_ms) { best_ms = ms; best_plan = p; best_method = a; current_is_best = 1; }
+        }
+        if (!current_is_best) {
+            rc = spmv_shim_build(st->dev, &best_plan);
+            if (rc) {
+                spmv_set_error(rc, "create/inspect", spmv_shim_error_text());
+                spmv_shim_matrix_destroy(st->dev);
+                st->dev = NULL;
+                return rc;
+            }
+        }
+        st->plan = best_plan;
+        actual = best_method;
     }
     if (st->stream_set) spmv_shim_set_stream(st->dev, st->stream);
     spmv_shim_set_async(st->dev, st->async);

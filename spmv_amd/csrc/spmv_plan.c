@@ -40,7 +40,8 @@ static opt_t g_opts[] = {
     {"slab_kib", 0, 0, 1 << 16, 1, 0},     /* ... KiB of x per column slab (0 = as narrow as the cell table allows) */
     {"block_rows", 0, 0, 32768, 1, 0},     /* ... rows per block (0 = 64 KiB of y) */
     {"variant", 0, 0, 1 << 20, 0, 0},      /* kernel-form selector of the A/B harness and the variant tests, 0 = default */
-    {"auto_method", 0, 0, 1, 0, 0},        /* 1: create() picks the schedule from the matrix (two stages, spmv_api.c) */
+    {"auto_method", 0, 0, 2, 0, 0},        /* 1: create() picks the schedule from the matrix by rules (two stages, spmv_api.c);
+                                            * 2: ... by building the candidate schedules and timing them */
     {"autotune", 1, 0, 1, 0, 0},           /* 1: create() times the CSR-vector kernel forms on matrices >= 2^24 nnz */
     {"reorder", 0, 0, 1, 0, 0},            /* 1: square matrices are RCM-reordered at create; handle->index = permutation */
 };
@@ -211,7 +212,7 @@ void spmv_plan_choose_ex(SPMV_METHODS requested, const spmv_stats *st, size_t va
      * (measured: CSR-vector leads on regular shapes that fill its chunks, CSR5 elsewhere -- DESIGN.md
      * section 3).  spmv_api.c adds a second stage for matrices without column locality.  The handle reports
      * the method actually used. */
-    if (allow_auto && spmv_hip_get_option("auto_method") == 1 && st->m > 0) {
+    if (allow_auto && spmv_hip_get_option("auto_method") >= 1 && st->m > 0) {
         const int regular = st->mean_row_len >= 4.0 && (double) st->max_row_len <= 4.0 * st->mean_row_len &&
                             (double) st->empty_rows <= 0.01 * (double) st->m;
         /* chunk fill of CSR-vector with the L just chosen: nnz / sum over rows of ceil(len / 4L) * 4L, rows

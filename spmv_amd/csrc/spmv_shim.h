@@ -69,6 +69,8 @@ int spmv_shim_set_async(spmv_dev *d, int async);
 int spmv_shim_sync(spmv_dev *d);
 int spmv_shim_info(const spmv_dev *d, spmv_hip_info *out);
 double spmv_shim_time(spmv_dev *d, const void *x, void *y, int warmup, int iters, float *ms_out);
+/* min over `iters` (<= 64) launches on scratch vectors, in ms; < 0 on failure */
+double spmv_shim_time_self(spmv_dev *d, int iters);
 void spmv_shim_matrix_destroy(spmv_dev *d);
 /* memcpy that accepts a host or a device source (the reordering inspector works on host copies) */
 int spmv_shim_copy_to_host(void *dst, const void *src, size_t bytes);

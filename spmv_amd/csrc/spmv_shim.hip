@@ -291,6 +291,30 @@ extern "C" double spmv_shim_time(spmv_dev *d, const void *x, void *y, int warmup
     return mean;
 }
 
+// min over `iters` launches of the built schedule on scratch vectors (x = 1): what the measured automatic
+// choice (spmv_api.c, auto_method = 2) compares.  Returns ms, < 0 on failure.
+extern "C" double spmv_shim_time_self(spmv_dev *d, int iters)
+{
+    if (!d || !d->built || iters <= 0 || iters > 64) { fail(SPMV_HIP_E_ARG, "time_self: bad arguments"); return -1.0; }
+    void *x = nullptr, *y = nullptr;
+    if (hipMalloc(&x, d->vsize * (size_t) (d->n > 0 ? d->n : 1)) != hipSuccess || hipMalloc(&y, d->vsize * (size_t) (d->m > 0 ? d->m : 1)) != hipSuccess) {
+        (void) hipGetLastError();
+        if (x) (void) hipFree(x);
+        fail(SPMV_HIP_E_ALLOC, "time_self: scratch vectors");
+        return -1.0;
+    }
+    if (d->vsize == sizeof(double)) fill_value_kernel<double><<<grid_for(d->n, kBlock, d->cus * 8), kBlock, 0, d->stream>>>(d->n, (double *) x, 1.0);
+    else fill_value_kernel<float><<<grid_for(d->n, kBlock, d->cus * 8), kBlock, 0, d->stream>>>(d->n, (float *) x, 1.0f);
+    float ms[64];
+    const double mean = spmv_shim_time(d, x, y, 2, iters, ms);
+    (void) hipFree(x);
+    (void) hipFree(y);
+    if (mean < 0) return -1.0;
+    float best = ms[0];
+    for (int i = 1; i < iters; ++i) best = ms[i] < best ? ms[i] : best;
+    return (double) best;
+}
+
 // ------------------------------------------------------------------------------------ info
 static const char *kSchedNames[] = {"csr-scalar", "csr-vector", "row-block", "nnz-split", "sell-c-sigma", "csr5"};
 static const char *kKernelNames[] = {"csr_scalar_kernel", "csr_vector_pipe_kernel", "csr_vector_rows_kernel",

@@ -444,3 +444,27 @@ def test_results_are_bit_reproducible_across_handles(name, method):
     y1, _ = run_host(csr, x, method)
     y2, _ = run_host(csr, x, method)
     assert np.array_equal(y1.view(np.uint8), y2.view(np.uint8))
+
+
+def test_auto_method_measured_mode_builds_times_and_keeps_a_candidate():
+    """auto_method = 2: create() builds the candidate schedules, times each on scratch vectors and keeps the
+    fastest (spmv_api.c).  Whatever wins, the handle must report it and the result must be exact."""
+    import torch
+    dev = torch.device("cuda:0")
+    m, n, rp, ci, va = synth.banded_device(200_000, 200_000, 32, "eighths", torch.float64, dev, 3)
+    g = torch.Generator(device=dev); g.manual_seed(2)
+    x = torch.randint(-8, 9, (n,), generator=g, device=dev).double() * 0.125
+    want = (va.double() * x[ci.long()]).view(m, 32).sum(1)
+    api.set_option("auto_method", 2)
+    try:
+        y = torch.full((m,), float("nan"), dtype=torch.float64, device=dev)
+        with api.Handle(m, n, rp, ci, va, M.Method_Serial) as h:
+            h.spmv(x, y)
+            chosen = h.method
+            sched = h.info()["schedule_name"]
+    finally:
+        api.set_option("auto_method", 0)
+    torch.cuda.synchronize()
+    assert chosen in (M.Method_Parallel, M.Method_CSR5SPMV, M.Method_SellCSigma, M.Method_Balanced_Yid, M.Method_Balanced, M.Method_Balanced2)
+    assert sched in ("csr-vector", "csr5", "sell-c-sigma", "nnz-split", "row-block")
+    assert torch.equal(y, want)
