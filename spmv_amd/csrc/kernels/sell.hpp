@@ -201,14 +201,25 @@ __device__ __forceinline__ void sell_chunk(const int *__restrict__ pc, const uns
             else if (cc[u] >= 0) sum = fmadd(vv[u], x[cc[u]], sum);
         }
     }
-    for (; j < width; ++j) {
-        const T vv = ld_stream(pv + (size_t) j * kSellC);
-        if (STAGED) {
-            sum = fmadd(vv, xs[ld_stream(pc16 + (size_t) j * kSellC)], sum);
-        } else {
-            const int cc = ld_stream(pc + (size_t) j * kSellC);
-            if (cc >= 0) sum = fmadd(vv, x[cc], sum);
-        }
+    // the last 1..7 elements: one block whose loads are all issued before the first use (the chunk width is
+    // wave-uniform, so the guards are scalar branches) -- a chunk of 5-entry rows costs one load round, not five
+    const int r = __builtin_amdgcn_readfirstlane(width - j);
+    if (r > 0) {
+        int cc[U - 1];
+        T vv[U - 1];
+#pragma unroll
+        for (int u = 0; u < U - 1; ++u)
+            if (u < r) {
+                if (STAGED) cc[u] = ld_stream(pc16 + (size_t) (j + u) * kSellC);
+                else cc[u] = ld_stream(pc + (size_t) (j + u) * kSellC);
+                vv[u] = ld_stream(pv + (size_t) (j + u) * kSellC);
+            }
+#pragma unroll
+        for (int u = 0; u < U - 1; ++u)
+            if (u < r) {
+                if (STAGED) sum = fmadd(vv[u], xs[cc[u]], sum);
+                else if (cc[u] >= 0) sum = fmadd(vv[u], x[cc[u]], sum);
+            }
     }
 }
 

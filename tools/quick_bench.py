@@ -46,6 +46,13 @@ elif a.kind == "stencil27":   # 3-D 27-point stencil on an nx^3 grid (periodic):
         rows = torch.arange(r0, r1, device=dev)
         ci[r0 * 27:r1 * 27] = ((rows[:, None] + offs[None, :]) % n).reshape(-1).to(torch.int32)
     va = torch.rand(m * 27, device=dev, dtype=dt) * 2 - 1
+elif a.kind == "stencil5":    # 2-D 5-point stencil on an nx^2 periodic grid: 5 nnz per row, three bands
+    nx = round(a.m ** 0.5); m = n = nx * nx
+    offs = torch.tensor([-nx, -1, 0, 1, nx], device=dev)
+    rp = torch.arange(0, (m + 1) * 5, 5, dtype=torch.int32, device=dev)
+    rows = torch.arange(m, device=dev)
+    ci = ((rows[:, None] + offs[None, :]) % n).reshape(-1).to(torch.int32)
+    va = torch.rand(m * 5, device=dev, dtype=dt) * 2 - 1
 elif a.kind == "random":
     m, n, rp, ci, va = synth.uniform_k_device(a.m, a.m, a.k, "uniform", dt, dev, 1)
 elif a.kind == "skewed":
