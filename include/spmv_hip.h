@@ -63,7 +63,8 @@ int spmv_hip_synchronize(spmv_Handle_t handle);
  *                      Method_Balanced_Yid with the cache-blocked executor; the handle reports it)
  *       "cache_block" (0 never / 1 automatic (default) / 2 always: the Balanced family -- Method_Balanced,
  *                      _Balanced2, _Balanced_Yid -- runs a row-block x column-slab executor when no x window
- *                      fits LDS, nnz >= 2^22 and n * size >= 16 MiB: ~3x faster on columns without locality;
+ *                      fits LDS, nnz >= 2^21 and n * size >= 6 MiB (x larger than one XCD's L2): up to ~3x faster on columns
+ *                      without locality;
  *                      y of a row block is accumulated by LDS floating-point atomics, so results are
  *                      bit-reproducible only for exactly representable data)
  *       "slab_kib" (KiB of x per column slab, 0 = 256)  "block_rows" (rows per block, 0 = 64 KiB of y)

@@ -458,7 +458,9 @@ static int build_csr5(spmv_dev *d, Csr5Plan &P, int m, long long nnz, const int 
 template <typename T>
 static int build_blocked(spmv_dev *d)
 {
-    const int R = d->plan.block_rows > 0 ? d->plan.block_rows : (int) (64 * 1024 / sizeof(T));
+    int R = d->plan.block_rows > 0 ? d->plan.block_rows : (int) (64 * 1024 / sizeof(T));
+    if (d->plan.block_rows == 0) // small matrices: at least ~256 blocks, so that every CU gets one (down to 1024 rows)
+        while (R > 1024 && (long long) d->m / R < 256) R >>= 1;
     // Slab width: as narrow as the cell table allows (2^25 cells: ~400 MB of inspector scratch), down to 32
     // columns.  Narrow slabs cost nothing in L2 locality (the sweep over x is the same) and put entries that
     // gather from the same cache line into neighbouring lanes, which the L1/TA path merges into one L2

@@ -168,7 +168,7 @@ static int state_build(spmv_Handle_t h, spmv_hip_state *st, int m, int n, const 
         (st->plan.sched == SPMV_SCHED_CSR_VECTOR || st->plan.sched == SPMV_SCHED_CSR5)) {
         spmv_hip_info info;
         if (spmv_shim_info(st->dev, &info) == SPMV_HIP_OK && info.x_groups > 0 && info.x_groups_staged == 0 &&
-            info.nnz >= (1ll << 22) && (long long) n * (long long) h->data_size >= (16ll << 20)) {
+            info.nnz >= (1ll << 21) && (long long) n * (long long) h->data_size >= (6ll << 20)) {
             spmv_plan second;
             SPMV_METHODS second_actual = Method_Balanced_Yid;
             spmv_plan_choose_ex(Method_Balanced_Yid, &stats, (size_t) h->data_size, &second, &second_actual, 0);

@@ -183,7 +183,7 @@ extern "C" int spmv_shim_build(spmv_dev *d, const spmv_plan *plan)
         // columns without locality (no tile group's x windows fit LDS) and x far larger than an L2: gathers are
         // fabric-bound -> row blocks x column slabs (kernels/blocked.hpp)
         if (!rc && (plan->cache_block == 2 ||
-                    (plan->cache_block == 1 && d->ns.staged == 0 && d->nnz >= (1ll << 22) && (long long) d->n * (long long) d->vsize >= (16ll << 20))))
+                    (plan->cache_block == 1 && d->ns.staged == 0 && d->nnz >= (1ll << 21) && (long long) d->n * (long long) d->vsize >= (6ll << 20))))
             rc = f64 ? build_blocked<double>(d) : build_blocked<float>(d);
         break;
     case SPMV_SCHED_ROWBLOCK:
@@ -193,7 +193,7 @@ extern "C" int spmv_shim_build(spmv_dev *d, const spmv_plan *plan)
         if (!rc) rc = f64 ? build_rowblock_tiles<double>(d) : build_rowblock_tiles<float>(d);
         // same fall-back as nnz-split for columns without locality (Method_Balanced and Method_Balanced2 are one family)
         if (!rc && (plan->cache_block == 2 ||
-                    (plan->cache_block == 1 && d->vt_staged == 0 && d->nnz >= (1ll << 22) && (long long) d->n * (long long) d->vsize >= (16ll << 20))))
+                    (plan->cache_block == 1 && d->vt_staged == 0 && d->nnz >= (1ll << 21) && (long long) d->n * (long long) d->vsize >= (6ll << 20))))
             rc = f64 ? build_blocked<double>(d) : build_blocked<float>(d);
         break;
     case SPMV_SCHED_SELL: rc = f64 ? build_sell<double>(d) : build_sell<float>(d); break;
