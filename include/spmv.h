@@ -6,7 +6,10 @@
  * header unchanged and links libspmv_hip.so in place of libmv_l2.so.
  *
  * Differences a caller can observe:
- *   - no <omp.h> / <immintrin.h> are pulled in (the reference leaks them, spmv.h:9-10);
+ *   - <omp.h> and <immintrin.h> are pulled in when the compiler has them, as the reference's header does
+ *     (spmv.h:9-10): its own sample calls omp_set_num_threads() and uses intrinsics with only <spmv.h>
+ *     included (test_spmv.c:88), so it compiles against this header without extra flags.  Define
+ *     SPMV_HIP_NO_COMPAT_INCLUDES to keep them out;
  *   - X and Y (and the CSR arrays) may be HOST or DEVICE pointers; the library classifies each
  *     pointer (hipPointerGetAttributes).  Host vectors are staged through HBM (correct, PCIe
  *     bound); device vectors are used in place.  See spmv_hip.h for stream control.
@@ -22,6 +25,15 @@ extern "C" {
 #endif
 #ifndef SPMV_HIP_SPMV_H
 #define SPMV_HIP_SPMV_H
+
+#if !defined(SPMV_HIP_NO_COMPAT_INCLUDES) && defined(__has_include)
+#if __has_include(<omp.h>)
+#include <omp.h>
+#endif
+#if (defined(__x86_64__) || defined(__i386__)) && __has_include(<immintrin.h>)
+#include <immintrin.h>
+#endif
+#endif
 
 #define ALIGENED_SIZE 64 /* reference spmv.h:12; callers use it for aligned_alloc */
 
@@ -70,6 +82,9 @@ void spmv_create_handle_all_in_one(spmv_Handle_t *Handle,
  *                 the reference re-reads these on every call.  Here: if they are the pointers
  *                 (and m) seen at create, the HBM-resident copy is used; if they differ the
  *                 matrix is re-inspected first (correct, slow -- see DESIGN.md "CSR arguments").
+ *                 VALUES CHANGED IN PLACE behind an unchanged Matrix_Val pointer are not seen: call
+ *                 spmv_hip_update_values(handle, Matrix_Val) (spmv_hip.h) after changing them, or run with
+ *                 SPMV_HIP_CHECK_VALUES=1, which checksums Matrix_Val on every call and refreshes by itself.
  *   Vector_Val_X  n values  (host or device)
  *   Vector_Val_Y  m values, all overwritten (host or device)
  *

@@ -101,6 +101,30 @@ typedef struct spmv_Handle {
 
 typedef spmv_Handle *spmv_Handle_t;
 
+/*
+ * Type-punning helpers the reference publishes for code that is generic over data_size
+ * (spmv_Defines.h:73-81); kept so that callers using them keep compiling.  `size` is the handle's
+ * data_size: sizeof(double) selects double, anything else float (serial_spmv.c:48-54).
+ */
+#define CONVERT_FLOAT_T(pointer) ((float *) (pointer))
+#define CONVERT_DOUBLE_T(pointer) ((double *) (pointer))
+#define CONVERT_FLOAT(pointer) (*CONVERT_FLOAT_T(pointer))
+#define CONVERT_DOUBLE(pointer) (*CONVERT_DOUBLE_T(pointer))
+#define CONVERT_EQU(pointer, size, other) \
+    (((size) == sizeof(double)) ? (CONVERT_DOUBLE(pointer) = (other)) : (CONVERT_FLOAT(pointer) = (other)))
+#define CONVERT_ADDEQU(pointer1, size, pointer2)                                          \
+    (((size) == sizeof(double)) ? (CONVERT_DOUBLE(pointer1) += CONVERT_DOUBLE(pointer2)) \
+                                : (CONVERT_FLOAT(pointer1) += CONVERT_FLOAT(pointer2)))
+
+/*
+ * Sparse dot product of one CSR row with x, indexed by VECTORIZED_WAY (reference spmv_Defines.h:84-91,
+ * tables in inner_spmv.h).  VECTOR_TOTAL_SIZE entries each.  These are HOST functions (a caller hands
+ * them host pointers); on this build every entry is the same plain-C loop (csrc/host_rows.c) -- the GPU
+ * schedules do not go through them.
+ */
+extern float (*const Dot_s_Products[])(BASIC_INT_TYPE len, const BASIC_INT_TYPE *indx, const float *Val, const float *X);
+extern double (*const Dot_d_Products[])(BASIC_INT_TYPE len, const BASIC_INT_TYPE *indx, const double *Val, const double *X);
+
 #endif /* SPMV_HIP_DEFINES_H */
 
 #if defined(__cplusplus)

@@ -44,7 +44,20 @@ int spmv_hip_set_stream(spmv_Handle_t handle, void *hip_stream);
 int spmv_hip_set_async(spmv_Handle_t handle, int async);
 int spmv_hip_synchronize(spmv_Handle_t handle);
 
-/* ---- options (process-wide; read at create) ---------------------------------------------- */
+/* ---- values changed in place ---------------------------------------------------------------- */
+/* The reference re-reads Matrix_Val on every spmv() (common.c:286-298); this library multiplies its
+ * HBM-resident copy.  After changing values IN PLACE (same pattern) call this with the array (host or device
+ * pointer, RowPtr[m] entries in CSR order): the values are copied to HBM and re-permuted into the schedule's
+ * private layouts by device kernels -- no re-inspection, no autotune.  Alternatively option "check_values"
+ * (env SPMV_HIP_CHECK_VALUES=1) makes spmv() checksum Matrix_Val on every call and refresh by itself: a pure
+ * drop-in, at the price of reading the values once more per call.  Not available on handles created with
+ * option "reorder".  Returns 0 or an SPMV_HIP_E_* code. */
+int spmv_hip_update_values(spmv_Handle_t handle, const void *Matrix_Val);
+
+/* ---- options --------------------------------------------------------------------------------
+ * Resolved once per handle, at create: process-wide value (spmv_hip_set_option / env), overridden by the
+ * calling thread's value (spmv_hip_set_thread_option) -- so two threads can create differently tuned handles
+ * without racing -- and stored in the handle (spmv_hip_get_handle_option). */
 /* keys: "lanes_per_row" (CSR-vector, 0 = auto, else 1..64 power of two)
  *       "sell_c" (64)  "sell_sigma" (1024)  "sell_lds_x" (0/1: stage narrow x windows in LDS)
  *       "sell_long_thr" (rows longer than this stay out of the slabs, 0 = max(64, 8 x mean row length))
@@ -61,17 +74,25 @@ int spmv_hip_synchronize(spmv_Handle_t handle);
  *                      favour -- CSR-vector for regular rows, CSR5 otherwise -- and, if that schedule cannot
  *                      stage a single x window on a matrix whose x is far larger than an L2, by
  *                      Method_Balanced_Yid with the cache-blocked executor; the handle reports it)
- *       "cache_block" (0 never / 1 automatic (default) / 2 always: the Balanced family -- Method_Balanced,
- *                      _Balanced2, _Balanced_Yid -- runs a row-block x column-slab executor when no x window
- *                      fits LDS, nnz >= 2^21 and n * size >= 6 MiB (x larger than one XCD's L2): up to ~3x faster on columns
- *                      without locality;
- *                      y of a row block is accumulated by LDS floating-point atomics, so results are
- *                      bit-reproducible only for exactly representable data)
- *       "slab_kib" (KiB of x per column slab, 0 = 256)  "block_rows" (rows per block, 0 = 64 KiB of y)
+ *       "cache_block" (0 never / 1 automatic (default) / 2 always: every schedule but CSR-scalar and SELL hands the
+ *                      multiply to the row-block x column-slab executor when no x window of the matrix fits LDS,
+ *                      nnz >= 2^21 and n * size >= 6 MiB (x larger than one XCD's L2): ~3x faster on columns
+ *                      without locality.  One wavefront owns a row block, so results are bit-reproducible.)
+ *       "slab_kib" (KiB of x per column slab, 0 = as narrow as the cell table allows)
+ *       "block_rows" (rows per block, 0 = 64 KiB of y)
+ *       "host_rows" (0/1, default 0: 1 = handles created with VECTOR_NONE and Method_Serial / Method_Parallel run
+ *                    a plain-C row loop on the HOST over the caller's arrays (BASELINE config 1: the reference's
+ *                    plumbing case); never selected automatically -- without it a missing GPU is an error)
+ *       "check_values" (0/1, default 0: see spmv_hip_update_values)
+ *       "gpus" (0 = this handle lives on the current device; G > 0: row blocks over min(G, visible devices) GPUs
+ *               of this process, see "multi-GPU" below)   "x_exchange" (multi-GPU: 0 allgather, 1 halo, 2 broadcast)
  * Each key can also be preset with the environment variable SPMV_HIP_<KEY IN CAPS>.
  * Returns 0, or SPMV_HIP_E_ARG for an unknown key / illegal value. */
 int spmv_hip_set_option(const char *key, long value);
-long spmv_hip_get_option(const char *key);
+long spmv_hip_get_option(const char *key);            /* the value a create() on this thread would use */
+int spmv_hip_set_thread_option(const char *key, long value); /* override for handles created by the calling thread */
+void spmv_hip_clear_thread_options(void);
+long spmv_hip_get_handle_option(spmv_Handle_t handle, const char *key); /* what the handle was created with; -1 unknown */
 
 /* ---- introspection ------------------------------------------------------------------------ */
 typedef struct spmv_hip_info {
@@ -95,6 +116,12 @@ typedef struct spmv_hip_info {
     int x_groups;               /* tiles / tile groups / sigma windows the inspector analysed for x windows */
     int x_groups_staged;        /* ... of which have their x windows staged in LDS (0: every gather goes to L1/L2) */
     int cache_blocked;          /* 1: the row-block x column-slab executor runs (option "cache_block") */
+    long long stream_bytes;     /* HBM bytes ONE spmv() has to move given the schedule's storage format: the value and
+                                 * column streams as stored (2 B/nnz LDS slots where x windows are staged, padding
+                                 * included), row pointers / descriptors / window tables, the x elements staged (or n
+                                 * once where x is gathered through L2), y written once, carries.  This -- not alg_bytes --
+                                 * is what divides by the launch time to give the HBM rate actually sustained. */
+    long long x_bytes;          /* the part of stream_bytes charged for reading x */
 } spmv_hip_info;
 int spmv_hip_get_info(spmv_Handle_t handle, spmv_hip_info *out);
 

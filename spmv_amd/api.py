@@ -6,8 +6,9 @@ order and meaning, same void returns (reference: include/spmv.h:19-71, common.c:
 Arrays may be numpy arrays (host) or torch tensors (host or cuda); only their raw pointers cross
 the boundary.  torch is used for device memory, streams and torch.distributed only.
 
-There is no CPU compute here and no fallback: if libspmv_hip.so is missing or cannot be loaded
-`load()` raises, and without a GPU every call reports SPMV_HIP_E_NODEVICE.
+There is no fallback: if libspmv_hip.so is missing or cannot be loaded `load()` raises, and without
+a GPU every call reports SPMV_HIP_E_NODEVICE.  (The library's one host loop -- VECTOR_NONE with option
+"host_rows", BASELINE config 1 -- is a configuration the caller switches on, csrc/host_rows.c.)
 """
 from __future__ import annotations
 
@@ -65,7 +66,8 @@ class spmv_hip_info(C.Structure):
                 ("alg_bytes", C.c_longlong), ("inspect_ms", C.c_double),
                 ("schedule_name", C.c_char_p), ("kernel_name", C.c_char_p),
                 ("tuned_choice", C.c_int), ("tune_ms", C.c_float * 3),
-                ("x_groups", C.c_int), ("x_groups_staged", C.c_int), ("cache_blocked", C.c_int)]
+                ("x_groups", C.c_int), ("x_groups_staged", C.c_int), ("cache_blocked", C.c_int),
+                ("stream_bytes", C.c_longlong), ("x_bytes", C.c_longlong)]
 
 
 # Every symbol include/*.h declares: functions with their prototypes, then data symbols.
@@ -84,6 +86,10 @@ FUNCTIONS = {
     "spmv_hip_synchronize": (C.c_int, [spmv_Handle_t]),
     "spmv_hip_set_option": (C.c_int, [C.c_char_p, C.c_long]),
     "spmv_hip_get_option": (C.c_long, [C.c_char_p]),
+    "spmv_hip_set_thread_option": (C.c_int, [C.c_char_p, C.c_long]),
+    "spmv_hip_clear_thread_options": (None, []),
+    "spmv_hip_get_handle_option": (C.c_long, [spmv_Handle_t, C.c_char_p]),
+    "spmv_hip_update_values": (C.c_int, [spmv_Handle_t, _V]),
     "spmv_hip_get_info": (C.c_int, [spmv_Handle_t, C.POINTER(spmv_hip_info)]),
     "spmv_hip_time_launches": (C.c_double, [spmv_Handle_t, _V, _V, C.c_int, C.c_int, C.POINTER(C.c_float)]),
     # include/spmv_io.h (host only)
@@ -94,7 +100,7 @@ FUNCTIONS = {
     "spmv_io_load": (C.c_int, [C.c_char_p, C.c_size_t, _I, _I, _I, _I, C.POINTER(_I), C.POINTER(_I), C.POINTER(_V), _I]),
     "spmv_io_free": (None, [_V]),
 }
-DATA_SYMBOLS = ("Methods_names", "Vectorized_names", "funcNames")
+DATA_SYMBOLS = ("Methods_names", "Vectorized_names", "funcNames", "Dot_s_Products", "Dot_d_Products")
 
 _lib = None
 
@@ -209,6 +215,23 @@ def get_option(key):
     return load().spmv_hip_get_option(key.encode())
 
 
+def set_thread_option(key, value):
+    """Override for handles created by the calling thread (spmv_hip_set_thread_option)."""
+    if load().spmv_hip_set_thread_option(key.encode(), int(value)) != 0:
+        load().spmv_hip_clear_error()
+        raise ValueError(f"bad option {key}={value}")
+
+
+def clear_thread_options():
+    load().spmv_hip_clear_thread_options()
+
+
+def update_values(handle, Matrix_Val):
+    """New values behind the same pattern (spmv_hip_update_values): no re-inspection."""
+    if load().spmv_hip_update_values(handle, _ptr(Matrix_Val)) != 0:
+        _raise_if_error("spmv_hip_update_values")
+
+
 def get_info(handle):
     info = spmv_hip_info()
     if load().spmv_hip_get_info(handle, C.byref(info)) != 0:
@@ -316,6 +339,14 @@ class Handle:
         rp, ci, va = self._keep
         spmv(self.h, self.m, rp, ci, va, x, y)
         return y
+
+    def update_values(self, val):
+        """The caller changed the values (in place or in a new array of the same pattern)."""
+        update_values(self.h, val)
+        self._keep = (self._keep[0], self._keep[1], val)
+
+    def option(self, key):
+        return load().spmv_hip_get_handle_option(self.h, key.encode())
 
     def attach_stream(self, stream_ptr, async_=True):
         set_stream(self.h, stream_ptr, async_)

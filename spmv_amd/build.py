@@ -26,14 +26,14 @@ HIPCC = os.environ.get("HIPCC") or shutil.which("hipcc") or "/opt/rocm/bin/hipcc
 CC = os.environ.get("CC") or "gcc"
 ARCH = "gfx950"
 
-C_SOURCES = ["spmv_api.c", "spmv_plan.c", os.path.join("io", "mtx_io.c"), os.path.join("reorder", "rcm.c")]
+C_SOURCES = ["spmv_api.c", "spmv_plan.c", "host_rows.c", os.path.join("io", "mtx_io.c"), os.path.join("reorder", "rcm.c")]
 TOOL_SOURCES = {"test_spmv": os.path.join("tools", "test_spmv_csv.c")}   # -> spmv_amd/bin/<name>
 BINDIR = os.path.join(PKG, "bin")
 ROCM = os.environ.get("ROCM_PATH", "/opt/rocm")
 HIP_SOURCES = ["spmv_shim.hip"]
 HIP_FLAGS = ["-O3", "-std=c++17", "-fPIC", f"--offload-arch={ARCH}", "-Wall", "-Wno-unused-function",
              "-ffp-contract=fast"]
-C_FLAGS = ["-O2", "-std=c11", "-fPIC", "-Wall", "-Wextra", "-D_POSIX_C_SOURCE=200809L"]
+C_FLAGS = ["-O2", "-std=c11", "-fPIC", "-fopenmp", "-Wall", "-Wextra", "-D_POSIX_C_SOURCE=200809L"]
 
 
 def _newest(paths):
@@ -80,7 +80,9 @@ def build(force=False, verbose=False):
             print(" ".join(cmd))
         _run(cmd)
         objs.append(obj)
-    cmd = [HIPCC, "-shared", "-fPIC", f"--offload-arch={ARCH}", "-o", LIB, *objs]
+    # host_rows.c is compiled with -fopenmp by gcc: link GNU libgomp by path (hipcc's own -fopenmp would pull LLVM's runtime)
+    gomp = subprocess.run([CC, "-print-file-name=libgomp.so"], capture_output=True, text=True).stdout.strip()
+    cmd = [HIPCC, "-shared", "-fPIC", f"--offload-arch={ARCH}", "-o", LIB, *objs, gomp, "-lpthread", "-lm"]
     if verbose:
         print(" ".join(cmd))
     _run(cmd)

@@ -9,6 +9,7 @@
 #include <limits.h>
 #include <stdint.h>
 #include <stdio.h>
+#include <sys/stat.h>
 #include <stdlib.h>
 #include <string.h>
 
@@ -226,6 +227,12 @@ int spmv_io_read_bin(const char *bin_path, size_t value_size, int *m, int *n, in
              fread(ci, sizeof(int32_t), (size_t) hdr[2], f) != (size_t) hdr[2] ||
              fread(v, vsize, (size_t) hdr[2], f) != (size_t) hdr[2] || rp[hdr[0]] != hdr[2])
         rc = SPMV_IO_E_DATA;
+    /* The format does not record the value width (nor does the reference's, mmio_highlevel.h:531-584), so a
+     * cache written as fp64 would read back "successfully" as fp32 -- the first half of the doubles taken
+     * as floats.  The file must end exactly after nnz values of the width asked for; otherwise the caller
+     * (spmv_io_load) re-parses the .mtx file and rewrites the cache in its own width. */
+    else if (hdr[2] > 0 && fgetc(f) != EOF)
+        rc = SPMV_IO_E_DATA;
     fclose(f);
     if (rc) { free(rp); free(ci); free(v); return rc; }
     *m = hdr[0]; *n = hdr[1]; *nnz = hdr[2];
@@ -246,7 +253,9 @@ int spmv_io_load(const char *mtx_path, size_t value_size, int *m, int *n, int *n
         return SPMV_IO_OK;
     }
     rc = spmv_io_read_mtx(mtx_path, value_size, m, n, nnz, is_symmetric, rowptr, colidx, val);
-    if (rc == SPMV_IO_OK && spmv_io_cache_path(mtx_path, bin, sizeof bin) == 0)
+    if (rc == SPMV_IO_OK && spmv_io_cache_path(mtx_path, bin, sizeof bin) == 0) {
+        (void) mkdir("mtx_cache", 0777); /* the reference expects the directory to exist; create it if we can */
         (void) spmv_io_write_bin(bin, *m, *n, *nnz, *rowptr, *colidx, *val, value_size); /* best effort */
+    }
     return rc;
 }

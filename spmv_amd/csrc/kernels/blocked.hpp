@@ -1,9 +1,9 @@
-// blocked.hpp -- row blocks x column slabs: the executor of the nnz-split family for matrices whose
-// columns have NO locality (uniformly random / social-graph structure).
+// blocked.hpp -- row blocks x column slabs: the executor for matrices whose columns have NO locality
+// (uniformly random / social-graph structure), whatever the method asked for.
 //
 // Why.  When no x window of a tile group fits LDS (xwindows.hpp), every gather of x is a scattered
 // 8-byte read.  x itself stays resident in the 256 MiB Infinity Cache, but each gather pulls a whole
-// line across the fabric into an XCD's L2: 3.2e8 gathers = ~41 GB of line traffic, ~6 ms for a
+// line across the fabric into an XCD's L2: 3.2e8 gathers = ~21 GB of line traffic, ~6 ms for a
 // matrix whose own stream is 3.8 GB.  The reference meets the same wall on the CPU
 // and does nothing about it; its Balanced2 workers own consecutive non-zeros
 // (parallel_balanced2_spmv.c:41-53) and gather x wherever the columns point.
@@ -12,37 +12,34 @@
 //   inspector   rows are cut into blocks of R rows, columns into slabs of W columns -- as narrow as a
 //               table of 2^25 (block, slab) cells allows, down to 32 columns: the sweep over x is what
 //               keeps x in L2, and narrow slabs additionally put gathers from one cache line into
-//               neighbouring lanes, which merge into one L2 request.  The entries of a
-//               row block are stored sorted by SLAB (counting sort on the device: histogram of
-//               (block, slab) cells, scans, scatter), as three streams: value, global column, and
-//               the 16-bit row number inside the block.  Block regions start at multiples of 8
-//               entries so every load is a 16-byte load.
-//   executor    one workgroup per row block.  y of the block lives in LDS (R * sizeof(T) = 64 KiB: two
-//               workgroups per CU -- more resident workgroups drift apart in their slab position and
-//               thrash L2: 32 KiB blocks ran 3.9 ms where 64 KiB blocks run 2.2 ms),
-//               the workgroup walks the block's entries in stored order -- i.e. slab after slab, and
-//               since workgroups are dispatched in order and blocks hold similar work, all
-//               workgroups of an XCD gather from the same one or two slabs of x at a time, which
-//               therefore stay in L2 -- and adds every product into y's LDS copy with an LDS
-//               floating-point atomic.  At the end the block's y is written once, coalesced: no
-//               partial sums, no carries, no read-modify-write of y in HBM.
+//               neighbouring lanes, which merge into one L2 request.  The entries of a row block are
+//               stored sorted by SLAB, and inside a (block, slab) cell in CSR order -- a STABLE counting
+//               sort, done by ONE wavefront per block that walks the block's entries in CSR order and
+//               ranks the 64 entries of a batch against each other with ballots (blk_fill_kernel), so the
+//               stored order is a function of the matrix alone.  Three streams: value, global column,
+//               16-bit row number inside the block; block regions start at multiples of 8 entries so
+//               every load is a 16-byte load.
+//   executor    ONE WAVEFRONT per row block (a 64-thread workgroup).  y of the block lives in LDS
+//               (R * sizeof(T) = 64 KiB: two blocks per CU -- more resident blocks drift apart in their
+//               slab position and thrash L2), the wave walks the block's entries in stored order -- slab
+//               after slab; blocks are dispatched in order and hold similar work, so the blocks of an XCD
+//               gather from the same few slabs of x at a time, which therefore stay in L2 -- with 16
+//               gathers in flight per lane, and adds every product into y's LDS copy (ds_add).  At the end
+//               the block's y is written once, coalesced: no partial sums, no carries, no read-modify-write
+//               of y in HBM.
+//   determinism every row is touched by exactly one wavefront, whose additions happen in program order
+//               over a stream whose order is fixed by the inspector: the result is reproducible bit for
+//               bit, run to run and handle to handle (the first version of this executor used a
+//               256-thread workgroup per block, whose four waves raced on the rows: kept as variant 23).
 //
-// Measured (config 2 with uniformly random columns, fp64): 84 % of the L2 requests hit (5 % for the tile
-// executors), 5.9 -> 2.0 ms; Orkut-style stand-in (74 nnz/row, 3e6 columns): 3.5 -> 1.13 ms.  What bounds it now is the L2's rate of random requests (~1.4e11/s over
-// the chip; the LDS atomics are free: removing them changes nothing).
-//
-// The order in which the atomics of one row arrive is not fixed, so results are reproducible
-// bit for bit only for exactly-representable data (the "eighths" fixtures); otherwise they vary in
-// the last bits from run to run, within the parity tolerance.  That is why this executor is used
-// only where it pays by a large factor (option "cache_block", default 1 = automatic) and never for
-// matrices whose x windows can be staged.
+// What bounds it is the L2's rate of random requests (one request per gather that is not merged with a
+// neighbour's; ~1.4-1.7e11/s over the chip), not HBM: DESIGN.md 3.7 has the counters.
 #pragma once
 #include <climits>
 #include "common.hpp"
 
 namespace spmv {
 
-constexpr int kBlkThreads = 256;
 
 // cell histogram: cnt[(r / R) * K + (c >> wshift)] += 1 for every entry; 16 lanes sweep a row
 __global__ __launch_bounds__(kBlock) void blk_count_kernel(int m, int R, int K, int wshift, const int *__restrict__ rowptr,
@@ -81,25 +78,65 @@ __global__ __launch_bounds__(kBlock) void blk_cells_kernel(int B, int K, const i
     end[b] = p;
 }
 
-// scatter every entry to its cell (the order inside a cell is the order the atomics arrive in)
-template <typename T>
-__global__ __launch_bounds__(kBlock) void blk_fill_kernel(int m, int R, int K, int wshift, const int *__restrict__ rowptr,
-                                                          const int *__restrict__ colidx, const T *__restrict__ val,
-                                                          unsigned long long *__restrict__ cursor, T *__restrict__ bval,
-                                                          int *__restrict__ bcol, unsigned short *__restrict__ brow)
+// Stable scatter: ONE wavefront per row block walks the block's entries in CSR order, 64 at a time.  Inside a
+// batch, entries of the same cell are ranked by lane (ballot per distinct cell); the first of each cell
+// advances the cell's cursor by the cell's count in this batch.  Only this wave touches the cursors of its
+// block and it does so batch after batch, so position = cell start + number of earlier entries (CSR order)
+// of the same cell: the stored order does not depend on timing.  VALUES_ONLY: re-permute new values into
+// the same positions (spmv_hip_update_values).  Dynamic LDS: (R + 1) ints, the block's row pointers.
+template <typename T, bool VALUES_ONLY>
+__global__ __launch_bounds__(kWave) void blk_fill_kernel(int m, int R, int K, int wshift, const int *__restrict__ rowptr,
+                                                         const int *__restrict__ colidx, const T *__restrict__ val,
+                                                         unsigned long long *__restrict__ cursor, T *__restrict__ bval,
+                                                         int *__restrict__ bcol, unsigned short *__restrict__ brow)
 {
-    const int sub = threadIdx.x / 16, l = threadIdx.x % 16;
-    const long long stride = (long long) gridDim.x * (kBlock / 16);
-    for (long long r = (long long) blockIdx.x * (kBlock / 16) + sub; r < m; r += stride) {
-        const int p0 = rowptr[r], p1 = rowptr[r + 1];
-        const long long cell0 = (r / R) * K;
-        const unsigned short rl = (unsigned short) (r % R);
-        for (int p = p0 + l; p < p1; p += 16) {
-            const int c = colidx[p];
-            const unsigned long long pos = atomicAdd(&cursor[cell0 + (c >> wshift)], 1ull);
+    extern __shared__ __attribute__((aligned(16))) unsigned char blk_fill_lds[];
+    int *rp = reinterpret_cast<int *>(blk_fill_lds);
+    const int lane = threadIdx.x;
+    const long long r0 = (long long) blockIdx.x * R;
+    const int nr = (int) (r0 + R <= m ? R : m - r0);
+    for (int i = lane; i <= nr; i += kWave) rp[i] = rowptr[r0 + i];
+    __syncthreads();
+    const int p0 = rp[0], p1 = rp[nr];
+    unsigned long long *cur = cursor + (long long) blockIdx.x * K;
+    int row = 0; // rp[row] <= p: p only grows, so the search restarts from the last answer
+    for (int q = p0; q < p1; q += kWave) {
+        const int p = q + lane;
+        const bool valid = p < p1;
+        const int c = valid ? colidx[p] : 0;
+        const int cell = c >> wshift;
+        if (valid) {
+            int lo = row, hi = nr; // rp[lo] <= p < rp[hi]
+            while (hi - lo > 1) {
+                const int mid = (lo + hi) >> 1;
+                if (rp[mid] <= p) lo = mid; else hi = mid;
+            }
+            row = lo;
+        }
+        unsigned long long todo = __ballot(valid);
+        int rank = 0, cnt = 0, leader = lane;
+        while (todo) { // one pass per distinct cell of the batch
+            const int l0 = __ffsll((long long) todo) - 1;
+            const int k0 = __shfl(cell, l0, kWave);
+            const bool mine = valid && cell == k0;
+            const unsigned long long mk = __ballot(mine);
+            if (mine) {
+                rank = __popcll(mk & ((1ull << lane) - 1ull));
+                cnt = __popcll(mk);
+                leader = l0;
+            }
+            todo &= ~mk;
+        }
+        unsigned long long base = 0;
+        if (valid && rank == 0) base = atomicAdd(&cur[cell], (unsigned long long) cnt); // L2 atomic: coherent batch to batch
+        base = __shfl(base, leader, kWave);
+        if (valid) {
+            const unsigned long long pos = base + (unsigned long long) rank;
             bval[pos] = val[p];
-            bcol[pos] = c;
-            brow[pos] = rl;
+            if constexpr (!VALUES_ONLY) {
+                bcol[pos] = c;
+                brow[pos] = (unsigned short) row;
+            }
         }
     }
 }
@@ -107,8 +144,9 @@ __global__ __launch_bounds__(kBlock) void blk_fill_kernel(int m, int R, int K, i
 __device__ __forceinline__ void lds_add(float *p, float v) { (void) unsafeAtomicAdd(p, v); }
 __device__ __forceinline__ void lds_add(double *p, double v) { (void) unsafeAtomicAdd(p, v); }
 
-// Executor.  Dynamic LDS: R * sizeof(T) bytes (the block's y).
-template <typename T, int NT = kBlkThreads>
+// Executor.  Dynamic LDS: R * sizeof(T) bytes (the block's y).  NT = 64: one wavefront per block (deterministic);
+// UN load groups of 16 bytes of values in flight per lane.
+template <typename T, int NT = kWave, int UN = 8>
 __global__ __launch_bounds__(NT) void blk_kernel(int m, int R, const long long *__restrict__ start, const long long *__restrict__ end,
                                                           const T *__restrict__ bval, const int *__restrict__ bcol,
                                                           const unsigned short *__restrict__ brow, const T *__restrict__ x, T *__restrict__ y)
@@ -116,7 +154,6 @@ __global__ __launch_bounds__(NT) void blk_kernel(int m, int R, const long long *
     extern __shared__ __attribute__((aligned(16))) unsigned char blk_y_lds[];
     T *ys = reinterpret_cast<T *>(blk_y_lds);
     constexpr int EPL = 16 / (int) sizeof(T); // entries per 16-byte value load
-    constexpr int UN = 4;                     // load groups in flight per thread (2, 8, 16 measured no better)
     for (int i = threadIdx.x; i < R; i += NT) ys[i] = T(0);
     __syncthreads();
     const long long s = start[blockIdx.x], e = end[blockIdx.x];

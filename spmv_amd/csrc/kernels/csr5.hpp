@@ -211,7 +211,7 @@ __global__ __launch_bounds__(kBlock) void csr5_transpose_kernel(int nnz, int p, 
     for (int i = 0; i < SIGMA; ++i) {
         const long long src = base + (long long) lane * SIGMA + i;
         const bool in = src < nnz;
-        tcol[base + i * kWave + lane] = in ? colidx[src] : -1;
+        if (tcol) tcol[base + i * kWave + lane] = in ? colidx[src] : -1; // NULL: values only (spmv_hip_update_values)
         tval[base + i * kWave + lane] = in ? val[src] : T(0);
     }
 }

@@ -46,72 +46,6 @@ __device__ __forceinline__ T group_sum_dpp(T v)
     return v;
 }
 
-template <typename T, int L, int RED, int U, int ABL = 0>
-__global__ __launch_bounds__(kBlock) void csr_vector4_kernel(int m, const int *__restrict__ rowptr,
-                                                             const int *__restrict__ colidx,
-                                                             const T *__restrict__ val,
-                                                             const T *__restrict__ x, T *__restrict__ y)
-{
-    constexpr int kRows = kBlock / L;       // rows per workgroup and sub-step
-    const int lane = threadIdx.x % L;
-    const int sub = threadIdx.x / L;
-    const long long groups = ((long long) m + kRows * U - 1) / (kRows * U);
-    for (long long g = blockIdx.x; g < groups; g += gridDim.x) {
-        int p0[U], p1[U];
-        T sum[U];
-#pragma unroll
-        for (int u = 0; u < U; ++u) {
-            const long long row = (g * U + u) * kRows + sub;
-            const bool ok = row < m;
-            if (ABL & 1) { p0[u] = ok ? (int) row * 32 : 0; p1[u] = ok ? (int) row * 32 + 32 : 0; } // ablation: no RowPtr chain
-            else { p0[u] = ok ? rowptr[row] : 0; p1[u] = ok ? rowptr[row + 1] : 0; }
-            sum[u] = 0;
-        }
-        bool more = true;
-        int a[U];
-#pragma unroll
-        for (int u = 0; u < U; ++u) a[u] = (p0[u] & ~3) + lane * 4;
-        while (more) {
-            int c[U][4];
-            T v[U][4];
-            bool act[U];
-            more = false;
-#pragma unroll
-            for (int u = 0; u < U; ++u) {
-                act[u] = a[u] < p1[u];
-                if (act[u]) { ld_stream4(colidx + a[u], c[u]); ld_stream4(val + a[u], v[u]); }
-            }
-#pragma unroll
-            for (int u = 0; u < U; ++u) {
-                if (act[u]) {
-                    if (a[u] >= p0[u] && a[u] + 4 <= p1[u]) { // interior: no masking
-                        T xv[4];
-#pragma unroll
-                        for (int k = 0; k < 4; ++k) xv[k] = (ABL & 8) ? (T) c[u][k] : ((ABL & 2) ? x[(c[u][k] & 1) + threadIdx.x] : x[c[u][k]]); // ablation: no gather / no x
-#pragma unroll
-                        for (int k = 0; k < 4; ++k) sum[u] = fmadd(v[u][k], xv[k], sum[u]);
-                    } else {
-#pragma unroll
-                        for (int k = 0; k < 4; ++k) {
-                            const int i = a[u] + k;
-                            if (i >= p0[u] && i < p1[u]) sum[u] = fmadd(v[u][k], x[c[u][k]], sum[u]);
-                        }
-                    }
-                    a[u] += 4 * L;
-                    more |= a[u] < p1[u];
-                }
-            }
-            more = __any(more);
-        }
-#pragma unroll
-        for (int u = 0; u < U; ++u) {
-            const T tot = (ABL & 4) ? sum[u] : (RED ? group_sum_dpp<L>(sum[u]) : group_sum<L>(sum[u])); // ablation: no reduce
-            const long long row = (g * U + u) * kRows + sub;
-            if ((ABL & 16) ? (tot == T(1.2345)) : (lane == 0 && row < m)) y[row] = tot; // ablation: no store
-        }
-    }
-}
-
 } // namespace spmv
 
 namespace spmv {

@@ -124,7 +124,7 @@ __global__ __launch_bounds__(kBlock) void sell_fill_kernel(int nchunks, const in
     for (int j = 0; j < width; ++j) {
         const size_t o = (size_t) (c0 + j) * kSellC + lane;
         const bool in = j < len;
-        scol[o] = in ? colidx[p0 + j] : -1;
+        if (scol) scol[o] = in ? colidx[p0 + j] : -1; // NULL: values only (spmv_hip_update_values)
         sval[o] = in ? val[p0 + j] : T(0);
     }
 }

@@ -32,6 +32,18 @@ struct TileWindows {
     int base[kWinMax];   // LDS slot of the window's first column
 };
 
+// sum of TileWindows::total over `count` tiles: the x elements one launch stages (traffic model, spmv_hip_info.stream_bytes)
+__global__ __launch_bounds__(kBlock) void wins_total_kernel(int count, const TileWindows *__restrict__ wins, unsigned long long *__restrict__ sum,
+                                                            unsigned long long *__restrict__ staged_tiles)
+{
+    unsigned long long t = 0, c = 0;
+    for (long long i = (long long) blockIdx.x * kBlock + threadIdx.x; i < count; i += (long long) gridDim.x * kBlock)
+        if (wins[i].nwin > 0) { t += (unsigned long long) wins[i].total; c += 1; }
+#pragma unroll
+    for (int o = kWave / 2; o > 0; o >>= 1) { t += __shfl_xor(t, o, kWave); c += __shfl_xor(c, o, kWave); }
+    if ((threadIdx.x & (kWave - 1)) == 0 && c) { atomicAdd(sum, t); atomicAdd(staged_tiles, c); }
+}
+
 // Stage the tile's windows: xs[base_w + i] = x[start_w + i].  NT = threads of the workgroup.
 template <int NT, typename T>
 __device__ __forceinline__ void stage_windows(const TileWindows &tw, const T *__restrict__ x, T *__restrict__ xs)

@@ -43,37 +43,6 @@ template <typename T> static int autotune_vector(spmv_dev *d);
 template <typename T> static int build_tile_windows(spmv_dev *d, int tiles, const int *split, int rows_per_tile = kVecTileRows, bool wide = false);
 constexpr size_t kVecWideXTileBytes = 96 * 1024; // budget of the wide form (slot indices; two workgroups per CU)
 
-constexpr size_t kSplitXTileBytes = 48 * 1024; // LDS budget of one nnz-split tile group's x span
-
-template <typename T>
-static int build_nnz_split(spmv_dev *d)
-{
-    constexpr int tile = SplitCfg<T>::Tile;
-    d->ntiles = (int) ((d->nnz + tile - 1) / tile);
-    if (d->ntiles == 0) return SPMV_HIP_OK;
-    ALLOC_TRY(d, &d->tile_first, sizeof(int) * ((size_t) d->ntiles + 1), true);
-    ALLOC_TRY(d, &d->carry, sizeof(T) * (size_t) d->ntiles, true);
-    int *flag = nullptr;
-    ALLOC_TRY(d, &flag, sizeof(int), true);
-    HIP_TRY(hipMemsetAsync(flag, 0, sizeof(int), d->stream));
-    nnz_tile_first_kernel<<<grid_for((long long) d->ntiles + 1, kBlock, INT_MAX), kBlock, 0, d->stream>>>(
-        d->m, d->ntiles, tile, d->rowptr, d->tile_first, flag);
-    HIP_TRY(hipGetLastError());
-    HIP_TRY(hipMemcpyAsync(&d->need_fixup, flag, sizeof(int), hipMemcpyDeviceToHost, d->stream));
-    HIP_TRY(hipStreamSynchronize(d->stream));
-    // x windows of every group of kSplitGroupTiles tiles (xwindows.hpp) on a private ColIdx copy
-    d->ns_groups = (d->ntiles + kSplitGroupTiles - 1) / kSplitGroupTiles;
-    ALLOC_TRY(d, &d->ns_col, sizeof(unsigned short) * ((size_t) d->nnz + kStreamPad), true);
-    ALLOC_TRY(d, &d->ns_wins, sizeof(TileWindows) * (size_t) d->ns_groups, true);
-    HIP_TRY(hipMemsetAsync(d->ns_col, 0, sizeof(unsigned short) * ((size_t) d->nnz + kStreamPad), d->stream));
-    {
-        const int rc = build_range_windows(d, d->plan.variant == 3 ? 0 : d->ns_groups, d->nnz, (long long) kSplitGroupTiles * tile, nullptr, 1, 1,
-                                           (int) (kSplitXTileBytes / sizeof(T)) - 1, d->colidx, d->ns_wins, &d->ns_staged, &d->ns_maxspan, d->ns_col, 0);
-        if (rc) return rc;
-    }
-    return SPMV_HIP_OK;
-}
-
 static int build_rowblock(spmv_dev *d)
 {
     d->rb_stride = d->plan.rowblock_nnz;
@@ -140,21 +109,18 @@ static int build_tile_windows(spmv_dev *d, int tiles, const int *split, int rows
 // window; fp32 24576 columns, fp64 12288 columns).
 constexpr size_t kSellXTileBytes = 96 * 1024;
 
-constexpr size_t kLongXTileBytes = 48 * 1024; // LDS budget of one long-row segment's x span
-
-// Rows longer than thr -> long_rows[] (row order).  Default: gathered into a sub-CSR with its own CSR5
-// plan (d->c5_long); variant 13: cut into kLongSeg segments for long_rows_kernel (kernels/long_rows.hpp).
+// Rows longer than thr -> long_rows[] (row order), gathered into a sub-CSR with its own CSR5 plan
+// (d->c5_long; kernels/long_rows.hpp).
 template <typename T>
 static int build_long_rows(spmv_dev *d, int thr)
 {
     d->long_thr = thr;
     d->nlong = 0;
-    d->lr_segs = 0;
     d->c5_long = Csr5Plan();
     if (d->stats.max_row_len <= thr) return SPMV_HIP_OK;
     // deterministic compaction of the long rows (flags -> scan -> scatter), as csr5 does for non-empty rows
     const int nb = (int) (((long long) d->m + kScanTile - 1) / kScanTile);
-    int *flags = nullptr, *sums = nullptr, *total = nullptr, *scratch = nullptr, *seg_cnt = nullptr;
+    int *flags = nullptr, *sums = nullptr, *total = nullptr, *scratch = nullptr;
     ALLOC_TRY(d, &sums, sizeof(int) * (size_t) nb, true);
     ALLOC_TRY(d, &total, sizeof(int), true);
     HIP_TRY(hipMalloc((void **) &flags, sizeof(int) * (size_t) d->m));
@@ -176,7 +142,7 @@ static int build_long_rows(spmv_dev *d, int thr)
     if (e != hipSuccess) { d->nlong = 0; return fail(SPMV_HIP_E_RUNTIME, "long-row compaction: %s", hipGetErrorString(e)); }
     ALLOC_TRY(d, &d->lr_seg_start, sizeof(long long) * ((size_t) d->nlong + 1), true);
 
-    if (d->plan.variant != 13) { // sub-CSR of the long rows + CSR5 over it
+    { // sub-CSR of the long rows + CSR5 over it
         long long sub_nnz = 0;
         long_rows_len_kernel<<<grid_for(d->nlong, kBlock, INT_MAX), kBlock, 0, d->stream>>>(d->nlong, d->long_rows, d->rowptr, scratch);
         scan_i32_to_i64_kernel<<<1, kBlock, 0, d->stream>>>(d->nlong, scratch, d->lr_seg_start);
@@ -194,28 +160,6 @@ static int build_long_rows(spmv_dev *d, int thr)
         return build_csr5<T>(d, d->c5_long, d->nlong, sub_nnz, d->lsub_rowptr, d->lsub_colidx, (const T *) d->lsub_val, 0,
                              (double) sub_nnz / (double) d->nlong, d->long_rows);
     }
-
-    int *cnt = total;
-    ALLOC_TRY(d, &seg_cnt, sizeof(int) * (size_t) d->nlong, true);
-    long_rows_segcount_kernel<<<grid_for(d->nlong, kBlock, INT_MAX), kBlock, 0, d->stream>>>(d->nlong, d->long_rows, d->rowptr, seg_cnt);
-    scan_i32_to_i64_kernel<<<1, kBlock, 0, d->stream>>>(d->nlong, seg_cnt, d->lr_seg_start);
-    HIP_TRY(hipGetLastError());
-    long long nsegs = 0;
-    HIP_TRY(hipMemcpyAsync(&nsegs, d->lr_seg_start + d->nlong, sizeof(long long), hipMemcpyDeviceToHost, d->stream));
-    HIP_TRY(hipStreamSynchronize(d->stream));
-    d->lr_segs = (int) nsegs;
-    ALLOC_TRY(d, &d->lr_seg_lr, sizeof(int) * (size_t) nsegs, true);
-    ALLOC_TRY(d, &d->lr_part, sizeof(T) * (size_t) nsegs, true);
-    ALLOC_TRY(d, &d->lr_seg_lo, sizeof(int) * (size_t) nsegs, true);
-    ALLOC_TRY(d, &d->lr_seg_span, sizeof(int) * (size_t) nsegs, true);
-    long_rows_segfill_kernel<<<grid_for(d->nlong, kBlock, INT_MAX), kBlock, 0, d->stream>>>(d->nlong, d->lr_seg_start, d->lr_seg_lr);
-    HIP_TRY(hipMemsetAsync(cnt, 0, sizeof(int), d->stream));
-    long_rows_segspan_kernel<<<(int) nsegs, kBlock, 0, d->stream>>>(d->lr_seg_lr, d->lr_seg_start, d->long_rows, d->rowptr, d->colidx,
-                                                                    d->lr_seg_lo, d->lr_seg_span, (int) (kLongXTileBytes / sizeof(T)), cnt);
-    HIP_TRY(hipGetLastError());
-    HIP_TRY(hipMemcpyAsync(&d->lr_maxspan, cnt, sizeof(int), hipMemcpyDeviceToHost, d->stream));
-    HIP_TRY(hipStreamSynchronize(d->stream));
-    return SPMV_HIP_OK;
 }
 
 
@@ -245,15 +189,7 @@ template <typename T> static int launch_csr5(spmv_dev *d, const Csr5Plan &P, con
 template <typename T>
 static void launch_long_rows(spmv_dev *d, const T *x, T *y)
 {
-    if (d->nlong <= 0) return;
-    if (d->c5_long.nnz > 0) { (void) launch_csr5<T>(d, d->c5_long, x, y); return; }
-    // LDS request = the largest span that is actually staged (keeps several workgroups per CU)
-    const size_t xbytes = (((size_t) d->lr_maxspan * sizeof(T)) + 1023) & ~(size_t) 1023;
-    long_rows_kernel<T><<<d->lr_segs, kBlock, xbytes, d->stream>>>(
-        d->lr_segs, (int) (kLongXTileBytes / sizeof(T)), d->lr_seg_lr, d->lr_seg_start, d->long_rows, d->lr_seg_lo, d->lr_seg_span, d->rowptr, d->colidx, (const T *) d->val, x, y, (T *) d->lr_part);
-    if (d->lr_segs > d->nlong)
-        long_rows_combine_kernel<T><<<grid_for(d->nlong, kBlock, INT_MAX), kBlock, 0, d->stream>>>(d->nlong, d->lr_seg_start, d->long_rows,
-                                                                                                  (const T *) d->lr_part, y);
+    if (d->nlong > 0 && d->c5_long.nnz > 0) (void) launch_csr5<T>(d, d->c5_long, x, y);
 }
 
 template <typename T>
@@ -318,7 +254,7 @@ static int build_sell(spmv_dev *d)
         }
         if (d->sell_staged == d->sell_nwin) { sched_free(d, d->scol); d->scol = nullptr; } // no window reads global columns
         else if (d->sell_staged == 0) { sched_free(d, d->scol16); d->scol16 = nullptr; }
-        HIP_TRY(hipFuncSetAttribute((const void *) sell_window_kernel<T>, hipFuncAttributeMaxDynamicSharedMemorySize, (int) kSellXTileBytes));
+        ensure_lds<sell_window_kernel<T>>(d, kSellXTileBytes);
     }
     HIP_TRY(hipStreamSynchronize(d->stream));
     return SPMV_HIP_OK;
@@ -453,14 +389,70 @@ static int build_csr5(spmv_dev *d, Csr5Plan &P, int m, long long nnz, const int 
     }
 }
 
-// Row blocks x column slabs (kernels/blocked.hpp).  R rows per block: y of a block = 64 KiB of LDS;
-// W columns per slab: see below.
+// Row blocks x column slabs (kernels/blocked.hpp).  R rows per block: y of a block = 64 KiB of LDS, one
+// wavefront per block; W columns per slab: see below.  blocked_fill does the stable counting sort (also for
+// spmv_hip_update_values: same positions, new values).
+template <typename T>
+static int blocked_fill(spmv_dev *d, int wshift, bool values_only)
+{
+    const int R = d->blk_R, K = d->blk_K, B = d->blk_B;
+    int *cnt = nullptr, *tot = nullptr;
+    long long *cursor = nullptr;
+    const size_t cells = (size_t) B * K;
+    HIP_TRY(hipMalloc((void **) &cnt, sizeof(int) * cells));
+    auto cleanup = [&]() { (void) hipFree(cnt); if (tot) (void) hipFree(tot); if (cursor) (void) hipFree(cursor); };
+    if (hipMalloc((void **) &tot, sizeof(int) * (size_t) B) != hipSuccess || hipMalloc((void **) &cursor, sizeof(long long) * cells) != hipSuccess) {
+        (void) hipGetLastError();
+        cleanup();
+        return fail(SPMV_HIP_E_ALLOC, "hipMalloc(block cells)");
+    }
+    hipError_t e = hipMemsetAsync(cnt, 0, sizeof(int) * cells, d->stream);
+    blk_count_kernel<<<grid_for(d->m, kBlock / 16, d->cus * 16), kBlock, 0, d->stream>>>(d->m, R, K, wshift, d->rowptr, d->colidx, cnt);
+    if (!values_only) {
+        blk_totals_kernel<<<grid_for(B, kBlock, INT_MAX), kBlock, 0, d->stream>>>(B, K, cnt, tot);
+        scan_i32_to_i64_kernel<<<1, kBlock, 0, d->stream>>>(B, tot, d->blk_start);
+    }
+    blk_cells_kernel<<<grid_for(B, kBlock, INT_MAX), kBlock, 0, d->stream>>>(B, K, cnt, d->blk_start, cursor, d->blk_end);
+    if (e == hipSuccess) e = hipGetLastError();
+    if (!values_only) {
+        long long total = 0;
+        if (e == hipSuccess) e = hipMemcpyAsync(&total, d->blk_start + B, sizeof(long long), hipMemcpyDeviceToHost, d->stream);
+        if (e == hipSuccess) e = hipStreamSynchronize(d->stream);
+        if (e != hipSuccess) { cleanup(); return fail(SPMV_HIP_E_RUNTIME, "block inspector: %s", hipGetErrorString(e)); }
+        const size_t slots = (size_t) total + 4096; // the last load groups of a block may start past its end (guarded) -- keep them in bounds
+        int rc = dev_alloc(d, &d->blk_val, sizeof(T) * slots, true);
+        if (!rc) rc = dev_alloc(d, (void **) &d->blk_col, sizeof(int) * slots, true);
+        if (!rc) rc = dev_alloc(d, (void **) &d->blk_row, sizeof(unsigned short) * slots, true);
+        if (rc) { cleanup(); return rc; }
+        d->blk_slots = (long long) slots;
+        (void) hipMemsetAsync(d->blk_val, 0, sizeof(T) * slots, d->stream); // padding entries: 0 * x[0]
+        (void) hipMemsetAsync(d->blk_col, 0, sizeof(int) * slots, d->stream);
+        (void) hipMemsetAsync(d->blk_row, 0, sizeof(unsigned short) * slots, d->stream);
+    }
+    const size_t lds = sizeof(int) * ((size_t) R + 1);
+    if (values_only) {
+        ensure_lds<blk_fill_kernel<T, true>>(d, lds);
+        blk_fill_kernel<T, true><<<B, kWave, lds, d->stream>>>(d->m, R, K, wshift, d->rowptr, d->colidx, (const T *) d->val,
+                                                             (unsigned long long *) cursor, (T *) d->blk_val, d->blk_col, d->blk_row);
+    } else {
+        ensure_lds<blk_fill_kernel<T, false>>(d, lds);
+        blk_fill_kernel<T, false><<<B, kWave, lds, d->stream>>>(d->m, R, K, wshift, d->rowptr, d->colidx, (const T *) d->val,
+                                                              (unsigned long long *) cursor, (T *) d->blk_val, d->blk_col, d->blk_row);
+    }
+    if (e == hipSuccess) e = hipGetLastError();
+    if (e == hipSuccess) e = hipStreamSynchronize(d->stream);
+    cleanup();
+    if (e != hipSuccess) return fail(SPMV_HIP_E_RUNTIME, "block fill: %s", hipGetErrorString(e));
+    return SPMV_HIP_OK;
+}
+
 template <typename T>
 static int build_blocked(spmv_dev *d)
 {
     int R = d->plan.block_rows > 0 ? d->plan.block_rows : (int) (64 * 1024 / sizeof(T));
-    if (d->plan.block_rows == 0) // small matrices: at least ~256 blocks, so that every CU gets one (down to 1024 rows)
-        while (R > 1024 && (long long) d->m / R < 256) R >>= 1;
+    if (d->plan.block_rows == 0) // small matrices: at least ~512 blocks (two single-wave blocks per CU), down to 1024 rows
+        while (R > 1024 && (long long) d->m / R < 512) R >>= 1;
+    if ((size_t) R * sizeof(T) > 128 * 1024) R = (int) (128 * 1024 / sizeof(T));
     // Slab width: as narrow as the cell table allows (2^25 cells: ~400 MB of inspector scratch), down to 32
     // columns.  Narrow slabs cost nothing in L2 locality (the sweep over x is the same) and put entries that
     // gather from the same cache line into neighbouring lanes, which the L1/TA path merges into one L2
@@ -477,40 +469,123 @@ static int build_blocked(spmv_dev *d)
     }
     const int K = (int) ((((long long) d->n - 1) >> wshift) + 1);
     if ((long long) B * K > (1ll << 26)) return SPMV_HIP_OK; // cell table too large: keep the tile executor
-    int *cnt = nullptr, *tot = nullptr;
-    long long *cursor = nullptr;
-    const size_t cells = (size_t) B * K;
-    HIP_TRY(hipMalloc((void **) &cnt, sizeof(int) * cells));
-    auto cleanup = [&]() { (void) hipFree(cnt); if (tot) (void) hipFree(tot); if (cursor) (void) hipFree(cursor); };
-    if (hipMalloc((void **) &tot, sizeof(int) * (size_t) B) != hipSuccess || hipMalloc((void **) &cursor, sizeof(long long) * cells) != hipSuccess) {
-        cleanup();
-        return fail(SPMV_HIP_E_ALLOC, "hipMalloc(block cells)");
-    }
     int rc = dev_alloc(d, (void **) &d->blk_start, sizeof(long long) * ((size_t) B + 1), true);
     if (!rc) rc = dev_alloc(d, (void **) &d->blk_end, sizeof(long long) * (size_t) B, true);
-    if (rc) { cleanup(); return rc; }
-    hipError_t e = hipMemsetAsync(cnt, 0, sizeof(int) * cells, d->stream);
-    blk_count_kernel<<<grid_for(d->m, kBlock / 16, d->cus * 16), kBlock, 0, d->stream>>>(d->m, R, K, wshift, d->rowptr, d->colidx, cnt);
-    blk_totals_kernel<<<grid_for(B, kBlock, INT_MAX), kBlock, 0, d->stream>>>(B, K, cnt, tot);
-    scan_i32_to_i64_kernel<<<1, kBlock, 0, d->stream>>>(B, tot, d->blk_start);
-    blk_cells_kernel<<<grid_for(B, kBlock, INT_MAX), kBlock, 0, d->stream>>>(B, K, cnt, d->blk_start, cursor, d->blk_end);
-    long long total = 0;
-    if (e == hipSuccess) e = hipGetLastError();
-    if (e == hipSuccess) e = hipMemcpyAsync(&total, d->blk_start + B, sizeof(long long), hipMemcpyDeviceToHost, d->stream);
-    if (e == hipSuccess) e = hipStreamSynchronize(d->stream);
-    if (e != hipSuccess) { cleanup(); return fail(SPMV_HIP_E_RUNTIME, "block inspector: %s", hipGetErrorString(e)); }
-    const size_t slots = (size_t) total + 4096; // the last groups of a block read up to 3 load groups past its end
-    rc = dev_alloc(d, &d->blk_val, sizeof(T) * slots, true);
-    if (!rc) rc = dev_alloc(d, (void **) &d->blk_col, sizeof(int) * slots, true);
-    if (!rc) rc = dev_alloc(d, (void **) &d->blk_row, sizeof(unsigned short) * slots, true);
-    if (rc) { cleanup(); return rc; }
-    blk_fill_kernel<T><<<grid_for(d->m, kBlock / 16, d->cus * 16), kBlock, 0, d->stream>>>(d->m, R, K, wshift, d->rowptr, d->colidx, (const T *) d->val,
-                                                                                       (unsigned long long *) cursor, (T *) d->blk_val, d->blk_col, d->blk_row);
-    e = hipGetLastError();
-    if (e == hipSuccess) e = hipStreamSynchronize(d->stream);
-    cleanup();
-    if (e != hipSuccess) return fail(SPMV_HIP_E_RUNTIME, "block fill: %s", hipGetErrorString(e));
-    d->blk_R = R; d->blk_K = K; d->blk_B = B;
+    if (rc) return rc;
+    d->blk_R = R; d->blk_K = K; d->blk_B = B; d->blk_wshift = wshift;
+    rc = blocked_fill<T>(d, wshift, false);
+    if (rc) return rc;
     d->blk_on = true;
+    return SPMV_HIP_OK;
+}
+
+// Does the schedule just built gather x from L1/L2 although x is far larger than an L2?  Then every gather
+// crosses the fabric (8 % of roofline): switch the executor (option "cache_block": 1 automatic, 2 always).
+static bool wants_blocked(const spmv_dev *d, int staged_groups)
+{
+    if (d->plan.cache_block == 2) return d->nnz > 0;
+    if (d->plan.variant == 3) return false; // A/B: the tile executors with global gathers
+    return d->plan.cache_block == 1 && staged_groups == 0 && d->nnz >= (1ll << 21) && (long long) d->n * (long long) d->vsize >= (6ll << 20);
+}
+
+// ------------------------------------------------------------------------------------ traffic model
+// spmv_hip_info.stream_bytes: the HBM bytes ONE launch of the built schedule has to move, from the sizes of
+// the arrays its executor streams (as stored: 16-bit slot streams where x windows are staged, padding
+// included), the x elements it stages (sum of the window sizes; n once where it gathers through L2), y written
+// once and the carries.  bench.py divides this by the measured launch time (roofline.achieved); the rocprofv3
+// FETCH_SIZE / WRITE_SIZE passes under profiles/ check the model (config 2: model 3.43 GB, counters 3.43 GB).
+struct Traffic {
+    long long bytes = 0, x_elems = 0;
+    bool gathers_global = false; // some tile reads x through L1/L2: charge the whole vector once
+};
+
+static int wins_sum(spmv_dev *d, const TileWindows *wins, int count, long long *elems, long long *tiles)
+{
+    *elems = *tiles = 0;
+    if (!wins || count <= 0) return SPMV_HIP_OK;
+    unsigned long long *dv = nullptr, hv[2] = {0, 0};
+    HIP_TRY(hipMalloc((void **) &dv, sizeof hv));
+    hipError_t e = hipMemsetAsync(dv, 0, sizeof hv, d->stream);
+    wins_total_kernel<<<grid_for(count, kBlock, d->cus * 4), kBlock, 0, d->stream>>>(count, wins, dv, dv + 1);
+    if (e == hipSuccess) e = hipGetLastError();
+    if (e == hipSuccess) e = hipMemcpyAsync(hv, dv, sizeof hv, hipMemcpyDeviceToHost, d->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(d->stream);
+    (void) hipFree(dv);
+    if (e != hipSuccess) return fail(SPMV_HIP_E_RUNTIME, "window totals: %s", hipGetErrorString(e));
+    *elems = (long long) hv[0];
+    *tiles = (long long) hv[1];
+    return SPMV_HIP_OK;
+}
+
+// value + column streams of `stored` entries of which the fraction fs sits in staged groups
+static long long stream_part(long long stored, long long s, double fs)
+{
+    return stored * s + (long long) ((double) stored * (2.0 * fs + 4.0 * (1.0 - fs)));
+}
+
+static int csr5_traffic(spmv_dev *d, const Csr5Plan &P, Traffic &t)
+{
+    if (P.nnz == 0) return SPMV_HIP_OK;
+    const long long s = (long long) d->vsize, TN = (long long) kWave * P.sigma, p = P.tiles;
+    long long welems = 0, wtiles = 0;
+    if (P.staged > 0) { const int rc = wins_sum(d, P.wins, P.groups, &welems, &wtiles); if (rc) return rc; }
+    const double fs = P.groups > 0 ? (double) wtiles / (double) P.groups : 0.0;
+    t.bytes += stream_part(P.natural ? P.nnz : p * TN, s, fs);
+    t.bytes += 4 * (p + 1) + 4 * kWave * p + s * p;            // tile_ptr, descriptors, carries written
+    if (P.fixup && p > 1) t.bytes += (s + 8) * p;               // fix-up launch: carries, tile_ptr, run_len
+    if (P.staged > 0) t.bytes += (long long) sizeof(TileWindows) * P.groups;
+    if (P.row_map) t.bytes += 4ll * P.m2;
+    t.bytes += s * P.m2 + (s + 4) * (long long) P.n_empty;      // y of the plan's rows; zero fill of the empty rows
+    t.x_elems += welems;
+    if (wtiles < P.groups) t.gathers_global = true;
+    return SPMV_HIP_OK;
+}
+
+static int account_stream_bytes(spmv_dev *d)
+{
+    const long long s = (long long) d->vsize, m = d->m, n = d->n;
+    Traffic t;
+    int rc = SPMV_HIP_OK;
+    if (d->blk_on) {
+        t.bytes = (d->blk_slots - 4096) * (s + 4 + 2) + 16ll * d->blk_B + s * m;
+        t.gathers_global = true;
+    } else {
+        switch (d->plan.sched) {
+        case SPMV_SCHED_CSR_VECTOR:
+        case SPMV_SCHED_ROWBLOCK: {
+            long long welems = 0, wtiles = 0;
+            rc = wins_sum(d, d->vt_wins, d->vt_tiles, &welems, &wtiles);
+            if (rc) return rc;
+            const bool tile_form = d->vt_tiles > 0 && (d->plan.sched == SPMV_SCHED_ROWBLOCK || d->vt_wide || d->vt_staged * 2 >= d->vt_tiles);
+            const double fs = tile_form && d->vt_tiles > 0 ? (double) wtiles / (double) d->vt_tiles : 0.0; // pipe form: int32 columns
+            t.bytes = 4 * (m + 1) + stream_part(d->nnz - d->lsub_nnz, s, fs) + s * (m - d->nlong);
+            if (tile_form) { t.bytes += (long long) sizeof(TileWindows) * d->vt_tiles; t.x_elems = welems; }
+            if (d->plan.sched == SPMV_SCHED_ROWBLOCK) t.bytes += 4ll * (d->nblocks + 1);
+            if (!tile_form || wtiles < d->vt_tiles) t.gathers_global = true;
+            rc = csr5_traffic(d, d->c5_long, t);
+            break;
+        }
+        case SPMV_SCHED_NNZ_SPLIT: rc = csr5_traffic(d, d->ns, t); break;
+        case SPMV_SCHED_CSR5: rc = csr5_traffic(d, d->c5, t); break;
+        case SPMV_SCHED_SELL: {
+            long long welems = 0, wtiles = 0;
+            if (d->sell_staged > 0) { rc = wins_sum(d, d->sell_wins, d->sell_nwin, &welems, &wtiles); if (rc) return rc; }
+            const double fs = d->sell_nwin > 0 ? (double) wtiles / (double) d->sell_nwin : 0.0;
+            t.bytes = stream_part(d->sell_cols * kSellC, s, fs) + 8ll * (d->nchunks + 1) + 4ll * d->nchunks * kSellC + s * (m - d->nlong);
+            if (d->sell_staged > 0) t.bytes += (long long) sizeof(TileWindows) * d->sell_nwin;
+            t.x_elems = welems;
+            if (wtiles < d->sell_nwin) t.gathers_global = true;
+            rc = csr5_traffic(d, d->c5_long, t);
+            break;
+        }
+        default: // CSR-scalar: the plain arrays
+            t.bytes = 4 * (m + 1) + d->nnz * (4 + s) + s * m;
+            t.gathers_global = d->nnz > 0;
+            break;
+        }
+    }
+    if (rc) return rc;
+    d->x_bytes = s * (t.x_elems + (t.gathers_global ? n : 0));
+    d->stream_bytes = t.bytes + d->x_bytes;
     return SPMV_HIP_OK;
 }

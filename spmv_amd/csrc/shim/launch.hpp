@@ -10,15 +10,13 @@ constexpr int kVecNB = 4;
 // Kernel forms of the CSR-vector schedule.  Which one is fastest differs between MI355X boxes by a
 // few percent, so create() times the applicable ones once on the resident matrix
 // (autotune_vector) and keeps the winner in d->vec_choice; plan.variant overrides for A/B runs.
-enum { VEC_AUTO = 0, VEC_STRIDED = 1, VEC_NO_LONG = 2, VEC_PIPE = 4, VEC_TILE_D2 = 5, VEC_TILE_D8 = 6, VEC_TILE_D4 = 10, VEC_TILE_D4_NOPRE = 11,
-       VEC_TILE_D2_NOPRE = 12, VEC_LONG_SEGMENTS = 13 /* long rows through long_rows_kernel instead of the CSR5 sub-matrix */ };
+enum { VEC_AUTO = 0, VEC_NO_LONG = 2, VEC_PIPE = 4, VEC_TILE_D2 = 5, VEC_TILE_D8 = 6, VEC_TILE_D4 = 10, VEC_TILE_D4_NOPRE = 11, VEC_TILE_D2_NOPRE = 12 };
 
 template <typename T, int L, int DEPTH, bool PRE = true>
 static void launch_vector_tile(spmv_dev *d, const T *x, T *y, int long_thr)
 {
     const size_t lds = ((((size_t) d->vt_maxspan + 1) * sizeof(T)) + 1023) & ~(size_t) 1023; // + the zero slot
-    if (lds > 64 * 1024)
-        (void) hipFuncSetAttribute((const void *) csr_vector_tile_kernel<T, L, DEPTH, PRE>, hipFuncAttributeMaxDynamicSharedMemorySize, (int) lds);
+    ensure_lds<csr_vector_tile_kernel<T, L, DEPTH, PRE>>(d, lds);
     csr_vector_tile_kernel<T, L, DEPTH, PRE><<<d->vt_tiles, kVecTileThreads, lds, d->stream>>>(d->m, long_thr, d->rowptr, d->colidx, d->vt_col, (const T *) d->val,
                                                                                            d->vt_wins, x, y);
 }
@@ -28,11 +26,6 @@ static void launch_vector(spmv_dev *d, const T *x, T *y)
 {
     const int v = d->plan.variant ? d->plan.variant : d->vec_choice;
     const int long_thr = v == VEC_NO_LONG ? INT_MAX : d->long_thr;
-    if (v == VEC_STRIDED) { // A/B: the first-round strided kernel
-        csr_vector_kernel<T, (L < 2 ? 2 : L)><<<grid_for(d->m, kBlock / (L < 2 ? 2 : L), d->cus * 32), kBlock, 0, d->stream>>>(
-            d->m, d->rowptr, d->colidx, (const T *) d->val, x, y);
-        return;
-    }
     const bool tile_default = d->vt_staged * 2 >= d->vt_tiles; // most x tiles fit LDS
     const bool tile_forced = v == VEC_TILE_D2 || v == VEC_TILE_D4 || v == VEC_TILE_D8 || v == VEC_TILE_D4_NOPRE || v == VEC_TILE_D2_NOPRE;
     if (d->vt_tiles > 0 && v != VEC_PIPE && (tile_default || tile_forced)) { // tile kernel (unstaged tiles gather from L1/L2)
@@ -117,16 +110,26 @@ static int autotune_vector(spmv_dev *d)
     return SPMV_HIP_OK;
 }
 
+// Row blocks x column slabs (kernels/blocked.hpp): one single-wave workgroup per row block.  Variants for A/B
+// runs: 20 / 22 = 4 / 16 load groups in flight per lane (default 8); 23 = the first-round 256-thread workgroup
+// per block, whose waves race on the rows (not bit-reproducible on inexact data).
 template <typename T>
 static void launch_blocked(spmv_dev *d, const T *x, T *y)
 {
     const size_t lds = (size_t) d->blk_R * sizeof(T);
-    if (lds > 64 * 1024) { // one 512-thread workgroup per CU: same 8 waves as two 256-thread ones
-        (void) hipFuncSetAttribute((const void *) blk_kernel<T, 512>, hipFuncAttributeMaxDynamicSharedMemorySize, (int) lds);
-        blk_kernel<T, 512><<<d->blk_B, 512, lds, d->stream>>>(d->m, d->blk_R, d->blk_start, d->blk_end, (const T *) d->blk_val, d->blk_col, d->blk_row, x, y);
-    } else {
-        blk_kernel<T, kBlkThreads><<<d->blk_B, kBlkThreads, lds, d->stream>>>(d->m, d->blk_R, d->blk_start, d->blk_end, (const T *) d->blk_val, d->blk_col, d->blk_row, x, y);
+#define SPMV_BLK_LAUNCH(NT, UN)                                                                                                  \
+    do {                                                                                                                         \
+        ensure_lds<blk_kernel<T, NT, UN>>(d, lds);                                                                               \
+        blk_kernel<T, NT, UN><<<d->blk_B, NT, lds, d->stream>>>(d->m, d->blk_R, d->blk_start, d->blk_end, (const T *) d->blk_val, \
+                                                                d->blk_col, d->blk_row, x, y);                                   \
+    } while (0)
+    switch (d->plan.variant) {
+    case 20: SPMV_BLK_LAUNCH(kWave, 4); break;
+    case 22: SPMV_BLK_LAUNCH(kWave, 16); break;
+    case 23: SPMV_BLK_LAUNCH(256, 4); break;
+    default: SPMV_BLK_LAUNCH(kWave, 8); break;
     }
+#undef SPMV_BLK_LAUNCH
 }
 
 template <typename T, int SIGMA, bool MAPPED>
@@ -140,18 +143,17 @@ static void launch_csr5_form(spmv_dev *d, const Csr5Plan &P, const T *x, T *y)
             constexpr size_t full = (size_t) (kBlock / kWave) * NatLds<T, SIGMA, false>::kBytes;
             const bool half = lds + full > 76 * 1024; // two workgroups no longer fit a CU's 160 KiB
             if (half) {
-                if (lds > 16 * 1024) (void) hipFuncSetAttribute((const void *) nat_group_kernel<T, SIGMA, MAPPED, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int) lds);
+                ensure_lds<nat_group_kernel<T, SIGMA, MAPPED, true>>(d, lds, (size_t) (kBlock / kWave) * NatLds<T, SIGMA, true>::kBytes);
                 nat_group_kernel<T, SIGMA, MAPPED, true><<<P.groups, kBlock, lds, d->stream>>>(P.group_tiles, P.tiles, (int) P.nnz, P.tile_ptr, P.desc, P.col, P.col16,
                                                                                               (const T *) P.val, P.row_map, P.wins, x, y, (T *) P.carry, P.n_empty, P.empty_list);
             } else {
-                if (lds > 16 * 1024) (void) hipFuncSetAttribute((const void *) nat_group_kernel<T, SIGMA, MAPPED, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int) lds);
+                ensure_lds<nat_group_kernel<T, SIGMA, MAPPED, false>>(d, lds, full);
                 nat_group_kernel<T, SIGMA, MAPPED, false><<<P.groups, kBlock, lds, d->stream>>>(P.group_tiles, P.tiles, (int) P.nnz, P.tile_ptr, P.desc, P.col, P.col16,
                                                                                                (const T *) P.val, P.row_map, P.wins, x, y, (T *) P.carry, P.n_empty, P.empty_list);
             }
             return;
         }
-        if (lds > 64 * 1024) // above the default dynamic-LDS limit: raise it for this instantiation (idempotent, cheap)
-            (void) hipFuncSetAttribute((const void *) csr5_group_kernel<T, SIGMA, MAPPED>, hipFuncAttributeMaxDynamicSharedMemorySize, (int) lds);
+        ensure_lds<csr5_group_kernel<T, SIGMA, MAPPED>>(d, lds);
         csr5_group_kernel<T, SIGMA, MAPPED><<<P.groups, kBlock, lds, d->stream>>>(P.group_tiles, P.tiles, P.tile_ptr, P.desc, P.col, P.col16, (const T *) P.val, P.row_map, P.wins,
                                                                                  x, y, (T *) P.carry, P.n_empty, P.empty_list);
         return;
@@ -195,12 +197,12 @@ static void launch_rows(spmv_dev *d, const T *x, T *y, const int *split)
     constexpr int DEPTH = sizeof(T) == 8 ? 4 : 2;
     const size_t lds = ((((size_t) d->vt_maxspan + 1) * sizeof(T)) + 1023) & ~(size_t) 1023; // + the zero slot
     if (d->vt_wide) {
-        if (lds > 64 * 1024) (void) hipFuncSetAttribute((const void *) csr_vector_rows_kernel<T, L, DEPTH, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int) lds);
+        ensure_lds<csr_vector_rows_kernel<T, L, DEPTH, true>>(d, lds);
         csr_vector_rows_kernel<T, L, DEPTH, true><<<d->vt_tiles, kVecTileThreads, lds, d->stream>>>(
             d->long_thr, split, d->vt_rows, d->m, d->rowptr, d->colidx, d->vt_col, (const T *) d->val, d->vt_wins, x, y);
         return;
     }
-    if (lds > 64 * 1024) (void) hipFuncSetAttribute((const void *) csr_vector_rows_kernel<T, L, DEPTH>, hipFuncAttributeMaxDynamicSharedMemorySize, (int) lds);
+    ensure_lds<csr_vector_rows_kernel<T, L, DEPTH, false>>(d, lds);
     csr_vector_rows_kernel<T, L, DEPTH><<<d->vt_tiles, kVecTileThreads, lds, d->stream>>>(
         d->long_thr, split, d->vt_rows, d->m, d->rowptr, d->colidx, d->vt_col, (const T *) d->val, d->vt_wins, x, y);
 }
@@ -234,37 +236,19 @@ static int launch(spmv_dev *d, const T *x, T *y)
         csr_scalar_kernel<T><<<grid_for(d->m, kBlock, d->cus * 8), kBlock, 0, d->stream>>>(d->m, d->rowptr, d->colidx, val, x, y);
         break;
     case SPMV_SCHED_CSR_VECTOR:
+        if (d->blk_on) { launch_blocked<T>(d, x, y); break; } // no x window could be staged (option "cache_block")
         if (d->vt_wide) launch_rows_any<T>(d, x, y, nullptr); // wide x windows: uniform 1024-row blocks, slot-index stream
         else launch_vector_any<T>(d, x, y);
         if (d->plan.variant != 2) launch_long_rows<T>(d, x, y);
         break;
     case SPMV_SCHED_NNZ_SPLIT: {
         if (d->blk_on) { launch_blocked<T>(d, x, y); break; }
-        if (d->plan.variant != 8) {
-            const int rc = launch_csr5<T>(d, d->ns, x, y);
-            if (rc) return rc;
-            break;
-        }
-        if (d->ns_staged > 0) {
-            const size_t lds = ((((size_t) d->ns_maxspan + 1) * sizeof(T)) + 1023) & ~(size_t) 1023;
-            nnz_group_kernel<T><<<d->ns_groups, kBlock, lds, d->stream>>>((int) d->nnz, d->ntiles, d->rowptr, d->colidx, d->ns_col, val, d->ns_wins,
-                                                                         x, y, d->tile_first, (T *) d->carry);
-        } else {
-            const int grid = grid_for(d->ntiles, kBlock / kWave, d->plan.variant == 1 ? d->cus * 8 : INT_MAX);
-            nnz_split_kernel<T><<<grid, kBlock, 0, d->stream>>>(d->m, (int) d->nnz, d->ntiles, d->rowptr, d->colidx, val, x, y,
-                                                                 d->tile_first, (T *) d->carry);
-        }
-        if (d->need_fixup && d->ntiles > 1)
-            nnz_fixup_kernel<T><<<grid_for(d->ntiles - 1, kBlock, INT_MAX), kBlock, 0, d->stream>>>(
-                d->ntiles, d->rowptr, d->tile_first, (const T *) d->carry, y);
+        const int rc = launch_csr5<T>(d, d->ns, x, y);
+        if (rc) return rc;
         break;
     }
     case SPMV_SCHED_ROWBLOCK:
         if (d->blk_on) { launch_blocked<T>(d, x, y); break; }
-        if (d->plan.variant == 7 && d->rb_stride <= 4096) { // A/B: the first-round LDS-products kernel
-            rowblock_kernel<T><<<d->nblocks, kBlock, 2 * (size_t) d->rb_stride * sizeof(T), d->stream>>>(d->rb_split, d->rowptr, d->colidx, val, x, y);
-            break;
-        }
         launch_rows_any<T>(d, x, y, d->rb_split);
         launch_long_rows<T>(d, x, y);
         break;
@@ -275,11 +259,12 @@ static int launch(spmv_dev *d, const T *x, T *y)
             sell_window_kernel<T><<<d->sell_nwin, kSellWinThreads, ((((size_t) d->sell_maxspan + 1) * sizeof(T)) + 1023) & ~(size_t) 1023, d->stream>>>(
                 d->sell_group * (d->plan.sell_sigma / kSellC), (long long) d->nchunks, d->chunk_ptr, d->scol, d->scol16, (const T *) d->sval, d->perm, d->sell_wins, x, y);
         else
-            sell_kernel<T><<<grid_for(d->nchunks, kBlock / kWave, d->plan.variant == 1 ? d->cus * 8 : INT_MAX), kBlock, 0, d->stream>>>(
+            sell_kernel<T><<<grid_for(d->nchunks, kBlock / kWave, INT_MAX), kBlock, 0, d->stream>>>(
                 d->nchunks, d->chunk_ptr, d->scol, (const T *) d->sval, d->perm, x, y);
         launch_long_rows<T>(d, x, y);
         break;
     case SPMV_SCHED_CSR5: {
+        if (d->blk_on) { launch_blocked<T>(d, x, y); break; }
         const int rc = launch_csr5<T>(d, d->c5, x, y);
         if (rc) return rc;
         break;

@@ -27,6 +27,19 @@ extern "C" const char *spmv_shim_error_text(void) { return t_err; }
         }                                                                                          \
     } while (0)
 
+// Makes `device` current for the life of the guard and restores the caller's device afterwards.
+struct DeviceGuard {
+    int prev = -1;
+    bool ok = true;
+    explicit DeviceGuard(int device)
+    {
+        if (hipGetDevice(&prev) != hipSuccess) { (void) hipGetLastError(); prev = -1; }
+        if (prev != device && hipSetDevice(device) != hipSuccess) { (void) hipGetLastError(); ok = false; }
+        if (prev == device) prev = -1; // nothing to restore
+    }
+    ~DeviceGuard() { if (prev >= 0) (void) hipSetDevice(prev); }
+};
+
 // ------------------------------------------------------------------------------------ state
 struct DevStats {
     int max_len, min_len, empty, bad, first, last;
@@ -63,13 +76,6 @@ struct spmv_dev {
     spmv_stats stats{};
     spmv_plan plan{};
     bool built = false;
-    // nnz-split
-    int ntiles = 0, need_fixup = 0;
-    int *tile_first = nullptr;
-    void *carry = nullptr;
-    int ns_groups = 0, ns_staged = 0, ns_maxspan = 0;
-    unsigned short *ns_col = nullptr; // 16-bit LDS slots of the staged groups' entries
-    TileWindows *ns_wins = nullptr;
     // row blocks
     int nblocks = 0, rb_stride = 0;
     int *rb_split = nullptr;
@@ -81,10 +87,9 @@ struct spmv_dev {
     unsigned short *vt_col = nullptr; // tile-local column stream: 16-bit LDS slots (staged tiles only)
     TileWindows *vt_wins = nullptr; // x windows of every tile
     // long rows (csr-vector, sell)
-    int nlong = 0, long_thr = INT_MAX, lr_segs = 0, lr_maxspan = 0;
-    int *long_rows = nullptr, *lr_seg_lr = nullptr, *lr_seg_lo = nullptr, *lr_seg_span = nullptr;
-    long long *lr_seg_start = nullptr;
-    void *lr_part = nullptr;
+    int nlong = 0, long_thr = INT_MAX;
+    int *long_rows = nullptr;
+    long long *lr_seg_start = nullptr; // int64 prefix sum of the long rows' lengths
     // sell
     int nchunks = 0;
     long long sell_cols = 0; // sum of chunk widths
@@ -98,7 +103,8 @@ struct spmv_dev {
     Csr5Plan c5, c5_long, ns; // ns: the natural-layout plan of the nnz-split schedule
     // row blocks x column slabs (kernels/blocked.hpp): the nnz-split executor for columns without locality
     bool blk_on = false;
-    int blk_R = 0, blk_K = 0, blk_B = 0;
+    int blk_R = 0, blk_K = 0, blk_B = 0, blk_wshift = 0;
+    long long blk_slots = 0;
     long long *blk_start = nullptr, *blk_end = nullptr;
     void *blk_val = nullptr;
     int *blk_col = nullptr;
@@ -108,10 +114,12 @@ struct spmv_dev {
     void *lsub_val = nullptr;
     long long lsub_nnz = 0;
     // staging for host x / y
-    void *x_stage = nullptr, *y_stage = nullptr;
+    void *x_stage = nullptr, *y_stage = nullptr, *scratch8 = nullptr;
+    long long stream_bytes = 0, x_bytes = 0; // traffic model of one launch (account_stream_bytes)
+    int x_groups_seen = 0;                   // tile groups analysed before the blocked executor took over
     long long device_bytes = 0;
     double inspect_ms = 0;
-    std::vector<void *> sched_allocs; // freed when the schedule is rebuilt
+    std::vector<std::pair<void *, size_t>> sched_allocs; // (pointer, bytes): freed when the schedule is rebuilt
 };
 
 static int dev_alloc(spmv_dev *d, void **p, size_t bytes, bool sched)
@@ -120,7 +128,7 @@ static int dev_alloc(spmv_dev *d, void **p, size_t bytes, bool sched)
     if (bytes == 0) bytes = 16;
     HIP_TRY(hipMalloc(p, bytes));
     d->device_bytes += (long long) bytes;
-    if (sched) d->sched_allocs.push_back(*p);
+    if (sched) d->sched_allocs.push_back({*p, bytes});
     return SPMV_HIP_OK;
 }
 #define ALLOC_TRY(d, p, bytes, sched)                                        \
@@ -133,29 +141,44 @@ static int dev_alloc(spmv_dev *d, void **p, size_t bytes, bool sched)
 static void sched_free(spmv_dev *d, void *p)
 {
     for (size_t i = 0; i < d->sched_allocs.size(); ++i)
-        if (d->sched_allocs[i] == p) {
+        if (d->sched_allocs[i].first == p) {
+            d->device_bytes -= (long long) d->sched_allocs[i].second;
             d->sched_allocs.erase(d->sched_allocs.begin() + (long) i);
             (void) hipFree(p);
             return;
         }
 }
 
-static void free_schedule(spmv_dev *d)
+static void reset_tile_fields(spmv_dev *d)
 {
-    for (void *p : d->sched_allocs) (void) hipFree(p);
-    d->sched_allocs.clear();
-    d->tile_first = nullptr; d->carry = nullptr; d->rb_split = nullptr; d->ns_col = nullptr; d->ns_wins = nullptr; d->ns_groups = d->ns_staged = 0;
-    d->perm = d->scol = d->long_rows = d->lr_seg_lr = d->lr_seg_lo = d->lr_seg_span = nullptr; d->sell_wins = nullptr; d->scol16 = nullptr; d->sell_staged = d->sell_nwin = 0; d->chunk_ptr = d->lr_seg_start = nullptr;
-    d->sval = d->lr_part = nullptr;
-    d->ntiles = d->nblocks = d->nchunks = d->nlong = d->lr_segs = 0;
+    d->rb_split = nullptr;
+    d->perm = d->scol = d->long_rows = nullptr; d->sell_wins = nullptr; d->scol16 = nullptr; d->sell_staged = d->sell_nwin = 0; d->chunk_ptr = d->lr_seg_start = nullptr;
+    d->sval = nullptr;
+    d->nblocks = d->nchunks = d->nlong = 0;
     d->long_thr = INT_MAX;
     d->vt_col = nullptr; d->vt_wins = nullptr; d->vt_tiles = d->vt_staged = d->vt_maxspan = 0; d->vt_wide = false; d->vt_rows = 256;
     d->c5 = Csr5Plan();
     d->c5_long = Csr5Plan();
     d->ns = Csr5Plan();
-    d->blk_on = false; d->blk_start = d->blk_end = nullptr; d->blk_val = nullptr; d->blk_col = nullptr; d->blk_row = nullptr;
     d->lsub_rowptr = d->lsub_colidx = nullptr; d->lsub_val = nullptr; d->lsub_nnz = 0;
+}
+
+static void free_schedule(spmv_dev *d)
+{
+    for (auto &a : d->sched_allocs) { (void) hipFree(a.first); d->device_bytes -= (long long) a.second; }
+    d->sched_allocs.clear();
+    reset_tile_fields(d);
+    d->blk_on = false; d->blk_slots = 0; d->blk_start = d->blk_end = nullptr; d->blk_val = nullptr; d->blk_col = nullptr; d->blk_row = nullptr;
     d->built = false;
+}
+
+// The row-block x column-slab executor has taken over: release what the tile schedule built (the first
+// `count` schedule allocations), keep the blocked streams.
+static void drop_tile_schedule(spmv_dev *d, size_t count)
+{
+    for (size_t i = 0; i < count && i < d->sched_allocs.size(); ++i) { (void) hipFree(d->sched_allocs[i].first); d->device_bytes -= (long long) d->sched_allocs[i].second; }
+    d->sched_allocs.erase(d->sched_allocs.begin(), d->sched_allocs.begin() + (long) (count < d->sched_allocs.size() ? count : d->sched_allocs.size()));
+    reset_tile_fields(d);
 }
 
 // true if the pointer is usable by a kernel as is (device or managed memory)
@@ -260,6 +283,18 @@ __global__ __launch_bounds__(kBlock) void fill_zero_kernel(long long n, T *y)
 {
     const long long stride = (long long) gridDim.x * kBlock;
     for (long long i = (long long) blockIdx.x * kBlock + threadIdx.x; i < n; i += stride) y[i] = T(0);
+}
+
+// Dynamic LDS above the 64 KiB default needs hipFuncAttributeMaxDynamicSharedMemorySize raised once per kernel
+// instantiation (and per device): remembered here, so that launches do not pay the call every time.
+template <auto Kernel>
+static void ensure_lds(const spmv_dev *d, size_t bytes, size_t static_bytes = 0)
+{
+    static size_t granted[64]; // per device ordinal; zero-initialised = the 64 KiB default
+    const int dev = d->device >= 0 && d->device < 64 ? d->device : 0;
+    if (bytes + static_bytes <= 64 * 1024 || bytes <= granted[dev]) return;
+    if (hipFuncSetAttribute((const void *) Kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int) bytes) == hipSuccess) granted[dev] = bytes;
+    else (void) hipGetLastError();
 }
 
 static int grid_for(long long work_items, int per_block, int cap)

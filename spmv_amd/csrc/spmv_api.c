@@ -11,8 +11,10 @@
  * What is different by design: the per-method "get_handle" inspectors and "_Selected" executors
  * of the reference (serial_spmv.c ... csr5_spmv.cpp) are CPU code; here create() asks the
  * planner (spmv_plan.c) for a GPU schedule and hands it to the HIP shim (spmv_shim.hip), and
- * spmv() forwards to the shim.  There is no CPU arithmetic in this library: without a working
- * HIP device every call reports SPMV_HIP_E_NODEVICE and computes nothing.
+ * spmv() forwards to the shim.  Without a working HIP device every call reports SPMV_HIP_E_NODEVICE
+ * and computes nothing.  The one piece of host arithmetic (host_rows.c: VECTOR_NONE + Method_Serial /
+ * Method_Parallel, BASELINE config 1) runs only when option "host_rows" switches it on -- it is a
+ * configuration the caller asks for, never a fallback.
  */
 #include <stdio.h>
 #include <stdlib.h>
@@ -116,6 +118,11 @@ static int upload_reordered(spmv_Handle_t h, spmv_hip_state *st, int m, int n, c
     if (!rp || spmv_shim_copy_to_host(rp, RowPtr, sizeof(int) * ((size_t) m + 1))) goto out;
     nnz = rp[m];
     if (rp[0] != 0 || nnz < 0) goto out;
+    { /* RowPtr must be monotone within [0, nnz] before anything indexes ColIdx/Val with it */
+        int i;
+        for (i = 0; i < m; ++i)
+            if (rp[i] > rp[i + 1] || rp[i + 1] > nnz) goto out;
+    }
     ci = (int *) malloc(sizeof(int) * (size_t) (nnz ? nnz : 1));
     va = malloc(vs * (size_t) (nnz ? nnz : 1));
     perm = (int *) malloc(sizeof(int) * (size_t) m);
@@ -146,13 +153,13 @@ static int state_build(spmv_Handle_t h, spmv_hip_state *st, int m, int n, const 
     }
     index_free(h);
     rc = -1;
-    if (spmv_hip_get_option("reorder") == 1 && m == n && m > 1 && RowPtr && ColIdx && Val)
+    if (st->opts.v[SPMV_OPT_REORDER] == 1 && m == n && m > 1 && RowPtr && ColIdx && Val)
         rc = upload_reordered(h, st, m, n, RowPtr, ColIdx, Val); /* 0 = uploaded the permuted matrix */
     if (rc != 0) rc = spmv_shim_matrix_create(&st->dev, m, n, RowPtr, ColIdx, Val, (size_t) h->data_size);
     if (rc) { spmv_set_error(rc, "create/upload", spmv_shim_error_text()); return rc; }
     rc = spmv_shim_matrix_stats(st->dev, &stats);
     if (rc) { spmv_set_error(rc, "create/stats", spmv_shim_error_text()); return rc; }
-    spmv_plan_choose(st->requested, &stats, (size_t) h->data_size, &st->plan, &actual);
+    spmv_plan_choose(st->requested, &stats, (size_t) h->data_size, &st->opts, &st->plan, &actual, 1);
     rc = spmv_shim_build(st->dev, &st->plan);
     if (rc) {
         spmv_set_error(rc, "create/inspect", spmv_shim_error_text());
@@ -160,37 +167,15 @@ static int state_build(spmv_Handle_t h, spmv_hip_state *st, int m, int n, const 
         st->dev = NULL;
         return rc;
     }
-    /* automatic choice, second stage: the row statistics cannot see whether the COLUMNS have locality.  If
-     * the schedule just built could not stage a single x window on a matrix whose x is far larger than an
-     * L2, every gather crosses the fabric -- rebuild as nnz-split, whose executor for that case keeps y of
-     * a row block in LDS and walks the entries column slab by column slab (kernels/blocked.hpp). */
-    if (spmv_hip_get_option("auto_method") >= 1 && spmv_hip_get_option("cache_block") != 0 &&
-        (st->plan.sched == SPMV_SCHED_CSR_VECTOR || st->plan.sched == SPMV_SCHED_CSR5)) {
-        spmv_hip_info info;
-        if (spmv_shim_info(st->dev, &info) == SPMV_HIP_OK && info.x_groups > 0 && info.x_groups_staged == 0 &&
-            info.nnz >= (1ll << 21) && (long long) n * (long long) h->data_size >= (6ll << 20)) {
-            spmv_plan second;
-            SPMV_METHODS second_actual = Method_Balanced_Yid;
-            spmv_plan_choose_ex(Method_Balanced_Yid, &stats, (size_t) h->data_size, &second, &second_actual, 0);
-            if (spmv_shim_build(st->dev, &second) == SPMV_HIP_OK) {
-                st->plan = second;
-                actual = second_actual;
-            } else { /* keep the first choice */
-                rc = spmv_shim_build(st->dev, &st->plan);
-                if (rc) {
-                    spmv_set_error(rc, "create/inspect", spmv_shim_error_text());
-                    spmv_shim_matrix_destroy(st->dev);
-                    st->dev = NULL;
-                    return rc;
-                }
-            }
-        }
-    }
+    /* A schedule that could not stage a single x window on a matrix whose x is far larger than an L2 is
+     * switched to the row-block x column-slab executor INSIDE spmv_shim_build (option "cache_block", default
+     * automatic) -- whatever the method, so Method_Parallel / Method_CSR5SPMV requests on matrices without
+     * column locality no longer run the gather-bound tile kernels. */
     /* automatic choice, measured (auto_method = 2): the rules above pick from row statistics; which schedule is
      * fastest also depends on the columns and, by a few percent, on the device.  For matrices
      * large enough to be worth it, every candidate schedule is built and timed on scratch vectors and the
      * fastest is kept (the rule-based choice stays on a tie within 2 %). */
-    if (spmv_hip_get_option("auto_method") == 2 && stats.nnz >= (1ll << 20)) {
+    if (st->opts.v[SPMV_OPT_AUTO_METHOD] == 2 && stats.nnz >= (1ll << 20)) {
         static const SPMV_METHODS cand[] = {Method_Parallel, Method_CSR5SPMV, Method_SellCSigma, Method_Balanced_Yid, Method_Balanced};
         spmv_plan best_plan = st->plan;
         SPMV_METHODS best_method = actual;
@@ -201,7 +186,7 @@ static int state_build(spmv_Handle_t h, spmv_hip_state *st, int m, int n, const 
             spmv_plan p;
             SPMV_METHODS a = cand[k];
             double ms;
-            spmv_plan_choose_ex(cand[k], &stats, (size_t) h->data_size, &p, &a, 0);
+            spmv_plan_choose(cand[k], &stats, (size_t) h->data_size, &st->opts, &p, &a, 0);
             if (a == actual && p.sched == st->plan.sched) continue; /* the one already built and timed */
             if (a == best_method && p.sched == best_plan.sched) continue;
             if (spmv_shim_build(st->dev, &p) != SPMV_HIP_OK) { current_is_best = 0; continue; }
@@ -225,6 +210,9 @@ static int state_build(spmv_Handle_t h, spmv_hip_state *st, int m, int n, const 
     spmv_shim_set_async(st->dev, st->async);
     st->m = m;
     st->n = n;
+    st->val_sum_valid = 0;
+    if (st->opts.v[SPMV_OPT_CHECK_VALUES] == 1 && spmv_shim_checksum(st->dev, Val, &st->val_sum) == SPMV_HIP_OK)
+        st->val_sum_valid = 1;
     h->spmvMethod = actual;
     h->RowPtr = (BASIC_INT_TYPE *) RowPtr;
     h->ColIdx = (BASIC_INT_TYPE *) ColIdx;
@@ -256,7 +244,27 @@ void spmv_create_handle_all_in_one(spmv_Handle_t *Handle, BASIC_INT_TYPE m, BASI
     st = (spmv_hip_state *) calloc(1, sizeof *st);
     if (!st) { spmv_set_error(SPMV_HIP_E_ALLOC, "create", "malloc(state)"); return; }
     st->requested = Function;
+    spmv_options_snapshot(&st->opts);
     h->extraHandle = st;
+    /* BASELINE config 1 ("reference plumbing, no GPU"): VECTOR_NONE + Method_Serial / Method_Parallel run
+     * the plain-C row loop of host_rows.c on the caller's arrays, which are BORROWED like the reference
+     * does (common.c:157-159) -- but only when option "host_rows" asks for it. */
+    if (st->opts.v[SPMV_OPT_HOST_ROWS] == 1 && vectorizedWay == VECTOR_NONE &&
+        (Function == Method_Serial || Function == Method_Parallel)) {
+        if (m < 0 || n < 0 || (m > 0 && (!RowPtr || (RowPtr[m] > 0 && (!ColIdx || !Matrix_Val))))) {
+            spmv_set_error(SPMV_HIP_E_ARG, "create(host_rows)", "negative size or NULL CSR array");
+            free(st);
+            h->extraHandle = NULL;
+            return;
+        }
+        st->host_rows = 1;
+        st->m = m;
+        st->n = n;
+        h->RowPtr = RowPtr;
+        h->ColIdx = ColIdx;
+        h->Matrix_Val = Matrix_Val;
+        return;
+    }
     if (state_build(h, st, m, n, RowPtr, ColIdx, Matrix_Val) != SPMV_HIP_OK) {
         /* keep a valid handle whose spmv() is a reported no-op */
         free(st);
@@ -271,6 +279,15 @@ void spmv(const spmv_Handle_t handle, BASIC_INT_TYPE m, const BASIC_INT_TYPE *Ro
     int rc;
     if (handle == NULL) return; /* common.c:285 */
     st = (spmv_hip_state *) handle->extraHandle;
+    if (st && st->host_rows) { /* the arguments of THIS call are what is multiplied (common.c:286-298) */
+        if (m > 0 && (!RowPtr || !Y || (RowPtr[m] > 0 && (!ColIdx || !Matrix_Val || !X)))) {
+            spmv_set_error(SPMV_HIP_E_ARG, "spmv(host_rows)", "NULL argument");
+            return;
+        }
+        spmv_host_rows(m, RowPtr, ColIdx, Matrix_Val, (size_t) handle->data_size, X, Y,
+                       handle->spmvMethod == Method_Parallel ? (int) (handle->nthreads > 0 ? handle->nthreads : 1) : 1);
+        return;
+    }
     if (!st || !st->dev) {
         spmv_set_error(SPMV_HIP_E_NOSTATE, "spmv", "handle has no device state (create failed?)");
         return;
@@ -285,6 +302,16 @@ void spmv(const spmv_Handle_t handle, BASIC_INT_TYPE m, const BASIC_INT_TYPE *Ro
             st->warned_rebuild = 1;
         }
         if (state_build(handle, st, m, st->n, RowPtr, ColIdx, Matrix_Val) != SPMV_HIP_OK) return;
+    } else if (st->val_sum_valid) {
+        /* option "check_values": the reference re-reads Matrix_Val on every call, so a caller may change the
+         * values in place between calls (Newton steps, time stepping).  Detect that by checksum and refresh
+         * the resident copies (no re-inspection: the pattern is the same). */
+        unsigned long long sum = 0;
+        if (spmv_shim_checksum(st->dev, Matrix_Val, &sum) == SPMV_HIP_OK && sum != st->val_sum) {
+            rc = spmv_shim_update_values(st->dev, Matrix_Val);
+            if (rc) { spmv_set_error(rc, "spmv/refresh values", spmv_shim_error_text()); return; }
+            st->val_sum = sum;
+        }
     }
     rc = spmv_shim_run(st->dev, X, Y);
     if (rc) spmv_set_error(rc, "spmv", spmv_shim_error_text());
@@ -330,9 +357,56 @@ int spmv_hip_synchronize(spmv_Handle_t h)
 
 int spmv_hip_get_info(spmv_Handle_t h, spmv_hip_info *out)
 {
-    spmv_hip_state *st = state_of(h, "get_info");
+    spmv_hip_state *st = h ? (spmv_hip_state *) h->extraHandle : NULL;
+    if (st && st->host_rows && out) { /* no device state: describe the host loop */
+        const long long s = h->data_size == sizeof(double) ? 8 : 4;
+        memset(out, 0, sizeof *out);
+        out->device = -1;
+        out->schedule = SPMV_SCHED_HOST_ROWS;
+        out->m = st->m;
+        out->n = st->n;
+        out->nnz = out->stored_nnz = st->m > 0 ? h->RowPtr[st->m] : 0;
+        out->mean_row_len = st->m > 0 ? (double) out->nnz / st->m : 0.0;
+        out->alg_bytes = 4ll * ((long long) st->m + 1) + out->nnz * (4 + s) + s * st->n + s * st->m;
+        out->stream_bytes = out->alg_bytes;
+        out->schedule_name = "host-rows";
+        out->kernel_name = "spmv_host_rows";
+        return SPMV_HIP_OK;
+    }
+    st = state_of(h, "get_info");
     if (!st || !out) return SPMV_HIP_E_NOSTATE;
     return spmv_shim_info(st->dev, out);
+}
+
+/* New values behind the pattern the handle was created with: Val (host or device, nnz entries in CSR order)
+ * is copied to HBM and re-permuted into the schedule's private layouts (SELL slabs, CSR5 tiles, long-row
+ * sub-matrix, row-block x column-slab streams) by device kernels; RowPtr / ColIdx, descriptors, x windows
+ * and the autotune result are kept.  Cost: one pass over the values (config 2: ~1 ms against ~30 ms of
+ * clear + create).  handle->Matrix_Val is set to Val, so later spmv() calls may pass either pointer. */
+int spmv_hip_update_values(spmv_Handle_t h, const void *Val)
+{
+    spmv_hip_state *st = h ? (spmv_hip_state *) h->extraHandle : NULL;
+    int rc;
+    if (st && st->host_rows) { h->Matrix_Val = (void *) Val; return SPMV_HIP_OK; } /* borrowed arrays: nothing resident */
+    st = state_of(h, "update_values");
+    if (!st) return SPMV_HIP_E_NOSTATE;
+    if (!Val) { spmv_set_error(SPMV_HIP_E_ARG, "update_values", "Val is NULL"); return SPMV_HIP_E_ARG; }
+    if (h->Level_3_opt_used) { /* the resident matrix is P A P^T: its value order is not the caller's */
+        spmv_set_error(SPMV_HIP_E_ARG, "update_values", "not available on a reordered handle (option \"reorder\")");
+        return SPMV_HIP_E_ARG;
+    }
+    rc = spmv_shim_update_values(st->dev, Val);
+    if (rc) { spmv_set_error(rc, "update_values", spmv_shim_error_text()); return rc; }
+    h->Matrix_Val = (void *) Val;
+    if (st->opts.v[SPMV_OPT_CHECK_VALUES] == 1)
+        st->val_sum_valid = spmv_shim_checksum(st->dev, Val, &st->val_sum) == SPMV_HIP_OK;
+    return SPMV_HIP_OK;
+}
+
+long spmv_hip_get_handle_option(spmv_Handle_t h, const char *key)
+{
+    spmv_hip_state *st = h ? (spmv_hip_state *) h->extraHandle : NULL;
+    return st ? spmv_options_get(&st->opts, key) : -1;
 }
 
 double spmv_hip_time_launches(spmv_Handle_t h, const void *x, void *y, int warmup, int iters, float *ms_out)

@@ -18,6 +18,7 @@
  *                           fp32, common.c:174-181; this build has a native fp32 CSR5)
  */
 #include <ctype.h>
+#include <pthread.h>
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
@@ -25,71 +26,127 @@
 #include "spmv_hip.h"
 #include "spmv_internal.h"
 
-/* ---------------------------------------------------------------- options */
+/* ---------------------------------------------------------------- options
+ * Three layers, resolved ONCE per handle at create (spmv_options_snapshot) and stored in the handle:
+ *   process-wide defaults   spmv_hip_set_option / env SPMV_HIP_<KEY>      (mutex-protected)
+ *   per-thread overrides    spmv_hip_set_thread_option                    (thread-local: two threads
+ *                           creating handles with different tunings do not race)
+ *   the handle's snapshot   spmv_hip_get_handle_option; re-used when spmv() is handed another matrix
+ * The reference has no options at all: its constants are compiled in (common.c:139-140, csr5_spmv.cpp:30). */
 typedef struct { const char *key; long value; long lo, hi; int pow2; int env_read; } opt_t;
-static opt_t g_opts[] = {
-    {"lanes_per_row", 0, 0, 64, 1, 0},     /* CSR-vector: 0 = from the row-length histogram */
-    {"sell_c", 64, 64, 64, 1, 0},          /* one wavefront per chunk: C is the wave width */
-    {"sell_sigma", 1024, 64, 1 << 20, 1, 0},
-    {"sell_lds_x", 1, 0, 1, 0, 0},         /* SELL: stage the x windows of the sigma windows in LDS */
-    {"sell_long_thr", 0, 0, 1 << 20, 0, 0},/* SELL: rows longer than this leave the slabs for the long-row path (0 = max(64, 8 x mean)) */
-    {"csr5_sigma", 0, 0, 16, 0, 0},        /* CSR5 / nnz-split tiles of 64 x sigma entries: 0 = auto, else 4, 8, 16 */
-    {"rowblock_nnz", 0, 0, 1 << 20, 0, 0}, /* Balanced: equal-nnz share of one row block, 0 = 256 mean-length rows */
-    {"cache_block", 1, 0, 2, 0, 0},        /* Balanced family: row-block x column-slab executor when no x window can
-                                            * be staged: 1 = automatic, 2 = always, 0 = never */
-    {"slab_kib", 0, 0, 1 << 16, 1, 0},     /* ... KiB of x per column slab (0 = as narrow as the cell table allows) */
-    {"block_rows", 0, 0, 32768, 1, 0},     /* ... rows per block (0 = 64 KiB of y) */
-    {"variant", 0, 0, 1 << 20, 0, 0},      /* kernel-form selector of the A/B harness and the variant tests, 0 = default */
-    {"auto_method", 0, 0, 2, 0, 0},        /* 1: create() picks the schedule from the matrix by rules (two stages, spmv_api.c);
-                                            * 2: ... by building the candidate schedules and timing them */
-    {"autotune", 1, 0, 1, 0, 0},           /* 1: create() times the CSR-vector kernel forms on matrices >= 2^24 nnz */
-    {"reorder", 0, 0, 1, 0, 0},            /* 1: square matrices are RCM-reordered at create; handle->index = permutation */
+static opt_t g_opts[SPMV_N_OPTS] = {
+    [SPMV_OPT_LANES_PER_ROW] = {"lanes_per_row", 0, 0, 64, 1, 0},     /* CSR-vector: 0 = from the row-length histogram */
+    [SPMV_OPT_SELL_C] = {"sell_c", 64, 64, 64, 1, 0},                 /* one wavefront per chunk: C is the wave width */
+    [SPMV_OPT_SELL_SIGMA] = {"sell_sigma", 1024, 64, 1 << 20, 1, 0},
+    [SPMV_OPT_SELL_LDS_X] = {"sell_lds_x", 1, 0, 1, 0, 0},            /* SELL: stage the x windows of the sigma windows in LDS */
+    [SPMV_OPT_SELL_LONG_THR] = {"sell_long_thr", 0, 0, 1 << 20, 0, 0},/* SELL: rows longer than this leave the slabs for the long-row path (0 = max(64, 8 x mean)) */
+    [SPMV_OPT_CSR5_SIGMA] = {"csr5_sigma", 0, 0, 16, 0, 0},           /* CSR5 / nnz-split tiles of 64 x sigma entries: 0 = auto, else 4, 8, 16 */
+    [SPMV_OPT_ROWBLOCK_NNZ] = {"rowblock_nnz", 0, 0, 1 << 20, 0, 0},  /* Balanced: equal-nnz share of one row block, 0 = 256 mean-length rows */
+    [SPMV_OPT_CACHE_BLOCK] = {"cache_block", 1, 0, 2, 0, 0},          /* row-block x column-slab executor when no x window can be staged:
+                                                                       * 1 = automatic (every schedule but CSR-scalar and SELL), 2 = always, 0 = never */
+    [SPMV_OPT_SLAB_KIB] = {"slab_kib", 0, 0, 1 << 16, 1, 0},          /* ... KiB of x per column slab (0 = as narrow as the cell table allows) */
+    [SPMV_OPT_BLOCK_ROWS] = {"block_rows", 0, 0, 32768, 1, 0},        /* ... rows per block (0 = 64 KiB of y) */
+    [SPMV_OPT_VARIANT] = {"variant", 0, 0, 1 << 20, 0, 0},            /* kernel-form selector of the A/B harness and the variant tests, 0 = default */
+    [SPMV_OPT_AUTO_METHOD] = {"auto_method", 0, 0, 2, 0, 0},          /* 1: create() picks the schedule from the matrix by rules (two stages, spmv_api.c);
+                                                                       * 2: ... by building the candidate schedules and timing them */
+    [SPMV_OPT_AUTOTUNE] = {"autotune", 1, 0, 1, 0, 0},                /* 1: create() times the CSR-vector kernel forms on matrices >= 2^24 nnz */
+    [SPMV_OPT_REORDER] = {"reorder", 0, 0, 1, 0, 0},                  /* 1: square matrices are RCM-reordered at create; handle->index = permutation */
+    [SPMV_OPT_HOST_ROWS] = {"host_rows", 0, 0, 1, 0, 0},              /* 1: VECTOR_NONE + Method_Serial / Method_Parallel run the plain-C row loop on
+                                                                       * the host (host_rows.c; BASELINE config 1).  Never chosen by itself. */
+    [SPMV_OPT_CHECK_VALUES] = {"check_values", 0, 0, 1, 0, 0},        /* 1: spmv() checksums Matrix_Val on every call and refreshes the resident
+                                                                       * copy when it changed behind an unchanged pointer (common.c:286-298 semantics) */
+    [SPMV_OPT_GPUS] = {"gpus", 0, 0, 64, 0, 0},                       /* > 0: row blocks over min(gpus, visible devices) GPUs in this one process (multi.hpp) */
+    [SPMV_OPT_X_EXCHANGE] = {"x_exchange", 0, 0, 2, 0, 0},            /* multi-GPU: 0 = allgather of the x slices, 1 = halo (referenced entries only), 2 = broadcast from device 0 */
 };
-#define N_OPTS ((int) (sizeof g_opts / sizeof g_opts[0]))
+
+static pthread_mutex_t g_opt_lock = PTHREAD_MUTEX_INITIALIZER;
+static _Thread_local long t_over[SPMV_N_OPTS];
+static _Thread_local unsigned char t_over_set[SPMV_N_OPTS];
 
 static int is_pow2_or_zero(long v) { return v == 0 || (v & (v - 1)) == 0; }
+static int opt_legal(const opt_t *o, long v) { return v >= o->lo && v <= o->hi && (!o->pow2 || is_pow2_or_zero(v)); }
 
-static opt_t *opt_find(const char *key)
+/* index of `key`, -1 if unknown; SPMV_HIP_<KEY> presets the process-wide value once (call under the lock) */
+static int opt_find(const char *key)
 {
     int i;
-    if (!key) return NULL;
-    for (i = 0; i < N_OPTS; ++i) {
-        if (strcmp(g_opts[i].key, key) == 0) {
-            opt_t *o = &g_opts[i];
-            if (!o->env_read) { /* SPMV_HIP_<KEY> presets the option once */
-                char name[64] = "SPMV_HIP_";
-                size_t k, off = strlen(name);
-                const char *e;
-                for (k = 0; key[k] && off + k + 1 < sizeof name; ++k) name[off + k] = (char) toupper((unsigned char) key[k]);
-                name[off + k] = 0;
-                e = getenv(name);
-                if (e && *e) {
-                    long v = strtol(e, NULL, 10);
-                    if (v >= o->lo && v <= o->hi && (!o->pow2 || is_pow2_or_zero(v))) o->value = v;
-                }
-                o->env_read = 1;
+    if (!key) return -1;
+    for (i = 0; i < SPMV_N_OPTS; ++i) {
+        opt_t *o = &g_opts[i];
+        if (strcmp(o->key, key) != 0) continue;
+        if (!o->env_read) {
+            char name[64] = "SPMV_HIP_";
+            size_t k, off = strlen(name);
+            const char *e;
+            for (k = 0; key[k] && off + k + 1 < sizeof name; ++k) name[off + k] = (char) toupper((unsigned char) key[k]);
+            name[off + k] = 0;
+            e = getenv(name);
+            if (e && *e) {
+                long v = strtol(e, NULL, 10);
+                if (opt_legal(o, v)) o->value = v;
             }
-            return o;
+            o->env_read = 1;
         }
+        return i;
     }
-    return NULL;
+    return -1;
 }
 
 int spmv_hip_set_option(const char *key, long value)
 {
-    opt_t *o = opt_find(key);
-    if (!o || value < o->lo || value > o->hi || (o->pow2 && !is_pow2_or_zero(value))) {
-        spmv_set_error(SPMV_HIP_E_ARG, "set_option", key ? key : "(null)");
-        return SPMV_HIP_E_ARG;
-    }
-    o->value = value;
-    return SPMV_HIP_OK;
+    int i, rc = SPMV_HIP_OK;
+    pthread_mutex_lock(&g_opt_lock);
+    i = opt_find(key);
+    if (i < 0 || !opt_legal(&g_opts[i], value)) rc = SPMV_HIP_E_ARG;
+    else g_opts[i].value = value;
+    pthread_mutex_unlock(&g_opt_lock);
+    if (rc) spmv_set_error(rc, "set_option", key ? key : "(null)");
+    return rc;
 }
 
 long spmv_hip_get_option(const char *key)
 {
-    opt_t *o = opt_find(key);
-    return o ? o->value : -1;
+    long v = -1;
+    int i;
+    pthread_mutex_lock(&g_opt_lock);
+    i = opt_find(key);
+    if (i >= 0) v = t_over_set[i] ? t_over[i] : g_opts[i].value;
+    pthread_mutex_unlock(&g_opt_lock);
+    return v;
+}
+
+int spmv_hip_set_thread_option(const char *key, long value)
+{
+    int i, rc = SPMV_HIP_OK;
+    pthread_mutex_lock(&g_opt_lock);
+    i = opt_find(key);
+    if (i < 0 || !opt_legal(&g_opts[i], value)) rc = SPMV_HIP_E_ARG;
+    pthread_mutex_unlock(&g_opt_lock);
+    if (rc) { spmv_set_error(rc, "set_thread_option", key ? key : "(null)"); return rc; }
+    t_over[i] = value;
+    t_over_set[i] = 1;
+    return SPMV_HIP_OK;
+}
+
+void spmv_hip_clear_thread_options(void) { memset(t_over_set, 0, sizeof t_over_set); }
+
+void spmv_options_snapshot(spmv_options *out)
+{
+    int i;
+    pthread_mutex_lock(&g_opt_lock);
+    for (i = 0; i < SPMV_N_OPTS; ++i) {
+        (void) opt_find(g_opts[i].key); /* env preset */
+        out->v[i] = t_over_set[i] ? t_over[i] : g_opts[i].value;
+    }
+    pthread_mutex_unlock(&g_opt_lock);
+}
+
+long spmv_options_get(const spmv_options *o, const char *key)
+{
+    int i;
+    for (i = 0; i < SPMV_N_OPTS; ++i)
+        if (key && strcmp(g_opts[i].key, key) == 0) return o->v[i];
+    return -1;
 }
 
 /* ---------------------------------------------------------------- policy */
@@ -164,28 +221,22 @@ static void choose_vector_shape(const spmv_stats *st, int *lanes_out, int *thr_o
     *thr_out = best_thr;
 }
 
-void spmv_plan_choose(SPMV_METHODS requested, const spmv_stats *st, size_t value_size,
-                      spmv_plan *plan, SPMV_METHODS *actual)
+void spmv_plan_choose(SPMV_METHODS requested, const spmv_stats *st, size_t value_size, const spmv_options *opt,
+                      spmv_plan *plan, SPMV_METHODS *actual, int allow_auto)
 {
-    spmv_plan_choose_ex(requested, st, value_size, plan, actual, 1);
-}
-
-void spmv_plan_choose_ex(SPMV_METHODS requested, const spmv_stats *st, size_t value_size,
-                         spmv_plan *plan, SPMV_METHODS *actual, int allow_auto)
-{
-    long lanes = spmv_hip_get_option("lanes_per_row");
-    long rb = spmv_hip_get_option("rowblock_nnz");
+    long lanes = opt->v[SPMV_OPT_LANES_PER_ROW];
+    long rb = opt->v[SPMV_OPT_ROWBLOCK_NNZ];
     memset(plan, 0, sizeof *plan);
-    plan->variant = (int) spmv_hip_get_option("variant");
-    plan->autotune = (int) spmv_hip_get_option("autotune");
-    plan->sell_c = (int) spmv_hip_get_option("sell_c");
-    plan->sell_sigma = (int) spmv_hip_get_option("sell_sigma");
-    plan->sell_lds_x = (int) spmv_hip_get_option("sell_lds_x");
-    plan->sell_long_thr = (int) spmv_hip_get_option("sell_long_thr");
-    plan->cache_block = (int) spmv_hip_get_option("cache_block");
-    plan->slab_kib = (int) spmv_hip_get_option("slab_kib");
-    plan->block_rows = (int) spmv_hip_get_option("block_rows");
-    plan->csr5_sigma = (int) spmv_hip_get_option("csr5_sigma");
+    plan->variant = (int) opt->v[SPMV_OPT_VARIANT];
+    plan->autotune = (int) opt->v[SPMV_OPT_AUTOTUNE];
+    plan->sell_c = (int) opt->v[SPMV_OPT_SELL_C];
+    plan->sell_sigma = (int) opt->v[SPMV_OPT_SELL_SIGMA];
+    plan->sell_lds_x = (int) opt->v[SPMV_OPT_SELL_LDS_X];
+    plan->sell_long_thr = (int) opt->v[SPMV_OPT_SELL_LONG_THR];
+    plan->cache_block = (int) opt->v[SPMV_OPT_CACHE_BLOCK];
+    plan->slab_kib = (int) opt->v[SPMV_OPT_SLAB_KIB];
+    plan->block_rows = (int) opt->v[SPMV_OPT_BLOCK_ROWS];
+    plan->csr5_sigma = (int) opt->v[SPMV_OPT_CSR5_SIGMA];
     /* one workgroup's equal-nnz share (Method_Balanced): the non-zeros of 256 mean-length rows, so that a
      * block is about one 256-row slab of the CSR-vector wave program (8192 for config 2; a share that is
      * not a multiple of the slab leaves three of the four waves idle in the block's last slab: on the
@@ -212,7 +263,7 @@ void spmv_plan_choose_ex(SPMV_METHODS requested, const spmv_stats *st, size_t va
      * (measured: CSR-vector leads on regular shapes that fill its chunks, CSR5 elsewhere -- DESIGN.md
      * section 3).  spmv_api.c adds a second stage for matrices without column locality.  The handle reports
      * the method actually used. */
-    if (allow_auto && spmv_hip_get_option("auto_method") >= 1 && st->m > 0) {
+    if (allow_auto && opt->v[SPMV_OPT_AUTO_METHOD] >= 1 && st->m > 0) {
         const int regular = st->mean_row_len >= 4.0 && (double) st->max_row_len <= 4.0 * st->mean_row_len &&
                             (double) st->empty_rows <= 0.01 * (double) st->m;
         /* chunk fill of CSR-vector with the L just chosen: nnz / sum over rows of ceil(len / 4L) * 4L, rows

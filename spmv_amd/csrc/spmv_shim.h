@@ -23,7 +23,8 @@ enum spmv_sched {
     SPMV_SCHED_NNZ_SPLIT = 3,
     SPMV_SCHED_SELL = 4,
     SPMV_SCHED_CSR5 = 5,
-    SPMV_SCHED_COUNT
+    SPMV_SCHED_COUNT,
+    SPMV_SCHED_HOST_ROWS = 100 /* no device schedule: the plain-C row loop (host_rows.c), reported by spmv_hip_get_info */
 };
 
 #define SPMV_LEN_BUCKETS 11 /* <=4, 8, 16, ..., 2048, longer */
@@ -74,6 +75,13 @@ double spmv_shim_time_self(spmv_dev *d, int iters);
 void spmv_shim_matrix_destroy(spmv_dev *d);
 /* memcpy that accepts a host or a device source (the reordering inspector works on host copies) */
 int spmv_shim_copy_to_host(void *dst, const void *src, size_t bytes);
+/* 1 if a kernel can use the pointer as is (device or managed memory), else 0 (also without any device) */
+int spmv_shim_is_device_ptr(const void *p);
+/* New values (host or device, nnz entries in CSR order) behind the same pattern: copied to HBM and
+ * re-permuted into the schedule's private value layouts; nothing else is rebuilt. */
+int spmv_shim_update_values(spmv_dev *d, const void *val);
+/* Order-independent 64-bit checksum (sum of the 32-bit words) of nnz values at `val` (host or device). */
+int spmv_shim_checksum(spmv_dev *d, const void *val, unsigned long long *out);
 
 #if defined(__cplusplus)
 }

@@ -23,7 +23,6 @@
 #include "kernels/common.hpp"
 #include "kernels/csr_rows.hpp"
 #include "kernels/csr_vector4.hpp"
-#include "kernels/nnz_split.hpp"
 #include "kernels/rowblock.hpp"
 #include "kernels/sell.hpp"
 #include "kernels/csr5.hpp"
@@ -145,6 +144,7 @@ extern "C" void spmv_shim_matrix_destroy(spmv_dev *d)
     if (d->val) (void) hipFree(d->val);
     if (d->x_stage) (void) hipFree(d->x_stage);
     if (d->y_stage) (void) hipFree(d->y_stage);
+    if (d->scratch8) (void) hipFree(d->scratch8);
     delete d;
 }
 
@@ -157,8 +157,10 @@ extern "C" int spmv_shim_build(spmv_dev *d, const spmv_plan *plan)
     free_schedule(d);
     d->plan = *plan;
     const auto t0 = std::chrono::steady_clock::now();
-    int rc = SPMV_HIP_OK;
+    int rc = SPMV_HIP_OK, staged = -1; // staged: tile groups with x windows in LDS (-1: schedule without windows)
     const bool f64 = d->vsize == sizeof(double);
+    DeviceGuard guard(d->device);
+    if (!guard.ok) return fail(SPMV_HIP_E_RUNTIME, "hipSetDevice(%d) failed", d->device);
     switch (plan->sched) {
     case SPMV_SCHED_CSR_SCALAR: break;
     case SPMV_SCHED_CSR_VECTOR: {
@@ -169,44 +171,135 @@ extern "C" int spmv_shim_build(spmv_dev *d, const spmv_plan *plan)
         const int thr = plan->long_thr > 0 ? plan->long_thr : (L * 64 > 256 ? L * 64 : 256);
         rc = f64 ? build_long_rows<double>(d, thr) : build_long_rows<float>(d, thr);
         if (!rc) rc = f64 ? build_vector_tiles<double>(d) : build_vector_tiles<float>(d);
-        if (!rc && plan->autotune) rc = f64 ? autotune_vector<double>(d) : autotune_vector<float>(d);
+        staged = d->vt_staged;
+        if (!rc && plan->autotune && !wants_blocked(d, staged)) rc = f64 ? autotune_vector<double>(d) : autotune_vector<float>(d);
         break;
     }
     case SPMV_SCHED_NNZ_SPLIT:
-        if (plan->variant == 8) { // A/B: the first-round 256-nnz tiles with LDS row marks (kernels/nnz_split.hpp)
-            rc = f64 ? build_nnz_split<double>(d) : build_nnz_split<float>(d);
-            break;
-        }
         // equal-nnz tiles over the matrix's own arrays: CSR5 descriptors + carry fix-up, natural layout
         rc = f64 ? build_csr5<double>(d, d->ns, d->m, d->nnz, d->rowptr, d->colidx, (const double *) d->val, d->stats.empty_rows, d->stats.mean_row_len, nullptr, true)
                  : build_csr5<float>(d, d->ns, d->m, d->nnz, d->rowptr, d->colidx, (const float *) d->val, d->stats.empty_rows, d->stats.mean_row_len, nullptr, true);
-        // columns without locality (no tile group's x windows fit LDS) and x far larger than an L2: gathers are
-        // fabric-bound -> row blocks x column slabs (kernels/blocked.hpp)
-        if (!rc && (plan->cache_block == 2 ||
-                    (plan->cache_block == 1 && d->ns.staged == 0 && d->nnz >= (1ll << 21) && (long long) d->n * (long long) d->vsize >= (6ll << 20))))
-            rc = f64 ? build_blocked<double>(d) : build_blocked<float>(d);
+        staged = d->ns.staged;
         break;
     case SPMV_SCHED_ROWBLOCK:
         if (plan->rowblock_nnz < 64) return fail(SPMV_HIP_E_ARG, "rowblock_nnz must be >= 64");
         if (d->stats.max_row_len > plan->rowblock_nnz) return fail(SPMV_HIP_E_ARG, "row-block schedule needs max_row_len <= rowblock_nnz");
         rc = build_rowblock(d);
         if (!rc) rc = f64 ? build_rowblock_tiles<double>(d) : build_rowblock_tiles<float>(d);
-        // same fall-back as nnz-split for columns without locality (Method_Balanced and Method_Balanced2 are one family)
-        if (!rc && (plan->cache_block == 2 ||
-                    (plan->cache_block == 1 && d->vt_staged == 0 && d->nnz >= (1ll << 21) && (long long) d->n * (long long) d->vsize >= (6ll << 20))))
-            rc = f64 ? build_blocked<double>(d) : build_blocked<float>(d);
+        staged = d->vt_staged;
         break;
     case SPMV_SCHED_SELL: rc = f64 ? build_sell<double>(d) : build_sell<float>(d); break;
     case SPMV_SCHED_CSR5:
         rc = f64 ? build_csr5<double>(d, d->c5, d->m, d->nnz, d->rowptr, d->colidx, (const double *) d->val, d->stats.empty_rows, d->stats.mean_row_len, nullptr)
                  : build_csr5<float>(d, d->c5, d->m, d->nnz, d->rowptr, d->colidx, (const float *) d->val, d->stats.empty_rows, d->stats.mean_row_len, nullptr);
+        staged = d->c5.staged;
         break;
     }
+    // Columns without locality (no tile group's x windows fit LDS) and x far larger than an L2: every gather of
+    // the tile executors crosses the fabric -> row blocks x column slabs (kernels/blocked.hpp) take over the
+    // multiply, whatever the method (SELL keeps its format: it is what the caller asked to see; CSR-scalar is
+    // the debug kernel).  The tile schedule's products are released once the blocked streams exist.
+    if (!rc && staged >= 0 && wants_blocked(d, staged)) {
+        const size_t keep_from = d->sched_allocs.size();
+        d->x_groups_seen = plan->sched == SPMV_SCHED_NNZ_SPLIT ? d->ns.groups : (plan->sched == SPMV_SCHED_CSR5 ? d->c5.groups : d->vt_tiles);
+        rc = f64 ? build_blocked<double>(d) : build_blocked<float>(d);
+        if (!rc && d->blk_on) drop_tile_schedule(d, keep_from);
+    }
+    if (!rc) rc = account_stream_bytes(d);
     if (rc) { free_schedule(d); return rc; }
     d->inspect_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
     d->built = true;
     return SPMV_HIP_OK;
 }
+
+// ------------------------------------------------------------------------------------ values changed in place
+template <typename T>
+static int refresh_csr5_values(spmv_dev *d, Csr5Plan &P, const T *src)
+{
+    if (P.nnz == 0 || P.natural) return SPMV_HIP_OK; // natural layout reads the matrix's own value array
+    const int grid = grid_for(P.tiles, kBlock / kWave, INT_MAX);
+    switch (P.sigma) {
+    case 4: csr5_transpose_kernel<T, 4><<<grid, kBlock, 0, d->stream>>>((int) P.nnz, P.tiles, nullptr, src, nullptr, (T *) P.val); break;
+    case 8: csr5_transpose_kernel<T, 8><<<grid, kBlock, 0, d->stream>>>((int) P.nnz, P.tiles, nullptr, src, nullptr, (T *) P.val); break;
+    default: csr5_transpose_kernel<T, 16><<<grid, kBlock, 0, d->stream>>>((int) P.nnz, P.tiles, nullptr, src, nullptr, (T *) P.val); break;
+    }
+    HIP_TRY(hipGetLastError());
+    return SPMV_HIP_OK;
+}
+
+template <typename T>
+static int update_values(spmv_dev *d, const void *val)
+{
+    if (d->nnz == 0) return SPMV_HIP_OK;
+    HIP_TRY(hipMemcpyAsync(d->val, val, sizeof(T) * (size_t) d->nnz, hipMemcpyDefault, d->stream));
+    const T *v = (const T *) d->val;
+    int rc = SPMV_HIP_OK;
+    if (d->blk_on) { // the blocked streams are the only copy the executor reads
+        rc = blocked_fill<T>(d, d->blk_wshift, true);
+    } else {
+        if (d->nlong > 0 && d->lsub_val) { // long-row sub-matrix, then its CSR5 tiles
+            long_rows_gather_kernel<T><<<d->nlong, kBlock, 0, d->stream>>>(d->long_rows, d->rowptr, nullptr, v, d->lsub_rowptr, nullptr, (T *) d->lsub_val);
+            HIP_TRY(hipGetLastError());
+            rc = refresh_csr5_values<T>(d, d->c5_long, (const T *) d->lsub_val);
+        }
+        if (!rc && d->plan.sched == SPMV_SCHED_SELL && d->nchunks > 0) {
+            sell_fill_kernel<T><<<grid_for(d->nchunks, kBlock / kWave, INT_MAX), kBlock, 0, d->stream>>>(
+                d->nchunks, d->rowptr, nullptr, v, d->perm, d->chunk_ptr, nullptr, (T *) d->sval);
+            HIP_TRY(hipGetLastError());
+        }
+        if (!rc && d->plan.sched == SPMV_SCHED_CSR5) rc = refresh_csr5_values<T>(d, d->c5, v);
+        // CSR-scalar, CSR-vector, Balanced and nnz-split read d->val itself
+    }
+    if (rc) return rc;
+    HIP_TRY(hipStreamSynchronize(d->stream)); // the caller may overwrite `val` again at once
+    return SPMV_HIP_OK;
+}
+
+extern "C" int spmv_shim_update_values(spmv_dev *d, const void *val)
+{
+    if (!d || !d->built) return fail(SPMV_HIP_E_NOSTATE, "update_values: schedule not built");
+    if (!val && d->nnz > 0) return fail(SPMV_HIP_E_ARG, "update_values: NULL");
+    DeviceGuard guard(d->device);
+    if (!guard.ok) return fail(SPMV_HIP_E_RUNTIME, "hipSetDevice(%d) failed", d->device);
+    return d->vsize == sizeof(double) ? update_values<double>(d, val) : update_values<float>(d, val);
+}
+
+__global__ __launch_bounds__(kBlock) void checksum_kernel(long long words, const unsigned *__restrict__ w, unsigned long long *__restrict__ out)
+{
+    unsigned long long s = 0;
+    const long long stride = (long long) gridDim.x * kBlock;
+    for (long long i = (long long) blockIdx.x * kBlock + threadIdx.x; i < words; i += stride) s += w[i];
+#pragma unroll
+    for (int o = kWave / 2; o > 0; o >>= 1) s += __shfl_xor(s, o, kWave);
+    if ((threadIdx.x & (kWave - 1)) == 0 && s) atomicAdd(out, s);
+}
+
+extern "C" int spmv_shim_checksum(spmv_dev *d, const void *val, unsigned long long *out)
+{
+    if (!d || !out) return fail(SPMV_HIP_E_ARG, "checksum: NULL");
+    *out = 0;
+    const long long words = d->nnz * (long long) (d->vsize / 4);
+    if (words == 0) return SPMV_HIP_OK;
+    if (!val) return fail(SPMV_HIP_E_ARG, "checksum: NULL values");
+    if (!is_device_ptr(val)) { // host array: summed where it lives
+        const unsigned *w = (const unsigned *) val;
+        unsigned long long s = 0;
+        for (long long i = 0; i < words; ++i) s += w[i];
+        *out = s;
+        return SPMV_HIP_OK;
+    }
+    DeviceGuard guard(d->device);
+    if (!guard.ok) return fail(SPMV_HIP_E_RUNTIME, "hipSetDevice(%d) failed", d->device);
+    if (!d->scratch8) ALLOC_TRY(d, &d->scratch8, 8, false);
+    HIP_TRY(hipMemsetAsync(d->scratch8, 0, 8, d->stream));
+    checksum_kernel<<<grid_for(words, kBlock * 8, d->cus * 8), kBlock, 0, d->stream>>>(words, (const unsigned *) val, (unsigned long long *) d->scratch8);
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipMemcpyAsync(out, d->scratch8, 8, hipMemcpyDeviceToHost, d->stream));
+    HIP_TRY(hipStreamSynchronize(d->stream));
+    return SPMV_HIP_OK;
+}
+
+extern "C" int spmv_shim_is_device_ptr(const void *p) { return is_device_ptr(p) ? 1 : 0; }
 
 #include "shim/launch.hpp"
 
@@ -214,8 +307,8 @@ extern "C" int spmv_shim_run(spmv_dev *d, const void *x, void *y)
 {
     if (!d || !d->built) return fail(SPMV_HIP_E_NOSTATE, "run: schedule not built");
     if ((d->n > 0 && d->nnz > 0 && !x) || (d->m > 0 && !y)) return fail(SPMV_HIP_E_ARG, "run: X or Y is NULL");
-    int cur = -1;
-    if (hipGetDevice(&cur) == hipSuccess && cur != d->device) HIP_TRY(hipSetDevice(d->device));
+    DeviceGuard guard(d->device); // the caller's current device is restored on return
+    if (!guard.ok) return fail(SPMV_HIP_E_RUNTIME, "hipSetDevice(%d) failed", d->device);
     const bool xdev = is_device_ptr(x), ydev = is_device_ptr(y);
     const void *xd = x;
     void *yd = y;
@@ -318,7 +411,7 @@ extern "C" double spmv_shim_time_self(spmv_dev *d, int iters)
 // ------------------------------------------------------------------------------------ info
 static const char *kSchedNames[] = {"csr-scalar", "csr-vector", "row-block", "nnz-split", "sell-c-sigma", "csr5"};
 static const char *kKernelNames[] = {"csr_scalar_kernel", "csr_vector_pipe_kernel", "csr_vector_rows_kernel",
-                                     "nnz_split_kernel", "sell_kernel", "csr5_kernel"};
+                                     "nat_kernel", "sell_kernel", "csr5_kernel"};
 
 extern "C" int spmv_shim_info(const spmv_dev *d, spmv_hip_info *o)
 {
@@ -329,7 +422,7 @@ extern "C" int spmv_shim_info(const spmv_dev *d, spmv_hip_info *o)
     o->lanes_per_row = d->plan.sched == SPMV_SCHED_CSR_VECTOR ? d->plan.lanes_per_row : 0;
     o->sell_c = d->plan.sched == SPMV_SCHED_SELL ? kSellC : 0;
     o->sell_sigma = d->plan.sched == SPMV_SCHED_SELL ? d->plan.sell_sigma : 0;
-    o->tile_nnz = d->plan.sched == SPMV_SCHED_NNZ_SPLIT ? (d->plan.variant == 8 ? (d->vsize == 8 ? SplitCfg<double>::Tile : SplitCfg<float>::Tile) : kWave * d->ns.sigma) : (d->plan.sched == SPMV_SCHED_ROWBLOCK ? d->rb_stride : (d->plan.sched == SPMV_SCHED_CSR5 ? kWave * d->c5.sigma : 0));
+    o->tile_nnz = d->plan.sched == SPMV_SCHED_NNZ_SPLIT ? kWave * d->ns.sigma : (d->plan.sched == SPMV_SCHED_ROWBLOCK ? d->rb_stride : (d->plan.sched == SPMV_SCHED_CSR5 ? kWave * d->c5.sigma : 0));
     o->m = d->m;
     o->n = d->n;
     o->nnz = d->nnz;
@@ -351,17 +444,20 @@ extern "C" int spmv_shim_info(const spmv_dev *d, spmv_hip_info *o)
         o->kernel_name = "csr_vector_tile_kernel";
     if (d->plan.sched == SPMV_SCHED_CSR_VECTOR && d->vt_wide) o->kernel_name = "csr_vector_rows_kernel";
     o->cache_blocked = d->blk_on ? 1 : 0;
-    switch (d->plan.sched) {
+    o->stream_bytes = d->stream_bytes;
+    o->x_bytes = d->x_bytes;
+    if (d->blk_on) { o->stored_nnz = d->blk_slots; o->x_groups = d->x_groups_seen; o->x_groups_staged = 0; }
+    if (!d->blk_on) switch (d->plan.sched) {
     case SPMV_SCHED_CSR_VECTOR:
     case SPMV_SCHED_ROWBLOCK: o->x_groups = d->vt_tiles; o->x_groups_staged = d->vt_staged; break;
-    case SPMV_SCHED_NNZ_SPLIT: o->x_groups = d->plan.variant == 8 ? d->ns_groups : d->ns.groups; o->x_groups_staged = d->plan.variant == 8 ? d->ns_staged : d->ns.staged; break;
+    case SPMV_SCHED_NNZ_SPLIT: o->x_groups = d->ns.groups; o->x_groups_staged = d->ns.staged; break;
     case SPMV_SCHED_SELL: o->x_groups = d->sell_nwin; o->x_groups_staged = d->sell_staged; break;
     case SPMV_SCHED_CSR5: o->x_groups = d->c5.groups; o->x_groups_staged = d->c5.staged; break;
     default: o->x_groups = o->x_groups_staged = 0; break;
     }
     if (d->blk_on) o->kernel_name = "blk_kernel";
     else if (d->plan.sched == SPMV_SCHED_NNZ_SPLIT)
-        o->kernel_name = d->plan.variant == 8 ? (d->ns_staged > 0 ? "nnz_group_kernel" : "nnz_split_kernel") : (d->ns.staged > 0 ? "nat_group_kernel" : "nat_kernel");
+        o->kernel_name = d->ns.staged > 0 ? "nat_group_kernel" : "nat_kernel";
     if (d->plan.sched == SPMV_SCHED_CSR5 && d->c5.staged > 0) o->kernel_name = "csr5_group_kernel";
     if (d->plan.sched == SPMV_SCHED_SELL && d->sell_staged > 0) o->kernel_name = "sell_window_kernel";
     return SPMV_HIP_OK;

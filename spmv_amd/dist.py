@@ -95,6 +95,7 @@ class ShardedSpMV:
         self.device, self.dtype = val.device, val.dtype
         self.rowptr, self.val = rowptr, val
         self.send_idx = None
+        self.any_halo = False
         self.send_counts = self.recv_counts = None
         if self.xchg == "halo":
             colidx = self._plan_halo(colidx)
@@ -178,6 +179,18 @@ class ShardedSpMV:
         _all_to_all_single(want, ghosts, output_split_sizes=self.send_counts,
                            input_split_sizes=self.recv_counts, group=self.group)
         self.send_idx = (want - self.c0).contiguous()                 # positions in my slice, peer-major
+        # Whether the per-step all_to_all happens at all is decided HERE, once and for the whole group: a rank
+        # whose block is purely diagonal (no ghosts, nobody needs its entries) must still enter the collective
+        # the other ranks enter -- skipping it on rank-local state deadlocks gloo and desynchronises RCCL's
+        # sequence numbers.
+        busy = torch.tensor([self.n_ghost + int(self.send_idx.numel())], dtype=torch.int64, device=dev)
+        if dist.get_backend(self.group) == "gloo" and busy.is_cuda:
+            b = busy.cpu()
+            dist.all_reduce(b, op=dist.ReduceOp.MAX, group=self.group)
+            busy = b
+        else:
+            dist.all_reduce(busy, op=dist.ReduceOp.MAX, group=self.group)
+        self.any_halo = bool(int(busy.item()) > 0)
         assert self.send_idx.numel() == 0 or (int(self.send_idx.min()) >= 0 and int(self.send_idx.max()) < self.n_local)
         # renumber: own column c -> c - c0 ; remote column -> n_local + rank in `ghosts`
         new = torch.where(remote_mask, torch.zeros_like(cols), cols - self.c0)
@@ -199,7 +212,7 @@ class ShardedSpMV:
         if self.xchg == "halo":
             if x_local.data_ptr() != self.x_ext.data_ptr():
                 self.x_ext[: self.n_local].copy_(x_local)
-            if self.n_ghost or self.send_idx.numel():
+            if self.any_halo:                       # group-wide decision (_plan_halo)
                 send = x_local[self.send_idx] if self.send_idx.numel() else x_local.new_empty(0)
                 _all_to_all_single(self.x_ext[self.n_local:], send, output_split_sizes=self.recv_counts,
                                    input_split_sizes=self.send_counts, group=self.group)
@@ -277,6 +290,15 @@ class ShardedSpMV:
         self._mul(self._A_bnd, self.x_ext, self.y_bnd)
         y_local.index_copy_(0, self.bnd_rows, self.y_bnd)
         return y_local
+
+    def exchange_only(self, x_local):
+        """The communication of one step without the multiply (bench.py reports it separately)."""
+        if self.split:
+            send = x_local[self.send_idx]
+            _all_to_all_single(self.x_ext[self.n_local:], send, output_split_sizes=self.recv_counts,
+                               input_split_sizes=self.send_counts, group=self.group)
+            return self.x_ext
+        return self.exchange(x_local)
 
     def close(self):
         for name in ("handle", "handle_bnd"):

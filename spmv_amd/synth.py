@@ -19,7 +19,7 @@ import numpy as np
 
 __all__ = [
     "CSR", "fill_values", "fill_x", "banded", "uniform_k", "powerlaw", "skewed_rows",
-    "from_row_lengths", "with_empty_rows", "dense_rows", "banded_device", "uniform_k_device",
+    "from_row_lengths", "with_empty_rows", "dense_rows", "banded_device", "uniform_k_device", "rmat_columns_device",
     "from_row_lengths_device", "skewed_lengths_device", "powerlaw_lengths_device",
 ]
 
@@ -214,10 +214,33 @@ def uniform_k_device(m, n, k=32, values="uniform", dtype=None, device="cuda", se
     return m, n, rowptr, colidx, val
 
 
-def from_row_lengths_device(lens, n, values="uniform", dtype=None, device="cuda", seed=1, local=0):
+def rmat_columns_device(row_of, m, n, device="cuda", seed=1, a=0.57, b=0.19, c=0.19, d=0.05):
+    """R-MAT column generator (Chakrabarti et al.): the column of every entry is drawn bit by bit, each bit
+    conditioned on the corresponding bit of the entry's ROW position as in the recursive-matrix model --
+    P(col bit = 0 | row bit = 0) = a / (a + b), P(col bit = 1 | row bit = 1) = d / (c + d).  With the Graph500
+    parameters this gives what uniform columns lack and real social / web graphs have: hub columns (low
+    indices are hot) and community structure (rows of one 2^-k fraction of the matrix prefer the columns
+    of the same fraction), which is what decides whether x windows stage and how well gathers merge.
+    row_of: int64 row index of every entry.  Returns int32 columns in [0, n)."""
+    torch = _torch()
+    g = torch.Generator(device=device)
+    g.manual_seed(seed + 31)
+    scale = max(1, int(n - 1).bit_length())
+    rpos = (row_of.to(torch.int64) << scale) // max(int(m), 1)          # row position on the 2^scale grid
+    col = torch.zeros_like(rpos)
+    p0, p1 = a / (a + b), d / (c + d)
+    for level in range(scale - 1, -1, -1):
+        rbit = (rpos >> level) & 1
+        u = torch.rand(rpos.shape[0], generator=g, device=device)
+        cbit = torch.where(rbit == 0, u >= p0, u < p1)
+        col |= cbit.to(torch.int64) << level
+    return ((col * int(n)) >> scale).to(torch.int32)                    # squeeze the power-of-two grid onto n columns
+
+
+def from_row_lengths_device(lens, n, values="uniform", dtype=None, device="cuda", seed=1, local=0, cols="uniform"):
     """Random columns for given per-row lengths (int64 tensor on `device`); columns sorted per row
     when local == 0 is not required by SpMV and is skipped.  local>0: columns within +-local of
-    the row's diagonal position."""
+    the row's diagonal position.  cols = "rmat": R-MAT columns (rmat_columns_device), sorted within each row."""
     torch = _torch()
     dtype = dtype or torch.float64
     lens = lens.to(device=device, dtype=torch.int64).clamp_(max=n)
@@ -233,6 +256,13 @@ def from_row_lengths_device(lens, n, values="uniform", dtype=None, device="cuda"
         centre = row_of * n // max(m, 1)
         jitter = torch.randint(-local, local + 1, (nnz,), generator=g, device=device, dtype=torch.int64)
         colidx = (centre + jitter).clamp_(0, n - 1).to(torch.int32)
+    elif cols == "rmat":
+        row_of = torch.repeat_interleave(torch.arange(m, device=device, dtype=torch.int64), lens)
+        colidx = rmat_columns_device(row_of, m, n, device, seed)
+        key = (row_of << 32) | colidx.to(torch.int64)                   # sort columns inside every row
+        del row_of
+        colidx = (torch.sort(key).values & 0xFFFFFFFF).to(torch.int32)
+        del key
     else:
         colidx = torch.randint(0, n, (nnz,), generator=g, device=device, dtype=torch.int32)
     val = _fill_device(nnz, values, dtype, device, seed)

@@ -68,11 +68,12 @@ static int check_plan(void)
     spmv_stats st;
     spmv_plan pl;
     SPMV_METHODS act;
+    spmv_options op;
     int rc = 0;
     /* equal rows of 32 (config 2): one pass per row with 8 lanes, nothing handed to the long-row path */
     memset(&st, 0, sizeof st); st.min_row_len = 1 << 30; st.n = 10000000;
     hist_put(&st, 32, 10000000); st.mean_row_len = 32.0;
-    spmv_plan_choose(Method_Parallel, &st, 8, &pl, &act);
+    (spmv_options_snapshot(&op), spmv_plan_choose(Method_Parallel, &st, 8, &op, &pl, &act, 1));
     printf("equal32: sched=%d L=%d thr=%d act=%d\n", pl.sched, pl.lanes_per_row, pl.long_thr, act);
     if (pl.sched != SPMV_SCHED_CSR_VECTOR || pl.lanes_per_row != 8 || pl.long_thr != 0 || act != Method_Parallel) rc = 1;
     /* config 4's shape: 90 % rows of ~16, 9 % of ~160, 1 % of ~2500 -> small L, the heavy classes to CSR5 */
@@ -80,41 +81,47 @@ static int check_plan(void)
     hist_put(&st, 8, 3000000); hist_put(&st, 14, 3000000); hist_put(&st, 22, 3000000);
     hist_put(&st, 100, 450000); hist_put(&st, 220, 450000); hist_put(&st, 2500, 100000);
     st.mean_row_len = (double) st.nnz / st.m;
-    spmv_plan_choose(Method_Parallel, &st, 4, &pl, &act);
+    (spmv_options_snapshot(&op), spmv_plan_choose(Method_Parallel, &st, 4, &op, &pl, &act, 1));
     printf("skewed: L=%d thr=%d\n", pl.lanes_per_row, pl.long_thr);
     if (pl.lanes_per_row < 4 || pl.lanes_per_row > 8 || pl.long_thr != 64) rc = 2;
     /* Balanced: a row longer than a worker's share flips the handle to Balanced2 (parallel_balanced2_spmv.c:72-92) */
-    spmv_plan_choose(Method_Balanced, &st, 4, &pl, &act);
+    (spmv_options_snapshot(&op), spmv_plan_choose(Method_Balanced, &st, 4, &op, &pl, &act, 1));
     if (act != Method_Balanced2 || pl.sched != SPMV_SCHED_NNZ_SPLIT) rc = 3;
     memset(&st, 0, sizeof st); st.min_row_len = 1 << 30; hist_put(&st, 32, 1000); st.mean_row_len = 32.0;
-    spmv_plan_choose(Method_Balanced2, &st, 8, &pl, &act);
+    (spmv_options_snapshot(&op), spmv_plan_choose(Method_Balanced2, &st, 8, &op, &pl, &act, 1));
     if (act != Method_Balanced || pl.sched != SPMV_SCHED_ROWBLOCK) rc = 4;
     /* no histogram (m = 0): the mean rule, no crash */
     memset(&st, 0, sizeof st);
-    spmv_plan_choose(Method_Parallel, &st, 8, &pl, &act);
+    (spmv_options_snapshot(&op), spmv_plan_choose(Method_Parallel, &st, 8, &op, &pl, &act, 1));
     if (pl.lanes_per_row != 1 || pl.long_thr != 0) rc = 5;
     /* very long equal rows: 64 lanes */
     memset(&st, 0, sizeof st); st.min_row_len = 1 << 30; hist_put(&st, 5000, 1000); st.mean_row_len = 5000.0;
-    spmv_plan_choose(Method_Parallel, &st, 8, &pl, &act);
+    (spmv_options_snapshot(&op), spmv_plan_choose(Method_Parallel, &st, 8, &op, &pl, &act, 1));
     printf("long5000: L=%d thr=%d\n", pl.lanes_per_row, pl.long_thr);
     if (pl.lanes_per_row != 64) rc = 6;
     /* out-of-range method -> serial (common.c:136); SELL / CSR5 map 1:1 */
-    spmv_plan_choose((SPMV_METHODS) 99, &st, 8, &pl, &act);
+    (spmv_options_snapshot(&op), spmv_plan_choose((SPMV_METHODS) 99, &st, 8, &op, &pl, &act, 1));
     if (act != Method_Serial || pl.sched != SPMV_SCHED_CSR_SCALAR) rc = 7;
-    spmv_plan_choose(Method_SellCSigma, &st, 8, &pl, &act);
+    (spmv_options_snapshot(&op), spmv_plan_choose(Method_SellCSigma, &st, 8, &op, &pl, &act, 1));
     if (pl.sched != SPMV_SCHED_SELL || pl.sell_c != 64 || pl.sell_sigma != 1024) rc = 8;
-    spmv_plan_choose(Method_CSR5SPMV, &st, 4, &pl, &act);
+    (spmv_options_snapshot(&op), spmv_plan_choose(Method_CSR5SPMV, &st, 4, &op, &pl, &act, 1));
     if (pl.sched != SPMV_SCHED_CSR5 || act != Method_CSR5SPMV) rc = 9;
-    /* auto_method: regular -> CSR-vector, skewed -> CSR5; spmv_plan_choose_ex(…, 0) ignores the option */
+    /* auto_method: regular -> CSR-vector, skewed -> CSR5; spmv_plan_choose(…, allow_auto = 0) ignores the option */
     if (spmv_hip_set_option("auto_method", 1) != 0) rc = 10;
-    spmv_plan_choose(Method_Serial, &st, 8, &pl, &act);
+    (spmv_options_snapshot(&op), spmv_plan_choose(Method_Serial, &st, 8, &op, &pl, &act, 1));
     if (act != Method_Parallel) rc = 11;
     st.max_row_len = 100000;
-    spmv_plan_choose(Method_Serial, &st, 8, &pl, &act);
+    (spmv_options_snapshot(&op), spmv_plan_choose(Method_Serial, &st, 8, &op, &pl, &act, 1));
     if (act != Method_CSR5SPMV) rc = 12;
-    spmv_plan_choose_ex(Method_Serial, &st, 8, &pl, &act, 0);
+    (spmv_options_snapshot(&op), spmv_plan_choose(Method_Serial, &st, 8, &op, &pl, &act, 0));
     if (act != Method_Serial) rc = 13;
     spmv_hip_set_option("auto_method", 0);
+    /* a thread-local override wins over the process-wide value for creates on this thread, and only there */
+    if (spmv_hip_set_thread_option("lanes_per_row", 16) != 0) rc = 15;
+    (spmv_options_snapshot(&op), spmv_plan_choose(Method_Parallel, &st, 8, &op, &pl, &act, 1));
+    if (pl.lanes_per_row != 16 || spmv_hip_get_option("lanes_per_row") != 16 || spmv_options_get(&op, "lanes_per_row") != 16) rc = 16;
+    spmv_hip_clear_thread_options();
+    if (spmv_hip_get_option("lanes_per_row") != 0) rc = 17;
     /* illegal option values are refused */
     if (spmv_hip_set_option("lanes_per_row", 3) == 0 || spmv_hip_set_option("nope", 1) == 0 || spmv_hip_set_option("cache_block", 3) == 0) rc = 14;
     printf("plan rc=%d\n", rc);

@@ -39,6 +39,19 @@ def _worker(rank, world, port, kind, xchg, out):
         elif kind == "rect":
             A = synth.uniform_k(900, 1300, 9, "eighths", np.float64, seed=4)
             n = 1300
+        elif kind == "diag_mid":
+            # three ranks: the middle rank's block is purely diagonal (no ghosts, nobody needs its slice), ranks 0
+            # and 2 reference each other -- the middle rank must still enter the halo collective
+            m = n = 900
+            base = synth.banded(m, n, 2, 2, "eighths", np.float64, seed=6)
+            rows = np.repeat(np.arange(m), np.diff(base.rowptr))
+            cols = base.colidx.copy()
+            blk = rows // 300
+            cols = np.clip(cols, blk * 300, blk * 300 + 299)               # every block diagonal ...
+            far = (blk != 1) & (np.arange(cols.size) % 7 == 0)
+            cols[far] = (cols[far] + 600) % 900                            # ... but 0 <-> 2 are coupled
+            order = np.lexsort((cols, rows))
+            A = synth.CSR(m, n, base.rowptr, cols[order].astype(np.int32), base.val[order])
         else:
             A = synth.powerlaw(m, n, 6.0, 500, 1.5, "eighths", np.float64, seed=5)
         x = synth.fill_x(n, "eighths", np.float64, 7)
@@ -82,6 +95,15 @@ def test_world2_matches_oracle(kind, xchg):
         assert all(out[r][3] and 0 < out[r][4] <= 16 for r in range(world)), dict(out)
     if xchg == "halo" and kind == "powerlaw":
         assert not any(out[r][3] for r in range(world))      # most rows touch ghosts: no split
+
+
+def test_world3_rank_with_a_purely_diagonal_block_still_joins_the_halo_collective():
+    world = 3
+    mgr = mp.Manager()
+    out = mgr.dict()
+    mp.spawn(_worker, args=(world, _free_port(), "diag_mid", "halo", out), nprocs=world, join=True)
+    assert all(out[r][0] for r in range(world)), dict(out)
+    assert out[1][1] == 0 and out[0][1] > 0 and out[2][1] > 0      # ghosts: none in the middle, some at both ends
 
 
 def test_slice_bounds_cover_and_are_contiguous():

@@ -99,25 +99,26 @@ def test_config2_random_columns_and_linearity():
     assert float((yx - want).abs().max()) <= 64 * 2.3e-16 * k
 
 
-def test_random_columns_balanced_family_runs_cache_blocked_and_auto_finds_it():
-    """Config 2 with uniformly random columns: no x window can be staged, x (80 MB) dwarfs an L2 -> the
-    Balanced family runs the row-block x column-slab executor (kernels/blocked.hpp); with auto_method the
-    second stage of the automatic choice (spmv_api.c) lands there too.  Exact inputs -> exact bits; random
-    inputs -> the north_star tolerance (LDS atomics: the order of a row's additions is not fixed)."""
+def test_random_columns_every_method_runs_cache_blocked_and_auto_finds_it():
+    """Config 2 with uniformly random columns: no x window can be staged, x (80 MB) dwarfs an L2 -> whatever the
+    method (Method_Parallel is what BASELINE names for config 2), the multiply runs the row-block x column-slab
+    executor (kernels/blocked.hpp), and so does the automatic choice.  Exact inputs -> exact bits; random inputs ->
+    the north_star tolerance AND the same bits from two handles (one wavefront owns a row block)."""
     m = n = 10_000_000
     k = 32
     _, _, rp, ci, va = synth.uniform_k_device(m, n, k, "eighths", torch.float64, DEV, seed=13)
     g = torch.Generator(device=DEV); g.manual_seed(15)
     x = torch.randint(0, 8, (n,), generator=g, device=DEV).double() * 0.125
     want = _definition_regular(m, k, ci, va, x)
-    for method in (M.Method_Balanced, M.Method_Balanced_Yid):
+    for method in (M.Method_Parallel, M.Method_Balanced, M.Method_Balanced_Yid, M.Method_CSR5SPMV):
         y = torch.full((m,), float("nan"), dtype=torch.float64, device=DEV)
         with api.Handle(m, n, rp, ci, va, method) as h:
             h.spmv(x, y)
             info = h.info()
+            assert h.method == method
         torch.cuda.synchronize()
-        assert info["cache_blocked"] == 1 and info["kernel_name"] == "blk_kernel" and info["x_groups_staged"] == 0
-        assert torch.equal(y, want)
+        assert info["cache_blocked"] == 1 and info["kernel_name"] == "blk_kernel" and info["x_groups_staged"] == 0, info
+        assert torch.equal(y, want), method
     api.set_option("auto_method", 1)
     try:
         y = torch.full((m,), float("nan"), dtype=torch.float64, device=DEV)
@@ -128,16 +129,20 @@ def test_random_columns_balanced_family_runs_cache_blocked_and_auto_finds_it():
     finally:
         api.set_option("auto_method", 0)
     torch.cuda.synchronize()
-    assert chosen == M.Method_Balanced_Yid and info["cache_blocked"] == 1
+    assert chosen == M.Method_Parallel and info["cache_blocked"] == 1
     assert torch.equal(y, want)
-    # random values: tolerance
+    # random values: tolerance, and bit-reproducible across handles
     _, _, rp, ci, va = synth.uniform_k_device(m, n, k, "uniform", torch.float64, DEV, seed=17)
     xr = torch.rand(n, generator=g, device=DEV, dtype=torch.float64) * 2 - 1
-    y = torch.empty(m, dtype=torch.float64, device=DEV)
-    with api.Handle(m, n, rp, ci, va, M.Method_Balanced_Yid) as h:
-        h.spmv(xr, y)
-    torch.cuda.synchronize()
-    assert float((y - _definition_regular(m, k, ci, va, xr)).abs().max()) <= 64 * 2.3e-16 * k
+    ys = []
+    for method in (M.Method_Balanced_Yid, M.Method_Parallel):
+        y = torch.empty(m, dtype=torch.float64, device=DEV)
+        with api.Handle(m, n, rp, ci, va, method) as h:
+            h.spmv(xr, y)
+        torch.cuda.synchronize()
+        ys.append(y)
+    assert float((ys[0] - _definition_regular(m, k, ci, va, xr)).abs().max()) <= 64 * 2.3e-16 * k
+    assert torch.equal(ys[0], ys[1])
     # option 0 switches it off
     api.set_option("cache_block", 0)
     try:
@@ -145,6 +150,88 @@ def test_random_columns_balanced_family_runs_cache_blocked_and_auto_finds_it():
             assert h.info()["cache_blocked"] == 0
     finally:
         api.set_option("cache_block", 1)
+
+
+def _exact_x(n, seed):
+    g = torch.Generator(device=DEV); g.manual_seed(seed)
+    return torch.randint(0, 8, (n,), generator=g, device=DEV).double() * 0.125
+
+
+@pytest.mark.parametrize("cols", ["uniform", "rmat"])
+def test_config3_webbase_style_powerlaw_at_full_size(cols):
+    """BASELINE config 3, stand-in for webbase-1M (1e6 rows, mean 3.1, longest row 4.7k; SuiteSparse files
+    are not available offline): Method_Balanced2 (the named schedule), Method_Balanced_Yid and CSR5 at full size,
+    exact-arithmetic fill, compared bit for bit with a torch fp64 evaluation of the definition.  Columns uniform and
+    R-MAT (hub columns + community structure)."""
+    m = n = 1_000_000
+    lens = synth.powerlaw_lengths_device(m, 3.1, 4700, 1.6, DEV, 1)
+    _, _, rp, ci, va = synth.from_row_lengths_device(lens, n, "eighths", torch.float64, DEV, 1, cols=cols)
+    assert int((rp[1:] - rp[:-1]).max()) >= 4000 and 2_000_000 < int(rp[-1]) < 4_000_000
+    x = _exact_x(n, 21)
+    want = _definition_segments(rp, ci, va, x)
+    for method in (M.Method_Balanced2, M.Method_Balanced_Yid, M.Method_CSR5SPMV, M.Method_Parallel):
+        y, sched = _run(m, n, rp, ci, va, x, method)
+        assert not torch.isnan(y).any(), (method, sched)
+        assert torch.equal(y, want), (method, sched, float((y - want).abs().max()))
+
+
+def test_config3_orkut_style_powerlaw_at_full_size():
+    """BASELINE config 3, stand-in for com-Orkut (3.07e6 rows, ~2.3e8 nnz, mean ~76, longest row 33k), R-MAT columns:
+    the named schedule Method_Balanced2 and CSR5 at full size against the definition, exact arithmetic."""
+    m = n = 3_070_000
+    lens = synth.powerlaw_lengths_device(m, 76, 33000, 1.5, DEV, 1)
+    _, _, rp, ci, va = synth.from_row_lengths_device(lens, n, "eighths", torch.float64, DEV, 1, cols="rmat")
+    assert int(rp[-1]) > 200_000_000 and int((rp[1:] - rp[:-1]).max()) >= 30000
+    x = _exact_x(n, 22)
+    want = _definition_segments(rp, ci, va, x)
+    for method in (M.Method_Balanced2, M.Method_CSR5SPMV):
+        y, sched = _run(m, n, rp, ci, va, x, method)
+        assert torch.equal(y, want), (method, sched, float((y - want).abs().max()))
+        del y
+    # uniform columns (no structure at all): the cache-blocked executor
+    _, _, rp, ci, va = synth.from_row_lengths_device(lens, n, "eighths", torch.float64, DEV, 2)
+    want = _definition_segments(rp, ci, va, x)
+    y = torch.full((m,), float("nan"), dtype=torch.float64, device=DEV)
+    with api.Handle(m, n, rp, ci, va, M.Method_Balanced2) as h:
+        h.spmv(x, y)
+        assert h.info()["cache_blocked"] == 1
+    torch.cuda.synchronize()
+    assert torch.equal(y, want)
+
+
+def test_config3_through_the_matrix_market_loader(tmp_path, monkeypatch):
+    """.mtx file -> spmv_io_load (csrc/io/mtx_io.c; reference mmio_highlevel.h:325-491: text parse, then the
+    mtx_cache/*.bin cache on the second load) -> create(Method_Balanced2) -> spmv, on the 1e6-row power-law
+    stand-in with R-MAT columns.  The loader must hand back exactly the CSR that was written, and the product
+    must equal the definition."""
+    import ctypes as C
+    m = n = 1_000_000
+    lens = synth.powerlaw_lengths_device(m, 3.1, 4700, 1.6, DEV, 3)
+    _, _, rp, ci, va = synth.from_row_lengths_device(lens, n, "eighths", torch.float64, DEV, 3, cols="rmat")
+    rp_h, ci_h, va_h = rp.cpu().numpy(), ci.cpu().numpy(), va.cpu().numpy()
+    nnz = int(rp_h[-1])
+    rows = np.repeat(np.arange(1, m + 1, dtype=np.int64), np.diff(rp_h))
+    monkeypatch.chdir(tmp_path)
+    with open("pl.mtx", "w") as f:
+        f.write("%%MatrixMarket matrix coordinate real general\n%d %d %d\n" % (m, n, nnz))
+        np.savetxt(f, np.column_stack([rows, ci_h.astype(np.int64) + 1, va_h]), fmt="%d %d %.6g")
+    lib = api.load()
+    I = C.POINTER(C.c_int)
+    for expect_cache in (0, 1):
+        mm, nn, nz, sym, fc = C.c_int(), C.c_int(), C.c_int(), C.c_int(), C.c_int()
+        prp, pci, pva = I(), I(), C.c_void_p()
+        assert lib.spmv_io_load(b"pl.mtx", 8, C.byref(mm), C.byref(nn), C.byref(nz), C.byref(sym), C.byref(prp), C.byref(pci), C.byref(pva), C.byref(fc)) == 0
+        assert (mm.value, nn.value, nz.value, fc.value) == (m, n, nnz, expect_cache)
+        csr = api._take_csr(mm, nn, nz, prp, pci, pva, np.dtype(np.float64))
+        assert np.array_equal(csr.rowptr, rp_h) and np.array_equal(csr.colidx, ci_h) and np.array_equal(csr.val, va_h)
+    x = _exact_x(n, 23)
+    want = _definition_segments(rp, ci, va, x).cpu().numpy()
+    xh = x.cpu().numpy()
+    for method in (M.Method_Balanced2, M.Method_Balanced_Yid):
+        y = np.full(m, np.nan)
+        with api.Handle(m, n, csr.rowptr, csr.colidx, csr.val, method) as h:      # host arrays, as the harness passes them
+            h.spmv(xh, y)
+        assert np.array_equal(y, want), method
 
 
 def test_config4_skewed_fp32_schedules_bit_identical():

@@ -55,6 +55,10 @@ def check(y, csr, x, y_ref, exact):
     err = np.abs(y.astype(np.float64) - ye)
     assert (err <= TOL[y.dtype] * s + 1e-300).all(), float((err / np.maximum(s, 1e-300)).max())
     assert (err <= SHARP[y.dtype] * np.maximum(1, np.diff(csr.rowptr)) * s + 1e-300).all()
+    # ... and against the bits the REFERENCE's Method_Serial produced for this fixture (tests/golden, y_ref):
+    # north_star's bar, |y - y_ref| <= tol * sum_j |a_ij x_j| per row
+    err_ref = np.abs(y.astype(np.float64) - y_ref.astype(np.float64))
+    assert (err_ref <= TOL[y.dtype] * s + 1e-300).all(), float((err_ref / np.maximum(s, 1e-300)).max())
 
 
 @pytest.mark.parametrize("method", ALL_METHODS, ids=lambda m: m.name)
@@ -82,22 +86,28 @@ def test_golden_device_pointers(name, method):
     check(yd.cpu().numpy(), csr, x, y_ref, exact=name.endswith("eighths"))
 
 
-@pytest.mark.parametrize("method", [M.Method_Balanced, M.Method_Balanced2, M.Method_Balanced_Yid], ids=lambda m: m.name)
+@pytest.mark.parametrize("method", [M.Method_Parallel, M.Method_Balanced, M.Method_Balanced2, M.Method_Balanced_Yid, M.Method_CSR5SPMV],
+                         ids=lambda m: m.name)
 @pytest.mark.parametrize("name", NAMES)
 def test_golden_row_block_column_slab_executor(name, method):
     """Option cache_block = 2 forces the executor that big matrices without column locality get
-    automatically (kernels/blocked.hpp): y of a row block accumulates in LDS by floating-point atomics, so
-    the bar is bit-exact on exact-arithmetic inputs and the north_star tolerance otherwise."""
+    automatically, whatever the method (kernels/blocked.hpp).  One wavefront owns a row block and walks a stream
+    whose order the inspector fixes, so the result is bit-exact on exact-arithmetic inputs, within the north_star
+    tolerance otherwise, and THE SAME BITS from handle to handle."""
     csr, x, y_ref = load_golden(name)
     api.set_option("cache_block", 2)
     try:
         y, actual = run_host(csr, x, method)
         y2, _ = run_host(csr, x, method)
+        api.set_option("block_rows", 1024)          # several blocks even on the small fixtures
+        y3, _ = run_host(csr, x, method)
     finally:
         api.set_option("cache_block", 1)
-    assert actual in (M.Method_Balanced2, M.Method_Balanced_Yid, M.Method_Balanced)
+        api.set_option("block_rows", 0)
+    assert actual in (method, M.Method_Balanced2, M.Method_Balanced)
     check(y, csr, x, y_ref, exact=name.endswith("eighths"))
-    check(y2, csr, x, y_ref, exact=name.endswith("eighths"))
+    check(y3, csr, x, y_ref, exact=name.endswith("eighths"))
+    assert np.array_equal(y.view(np.uint8), y2.view(np.uint8))
 
 
 @pytest.mark.parametrize("way", list(api.VECTORIZED_WAY)[:4], ids=lambda w: w.name)
@@ -223,10 +233,9 @@ def test_auto_method_picks_schedule_from_row_statistics():
     ("csr5_sigma", [4, 8, 16], M.Method_CSR5SPMV),
     ("rowblock_nnz", [64, 333, 4096, 100000], M.Method_Balanced),
     ("csr5_sigma", [4, 8, 16], M.Method_Balanced_Yid),           # nnz-split = natural-layout tiles of 64 x sigma
-    ("variant", [8], M.Method_Balanced2),                        # A/B form: 256-nnz tiles with LDS row marks
     ("variant", [3], M.Method_Balanced_Yid),                     # no x windows (global gathers)
-    ("variant", [1, 4, 5, 6, 10, 11, 12, 13], M.Method_Parallel),  # CSR-vector kernel forms / long-row segment kernel
-    ("variant", [3, 13], M.Method_SellCSigma),
+    ("variant", [4, 5, 6, 10, 11, 12], M.Method_Parallel),       # CSR-vector kernel forms
+    ("variant", [3], M.Method_SellCSigma),
     ("variant", [3], M.Method_CSR5SPMV),
 ])
 @pytest.mark.parametrize("name", ["skewed_f64_eighths", "empty_mix_f32_eighths", "banded_wide_f64_eighths"])
@@ -437,13 +446,148 @@ def test_wide_x_windows_use_the_slot_index_form():
 @pytest.mark.parametrize("method", ALL_METHODS, ids=lambda m: m.name)
 @pytest.mark.parametrize("name", ["skewed_f64_uniform", "powerlaw_f32_uniform", "empty_mix_f64_uniform"])
 def test_results_are_bit_reproducible_across_handles(name, method):
-    """No floating-point atomics anywhere in the tile / row schedules (carries are added in tile order by
-    one lane): two handles built from the same matrix give the same bits on inexact data.  (The cache-blocked
-    executor of the Balanced family is the documented exception and is not engaged on these sizes.)"""
+    """No racing floating-point atomics anywhere (carries are added in tile order by one lane; a row block of the
+    row-block x column-slab executor belongs to one wavefront): two handles built from the same matrix give the
+    same bits on inexact data."""
     csr, x, _ = load_golden(name)
     y1, _ = run_host(csr, x, method)
     y2, _ = run_host(csr, x, method)
     assert np.array_equal(y1.view(np.uint8), y2.view(np.uint8))
+
+
+@pytest.mark.parametrize("dtype", [np.float64, np.float32])
+@pytest.mark.parametrize("method", [M.Method_Parallel, M.Method_Balanced2, M.Method_CSR5SPMV], ids=lambda m: m.name)
+def test_matrix_without_column_locality_runs_the_blocked_executor_deterministically(method, dtype):
+    """2^21+ non-zeros on uniformly random columns over an x larger than an XCD's L2: no x window fits LDS, so
+    every method (not only the Balanced family) is routed to the row-block x column-slab executor by default, and
+    inexact data gives the same bits from two different handles and from repeated launches."""
+    import torch
+    dev = torch.device("cuda:0")
+    tdt = torch.float64 if dtype == np.float64 else torch.float32
+    m = n = 1_600_000 if dtype == np.float64 else 2_400_000
+    _, _, rp, ci, va = synth.uniform_k_device(m, n, 8, "uniform", tdt, dev, seed=11)
+    g = torch.Generator(device=dev); g.manual_seed(5)
+    x = torch.rand(n, generator=g, device=dev, dtype=tdt) * 2 - 1
+    ys = []
+    for _ in range(2):
+        y = torch.full((m,), float("nan"), dtype=tdt, device=dev)
+        with api.Handle(m, n, rp, ci, va, method) as h:
+            info = h.info()
+            assert info["cache_blocked"] == 1 and info["kernel_name"] == "blk_kernel", info
+            h.spmv(x, y)
+            y2 = torch.empty_like(y)
+            h.spmv(x, y2)
+        torch.cuda.synchronize()
+        assert torch.equal(y, y2)
+        ys.append(y)
+    assert torch.equal(ys[0], ys[1]), "two handles, same matrix: different bits"
+    want = (va.double() * x.double()[ci.long()]).view(m, 8).sum(1)
+    scale = (va.double() * x.double()[ci.long()]).abs().view(m, 8).sum(1)
+    assert bool(((ys[0].double() - want).abs() <= TOL[np.dtype(dtype)] * scale).all())
+
+
+@pytest.mark.parametrize("method", ALL_METHODS, ids=lambda m: m.name)
+@pytest.mark.parametrize("name", ["skewed_f64_uniform", "skewed_f32_uniform", "empty_mix_f64_uniform", "banded_wide_f32_uniform"])
+@pytest.mark.parametrize("blocked", [0, 1])
+def test_update_values_refreshes_every_private_layout(name, method, blocked):
+    """spmv_hip_update_values: the caller changes Matrix_Val IN PLACE (the reference would simply see it,
+    common.c:286-298); one call re-permutes the values into the schedule's layouts (SELL slabs, CSR5 tiles, long-row
+    sub-matrix, blocked streams) without re-inspection.  Result = the oracle on the new values."""
+    csr, x, _ = load_golden(name)
+    val = csr.val.copy()
+    if blocked:
+        api.set_option("cache_block", 2)
+    try:
+        h = api.Handle(csr.m, csr.n, csr.rowptr, csr.colidx, val, method)
+    finally:
+        api.set_option("cache_block", 1)
+    try:
+        y0 = h.spmv(x, np.full(csr.m, np.nan, dtype=val.dtype))
+        assert np.array_equal(y0, run_host(csr, x, method)[0])
+        stale = val.copy()
+        val[:] = (val * np.asarray(-1.5, dtype=val.dtype) + np.asarray(0.25, dtype=val.dtype)).astype(val.dtype)  # in place, same pointer
+        y_stale = h.spmv(x, np.full(csr.m, np.nan, dtype=val.dtype))
+        assert np.array_equal(y_stale, y0), "without a refresh the resident copy is what multiplies (documented)"
+        h.update_values(val)
+        y1 = h.spmv(x, np.full(csr.m, np.nan, dtype=val.dtype))
+        new = synth.CSR(csr.m, csr.n, csr.rowptr, csr.colidx, val)
+        assert np.array_equal(y1, run_host(new, x, method)[0]), "refreshed handle != handle created on the new values"
+        check(y1, new, x, oracle.spmv_serial(new, x), exact=False)
+        h.update_values(stale)                                  # another array of the same pattern
+        assert np.array_equal(h.spmv(x, np.empty(csr.m, dtype=val.dtype)), y0)
+    finally:
+        h.close()
+
+
+@pytest.mark.parametrize("devptr", [False, True])
+def test_check_values_option_makes_in_place_updates_visible(devptr):
+    """Option check_values (env SPMV_HIP_CHECK_VALUES=1): spmv() checksums Matrix_Val on every call and refreshes
+    by itself -- the pure drop-in for callers that update values in place."""
+    import torch
+    csr, x, _ = load_golden("skewed_f64_uniform")
+    if devptr:
+        dev = torch.device("cuda:0")
+        rp, ci, va = (torch.from_numpy(a).to(dev) for a in (csr.rowptr, csr.colidx, csr.val.copy()))
+        xd = torch.from_numpy(x).to(dev)
+    else:
+        rp, ci, va, xd = csr.rowptr, csr.colidx, csr.val.copy(), x
+    api.set_thread_option("check_values", 1)
+    try:
+        h = api.Handle(csr.m, csr.n, rp, ci, va, M.Method_CSR5SPMV)
+    finally:
+        api.clear_thread_options()
+    assert h.option("check_values") == 1
+    def mul():
+        y = torch.empty(csr.m, dtype=torch.float64, device=xd.device) if devptr else np.empty(csr.m)
+        h.spmv(xd, y)
+        return y.cpu().numpy() if devptr else y
+    y0 = mul()
+    if devptr:
+        va.mul_(3.0)
+    else:
+        va *= 3.0
+    y1 = mul()
+    h.close()
+    want = run_host(synth.CSR(csr.m, csr.n, csr.rowptr, csr.colidx, csr.val * 3.0), x, M.Method_CSR5SPMV)[0]
+    assert not np.array_equal(y0, y1) and np.array_equal(y1, want)
+
+
+def test_options_are_per_handle_and_thread_local_overrides_do_not_leak():
+    csr, x, y_ref = load_golden("rowlen_sweep_f64_eighths")
+    api.set_thread_option("lanes_per_row", 16)
+    try:
+        a = api.Handle(csr.m, csr.n, csr.rowptr, csr.colidx, csr.val, M.Method_Parallel)
+    finally:
+        api.clear_thread_options()
+    b = api.Handle(csr.m, csr.n, csr.rowptr, csr.colidx, csr.val, M.Method_Parallel)
+    try:
+        assert a.option("lanes_per_row") == 16 and a.info()["lanes_per_row"] == 16
+        assert b.option("lanes_per_row") == 0 and api.get_option("lanes_per_row") == 0
+        for h in (a, b):
+            assert np.array_equal(h.spmv(x, np.empty(csr.m)), y_ref)
+    finally:
+        a.close(); b.close()
+
+
+def test_stream_bytes_model_of_the_storage_format():
+    """spmv_hip_info.stream_bytes: what one launch has to move given the format -- below alg_bytes when the 16-bit
+    slot stream replaces ColIdx, above it for SELL's padding; x charged by the windows actually staged."""
+    import torch
+    dev = torch.device("cuda:0")
+    m, n, rp, ci, va = synth.banded_device(400_000, 400_000, 32, "eighths", torch.float64, dev, 3)
+    nnz = int(rp[-1].item())
+    with api.Handle(m, n, rp, ci, va, M.Method_Parallel) as h:
+        i = h.info()
+    assert i["kernel_name"] == "csr_vector_tile_kernel" and i["x_groups_staged"] == i["x_groups"]
+    fixed = 4 * (m + 1) + nnz * (8 + 2) + 8 * m                      # RowPtr, values + 16-bit slots, y
+    assert fixed < i["stream_bytes"] < fixed + 8 * 2 * n + 300 * i["x_groups"]   # + window tables + staged x (tiles overlap by the band)
+    assert 8 * n <= i["x_bytes"] < 8 * 2 * n and i["stream_bytes"] < i["alg_bytes"]
+    with api.Handle(m, n, rp, ci, va, M.Method_Serial) as h:
+        i = h.info()
+    assert i["stream_bytes"] == i["alg_bytes"]
+    with api.Handle(m, n, rp, ci, va, M.Method_SellCSigma) as h:
+        i = h.info()
+    assert i["stream_bytes"] >= i["stored_nnz"] * 10 + 8 * m
 
 
 def test_auto_method_measured_mode_builds_times_and_keeps_a_candidate():

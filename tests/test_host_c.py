@@ -16,7 +16,7 @@ def exe(tmp_path_factory):
     out = str(tmp_path_factory.mktemp("hostc") / "host_c_check")
     cmd = ["gcc", "-std=c11", "-O1", "-g", "-Wall", "-Wextra", "-fsanitize=address,undefined", "-fno-sanitize-recover=undefined",
            f"-I{os.path.join(ROOT, 'include')}", f"-I{CSRC}", os.path.join(ROOT, "tests", "c", "host_c_check.c"),
-           os.path.join(CSRC, "io", "mtx_io.c"), os.path.join(CSRC, "reorder", "rcm.c"), os.path.join(CSRC, "spmv_plan.c"), "-o", out]
+           os.path.join(CSRC, "io", "mtx_io.c"), os.path.join(CSRC, "reorder", "rcm.c"), os.path.join(CSRC, "spmv_plan.c"), "-lpthread", "-o", out]
     r = subprocess.run(cmd, capture_output=True, text=True)
     assert r.returncode == 0, r.stderr
     return out

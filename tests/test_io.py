@@ -109,6 +109,41 @@ def test_bin_cache_layout_and_roundtrip(tmp_path):
     assert api.cache_path("data/my dir\\a.mtx") == "mtx_cache/data_my_dir_a.mtx.bin"   # mmio_highlevel.h:533-541
 
 
+def test_cache_written_in_one_value_width_is_not_misread_in_the_other(tmp_path, monkeypatch):
+    """The cache format has no dtype field (mmio_highlevel.h:531-584): reading an fp64 cache as fp32 must be
+    refused (file longer than nnz floats), and the other way round (short file), so that spmv_io_load re-parses the
+    .mtx file instead of returning halves of doubles as floats."""
+    import ctypes as C
+    csr = synth.powerlaw(120, 120, 4.0, 40, 1.5, "uniform", np.float64, seed=8)
+    p64, p32 = str(tmp_path / "d.bin"), str(tmp_path / "s.bin")
+    api.write_bin(p64, csr)
+    with pytest.raises(OSError):
+        api.read_bin(p64, np.float32)
+    from spmv_amd.synth import CSR
+    api.write_bin(p32, CSR(csr.m, csr.n, csr.rowptr, csr.colidx, csr.val.astype(np.float32)))
+    with pytest.raises(OSError):
+        api.read_bin(p32, np.float64)
+    assert np.array_equal(api.read_bin(p32, np.float32).val, csr.val.astype(np.float32))
+    # spmv_io_load: load as f64 (writes the cache), then as f32 -> falls back to the .mtx text and gets real floats
+    monkeypatch.chdir(tmp_path)
+    a = sp.coo_matrix((csr.val, (np.repeat(np.arange(csr.m), np.diff(csr.rowptr)), csr.colidx)), shape=(csr.m, csr.n))
+    scipy.io.mmwrite("w.mtx", a, precision=17)
+    lib = api.load()
+    I = C.POINTER(C.c_int)
+    def load(vsize):
+        m, n, nnz, sym, fc = C.c_int(), C.c_int(), C.c_int(), C.c_int(), C.c_int()
+        rp, ci, va = I(), I(), C.c_void_p()
+        assert lib.spmv_io_load(b"w.mtx", vsize, C.byref(m), C.byref(n), C.byref(nnz), C.byref(sym), C.byref(rp), C.byref(ci), C.byref(va), C.byref(fc)) == 0
+        dt = np.float64 if vsize == 8 else np.float32
+        return api._take_csr(m, n, nnz, rp, ci, va, np.dtype(dt)), fc.value
+    d64, from_cache = load(8)
+    assert from_cache == 0 and os.path.exists(api.cache_path("w.mtx"))
+    d32, from_cache = load(4)
+    assert from_cache == 0, "an fp64 cache must not satisfy an fp32 load"
+    assert np.array_equal(d32.val, d64.val.astype(np.float32))
+    assert load(4)[1] == 1                          # ... and the cache now holds floats
+
+
 def test_spmv_of_loaded_matrix_matches_scipy(tmp_path):
     """End to end on the CPU side: loader -> oracle SpMV == scipy's A @ x."""
     import oracle
