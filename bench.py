@@ -5,6 +5,10 @@
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
         --master-port P bench.py --gpus N --steps K --warmup W
 
+`--gpus N` with N > 1 and no WORLD_SIZE in the environment: this process -- before it touches any GPU --
+starts N rank processes itself (one per device, LOCAL_RANK = device) and relays rank 0's JSON line; it fails
+loudly when the box has fewer than N devices.
+
 A "step" is one pass of the hot path: y = A x through the C ABI (spmv(), include/spmv.h) on a
 matrix that is already resident in HBM; x and y are device-resident (DESIGN.md gives the
 PCIe-inclusive host-pointer figure, it is never `value`).
@@ -13,15 +17,27 @@ Workload at N = 1 = BASELINE config 2: CSR fp64, 1e7 x 1e7, exactly 32 nnz/row, 
 (SURVEY 8d variant (i)), schedule Method_Parallel = CSR-vector.  At N > 1 = config 5 scaled
 weakly: every rank holds a 1e7-row block of the (N*1e7)^2 banded matrix (local int32 RowPtr,
 global columns) and the matching slice of x; each step first exchanges x over RCCL
-(spmv_amd.dist, mode --xchg, default "halo") and then multiplies.  No data-path collective
-besides that exchange; y stays distributed.
+(spmv_amd.dist) and then multiplies; y stays distributed.  All three exchanges are run and reported
+in the one JSON line ("exchanges"): "halo" (the library's default: only the referenced entries move,
+point to point; `value` is this one), "allgather" (every rank gathers the whole x each step: the
+solver-style loop) and "bcast" (north_star's literal broadcast of x from rank 0), each with the
+time of the exchange alone and of the multiply alone.
 
 Timing follows the driver contract: W untimed steps, then exactly K steps between
 barrier + torch.cuda.synchronize() pairs, MAX over ranks, rank 0 prints ONE JSON line.
 `value` = 2 * nnz(all ranks) * K / time (FLOPs per SpMV = 2 nnz: test_spmv.c:126).
-`roofline.achieved` = B_alg / mean launch duration, the duration taken from HIP events recorded
-around every launch of the timed region on the stream the kernel runs on;
-B_alg = 4(m+1) + nnz(4+s) + s n + s m.
+
+roofline (the dominant kernel; measured live): HIP events on the stream the kernel is launched on
+bracket the launches (N = 1: the K timed steps themselves; N > 1: a multiply-only pass after them).
+  achieved / frac        = bytes the kernel MOVES per launch / mean launch time (/ 8 TB/s).  The bytes are
+                           spmv_hip_info.stream_bytes: the arrays of the schedule's storage format as stored
+                           (16-bit LDS-slot stream where x windows are staged), the x elements staged, y, window
+                           tables -- checked against rocprofv3 FETCH_SIZE / WRITE_SIZE (profiles/);
+  achieved_alg / frac_alg_bytes = SURVEY 8d's ALGORITHMIC bytes B_alg = 4(m+1) + nnz(4+s) + s n + s m over the same
+                           time (an effective rate: it charges 4 B/nnz of ColIdx the kernel does not read);
+  traffic                = HBM bytes per launch from the committed rocprofv3 --pmc passes (2 x FETCH_SIZE +
+                           WRITE_SIZE, MI355X_MICROARCH.md "HBM") for exactly this kernel, shape and dtype
+                           (profiles/traffic_r02.json), or null.
 `cpu_baseline` (rank 0, N = 1): the real reference's OpenMP path (oracle/_ref, Method_Parallel,
 kind "reference") or, if that library is absent, the oracle's OpenMP port, on the first
 --cpu-rows rows of the same matrix, with the GPU result checked against it.
@@ -31,6 +47,8 @@ from __future__ import annotations
 import argparse
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
@@ -39,10 +57,6 @@ sys.path.insert(0, ROOT)
 os.environ.setdefault("OMP_PROC_BIND", "true")   # unbound Method_Parallel is 4x slower
 os.environ.setdefault("OMP_PLACES", "cores")
 os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-
-import numpy as np  # noqa: E402
-import torch  # noqa: E402
-import torch.distributed as dist  # noqa: E402
 
 HBM_PEAK_GBPS = 8000.0  # MI355X_MICROARCH.md "HBM3E peak BW 8.0 TB/s spec"
 
@@ -57,7 +71,8 @@ def parse():
     ap.add_argument("--dtype", default="f64", choices=["f64", "f32"])
     ap.add_argument("--workload", default="banded", choices=["banded", "random"])
     ap.add_argument("--method", type=int, default=1, help="SPMV_METHODS id (1 = Method_Parallel = CSR-vector)")
-    ap.add_argument("--xchg", default="halo", choices=["halo", "allgather", "bcast", "none"])
+    ap.add_argument("--xchg", default="all", choices=["all", "halo", "allgather", "bcast", "none"],
+                    help="N > 1: which x exchange(s) to run; 'all' = halo (headline), allgather, bcast")
     ap.add_argument("--cpu-rows", type=int, default=1_000_000)
     ap.add_argument("--cpu-seconds", type=float, default=10.0, help="CPU baseline: keep timing calls for about this long (at least 100 calls)")
     ap.add_argument("--no-cpu", action="store_true")
@@ -67,11 +82,45 @@ def parse():
     return ap.parse_args()
 
 
+# ---------------------------------------------------------------------------------------- launcher
+def spawn_ranks(args):
+    """--gpus N without a launcher: start the N ranks from here.  Nothing in this process has touched a GPU
+    (torch.cuda.device_count() does not initialise one on this image), and the ranks are fresh child
+    processes -- never an exec of a process that holds a GPU context."""
+    import torch
+    n = args.gpus
+    one_device = bool(os.environ.get("SPMV_BENCH_ONE_DEVICE"))
+    ndev = torch.cuda.device_count()
+    if ndev < n and not one_device:
+        sys.stderr.write(f"bench.py: --gpus {n} but this box exposes {ndev} GPU(s); refusing to run a {n}-GPU benchmark on fewer devices "
+                         "(SPMV_BENCH_ONE_DEVICE=1 --backend gloo rehearses the multi-rank path on one device)\n")
+        return 2
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    procs = []
+    for r in range(n):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n),
+                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env,
+                                      stdout=subprocess.PIPE if r == 0 else subprocess.DEVNULL, text=True))
+    out, _ = procs[0].communicate()
+    rc = procs[0].returncode
+    for p in procs[1:]:
+        rc = max(rc, abs(p.wait()))
+    sys.stdout.write(out)
+    sys.stdout.flush()
+    return rc
+
+
+# ---------------------------------------------------------------------------------------- CPU baseline
 def cpu_baseline(args, rp, ci, va, x, y_gpu, n_cols):
     """Time the reference's OpenMP CSR path on a bounded sample of the same workload (host cores
     of this box) and check the GPU result against it.  The oracle package is used here only as the
     thing being timed/checked against -- never by the product path."""
     import ctypes as C
+    import numpy as np
     import oracle
     rows = min(args.cpu_rows, rp.numel() - 1)
     p1 = int(rp[rows].item())
@@ -124,34 +173,38 @@ def cpu_baseline(args, rp, ci, va, x, y_gpu, n_cols):
     }
 
 
-def traffic_from_profiles(kernel_name):
-    """HBM bytes per launch of the dominant kernel from the committed rocprofv3 --pmc passes
-    (tools/profile_bench.sh writes profiles/traffic_latest.json); None if never collected."""
-    path = os.path.join(ROOT, "profiles", "traffic_latest.json")
+def traffic_from_profiles(kernel_name, m, nnz, dtype):
+    """HBM bytes per launch measured by rocprofv3 --pmc (separate FETCH_SIZE / WRITE_SIZE passes, tools/profile_configs.sh
+    -> profiles/traffic_r02.json) for THIS kernel on THIS shape; None when no matching entry is committed."""
     try:
-        with open(path) as f:
-            t = json.load(f)
-        if t.get("kernel") and kernel_name and kernel_name in t["kernel"]:
-            return t.get("hbm_bytes_per_launch")
+        with open(os.path.join(ROOT, "profiles", "traffic_r02.json")) as f:
+            entries = json.load(f).get("entries", [])
     except (OSError, ValueError):
-        pass
-    return None
+        return None, None
+    for e in entries:
+        if e.get("kernel_short") == kernel_name and e.get("m") == m and e.get("nnz") == nnz and e.get("dtype") == dtype:
+            return e.get("hbm_bytes_per_launch"), e.get("source")
+    return None, None
 
 
-def main():
-    args = parse()
+# ---------------------------------------------------------------------------------------- one rank
+def run_rank(args):
+    import numpy as np
+    import torch
+    import torch.distributed as dist
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     one_device = bool(os.environ.get("SPMV_BENCH_ONE_DEVICE"))      # rehearsal only: every rank on cuda:0
     dev_index = 0 if (one_device or world == 1) else local_rank
+    assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE {world}"
     if world > 1:
         torch.cuda.set_device(dev_index)
         if args.backend == "nccl":
             dist.init_process_group("nccl", device_id=torch.device("cuda", dev_index))
         else:
             dist.init_process_group("gloo")
-    assert world == args.gpus or world == 1, f"--gpus {args.gpus} but WORLD_SIZE {world}"
+        assert dist.get_world_size() == world
     dev = torch.device("cuda", dev_index)
     torch.cuda.set_device(dev)
 
@@ -175,61 +228,87 @@ def main():
     g = torch.Generator(device=dev)
     g.manual_seed(1234)                     # same full x on every rank, sliced by ownership
     x_full = torch.rand(n_glob, generator=g, device=dev, dtype=dt) * 2 - 1
-    y = torch.full((m_loc,), float("nan"), dtype=dt, device=dev)
-
-    t0 = time.perf_counter()
-    sh = ShardedSpMV(rp, ci, va, n_glob, xchg=args.xchg, method=args.method, overlap=not args.no_overlap)
-    if sh.xchg in ("none", "bcast"):
-        if sh.xchg == "none" or rank == 0:
-            sh.set_full_x(x_full)
-    x_loc = sh.x_local_view()            # x lives where the kernel reads it: exchange() is copy-free
-    x_loc.copy_(x_full[sh.c0:sh.c1])
-    if world > 1:
-        del x_full
-    torch.cuda.synchronize()
-    create_s = time.perf_counter() - t0
-    info = sh.handle.info()                 # split mode: the interior handle (dominant kernel)
+    rdev = dev if (world == 1 or args.backend == "nccl") else torch.device("cpu")
 
     def sync_all():
         if world > 1:
             dist.barrier()
         torch.cuda.synchronize()
 
-    for _ in range(args.warmup):
-        sh.step(x_loc, y)
+    def max_over_ranks(v):
+        if world == 1:
+            return v
+        t = torch.tensor([v], dtype=torch.float64, device=rdev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        return float(t.item())
+
+    def timed(fn, iters):
+        """iters calls of fn between barrier + synchronize pairs; MAX over ranks; seconds.  HIP events on the launch
+        stream bracket the same calls (torch's current stream is the handle's stream: attach_stream)."""
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        sync_all()
+        t0 = time.perf_counter()
+        e0.record()
+        for _ in range(iters):
+            fn()
+        e1.record()
+        sync_all()
+        return max_over_ranks(time.perf_counter() - t0), e0.elapsed_time(e1) / iters
+
     K = args.steps
-    # HIP events around the dominant multiply of every 4th step (an event pair costs the stream ~10 us of
-    # idle time; sampling keeps that out of `value` while the mean launch time still comes from the timed region)
-    sampled = [i for i in range(K) if i % 4 == 0]
-    ev = {i: (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for i in sampled}
-    sync_all()
-    t0 = time.perf_counter()
-    for i in range(K):              # events: torch's current stream == the handle's stream (attach_stream)
-        sh.step(x_loc, y, events=ev.get(i))
-    sync_all()
-    elapsed = time.perf_counter() - t0
-    launch_ms = np.array([ev[i][0].elapsed_time(ev[i][1]) for i in sampled])
+    modes = ["none"] if world == 1 else (["halo", "allgather", "bcast"] if args.xchg == "all" else [args.xchg])
+    results = {}
+    head = None
+    for mode in modes:
+        t0 = time.perf_counter()
+        sh = ShardedSpMV(rp, ci, va, n_glob, xchg=mode, method=args.method, overlap=not args.no_overlap)
+        if sh.xchg in ("none", "bcast") and (sh.xchg == "none" or rank == 0):
+            sh.set_full_x(x_full)
+        x_loc = sh.x_local_view()            # x lives where the kernel reads it: exchange() is copy-free
+        x_loc.copy_(x_full[sh.c0:sh.c1])
+        y = torch.full((m_loc,), float("nan"), dtype=dt, device=dev)
+        torch.cuda.synchronize()
+        create_s = time.perf_counter() - t0
+        info = sh.handle.info()                 # split mode: the interior handle (dominant kernel)
+        for _ in range(args.warmup):
+            sh.step(x_loc, y)
+        elapsed, ev_ms = timed(lambda: sh.step(x_loc, y), K)
+        r = {"ms_per_step": elapsed / K * 1e3, "create_s": create_s, "ghost_columns_rank0": sh.n_ghost, "overlap_split": bool(sh.split),
+             "boundary_rows_rank0": int(sh.bnd_rows.numel()) if sh.split else 0}
+        if world > 1:   # the pieces of a step, each alone (same barrier / MAX-over-ranks protocol, a quarter of the steps)
+            kk = max(5, K // 4)
+            t_x, _ = timed(lambda: sh.exchange_only(x_loc), kk)
+            t_m, mul_ms = timed(lambda: sh.multiply(y), kk)
+            r.update(exchange_only_ms=t_x / kk * 1e3, multiply_only_ms=t_m / kk * 1e3,
+                     exposed_comm_ms=max(0.0, (elapsed / K - t_m / kk) * 1e3))
+        else:
+            mul_ms = ev_ms
+        if head is None:
+            nnz_k = int(sh._A_int[1].numel()) if sh.split else nnz_loc
+            head = dict(sh=None, info=info, mul_ms=mul_ms, nnz_k=nnz_k, n_x=(sh.n_local if sh.split else sh.n_x), xchg=sh.xchg,
+                        x_ext=sh.x_ext.clone() if world == 1 else None, y=y.clone() if world == 1 else None)
+        results[mode] = r
+        sh.close()
+        del sh, y
+        torch.cuda.empty_cache()
+
+    nnz_all = nnz_loc
     if world > 1:
-        rdev = dev if args.backend == "nccl" else torch.device("cpu")
-        tt = torch.tensor([elapsed], dtype=torch.float64, device=rdev)
-        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-        elapsed = float(tt.item())
         nn = torch.tensor([nnz_loc], dtype=torch.int64, device=rdev)
         dist.all_reduce(nn, op=dist.ReduceOp.SUM)
         nnz_all = int(nn.item())
-    else:
-        nnz_all = nnz_loc
 
     if rank == 0:
-        ms_step = elapsed / K * 1e3
-        gflops = 2.0 * nnz_all * K / elapsed / 1e9
-        # per-launch algorithmic bytes of THIS rank's dominant kernel: its x footprint is what it reads
-        # (split mode: the interior kernel covers all rows but the few boundary ones)
-        nnz_k = int(sh._A_int[1].numel()) if sh.split else nnz_loc
-        alg_bytes = 4 * (m_loc + 1) + nnz_k * (4 + s) + s * (sh.n_local if sh.split else sh.n_x) + s * m_loc
-        mean_launch = float(launch_ms.mean())
-        achieved = alg_bytes / (mean_launch * 1e-3) / 1e9
-        traffic = traffic_from_profiles(info["kernel_name"])
+        info, mul_ms = head["info"], head["mul_ms"]
+        first = results[modes[0]]
+        ms_step = first["ms_per_step"]
+        gflops = 2.0 * nnz_all / (ms_step * 1e-3) / 1e9
+        # the dominant kernel of THIS rank: bytes it moves (storage-format model) and the SURVEY 8d algorithmic bytes
+        alg_bytes = 4 * (m_loc + 1) + head["nnz_k"] * (4 + s) + s * head["n_x"] + s * m_loc
+        moved = int(info["stream_bytes"])
+        achieved = moved / (mul_ms * 1e-3) / 1e9
+        achieved_alg = alg_bytes / (mul_ms * 1e-3) / 1e9
+        traffic, traffic_src = traffic_from_profiles(info["kernel_name"], info["m"], info["nnz"], args.dtype)
         out = {
             "metric": "SpMV GFLOP/s (fp64 CSR, y = A x through spmv())" if s == 8 else "SpMV GFLOP/s (fp32 CSR)",
             "value": round(gflops, 2), "unit": "GFLOP/s", "n_gpus": world, "steps": K, "warmup": args.warmup,
@@ -240,31 +319,48 @@ def main():
                             f"{k} nnz/row, {m_loc} rows per GPU",
                 "schedule": f"{api.SPMV_METHODS(args.method).name} -> {info['schedule_name']}"
                             + (f" L={info['lanes_per_row']}" if info['lanes_per_row'] else ""),
-                "x_exchange": sh.xchg, "ghost_columns_rank0": sh.n_ghost, "overlap_split": bool(sh.split),
-                "boundary_rows_rank0": int(sh.bnd_rows.numel()) if sh.split else 0, "vectors": "device-resident x, y",
-                "nnz_total": nnz_all, "create_seconds": round(create_s, 3), "inspect_ms": round(info["inspect_ms"], 3),
+                "x_exchange": head["xchg"], "rccl_ranks": (dist.get_world_size() if world > 1 else 1),
+                "backend": (args.backend if world > 1 else "none"),
+                "ghost_columns_rank0": first["ghost_columns_rank0"], "overlap_split": first["overlap_split"],
+                "boundary_rows_rank0": first["boundary_rows_rank0"], "vectors": "device-resident x, y",
+                "nnz_total": nnz_all, "create_seconds": round(first["create_s"], 3), "inspect_ms": round(info["inspect_ms"], 3),
             },
-            "hbm_gbps_alg": round(achieved, 1),
+            "hbm_gbps": round(achieved, 1),
             "roofline": {
                 "bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
-                "frac": round(achieved / HBM_PEAK_GBPS, 4), "traffic": traffic,
-                "sustained": None if traffic is None else round(traffic / 1e9 / (mean_launch / 1e3), 1),
-                "frac_sustained": None if traffic is None else round(traffic / 1e9 / (mean_launch / 1e3) / HBM_PEAK_GBPS, 4),
-                "kernel": info["kernel_name"], "alg_bytes_per_launch": alg_bytes,
-                "launch_ms_mean": round(mean_launch, 5), "launch_ms_min": round(float(launch_ms.min()), 5), "launches_timed": int(launch_ms.size),
-                "note": "achieved = SURVEY 8d algorithmic bytes (4 B ColIdx + value per nnz, RowPtr, x, y) / launch time; the kernel "
-                        "reads a 2 B/nnz column stream (16-bit LDS slots) instead of ColIdx, so traffic (rocprofv3 PMC, "
-                        "profiles/) is below alg_bytes_per_launch; sustained = traffic / launch time is the HBM rate actually moved",
+                "frac": round(achieved / HBM_PEAK_GBPS, 4), "traffic": traffic, "traffic_source": traffic_src,
+                "kernel": info["kernel_name"], "bytes_moved_per_launch": moved, "x_bytes_per_launch": int(info["x_bytes"]),
+                "alg_bytes_per_launch": alg_bytes, "achieved_alg": round(achieved_alg, 1),
+                "frac_alg_bytes": round(achieved_alg / HBM_PEAK_GBPS, 4),
+                "launch_ms_mean": round(mul_ms, 5), "launches_timed": K if world == 1 else max(5, K // 4),
+                "note": "achieved = bytes the kernel moves (storage-format model spmv_hip_info.stream_bytes, checked against the "
+                        "rocprofv3 counters in profiles/) / mean launch time from HIP events on the launch stream; achieved_alg "
+                        "divides SURVEY 8d's algorithmic bytes (4 B ColIdx per nnz, which this kernel replaces by a 2 B LDS-slot "
+                        "stream) by the same time and is an effective rate, not an HBM rate",
             },
         }
+        if world > 1:
+            out["exchanges"] = {
+                mode: {"gflops": round(2.0 * nnz_all / (r["ms_per_step"] * 1e-3) / 1e9, 2), "ms_per_step": round(r["ms_per_step"], 5),
+                       "exchange_only_ms": round(r["exchange_only_ms"], 5), "multiply_only_ms": round(r["multiply_only_ms"], 5),
+                       "exposed_comm_ms": round(r["exposed_comm_ms"], 5), "ghost_columns_rank0": r["ghost_columns_rank0"],
+                       "overlap_split": r["overlap_split"]}
+                for mode, r in results.items()}
         if world == 1 and not args.no_cpu:
-            out["cpu_baseline"] = cpu_baseline(args, rp, ci, va, sh.x_ext, y, sh.n_x)
+            out["cpu_baseline"] = cpu_baseline(args, rp, ci, va, head["x_ext"], head["y"], head["n_x"])
         print(json.dumps(out), flush=True)
-    sh.close()
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()
+    return 0
+
+
+def main():
+    args = parse()
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        return spawn_ranks(args)
+    return run_rank(args)
 
 
 if __name__ == "__main__":
-    main()
+    sys.exit(main())

@@ -251,6 +251,12 @@ void spmv_create_handle_all_in_one(spmv_Handle_t *Handle, BASIC_INT_TYPE m, BASI
      * does (common.c:157-159) -- but only when option "host_rows" asks for it. */
     if (st->opts.v[SPMV_OPT_HOST_ROWS] == 1 && vectorizedWay == VECTOR_NONE &&
         (Function == Method_Serial || Function == Method_Parallel)) {
+        if (spmv_shim_is_device_ptr(RowPtr) || spmv_shim_is_device_ptr(ColIdx) || spmv_shim_is_device_ptr(Matrix_Val)) {
+            spmv_set_error(SPMV_HIP_E_ARG, "create(host_rows)", "the host row loop needs HOST arrays; device pointers were passed");
+            free(st);
+            h->extraHandle = NULL;
+            return;
+        }
         if (m < 0 || n < 0 || (m > 0 && (!RowPtr || (RowPtr[m] > 0 && (!ColIdx || !Matrix_Val))))) {
             spmv_set_error(SPMV_HIP_E_ARG, "create(host_rows)", "negative size or NULL CSR array");
             free(st);
