@@ -54,36 +54,89 @@ __global__ __launch_bounds__(kBlock) void blk_count_kernel(int m, int R, int K, 
     }
 }
 
-// tot[b] = entries of block b, rounded up to 8 (block regions start 16-byte aligned in every stream)
-__global__ __launch_bounds__(kBlock) void blk_totals_kernel(int B, int K, const int *__restrict__ cnt, int *__restrict__ tot)
+// exclusive prefix sum of one value per lane over the wavefront
+__device__ __forceinline__ long long wave_excl_scan(long long v, int lane, long long *total)
 {
-    const int b = blockIdx.x * kBlock + threadIdx.x;
-    if (b >= B) return;
-    int s = 0;
-    for (int k = 0; k < K; ++k) s += cnt[(long long) b * K + k];
-    tot[b] = (s + 7) & ~7;
+    long long inc = v;
+#pragma unroll
+    for (int o = 1; o < kWave; o <<= 1) {
+        const long long t = __shfl_up(inc, o, kWave);
+        if (lane >= o) inc += t;
+    }
+    *total = __shfl(inc, kWave - 1, kWave);
+    return inc - v;
 }
 
-// cursor[b][k] = first position of cell (b, k); end[b] = one past the block's last real entry
-__global__ __launch_bounds__(kBlock) void blk_cells_kernel(int B, int K, const int *__restrict__ cnt, const long long *__restrict__ start,
-                                                           long long *__restrict__ cursor, long long *__restrict__ end)
+// tot[b] = entries of block b, rounded up to 8 (block regions start 16-byte aligned in every stream); one wave per block
+__global__ __launch_bounds__(kWave) void blk_totals_kernel(int B, int K, const int *__restrict__ cnt, int *__restrict__ tot)
 {
-    const int b = blockIdx.x * kBlock + threadIdx.x;
-    if (b >= B) return;
-    long long p = start[b];
-    for (int k = 0; k < K; ++k) {
+    const int b = blockIdx.x, lane = threadIdx.x;
+    long long s = 0;
+    for (int k = lane; k < K; k += kWave) s += cnt[(long long) b * K + k];
+#pragma unroll
+    for (int o = kWave / 2; o > 0; o >>= 1) s += __shfl_xor(s, o, kWave);
+    if (lane == 0) tot[b] = (int) ((s + 7) & ~7ll);
+}
+
+// cursor[b][k] = first position of cell (b, k); end[b] = one past the block's last real entry; one wave per block,
+// every lane owns a contiguous run of cells
+__global__ __launch_bounds__(kWave) void blk_cells_kernel(int B, int K, const int *__restrict__ cnt, const long long *__restrict__ start,
+                                                          long long *__restrict__ cursor, long long *__restrict__ end)
+{
+    const int b = blockIdx.x, lane = threadIdx.x;
+    const int per = (K + kWave - 1) / kWave, k0 = lane * per, k1 = k0 + per < K ? k0 + per : K;
+    long long mine = 0, total;
+    for (int k = k0; k < k1; ++k) mine += cnt[(long long) b * K + k];
+    long long p = start[b] + wave_excl_scan(mine, lane, &total);
+    for (int k = k0; k < k1; ++k) {
         cursor[(long long) b * K + k] = p;
         p += cnt[(long long) b * K + k];
     }
-    end[b] = p;
+    if (lane == 0) end[b] = start[b] + total;
+}
+
+// Stable rank of the 64 entries of a batch among the entries with the same key: rank = number of lower lanes with
+// my key, cnt = lanes with my key, leader = the lowest of them.  One pass per distinct key of the batch.
+__device__ __forceinline__ void batch_rank(bool valid, int key, int lane, int &rank, int &cnt, int &leader)
+{
+    unsigned long long todo = __ballot(valid);
+    rank = 0; cnt = 0; leader = lane;
+    while (todo) {
+        const int l0 = __ffsll((long long) todo) - 1;
+        const int k0 = __shfl(key, l0, kWave);
+        const bool mine = valid && key == k0;
+        const unsigned long long mk = __ballot(mine);
+        if (mine) {
+            rank = __popcll(mk & ((1ull << lane) - 1ull));
+            cnt = __popcll(mk);
+            leader = l0;
+        }
+        todo &= ~mk;
+    }
+}
+
+// row of CSR position p inside the block whose row pointers are rp[0..nr]: the largest r with rp[r] <= p, searched
+// upwards from `row` (p only grows along a lane)
+__device__ __forceinline__ int row_of_position(const int *rp, int nr, int row, int p)
+{
+    int lo = row, hi = nr; // rp[lo] <= p < rp[hi]
+    while (hi - lo > 1) {
+        const int mid = (lo + hi) >> 1;
+        if (rp[mid] <= p) lo = mid; else hi = mid;
+    }
+    return lo;
 }
 
 // Stable scatter: ONE wavefront per row block walks the block's entries in CSR order, 64 at a time.  Inside a
-// batch, entries of the same cell are ranked by lane (ballot per distinct cell); the first of each cell
-// advances the cell's cursor by the cell's count in this batch.  Only this wave touches the cursors of its
-// block and it does so batch after batch, so position = cell start + number of earlier entries (CSR order)
-// of the same cell: the stored order does not depend on timing.  VALUES_ONLY: re-permute new values into
-// the same positions (spmv_hip_update_values).  Dynamic LDS: (R + 1) ints, the block's row pointers.
+// batch, entries of the same cell are ranked by lane (batch_rank); the first of each cell advances the cell's
+// cursor by the cell's count in this batch.  Only this wave touches the cursors of its block and it does so batch
+// after batch, so position = cell start + number of earlier entries (CSR order) of the same cell: the stored order
+// does not depend on timing.  VALUES_ONLY: re-permute new values into the same positions
+// (spmv_hip_update_values).  Dynamic LDS: (R + 1) ints, the block's row pointers.
+// (Tried and dropped: a pre-pass that sorts the entries of a cell by x cache line, so that neighbouring lanes
+// gather from the same line -- no change on any shape: 2.32 vs 2.31 ms, 1.178 vs 1.176 ms, +40 ms of inspector.
+// The L1/TA path merges lanes of an instruction that hit the same line wherever they sit in the wave, and a cell
+// is only a few lines wide.)
 template <typename T, bool VALUES_ONLY>
 __global__ __launch_bounds__(kWave) void blk_fill_kernel(int m, int R, int K, int wshift, const int *__restrict__ rowptr,
                                                          const int *__restrict__ colidx, const T *__restrict__ val,
@@ -99,34 +152,15 @@ __global__ __launch_bounds__(kWave) void blk_fill_kernel(int m, int R, int K, in
     __syncthreads();
     const int p0 = rp[0], p1 = rp[nr];
     unsigned long long *cur = cursor + (long long) blockIdx.x * K;
-    int row = 0; // rp[row] <= p: p only grows, so the search restarts from the last answer
+    int row = 0;
     for (int q = p0; q < p1; q += kWave) {
         const int p = q + lane;
         const bool valid = p < p1;
         const int c = valid ? colidx[p] : 0;
         const int cell = c >> wshift;
-        if (valid) {
-            int lo = row, hi = nr; // rp[lo] <= p < rp[hi]
-            while (hi - lo > 1) {
-                const int mid = (lo + hi) >> 1;
-                if (rp[mid] <= p) lo = mid; else hi = mid;
-            }
-            row = lo;
-        }
-        unsigned long long todo = __ballot(valid);
-        int rank = 0, cnt = 0, leader = lane;
-        while (todo) { // one pass per distinct cell of the batch
-            const int l0 = __ffsll((long long) todo) - 1;
-            const int k0 = __shfl(cell, l0, kWave);
-            const bool mine = valid && cell == k0;
-            const unsigned long long mk = __ballot(mine);
-            if (mine) {
-                rank = __popcll(mk & ((1ull << lane) - 1ull));
-                cnt = __popcll(mk);
-                leader = l0;
-            }
-            todo &= ~mk;
-        }
+        if (valid) row = row_of_position(rp, nr, row, p);
+        int rank, cnt, leader;
+        batch_rank(valid, cell, lane, rank, cnt, leader);
         unsigned long long base = 0;
         if (valid && rank == 0) base = atomicAdd(&cur[cell], (unsigned long long) cnt); // L2 atomic: coherent batch to batch
         base = __shfl(base, leader, kWave);
@@ -141,59 +175,80 @@ __global__ __launch_bounds__(kWave) void blk_fill_kernel(int m, int R, int K, in
     }
 }
 
+constexpr int kBlkPad = 65536; // zero entries behind the last block: two executor steps of the widest form (256 threads x 4 entries x 16 groups x 2)
+
 __device__ __forceinline__ void lds_add(float *p, float v) { (void) unsafeAtomicAdd(p, v); }
 __device__ __forceinline__ void lds_add(double *p, double v) { (void) unsafeAtomicAdd(p, v); }
 
 // Executor.  Dynamic LDS: R * sizeof(T) bytes (the block's y).  NT = 64: one wavefront per block (deterministic);
-// UN load groups of 16 bytes of values in flight per lane.
-template <typename T, int NT = kWave, int UN = 8>
+// UN load groups of 16 bytes of values in flight per lane, and the NEXT step's stream loads are issued before
+// this step's gathers are waited for.
+//
+// No load sits behind a branch: the streams are padded past the last block (blocked_fill) and a load group that
+// starts past this block's end simply reads the next block's entries, whose products are masked at the LDS add.
+// With "if (p < e) load" the compiler had put a wait after every load -- one gather in flight per wave, 0.8 us
+// per 64 entries, and the kernel looked "L2-request bound" at a rate that was really one memory latency per
+// instruction (round 1: 2.0 ms on config 2 with random columns).
+template <typename T, int EPL>
+struct BlkGroup {
+    T v[EPL];
+    int c[EPL];
+    unsigned r[EPL];
+};
+
+template <typename T, int EPL>
+__device__ __forceinline__ void blk_load(long long p, const T *__restrict__ bval, const int *__restrict__ bcol,
+                                         const unsigned short *__restrict__ brow, BlkGroup<T, EPL> &g)
+{
+    if constexpr (EPL == 2) {
+        const f64x2 q = __builtin_nontemporal_load(reinterpret_cast<const f64x2 *>(bval + p));
+        const i32x2 cc = __builtin_nontemporal_load(reinterpret_cast<const i32x2 *>(bcol + p));
+        const unsigned w = (unsigned) __builtin_nontemporal_load(reinterpret_cast<const int *>(brow + p));
+        g.v[0] = q.x; g.v[1] = q.y; g.c[0] = cc.x; g.c[1] = cc.y; g.r[0] = w & 0xffffu; g.r[1] = w >> 16;
+    } else {
+        const f32x4 q = __builtin_nontemporal_load(reinterpret_cast<const f32x4 *>(bval + p));
+        const i32x4 cc = __builtin_nontemporal_load(reinterpret_cast<const i32x4 *>(bcol + p));
+        const i32x2 w = __builtin_nontemporal_load(reinterpret_cast<const i32x2 *>(brow + p));
+        g.v[0] = q.x; g.v[1] = q.y; g.v[2] = q.z; g.v[3] = q.w;
+        g.c[0] = cc.x; g.c[1] = cc.y; g.c[2] = cc.z; g.c[3] = cc.w;
+        g.r[0] = (unsigned) w.x & 0xffffu; g.r[1] = (unsigned) w.x >> 16; g.r[2] = (unsigned) w.y & 0xffffu; g.r[3] = (unsigned) w.y >> 16;
+    }
+}
+
+template <typename T, int NT = kWave, int UN = 4>
 __global__ __launch_bounds__(NT) void blk_kernel(int m, int R, const long long *__restrict__ start, const long long *__restrict__ end,
-                                                          const T *__restrict__ bval, const int *__restrict__ bcol,
-                                                          const unsigned short *__restrict__ brow, const T *__restrict__ x, T *__restrict__ y)
+                                                 const T *__restrict__ bval, const int *__restrict__ bcol,
+                                                 const unsigned short *__restrict__ brow, const T *__restrict__ x, T *__restrict__ y)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char blk_y_lds[];
     T *ys = reinterpret_cast<T *>(blk_y_lds);
     constexpr int EPL = 16 / (int) sizeof(T); // entries per 16-byte value load
+    constexpr int STEP = NT * EPL;            // entries one load group covers over the workgroup
     for (int i = threadIdx.x; i < R; i += NT) ys[i] = T(0);
     __syncthreads();
     const long long s = start[blockIdx.x], e = end[blockIdx.x];
-    for (long long base = s + (long long) threadIdx.x * EPL; base < e; base += (long long) NT * EPL * UN) {
-        T v[UN][EPL];
-        int c[UN][EPL];
-        unsigned rw[UN][EPL];
+    const long long lane0 = s + (long long) threadIdx.x * EPL;
+    BlkGroup<T, EPL> cur[UN], nxt[UN];
 #pragma unroll
-        for (int u = 0; u < UN; ++u) { // every instruction reads one contiguous run over the wave
-            const long long p = base + (long long) u * NT * EPL;
-            if (p < e) {
-                if constexpr (EPL == 2) {
-                    const f64x2 q = __builtin_nontemporal_load(reinterpret_cast<const f64x2 *>(bval + p));
-                    const i32x2 cc = __builtin_nontemporal_load(reinterpret_cast<const i32x2 *>(bcol + p));
-                    const unsigned w = (unsigned) __builtin_nontemporal_load(reinterpret_cast<const int *>(brow + p));
-                    v[u][0] = q.x; v[u][1] = q.y; c[u][0] = cc.x; c[u][1] = cc.y; rw[u][0] = w & 0xffffu; rw[u][1] = w >> 16;
-                } else {
-                    const f32x4 q = __builtin_nontemporal_load(reinterpret_cast<const f32x4 *>(bval + p));
-                    const i32x4 cc = __builtin_nontemporal_load(reinterpret_cast<const i32x4 *>(bcol + p));
-                    const i32x2 w = __builtin_nontemporal_load(reinterpret_cast<const i32x2 *>(brow + p));
-                    v[u][0] = q.x; v[u][1] = q.y; v[u][2] = q.z; v[u][3] = q.w;
-                    c[u][0] = cc.x; c[u][1] = cc.y; c[u][2] = cc.z; c[u][3] = cc.w;
-                    rw[u][0] = (unsigned) w.x & 0xffffu; rw[u][1] = (unsigned) w.x >> 16; rw[u][2] = (unsigned) w.y & 0xffffu; rw[u][3] = (unsigned) w.y >> 16;
-                }
-            }
-        }
+    for (int u = 0; u < UN; ++u) blk_load<T, EPL>(lane0 + (long long) u * STEP, bval, bcol, brow, cur[u]);
+    for (long long it = s; it < e; it += (long long) STEP * UN) { // wave-uniform trip count
         T xv[UN][EPL];
 #pragma unroll
-        for (int u = 0; u < UN; ++u) {
-            const long long p = base + (long long) u * NT * EPL;
+        for (int u = 0; u < UN; ++u)
 #pragma unroll
-            for (int j = 0; j < EPL; ++j) xv[u][j] = p + j < e ? x[c[u][j]] : T(0); // cached loads: the slab stays in L2
+            for (int j = 0; j < EPL; ++j) xv[u][j] = x[cur[u].c[j]]; // cached loads: the slab stays in L2
+        const long long pn = lane0 + (it - s) + (long long) STEP * UN;
+#pragma unroll
+        for (int u = 0; u < UN; ++u) blk_load<T, EPL>(pn + (long long) u * STEP, bval, bcol, brow, nxt[u]); // next step's stream (padded: always in bounds)
+#pragma unroll
+        for (int u = 0; u < UN; ++u) {
+            const long long p = lane0 + (it - s) + (long long) u * STEP;
+#pragma unroll
+            for (int j = 0; j < EPL; ++j) // unconditional: a masked entry adds 0 to a row of this block (its row number is the next block's or padding's, < R) -- a branch here makes the compiler sink gathers into it and wait for the whole queue
+                lds_add(&ys[cur[u].r[j]], p + j < e ? cur[u].v[j] * xv[u][j] : T(0));
         }
 #pragma unroll
-        for (int u = 0; u < UN; ++u) {
-            const long long p = base + (long long) u * NT * EPL;
-#pragma unroll
-            for (int j = 0; j < EPL; ++j)
-                if (p + j < e) lds_add(&ys[rw[u][j]], v[u][j] * xv[u][j]);
-        }
+        for (int u = 0; u < UN; ++u) cur[u] = nxt[u];
     }
     __syncthreads();
     const long long r0 = (long long) blockIdx.x * R;

@@ -409,17 +409,17 @@ static int blocked_fill(spmv_dev *d, int wshift, bool values_only)
     hipError_t e = hipMemsetAsync(cnt, 0, sizeof(int) * cells, d->stream);
     blk_count_kernel<<<grid_for(d->m, kBlock / 16, d->cus * 16), kBlock, 0, d->stream>>>(d->m, R, K, wshift, d->rowptr, d->colidx, cnt);
     if (!values_only) {
-        blk_totals_kernel<<<grid_for(B, kBlock, INT_MAX), kBlock, 0, d->stream>>>(B, K, cnt, tot);
+        blk_totals_kernel<<<B, kWave, 0, d->stream>>>(B, K, cnt, tot);
         scan_i32_to_i64_kernel<<<1, kBlock, 0, d->stream>>>(B, tot, d->blk_start);
     }
-    blk_cells_kernel<<<grid_for(B, kBlock, INT_MAX), kBlock, 0, d->stream>>>(B, K, cnt, d->blk_start, cursor, d->blk_end);
+    blk_cells_kernel<<<B, kWave, 0, d->stream>>>(B, K, cnt, d->blk_start, cursor, d->blk_end);
     if (e == hipSuccess) e = hipGetLastError();
     if (!values_only) {
         long long total = 0;
         if (e == hipSuccess) e = hipMemcpyAsync(&total, d->blk_start + B, sizeof(long long), hipMemcpyDeviceToHost, d->stream);
         if (e == hipSuccess) e = hipStreamSynchronize(d->stream);
         if (e != hipSuccess) { cleanup(); return fail(SPMV_HIP_E_RUNTIME, "block inspector: %s", hipGetErrorString(e)); }
-        const size_t slots = (size_t) total + 4096; // the last load groups of a block may start past its end (guarded) -- keep them in bounds
+        const size_t slots = (size_t) total + kBlkPad; // the executor loads up to two steps past a block's end, unguarded: keep that in bounds
         int rc = dev_alloc(d, &d->blk_val, sizeof(T) * slots, true);
         if (!rc) rc = dev_alloc(d, (void **) &d->blk_col, sizeof(int) * slots, true);
         if (!rc) rc = dev_alloc(d, (void **) &d->blk_row, sizeof(unsigned short) * slots, true);
@@ -547,7 +547,7 @@ static int account_stream_bytes(spmv_dev *d)
     Traffic t;
     int rc = SPMV_HIP_OK;
     if (d->blk_on) {
-        t.bytes = (d->blk_slots - 4096) * (s + 4 + 2) + 16ll * d->blk_B + s * m;
+        t.bytes = (d->blk_slots - kBlkPad) * (s + 4 + 2) + 16ll * d->blk_B + s * m;
         t.gathers_global = true;
     } else {
         switch (d->plan.sched) {

@@ -111,8 +111,10 @@ static int autotune_vector(spmv_dev *d)
 }
 
 // Row blocks x column slabs (kernels/blocked.hpp): one single-wave workgroup per row block.  Variants for A/B
-// runs: 20 / 22 = 4 / 16 load groups in flight per lane (default 8); 23 = the first-round 256-thread workgroup
-// per block, whose waves race on the rows (not bit-reproducible on inexact data).
+// runs: 19 / 21 / 22 = 2 / 8 / 16 load groups in flight per lane (default 4: 2.14 vs 2.33 ms on config 2 with random
+// columns, 0.83 vs 0.94 ms on the Orkut-style R-MAT stand-in; 8 wins by 6 % on Orkut-style with uniform columns);
+// 23 = the first-round 256-thread workgroup per block, whose waves race on the rows (not bit-reproducible on
+// inexact data).
 template <typename T>
 static void launch_blocked(spmv_dev *d, const T *x, T *y)
 {
@@ -124,10 +126,12 @@ static void launch_blocked(spmv_dev *d, const T *x, T *y)
                                                                 d->blk_col, d->blk_row, x, y);                                   \
     } while (0)
     switch (d->plan.variant) {
+    case 19: SPMV_BLK_LAUNCH(kWave, 2); break;
     case 20: SPMV_BLK_LAUNCH(kWave, 4); break;
+    case 21: SPMV_BLK_LAUNCH(kWave, 8); break;
     case 22: SPMV_BLK_LAUNCH(kWave, 16); break;
     case 23: SPMV_BLK_LAUNCH(256, 4); break;
-    default: SPMV_BLK_LAUNCH(kWave, 8); break;
+    default: SPMV_BLK_LAUNCH(kWave, 4); break;
     }
 #undef SPMV_BLK_LAUNCH
 }

@@ -446,7 +446,7 @@ extern "C" int spmv_shim_info(const spmv_dev *d, spmv_hip_info *o)
     o->cache_blocked = d->blk_on ? 1 : 0;
     o->stream_bytes = d->stream_bytes;
     o->x_bytes = d->x_bytes;
-    if (d->blk_on) { o->stored_nnz = d->blk_slots; o->x_groups = d->x_groups_seen; o->x_groups_staged = 0; }
+    if (d->blk_on) { o->stored_nnz = d->blk_slots - kBlkPad; o->x_groups = d->x_groups_seen; o->x_groups_staged = 0; }
     if (!d->blk_on) switch (d->plan.sched) {
     case SPMV_SCHED_CSR_VECTOR:
     case SPMV_SCHED_ROWBLOCK: o->x_groups = d->vt_tiles; o->x_groups_staged = d->vt_staged; break;

@@ -495,13 +495,11 @@ def test_update_values_refreshes_every_private_layout(name, method, blocked):
     sub-matrix, blocked streams) without re-inspection.  Result = the oracle on the new values."""
     csr, x, _ = load_golden(name)
     val = csr.val.copy()
-    if blocked:
-        api.set_option("cache_block", 2)
+    api.set_option("cache_block", 2 if blocked else 1)
+    h = None
     try:
         h = api.Handle(csr.m, csr.n, csr.rowptr, csr.colidx, val, method)
-    finally:
-        api.set_option("cache_block", 1)
-    try:
+        assert h.info()["cache_blocked"] == (1 if blocked and method not in (M.Method_Serial, M.Method_SellCSigma) else 0)
         y0 = h.spmv(x, np.full(csr.m, np.nan, dtype=val.dtype))
         assert np.array_equal(y0, run_host(csr, x, method)[0])
         stale = val.copy()
@@ -516,7 +514,9 @@ def test_update_values_refreshes_every_private_layout(name, method, blocked):
         h.update_values(stale)                                  # another array of the same pattern
         assert np.array_equal(h.spmv(x, np.empty(csr.m, dtype=val.dtype)), y0)
     finally:
-        h.close()
+        api.set_option("cache_block", 1)
+        if h is not None:
+            h.close()
 
 
 @pytest.mark.parametrize("devptr", [False, True])

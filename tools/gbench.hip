@@ -1,0 +1,185 @@
+// gbench.hip -- microbenchmark behind DESIGN.md 3.7: how many scattered 8-byte (or 4-byte) reads per second
+// can the chip serve from a region that is L2-resident / Infinity-Cache-resident, per load flavour?
+//   build: hipcc -O3 --offload-arch=gfx950 tools/gbench.hip -o build/gbench      run: build/gbench
+// Every lane reads G random elements per step from a table of `bytes` (indices from a hash, no index stream),
+// 16 loads in flight per lane; all waves use the same table, so after the first touch an XCD's L2 holds it
+// (tables <= 2 MiB) or the Infinity Cache does (tables of 64 MiB).
+#include <hip/hip_runtime.h>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+
+#define CK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { printf("%s -> %s\n", #x, hipGetErrorString(e_)); exit(1); } } while (0)
+
+__device__ __forceinline__ unsigned mix(unsigned h) { h ^= h >> 16; h *= 0x7feb352du; h ^= h >> 15; h *= 0x846ca68bu; h ^= h >> 16; return h; }
+
+template <int MODE> __device__ __forceinline__ void ld8(double &v, const double *p)
+{
+    if constexpr (MODE == 0) asm volatile("global_load_dwordx2 %0, %1, off" : "=v"(v) : "v"(p) : "memory");
+    else if constexpr (MODE == 1) asm volatile("global_load_dwordx2 %0, %1, off nt" : "=v"(v) : "v"(p) : "memory");
+    else if constexpr (MODE == 2) asm volatile("global_load_dwordx2 %0, %1, off sc0" : "=v"(v) : "v"(p) : "memory");
+    else if constexpr (MODE == 3) asm volatile("global_load_dwordx2 %0, %1, off sc1" : "=v"(v) : "v"(p) : "memory");
+    else asm volatile("global_load_dwordx2 %0, %1, off sc0 sc1" : "=v"(v) : "v"(p) : "memory");
+}
+
+// sorted != 0: the 64 lanes of an instruction read from `sorted` consecutive 128-byte lines... (lane-adjacent elements share lines)
+// cluster > 0: `cluster` adjacent lanes read consecutive elements of one aligned run; cluster < 0: -cluster adjacent lanes read
+// the same 128-byte line at RANDOM offsets inside it (what a line-sorted gather stream looks like)
+template <int MODE, int U>
+__global__ __launch_bounds__(64) void gather8(const double *__restrict__ tab, unsigned mask, int steps, int cluster, double *__restrict__ out)
+{
+    if (cluster < 0) {
+        const unsigned gid = blockIdx.x * 64 + threadIdx.x, cl = (unsigned) -cluster;
+        double acc = 0;
+        for (int s = 0; s < steps; ++s) {
+            double v[U];
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                const unsigned h = mix((gid / cl) * 0x9e3779b9u + (unsigned) (s * U + u) * 0x85ebca6bu);
+                const unsigned off = mix(gid * 0x2545f491u + (unsigned) (s * U + u)) & 15u;
+                ld8<MODE>(v[u], tab + (((h & mask) & ~15u) | off));
+            }
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#pragma unroll
+            for (int u = 0; u < U; ++u) { asm volatile("" : "+v"(v[u])); acc += v[u]; }
+        }
+        if (acc == 1.2345) out[gid] = acc;
+        return;
+    }
+    const unsigned gid = blockIdx.x * 64 + threadIdx.x;
+    double acc = 0;
+    for (int s = 0; s < steps; ++s) {
+        double v[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            unsigned h = mix((gid / cluster) * 0x9e3779b9u + (unsigned) (s * U + u) * 0x85ebca6bu);
+            const unsigned idx = ((h & mask) & ~(unsigned) (cluster - 1)) | (gid & (cluster - 1)); // `cluster` adjacent lanes share one aligned run
+            ld8<MODE>(v[u], tab + idx);
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#pragma unroll
+        for (int u = 0; u < U; ++u) { asm volatile("" : "+v"(v[u])); acc += v[u]; }
+    }
+    if (acc == 1.2345) out[gid] = acc;
+}
+
+template <int U>
+__global__ __launch_bounds__(64) void gather4(const float *__restrict__ tab, unsigned mask, int steps, float *__restrict__ out)
+{
+    const unsigned gid = blockIdx.x * 64 + threadIdx.x;
+    float acc = 0;
+    for (int s = 0; s < steps; ++s) {
+        float v[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const unsigned idx = mix(gid * 0x9e3779b9u + (unsigned) (s * U + u) * 0x85ebca6bu) & mask;
+            asm volatile("global_load_dword %0, %1, off" : "=v"(v[u]) : "v"(tab + idx) : "memory");
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#pragma unroll
+        for (int u = 0; u < U; ++u) { asm volatile("" : "+v"(v[u])); acc += v[u]; }
+    }
+    if (acc == 1.2345f) out[gid] = acc;
+}
+
+// the blocked executor's mix: per gather 14 bytes of nt stream (8 + 4 + 2) next to the scattered read
+template <int U>
+__global__ __launch_bounds__(64) void stream_gather(const double *__restrict__ tab, unsigned mask, int steps, const double *__restrict__ sv,
+                                                    const int *__restrict__ sc, const unsigned short *__restrict__ sr, int do_gather, int do_stream,
+                                                    double *__restrict__ out)
+{
+    const unsigned gid = blockIdx.x * 64 + threadIdx.x;
+    const size_t base = (size_t) blockIdx.x * steps * U * 128 + threadIdx.x * 2; // two entries per lane and group, like the executor
+    double acc = 0;
+    for (int s = 0; s < steps; ++s) {
+        double v[U];
+        double a[U][2]; int c[U][2]; int r[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            if (do_stream) {
+                const size_t p = base + ((size_t) s * U + u) * 128;
+                typedef double d2_t __attribute__((ext_vector_type(2)));
+                typedef int i2_t __attribute__((ext_vector_type(2)));
+                const d2_t q = __builtin_nontemporal_load(reinterpret_cast<const d2_t *>(sv + p));
+                const i2_t cc = __builtin_nontemporal_load(reinterpret_cast<const i2_t *>(sc + p));
+                r[u] = __builtin_nontemporal_load(reinterpret_cast<const int *>(sr + p));
+                a[u][0] = q.x; a[u][1] = q.y; c[u][0] = cc.x; c[u][1] = cc.y;
+            } else { a[u][0] = a[u][1] = 1; c[u][0] = c[u][1] = r[u] = 0; }
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const unsigned idx = mix(gid * 0x9e3779b9u + (unsigned) (s * U + u) * 0x85ebca6bu) & mask;
+            if (do_gather) v[u] = tab[idx + (c[u][0] & 1)]; else v[u] = 1;
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u) acc += v[u] * (a[u][0] + a[u][1]) + (double) (c[u][1] + r[u]);
+    }
+    if (acc == 1.2345) out[gid] = acc;
+}
+
+template <typename F> static float time_ms(F f, int reps)
+{
+    hipEvent_t a, b;
+    CK(hipEventCreate(&a)); CK(hipEventCreate(&b));
+    f();
+    CK(hipDeviceSynchronize());
+    float best = 1e30f;
+    for (int r = 0; r < reps; ++r) {
+        CK(hipEventRecord(a));
+        f();
+        CK(hipEventRecord(b));
+        CK(hipEventSynchronize(b));
+        float ms; CK(hipEventElapsedTime(&ms, a, b));
+        if (ms < best) best = ms;
+    }
+    return best;
+}
+
+int main()
+{
+    const size_t maxb = 256u << 20;
+    double *tab, *out;
+    CK(hipMalloc(&tab, maxb));
+    CK(hipMemset(tab, 0, maxb));
+    CK(hipMalloc(&out, 64u << 20));
+    const int steps = 64;
+    constexpr int U = 16;
+    for (int wpc : {2, 8}) {              // waves per CU
+        const int grid = 256 * wpc;
+        const double lanes = (double) grid * 64 * steps * U;
+        for (size_t bytes : {(size_t) 1 << 20, (size_t) 2 << 20, (size_t) 64 << 20}) {
+            const unsigned mask = (unsigned) (bytes / 8 - 1);
+            printf("waves/CU %2d table %3zu MiB:", wpc, bytes >> 20);
+            float t;
+            t = time_ms([&] { gather8<0, U><<<grid, 64>>>(tab, mask, steps, 1, out); }, 3); printf("  plain %.3g/s", lanes / t * 1e3);
+            t = time_ms([&] { gather8<1, U><<<grid, 64>>>(tab, mask, steps, 1, out); }, 3); printf("  nt %.3g/s", lanes / t * 1e3);
+            t = time_ms([&] { gather8<2, U><<<grid, 64>>>(tab, mask, steps, 1, out); }, 3); printf("  sc0 %.3g/s", lanes / t * 1e3);
+            t = time_ms([&] { gather8<3, U><<<grid, 64>>>(tab, mask, steps, 1, out); }, 3); printf("  sc1 %.3g/s", lanes / t * 1e3);
+            t = time_ms([&] { gather8<4, U><<<grid, 64>>>(tab, mask, steps, 1, out); }, 3); printf("  sc0sc1 %.3g/s", lanes / t * 1e3);
+            t = time_ms([&] { gather4<U><<<grid, 64>>>((const float *) tab, (unsigned) (bytes / 4 - 1), steps, (float *) out); }, 3); printf("  f32 %.3g/s", lanes / t * 1e3);
+            for (int cl : {2, 4, 8, 16}) {
+                t = time_ms([&] { gather8<0, U><<<grid, 64>>>(tab, mask, steps, cl, out); }, 3); printf("  cl%d %.3g/s", cl, lanes / t * 1e3);
+            }
+            for (int cl : {2, 4, 8}) {
+                t = time_ms([&] { gather8<0, U><<<grid, 64>>>(tab, mask, steps, -cl, out); }, 3); printf("  sameline%d %.3g/s", cl, lanes / t * 1e3);
+            }
+            printf("\n");
+        }
+    }
+    { // stream + gather: is the sum of the two what the chip does, or the max?
+        const int wpc = 2, grid = 256 * wpc, st = 256;
+        const size_t entries = (size_t) grid * st * 8 * 128;
+        double *sv; int *sc; unsigned short *sr;
+        CK(hipMalloc(&sv, entries * 8 + 4096)); CK(hipMalloc(&sc, entries * 4 + 4096)); CK(hipMalloc(&sr, entries * 2 + 4096));
+        CK(hipMemset(sv, 0, entries * 8)); CK(hipMemset(sc, 0, entries * 4)); CK(hipMemset(sr, 0, entries * 2));
+        const unsigned mask = (unsigned) ((2u << 20) / 8 - 1) & ~1u;
+        const double gathers = (double) grid * 64 * st * 8;
+        for (int mode = 0; mode < 3; ++mode) {
+            const int g = mode != 1, s = mode != 0;
+            float t = time_ms([&] { stream_gather<8><<<grid, 64>>>(tab, mask, st, sv, sc, sr, g, s, out); }, 3);
+            printf("stream_gather %s%s: %.3f ms for %.3g gathers (%.3g/s) and %.2f GB of stream (%.0f GB/s)\n", g ? "gather " : "", s ? "stream" : "", t, gathers,
+                   g ? gathers / t * 1e3 : 0.0, s ? entries * 14 / 1e9 : 0.0, s ? entries * 14 / t / 1e6 : 0.0);
+        }
+    }
+    return 0;
+}
