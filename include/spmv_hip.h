@@ -125,6 +125,25 @@ typedef struct spmv_hip_info {
 } spmv_hip_info;
 int spmv_hip_get_info(spmv_Handle_t handle, spmv_hip_info *out);
 
+/* ---- multi-GPU: row blocks over the GPUs of ONE process (option "gpus"; BASELINE config 5) --------------
+ * A handle created while option "gpus" = G > 0 splits the matrix into min(G, visible devices) equal-nnz row blocks, one
+ * per device, each with its own schedule, stream, full-length x buffer and y block (the GPU analogue of the reference's
+ * NUMA experiment, src/samples/numa.c:277-304).  spmv() keeps its signature and meaning: X and Y are FULL vectors (host
+ * or device pointers); per call X is distributed (option "x_exchange": 0 = every device receives its slice and the
+ * slices are all-gathered over xGMI with RCCL, 2 = X goes to device 0 and is broadcast -- north_star's literal form),
+ * every device multiplies its block, and the y blocks are collected into Y.
+ * A solver loop keeps the vectors DISTRIBUTED instead: write this step's x into the devices' slices, call
+ * spmv_hip_multi_step (exchange + multiply, nothing crosses PCIe), read y from the devices' blocks.
+ * RCCL is dlopen'ed only when G > 1; without it the exchange uses peer-to-peer copies. */
+int spmv_hip_multi_gpus(spmv_Handle_t handle);        /* devices the handle spans; 0 for an ordinary handle */
+int spmv_hip_multi_uses_rccl(spmv_Handle_t handle);   /* 1: the x exchange runs through RCCL communicators */
+/* Device `gpu`'s slice of x (x_count elements from global index x_first, device memory on *device, inside that device's
+ * full-length copy) and its block of y (rows y_first ... y_first + y_count - 1).  Any out-pointer may be NULL. */
+int spmv_hip_multi_slices(spmv_Handle_t handle, int gpu, void **x_slice, long long *x_first, long long *x_count,
+                          void **y_block, long long *y_first, long long *y_count, int *device);
+/* Exchange the x slices between the devices and multiply; y stays distributed.  Synchronous. */
+int spmv_hip_multi_step(spmv_Handle_t handle);
+
 /* ---- measurement -------------------------------------------------------------------------- */
 /* `warmup` untimed + `iters` timed spmv() launches back to back on the handle's stream, each
  * timed launch bracketed by hipEvents recorded on that stream; ms_out[i] (may be NULL) receives

@@ -90,6 +90,11 @@ FUNCTIONS = {
     "spmv_hip_clear_thread_options": (None, []),
     "spmv_hip_get_handle_option": (C.c_long, [spmv_Handle_t, C.c_char_p]),
     "spmv_hip_update_values": (C.c_int, [spmv_Handle_t, _V]),
+    "spmv_hip_multi_gpus": (C.c_int, [spmv_Handle_t]),
+    "spmv_hip_multi_uses_rccl": (C.c_int, [spmv_Handle_t]),
+    "spmv_hip_multi_slices": (C.c_int, [spmv_Handle_t, C.c_int, C.POINTER(_V), C.POINTER(C.c_longlong), C.POINTER(C.c_longlong),
+                                        C.POINTER(_V), C.POINTER(C.c_longlong), C.POINTER(C.c_longlong), _I]),
+    "spmv_hip_multi_step": (C.c_int, [spmv_Handle_t]),
     "spmv_hip_get_info": (C.c_int, [spmv_Handle_t, C.POINTER(spmv_hip_info)]),
     "spmv_hip_time_launches": (C.c_double, [spmv_Handle_t, _V, _V, C.c_int, C.c_int, C.POINTER(C.c_float)]),
     # include/spmv_io.h (host only)
@@ -347,6 +352,22 @@ class Handle:
 
     def option(self, key):
         return load().spmv_hip_get_handle_option(self.h, key.encode())
+
+    # multi-GPU handles (option "gpus")
+    def multi_gpus(self):
+        return load().spmv_hip_multi_gpus(self.h)
+
+    def multi_slices(self, gpu):
+        """-> dict(x_ptr, x_first, x_count, y_ptr, y_first, y_count, device) of device `gpu`'s slice of x and block of y."""
+        xs, ys = _V(), _V()
+        xf, xc, yf, yc, dv = C.c_longlong(), C.c_longlong(), C.c_longlong(), C.c_longlong(), C.c_int()
+        if load().spmv_hip_multi_slices(self.h, gpu, C.byref(xs), C.byref(xf), C.byref(xc), C.byref(ys), C.byref(yf), C.byref(yc), C.byref(dv)) != 0:
+            _raise_if_error("spmv_hip_multi_slices")
+        return dict(x_ptr=xs.value, x_first=xf.value, x_count=xc.value, y_ptr=ys.value, y_first=yf.value, y_count=yc.value, device=dv.value)
+
+    def multi_step(self):
+        if load().spmv_hip_multi_step(self.h) != 0:
+            _raise_if_error("spmv_hip_multi_step")
 
     def attach_stream(self, stream_ptr, async_=True):
         set_stream(self.h, stream_ptr, async_)

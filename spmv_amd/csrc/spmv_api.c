@@ -84,6 +84,7 @@ static void state_free(spmv_Handle_t h)
     spmv_hip_state *st = (spmv_hip_state *) h->extraHandle;
     if (st) {
         if (st->dev) spmv_shim_matrix_destroy(st->dev);
+        if (st->multi) spmv_shim_multi_destroy(st->multi);
         free(st);
         h->extraHandle = NULL;
     }
@@ -139,6 +140,47 @@ out:
     return rc;
 }
 
+/* Option "gpus" > 0: row blocks over the GPUs of this process (shim/multi.hpp; BASELINE config 5, SURVEY 8e, the GPU
+ * analogue of numa.c:277-304).  Every shard is planned from ITS row statistics and built on its device. */
+static int state_build_multi(spmv_Handle_t h, spmv_hip_state *st, int m, int n, const int *RowPtr,
+                             const int *ColIdx, const void *Val)
+{
+    SPMV_METHODS actual = st->requested;
+    int g, G, rc;
+    if (st->multi) { spmv_shim_multi_destroy(st->multi); st->multi = NULL; }
+    index_free(h);
+    rc = spmv_shim_multi_create(&st->multi, (int) st->opts.v[SPMV_OPT_GPUS], (int) st->opts.v[SPMV_OPT_X_EXCHANGE], m, n, RowPtr, ColIdx, Val,
+                                (size_t) h->data_size);
+    if (rc) { spmv_set_error(rc, "create/multi", spmv_shim_error_text()); return rc; }
+    G = spmv_shim_multi_count(st->multi);
+    for (g = 0; g < G; ++g) {
+        spmv_dev *dev = spmv_shim_multi_shard(st->multi, g);
+        spmv_stats stats;
+        spmv_plan plan;
+        SPMV_METHODS a = st->requested;
+        rc = spmv_shim_matrix_stats(dev, &stats);
+        if (!rc) {
+            spmv_plan_choose(st->requested, &stats, (size_t) h->data_size, &st->opts, &plan, &a, 1);
+            rc = spmv_shim_build(dev, &plan);
+        }
+        if (rc) {
+            spmv_set_error(rc, "create/multi shard", spmv_shim_error_text());
+            spmv_shim_multi_destroy(st->multi);
+            st->multi = NULL;
+            return rc;
+        }
+        if (g == 0) { actual = a; st->plan = plan; }
+    }
+    st->m = m;
+    st->n = n;
+    st->val_sum_valid = 0;
+    h->spmvMethod = actual; /* shard 0's: the shards of a skewed matrix may differ (Balanced vs Balanced2) */
+    h->RowPtr = (BASIC_INT_TYPE *) RowPtr;
+    h->ColIdx = (BASIC_INT_TYPE *) ColIdx;
+    h->Matrix_Val = (void *) Val;
+    return SPMV_HIP_OK;
+}
+
 /* Upload + plan + inspect.  Used by create and by spmv() when it is handed another matrix. */
 static int state_build(spmv_Handle_t h, spmv_hip_state *st, int m, int n, const int *RowPtr,
                        const int *ColIdx, const void *Val)
@@ -146,6 +188,7 @@ static int state_build(spmv_Handle_t h, spmv_hip_state *st, int m, int n, const 
     spmv_stats stats;
     SPMV_METHODS actual = st->requested;
     int rc;
+    if (st->opts.v[SPMV_OPT_GPUS] > 0) return state_build_multi(h, st, m, n, RowPtr, ColIdx, Val);
     if (st->dev) { spmv_shim_matrix_destroy(st->dev); st->dev = NULL; }
     if (m < 0 || n < 0 || (m > 0 && !RowPtr)) {
         spmv_set_error(SPMV_HIP_E_ARG, "create", "negative size or NULL RowPtr");
@@ -294,7 +337,7 @@ void spmv(const spmv_Handle_t handle, BASIC_INT_TYPE m, const BASIC_INT_TYPE *Ro
                        handle->spmvMethod == Method_Parallel ? (int) (handle->nthreads > 0 ? handle->nthreads : 1) : 1);
         return;
     }
-    if (!st || !st->dev) {
+    if (!st || (!st->dev && !st->multi)) {
         spmv_set_error(SPMV_HIP_E_NOSTATE, "spmv", "handle has no device state (create failed?)");
         return;
     }
@@ -319,7 +362,7 @@ void spmv(const spmv_Handle_t handle, BASIC_INT_TYPE m, const BASIC_INT_TYPE *Ro
             st->val_sum = sum;
         }
     }
-    rc = spmv_shim_run(st->dev, X, Y);
+    rc = st->multi ? spmv_shim_multi_run(st->multi, X, Y) : spmv_shim_run(st->dev, X, Y);
     if (rc) spmv_set_error(rc, "spmv", spmv_shim_error_text());
 }
 
@@ -327,11 +370,59 @@ void spmv(const spmv_Handle_t handle, BASIC_INT_TYPE m, const BASIC_INT_TYPE *Ro
 static spmv_hip_state *state_of(spmv_Handle_t h, const char *where)
 {
     spmv_hip_state *st = h ? (spmv_hip_state *) h->extraHandle : NULL;
+    if (st && st->multi && !st->dev) {
+        spmv_set_error(SPMV_HIP_E_ARG, where, "not available on a multi-GPU handle (option \"gpus\"): it owns one stream per device");
+        return NULL;
+    }
     if (!st || !st->dev) {
         spmv_set_error(SPMV_HIP_E_NOSTATE, where, "handle has no device state");
         return NULL;
     }
     return st;
+}
+
+static spmv_multi *multi_of(spmv_Handle_t h, const char *where)
+{
+    spmv_hip_state *st = h ? (spmv_hip_state *) h->extraHandle : NULL;
+    if (!st || !st->multi) {
+        spmv_set_error(SPMV_HIP_E_NOSTATE, where, "not a multi-GPU handle (create it with option \"gpus\" > 0)");
+        return NULL;
+    }
+    return st->multi;
+}
+
+/* Number of GPUs the handle's row blocks live on (0: not a multi-GPU handle). */
+int spmv_hip_multi_gpus(spmv_Handle_t h)
+{
+    spmv_hip_state *st = h ? (spmv_hip_state *) h->extraHandle : NULL;
+    return st && st->multi ? spmv_shim_multi_count(st->multi) : 0;
+}
+
+int spmv_hip_multi_uses_rccl(spmv_Handle_t h)
+{
+    spmv_hip_state *st = h ? (spmv_hip_state *) h->extraHandle : NULL;
+    return st && st->multi ? spmv_shim_multi_uses_rccl(st->multi) : 0;
+}
+
+int spmv_hip_multi_slices(spmv_Handle_t h, int gpu, void **x_slice, long long *x_first, long long *x_count,
+                          void **y_block, long long *y_first, long long *y_count, int *device)
+{
+    spmv_multi *mt = multi_of(h, "multi_slices");
+    int rc;
+    if (!mt) return SPMV_HIP_E_NOSTATE;
+    rc = spmv_shim_multi_slices(mt, gpu, x_slice, x_first, x_count, y_block, y_first, y_count, device);
+    if (rc) spmv_set_error(rc, "multi_slices", spmv_shim_error_text());
+    return rc;
+}
+
+int spmv_hip_multi_step(spmv_Handle_t h)
+{
+    spmv_multi *mt = multi_of(h, "multi_step");
+    int rc;
+    if (!mt) return SPMV_HIP_E_NOSTATE;
+    rc = spmv_shim_multi_step(mt);
+    if (rc) spmv_set_error(rc, "multi_step", spmv_shim_error_text());
+    return rc;
 }
 
 int spmv_hip_set_stream(spmv_Handle_t h, void *stream)
@@ -379,6 +470,11 @@ int spmv_hip_get_info(spmv_Handle_t h, spmv_hip_info *out)
         out->kernel_name = "spmv_host_rows";
         return SPMV_HIP_OK;
     }
+    if (st && st->multi && out) { /* shard 0 speaks for the handle; the totals are the whole matrix's */
+        int rc = spmv_shim_info(spmv_shim_multi_shard(st->multi, 0), out);
+        if (rc == SPMV_HIP_OK) { out->m = st->m; out->n = st->n; out->nnz = spmv_shim_multi_nnz(st->multi); }
+        return rc;
+    }
     st = state_of(h, "get_info");
     if (!st || !out) return SPMV_HIP_E_NOSTATE;
     return spmv_shim_info(st->dev, out);
@@ -394,6 +490,13 @@ int spmv_hip_update_values(spmv_Handle_t h, const void *Val)
     spmv_hip_state *st = h ? (spmv_hip_state *) h->extraHandle : NULL;
     int rc;
     if (st && st->host_rows) { h->Matrix_Val = (void *) Val; return SPMV_HIP_OK; } /* borrowed arrays: nothing resident */
+    if (st && st->multi) {
+        if (!Val) { spmv_set_error(SPMV_HIP_E_ARG, "update_values", "Val is NULL"); return SPMV_HIP_E_ARG; }
+        rc = spmv_shim_multi_update_values(st->multi, Val);
+        if (rc) { spmv_set_error(rc, "update_values", spmv_shim_error_text()); return rc; }
+        h->Matrix_Val = (void *) Val;
+        return SPMV_HIP_OK;
+    }
     st = state_of(h, "update_values");
     if (!st) return SPMV_HIP_E_NOSTATE;
     if (!Val) { spmv_set_error(SPMV_HIP_E_ARG, "update_values", "Val is NULL"); return SPMV_HIP_E_ARG; }

@@ -83,6 +83,26 @@ int spmv_shim_update_values(spmv_dev *d, const void *val);
 /* Order-independent 64-bit checksum (sum of the 32-bit words) of nnz values at `val` (host or device). */
 int spmv_shim_checksum(spmv_dev *d, const void *val, unsigned long long *out);
 
+/* ---- row blocks over several GPUs of this process (shim/multi.hpp; option "gpus") ---- */
+typedef struct spmv_multi spmv_multi;
+/* Split the matrix into min(gpus, visible devices) equal-nnz row blocks, one shard (spmv_dev) per device, each with its
+ * x buffer, y block and stream; xchg: 0 allgather, 2 broadcast.  The caller then plans + builds every shard. */
+int spmv_shim_multi_create(spmv_multi **out, int gpus, int xchg, int m, int n, const int *rowptr, const int *colidx,
+                           const void *val, size_t value_size);
+int spmv_shim_multi_count(const spmv_multi *mt);
+int spmv_shim_multi_uses_rccl(const spmv_multi *mt);
+long long spmv_shim_multi_nnz(const spmv_multi *mt);
+spmv_dev *spmv_shim_multi_shard(spmv_multi *mt, int g);
+/* y = A x with full-length host or device vectors: upload / exchange / multiply / collect */
+int spmv_shim_multi_run(spmv_multi *mt, const void *x, void *y);
+/* distributed vectors: shard g's slice of x (inside its full-length copy) and its block of y, on device *device */
+int spmv_shim_multi_slices(spmv_multi *mt, int g, void **x_slice, long long *x_first, long long *x_count, void **y_block,
+                           long long *y_first, long long *y_count, int *device);
+/* exchange the x slices between the devices and multiply; y stays in the shards' blocks */
+int spmv_shim_multi_step(spmv_multi *mt);
+int spmv_shim_multi_update_values(spmv_multi *mt, const void *val);
+void spmv_shim_multi_destroy(spmv_multi *mt);
+
 #if defined(__cplusplus)
 }
 #endif

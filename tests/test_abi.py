@@ -99,6 +99,20 @@ def test_fails_loudly_without_a_device(lib, monkeypatch):
     api.spmv_destory_handle(h)
 
 
+def test_multi_gpu_option_fails_loudly_without_a_device(lib, monkeypatch):
+    if lib.spmv_hip_device_count() > 0:
+        pytest.skip("a GPU is visible")
+    monkeypatch.setenv("SPMV_HIP_QUIET", "1")
+    csr = synth.banded(64, 64)
+    api.set_thread_option("gpus", 4)
+    try:
+        with pytest.raises(api.SpmvError, match="no HIP device"):
+            api.Handle(csr.m, csr.n, csr.rowptr, csr.colidx, csr.val)
+    finally:
+        api.clear_thread_options()
+    lib.spmv_hip_clear_error()
+
+
 def test_product_package_never_imports_the_oracle():
     pkg = os.path.join(ROOT, "spmv_amd")
     for base, _, files in os.walk(pkg):

@@ -213,7 +213,7 @@ def test_config3_through_the_matrix_market_loader(tmp_path, monkeypatch):
     rows = np.repeat(np.arange(1, m + 1, dtype=np.int64), np.diff(rp_h))
     monkeypatch.chdir(tmp_path)
     with open("pl.mtx", "w") as f:
-        f.write("%%MatrixMarket matrix coordinate real general\n%d %d %d\n" % (m, n, nnz))
+        f.write("%%%%MatrixMarket matrix coordinate real general\n%d %d %d\n" % (m, n, nnz))
         np.savetxt(f, np.column_stack([rows, ci_h.astype(np.int64) + 1, va_h]), fmt="%d %d %.6g")
     lib = api.load()
     I = C.POINTER(C.c_int)

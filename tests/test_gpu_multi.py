@@ -1,0 +1,154 @@
+"""GPU: row blocks over the GPUs of ONE process behind the unchanged C signature (option "gpus"; csrc/shim/multi.hpp;
+BASELINE config 5; reference analogue: src/samples/numa.c:277-304).
+
+This box has one GPU, so what can be exercised here is: (a) the degradation to G = 1, (b) the whole partition /
+exchange / multiply / collect logic with several shards SHARING the device (SPMV_HIP_GPUS_VIRTUAL=1: the exchange
+then runs on peer copies), (c) the RCCL calls themselves with a one-rank communicator (SPMV_HIP_RCCL_SINGLE=1).
+G > 1 on distinct devices over xGMI is not measurable here and is stated as unmeasured in DESIGN.md."""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+from conftest import load_golden
+from spmv_amd import api, build
+
+pytestmark = pytest.mark.gpu
+M = api.SPMV_METHODS
+ALL_METHODS = [M.Method_Serial, M.Method_Parallel, M.Method_Balanced, M.Method_Balanced2,
+               M.Method_Balanced_Yid, M.Method_SellCSigma, M.Method_CSR5SPMV]
+
+
+@pytest.fixture(scope="module", autouse=True)
+def _lib():
+    build.build()
+    lib = api.load()
+    assert lib.spmv_hip_device_count() > 0
+    return lib
+
+
+@pytest.fixture()
+def virtual(monkeypatch):
+    monkeypatch.setenv("SPMV_HIP_GPUS_VIRTUAL", "1")
+
+
+def _multi_handle(csr, method, gpus, xchg=0, arrays=None):
+    rp, ci, va = arrays or (csr.rowptr, csr.colidx, csr.val)
+    api.set_thread_option("gpus", gpus)
+    api.set_thread_option("x_exchange", xchg)
+    try:
+        return api.Handle(csr.m, csr.n, rp, ci, va, method)
+    finally:
+        api.clear_thread_options()
+
+
+@pytest.mark.parametrize("method", ALL_METHODS, ids=lambda m: m.name)
+@pytest.mark.parametrize("name", ["banded_f64_eighths", "powerlaw_f32_eighths", "skewed_f64_eighths", "empty_mix_f64_eighths",
+                                  "dense_row0_f32_eighths", "single_long_f64_eighths", "tiny_f64_eighths"])
+@pytest.mark.parametrize("gpus,xchg", [(2, 0), (3, 2)])
+def test_sharded_handle_matches_the_reference_bits(virtual, name, method, gpus, xchg):
+    csr, x, y_ref = load_golden(name)
+    h = _multi_handle(csr, method, gpus, xchg)
+    try:
+        assert h.multi_gpus() == min(gpus, max(csr.m, 1)) and h.option("gpus") == gpus
+        info = h.info()
+        assert info["m"] == csr.m and info["nnz"] == csr.nnz
+        y = h.spmv(x, np.full(csr.m, np.nan, dtype=csr.val.dtype))      # host vectors
+        assert np.array_equal(y.view(np.uint8), y_ref.view(np.uint8))
+        y2 = h.spmv(x, np.full(csr.m, np.nan, dtype=csr.val.dtype))
+        assert np.array_equal(y2, y)
+        rows = sum(h.multi_slices(g)["y_count"] for g in range(h.multi_gpus()))
+        cols = sum(h.multi_slices(g)["x_count"] for g in range(h.multi_gpus()))
+        assert rows == csr.m and cols == csr.n
+    finally:
+        h.close()
+
+
+def test_device_vectors_and_device_csr(virtual):
+    import torch
+    dev = torch.device("cuda:0")
+    csr, x, y_ref = load_golden("skewed_f64_uniform")
+    arrays = tuple(torch.from_numpy(a).to(dev) for a in (csr.rowptr, csr.colidx, csr.val))
+    xd = torch.from_numpy(x).to(dev)
+    single = api.Handle(csr.m, csr.n, *arrays, M.Method_CSR5SPMV)
+    want = torch.empty(csr.m, dtype=torch.float64, device=dev)
+    single.spmv(xd, want)
+    single.close()
+    h = _multi_handle(csr, M.Method_CSR5SPMV, 4, 0, arrays)
+    try:
+        yd = torch.full((csr.m,), float("nan"), dtype=torch.float64, device=dev)
+        h.spmv(xd, yd)
+        torch.cuda.synchronize()
+        err = (yd.cpu().numpy() - y_ref)
+        import oracle
+        assert (np.abs(err) <= 1e-6 * oracle.row_abs_sum(csr, x) + 1e-300).all()
+        assert torch.cuda.current_device() == 0
+    finally:
+        h.close()
+
+
+def test_without_the_virtual_switch_the_handle_degrades_to_the_devices_present():
+    csr, x, y_ref = load_golden("banded_f64_eighths")
+    h = _multi_handle(csr, M.Method_Parallel, 8)
+    try:
+        import torch
+        assert h.multi_gpus() == min(8, torch.cuda.device_count())
+        assert np.array_equal(h.spmv(x, np.empty(csr.m)), y_ref)
+    finally:
+        h.close()
+
+
+def test_rccl_entry_points_with_a_one_rank_communicator(monkeypatch):
+    """dlopen(librccl.so), ncclCommInitAll, ncclAllGather / ncclBroadcast inside a group, ncclCommDestroy -- with the one
+    rank this box allows."""
+    monkeypatch.setenv("SPMV_HIP_RCCL_SINGLE", "1")
+    csr, x, y_ref = load_golden("powerlaw_f64_eighths")
+    for xchg in (0, 2):
+        h = _multi_handle(csr, M.Method_Balanced2, 1, xchg)
+        try:
+            assert h.multi_gpus() == 1
+            if not api.load().spmv_hip_multi_uses_rccl(h.h):
+                pytest.skip("librccl.so could not be loaded on this box")
+            assert np.array_equal(h.spmv(x, np.empty(csr.m)), y_ref)
+        finally:
+            h.close()
+
+
+def test_distributed_vectors_step(virtual):
+    """Solver-style use: x lives in the devices' slices, spmv_hip_multi_step exchanges + multiplies, y is read from the
+    devices' blocks -- nothing crosses PCIe per step."""
+    hip = C.CDLL("libamdhip64.so")
+    hip.hipMemcpy.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_int]
+    csr, x, y_ref = load_golden("banded_wide_f64_eighths")
+    h = _multi_handle(csr, M.Method_Parallel, 3, 0)
+    try:
+        G = h.multi_gpus()
+        for g in range(G):
+            s = h.multi_slices(g)
+            part = np.ascontiguousarray(x[s["x_first"]: s["x_first"] + s["x_count"]])
+            assert hip.hipMemcpy(s["x_ptr"], part.ctypes.data, part.nbytes, 4) == 0
+        h.multi_step()
+        y = np.full(csr.m, np.nan)
+        for g in range(G):
+            s = h.multi_slices(g)
+            blk = np.empty(s["y_count"])
+            assert hip.hipMemcpy(blk.ctypes.data, s["y_ptr"], blk.nbytes, 4) == 0
+            y[s["y_first"]: s["y_first"] + s["y_count"]] = blk
+        assert np.array_equal(y, y_ref)
+    finally:
+        h.close()
+
+
+def test_update_values_and_stream_calls_on_a_sharded_handle(virtual):
+    csr, x, _ = load_golden("skewed_f64_eighths")
+    val = csr.val.copy()
+    h = _multi_handle(csr, M.Method_SellCSigma, 2, 0, (csr.rowptr, csr.colidx, val))
+    try:
+        y0 = h.spmv(x, np.empty(csr.m))
+        val *= 2.0
+        h.update_values(val)
+        assert np.array_equal(h.spmv(x, np.empty(csr.m)), 2.0 * y0)
+        assert api.load().spmv_hip_set_async(h.h, 1) != 0 and api.last_error()[0] == 3   # E_ARG: a sharded handle owns its streams
+        api.load().spmv_hip_clear_error()
+    finally:
+        h.close()
