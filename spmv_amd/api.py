@@ -81,6 +81,7 @@ FUNCTIONS = {
     "spmv_hip_last_error_string": (C.c_char_p, []),
     "spmv_hip_clear_error": (None, []),
     "spmv_hip_device_count": (C.c_int, []),
+    "spmv_hip_trim_pool": (None, []),
     "spmv_hip_set_stream": (C.c_int, [spmv_Handle_t, _V]),
     "spmv_hip_set_async": (C.c_int, [spmv_Handle_t, C.c_int]),
     "spmv_hip_synchronize": (C.c_int, [spmv_Handle_t]),

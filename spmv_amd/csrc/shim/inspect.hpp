@@ -16,7 +16,7 @@ static int build_range_windows(spmv_dev *d, int groups, long long total, long lo
     int host2[2] = {0, 0};
     *staged_out = *maxtotal_out = 0;
     if (groups <= 0) return SPMV_HIP_OK;
-    HIP_TRY(hipMalloc((void **) &cnt, 2 * sizeof(int)));
+    HIP_TRY(pool_malloc((void **) &cnt, 2 * sizeof(int)));
     hipError_t e = hipMemsetAsync(cnt, 0, 2 * sizeof(int), d->stream);
     range_windows_kernel<<<groups, kBlock, 0, d->stream>>>(total, group_len, bounds, bstride, scale, nbounds, d->n, max_cols, cols, cols16, pack16, wins, cnt, 0);
     if (e == hipSuccess) e = hipGetLastError();
@@ -29,7 +29,7 @@ static int build_range_windows(spmv_dev *d, int groups, long long total, long lo
         *staged_out = host2[0];
         *maxtotal_out = host2[1];
     }
-    (void) hipFree(cnt);
+    (void) pool_free(cnt);
     if (e != hipSuccess) return fail(SPMV_HIP_E_RUNTIME, "x-window inspector: %s", hipGetErrorString(e));
     return SPMV_HIP_OK;
 }
@@ -123,22 +123,22 @@ static int build_long_rows(spmv_dev *d, int thr)
     int *flags = nullptr, *sums = nullptr, *total = nullptr, *scratch = nullptr;
     ALLOC_TRY(d, &sums, sizeof(int) * (size_t) nb, true);
     ALLOC_TRY(d, &total, sizeof(int), true);
-    HIP_TRY(hipMalloc((void **) &flags, sizeof(int) * (size_t) d->m));
+    HIP_TRY(pool_malloc((void **) &flags, sizeof(int) * (size_t) d->m));
     long_rows_flag_kernel<<<grid_for(d->m, kBlock, d->cus * 8), kBlock, 0, d->stream>>>(d->m, thr, d->rowptr, flags);
     scan_block_sums_kernel<<<nb, kBlock, 0, d->stream>>>(d->m, flags, sums);
     scan_sums_inplace_kernel<<<1, kBlock, 0, d->stream>>>(nb, sums, total);
     if (hipMemcpyAsync(&d->nlong, total, sizeof(int), hipMemcpyDeviceToHost, d->stream) != hipSuccess || hipStreamSynchronize(d->stream) != hipSuccess) {
-        (void) hipFree(flags);
+        (void) pool_free(flags);
         d->nlong = 0;
         return fail(SPMV_HIP_E_RUNTIME, "long-row scan failed");
     }
-    if (d->nlong == 0) { (void) hipFree(flags); return SPMV_HIP_OK; }
+    if (d->nlong == 0) { (void) pool_free(flags); return SPMV_HIP_OK; }
     int rc = dev_alloc(d, (void **) &d->long_rows, sizeof(int) * (size_t) d->nlong, true);
     if (!rc) rc = dev_alloc(d, (void **) &scratch, sizeof(int) * (size_t) d->nlong, true);
-    if (rc) { (void) hipFree(flags); d->nlong = 0; return rc; }
+    if (rc) { (void) pool_free(flags); d->nlong = 0; return rc; }
     csr5_compact_kernel<<<nb, kBlock, 0, d->stream>>>(d->m, flags, sums, d->rowptr, scratch, d->long_rows);
     hipError_t e = hipStreamSynchronize(d->stream);
-    (void) hipFree(flags);
+    (void) pool_free(flags);
     if (e != hipSuccess) { d->nlong = 0; return fail(SPMV_HIP_E_RUNTIME, "long-row compaction: %s", hipGetErrorString(e)); }
     ALLOC_TRY(d, &d->lr_seg_start, sizeof(long long) * ((size_t) d->nlong + 1), true);
 
@@ -359,8 +359,8 @@ static int build_csr5(spmv_dev *d, Csr5Plan &P, int m, long long nnz, const int 
         if (out_rows) return fail(SPMV_HIP_E_ARG, "csr5: a row map and empty rows cannot be combined");
         const int nb = (int) (((long long) m + kScanTile - 1) / kScanTile);
         int *flags = nullptr, *sums = nullptr, *total = nullptr, *rp2 = nullptr, *rmap = nullptr, *elist = nullptr;
-        HIP_TRY(hipMalloc((void **) &flags, sizeof(int) * (size_t) m));
-        auto cleanup = [&]() { (void) hipFree(flags); };
+        HIP_TRY(pool_malloc((void **) &flags, sizeof(int) * (size_t) m));
+        auto cleanup = [&]() { (void) pool_free(flags); };
         if (dev_alloc(d, (void **) &sums, sizeof(int) * (size_t) nb, true) || dev_alloc(d, (void **) &total, sizeof(int), true)) { cleanup(); return SPMV_HIP_E_ALLOC; }
         csr5_nonempty_kernel<<<grid_for(m, kBlock, d->cus * 8), kBlock, 0, d->stream>>>(m, rowptr, flags);
         scan_block_sums_kernel<<<nb, kBlock, 0, d->stream>>>(m, flags, sums);
@@ -399,12 +399,12 @@ static int blocked_fill(spmv_dev *d, int wshift, bool values_only)
     int *cnt = nullptr, *tot = nullptr;
     long long *cursor = nullptr;
     const size_t cells = (size_t) B * K;
-    HIP_TRY(hipMalloc((void **) &cnt, sizeof(int) * cells));
-    auto cleanup = [&]() { (void) hipFree(cnt); if (tot) (void) hipFree(tot); if (cursor) (void) hipFree(cursor); };
-    if (hipMalloc((void **) &tot, sizeof(int) * (size_t) B) != hipSuccess || hipMalloc((void **) &cursor, sizeof(long long) * cells) != hipSuccess) {
+    HIP_TRY(pool_malloc((void **) &cnt, sizeof(int) * cells));
+    auto cleanup = [&]() { (void) pool_free(cnt); if (tot) (void) pool_free(tot); if (cursor) (void) pool_free(cursor); };
+    if (pool_malloc((void **) &tot, sizeof(int) * (size_t) B) != hipSuccess || pool_malloc((void **) &cursor, sizeof(long long) * cells) != hipSuccess) {
         (void) hipGetLastError();
         cleanup();
-        return fail(SPMV_HIP_E_ALLOC, "hipMalloc(block cells)");
+        return fail(SPMV_HIP_E_ALLOC, "pool_malloc(block cells)");
     }
     hipError_t e = hipMemsetAsync(cnt, 0, sizeof(int) * cells, d->stream);
     blk_count_kernel<<<grid_for(d->m, kBlock / 16, d->cus * 16), kBlock, 0, d->stream>>>(d->m, R, K, wshift, d->rowptr, d->colidx, cnt);
@@ -504,13 +504,13 @@ static int wins_sum(spmv_dev *d, const TileWindows *wins, int count, long long *
     *elems = *tiles = 0;
     if (!wins || count <= 0) return SPMV_HIP_OK;
     unsigned long long *dv = nullptr, hv[2] = {0, 0};
-    HIP_TRY(hipMalloc((void **) &dv, sizeof hv));
+    HIP_TRY(pool_malloc((void **) &dv, sizeof hv));
     hipError_t e = hipMemsetAsync(dv, 0, sizeof hv, d->stream);
     wins_total_kernel<<<grid_for(count, kBlock, d->cus * 4), kBlock, 0, d->stream>>>(count, wins, dv, dv + 1);
     if (e == hipSuccess) e = hipGetLastError();
     if (e == hipSuccess) e = hipMemcpyAsync(hv, dv, sizeof hv, hipMemcpyDeviceToHost, d->stream);
     if (e == hipSuccess) e = hipStreamSynchronize(d->stream);
-    (void) hipFree(dv);
+    (void) pool_free(dv);
     if (e != hipSuccess) return fail(SPMV_HIP_E_RUNTIME, "window totals: %s", hipGetErrorString(e));
     *elems = (long long) hv[0];
     *tiles = (long long) hv[1];

@@ -64,9 +64,9 @@ static int autotune_vector(spmv_dev *d)
     if (d->nnz < (1ll << 24) || d->plan.variant != 0 || d->vt_tiles <= 0) return SPMV_HIP_OK;
     if (d->vt_wide || d->vt_staged * 2 < d->vt_tiles) return SPMV_HIP_OK; // wide form: one kernel form; x windows not staged: the pipe form runs, nothing to choose (and 45 gather-bound launches would cost ~0.3 s)
     T *x = nullptr, *y = nullptr;
-    if (hipMalloc((void **) &x, sizeof(T) * (size_t) d->n) != hipSuccess || hipMalloc((void **) &y, sizeof(T) * (size_t) d->m) != hipSuccess) {
+    if (pool_malloc((void **) &x, sizeof(T) * (size_t) d->n) != hipSuccess || pool_malloc((void **) &y, sizeof(T) * (size_t) d->m) != hipSuccess) {
         (void) hipGetLastError();
-        if (x) (void) hipFree(x);
+        if (x) (void) pool_free(x);
         return SPMV_HIP_OK; // no room to tune: keep the default
     }
     fill_value_kernel<T><<<grid_for(d->n, kBlock, d->cus * 8), kBlock, 0, d->stream>>>(d->n, x, T(1));
@@ -104,8 +104,8 @@ static int autotune_vector(spmv_dev *d)
     d->vec_choice = best_c;
     (void) hipEventDestroy(e0);
     (void) hipEventDestroy(e1);
-    (void) hipFree(x);
-    (void) hipFree(y);
+    (void) pool_free(x);
+    (void) pool_free(y);
     if (hipGetLastError() != hipSuccess) d->vec_choice = VEC_AUTO;
     return SPMV_HIP_OK;
 }

@@ -82,8 +82,8 @@ static void multi_free(spmv_multi *mt)
         (void) hipSetDevice(s.device);
         if (s.comm && rccl_api().ok) (void) rccl_api().CommDestroy(s.comm);
         if (s.dev) spmv_shim_matrix_destroy(s.dev);
-        if (s.x) (void) hipFree(s.x);
-        if (s.y) (void) hipFree(s.y);
+        if (s.x) (void) pool_free(s.x);
+        if (s.y) (void) pool_free(s.y);
         if (s.ready) (void) hipEventDestroy(s.ready);
         if (s.stream) (void) hipStreamDestroy(s.stream);
     }
@@ -162,7 +162,7 @@ extern "C" int spmv_shim_multi_create(spmv_multi **out, int gpus, int xchg, int 
         (void) spmv_shim_set_stream(s.dev, s.stream);
         (void) spmv_shim_set_async(s.dev, 1);
         const size_t xb = mt->vsize * (size_t) (mt->slice * G > 0 ? mt->slice * G : 1), yb = mt->vsize * (size_t) (s.rows > 0 ? s.rows : 1);
-        if (hipMalloc(&s.x, xb) != hipSuccess || hipMalloc(&s.y, yb) != hipSuccess) {
+        if (pool_malloc(&s.x, xb) != hipSuccess || pool_malloc(&s.y, yb) != hipSuccess) {
             (void) hipGetLastError();
             return bail(fail(SPMV_HIP_E_ALLOC, "multi: x / y buffers on device %d", s.device));
         }

@@ -27,6 +27,95 @@ extern "C" const char *spmv_shim_error_text(void) { return t_err; }
         }                                                                                          \
     } while (0)
 
+// ------------------------------------------------------------------------------------ device-memory pool
+// hipFree is lazy on this runtime: it returns at once and the release happens later -- inside some LATER hipMalloc,
+// which then takes 0.4-3 s for a few GB (tools/malloc_probe.py: "malloc 3 x 2 GiB again: 480 ms"; config 4: the schedule
+// created right after another handle was destroyed took 3.2 s of which 16 ms were inspector kernels).  create() frees
+// and allocates in quick succession (re-inspection, auto_method = 2 building five schedules, the blocked executor
+// replacing a tile schedule), so freed blocks are kept in a small per-process pool and handed out again: same
+// device, at least the size asked for and at most 25 % more.  Cap: SPMV_HIP_POOL_MB (default 8192 MiB; 0 = no
+// pool); spmv_hip_trim_pool() releases everything; an allocation that fails trims the pool and retries.
+struct PoolBlock { void *p; size_t bytes; int device; };
+static std::mutex g_pool_lock;
+static std::vector<PoolBlock> g_pool;              // free blocks
+static std::vector<PoolBlock> g_pool_live;         // blocks handed out (to learn their size at free time)
+static size_t g_pool_bytes = 0;
+
+static size_t pool_cap()
+{
+    static long long cap = -1;
+    if (cap < 0) {
+        const char *e = getenv("SPMV_HIP_POOL_MB");
+        cap = (e && *e ? atoll(e) : 8192ll) << 20;
+        if (cap < 0) cap = 0;
+    }
+    return (size_t) cap;
+}
+
+static void pool_trim_locked()
+{
+    for (auto &b : g_pool) (void) hipFree(b.p);
+    g_pool.clear();
+    g_pool_bytes = 0;
+}
+
+static hipError_t pool_malloc(void **p, size_t bytes)
+{
+    *p = nullptr;
+    if (bytes == 0) bytes = 16;
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess) { (void) hipGetLastError(); dev = 0; }
+    const size_t want = bytes >= (1u << 20) ? (bytes + ((1u << 21) - 1)) & ~(size_t) ((1u << 21) - 1) : bytes; // large blocks in 2 MiB steps
+    std::lock_guard<std::mutex> g(g_pool_lock);
+    if (want >= (1u << 20)) {
+        size_t best = (size_t) -1;
+        for (size_t i = 0; i < g_pool.size(); ++i)
+            if (g_pool[i].device == dev && g_pool[i].bytes >= want && g_pool[i].bytes <= want + want / 4 &&
+                (best == (size_t) -1 || g_pool[i].bytes < g_pool[best].bytes)) best = i;
+        if (best != (size_t) -1) {
+            PoolBlock b = g_pool[best];
+            g_pool.erase(g_pool.begin() + (long) best);
+            g_pool_bytes -= b.bytes;
+            g_pool_live.push_back(b);
+            *p = b.p;
+            return hipSuccess;
+        }
+    }
+    hipError_t e = hipMalloc(p, want);
+    if (e != hipSuccess && !g_pool.empty()) { // make room and try once more
+        (void) hipGetLastError();
+        pool_trim_locked();
+        e = hipMalloc(p, want);
+    }
+    if (e == hipSuccess && want >= (1u << 20)) g_pool_live.push_back({*p, want, dev});
+    return e;
+}
+template <typename T> static hipError_t pool_malloc(T **p, size_t bytes) { return pool_malloc((void **) p, bytes); }
+
+static hipError_t pool_free(void *p)
+{
+    if (!p) return hipSuccess;
+    std::lock_guard<std::mutex> g(g_pool_lock);
+    for (size_t i = 0; i < g_pool_live.size(); ++i)
+        if (g_pool_live[i].p == p) {
+            PoolBlock b = g_pool_live[i];
+            g_pool_live.erase(g_pool_live.begin() + (long) i);
+            if (g_pool_bytes + b.bytes <= pool_cap()) {
+                g_pool.push_back(b);
+                g_pool_bytes += b.bytes;
+                return hipSuccess;
+            }
+            break;
+        }
+    return hipFree(p);
+}
+
+extern "C" void spmv_shim_trim_pool(void)
+{
+    std::lock_guard<std::mutex> g(g_pool_lock);
+    pool_trim_locked();
+}
+
 // Makes `device` current for the life of the guard and restores the caller's device afterwards.
 struct DeviceGuard {
     int prev = -1;
@@ -126,7 +215,7 @@ static int dev_alloc(spmv_dev *d, void **p, size_t bytes, bool sched)
 {
     *p = nullptr;
     if (bytes == 0) bytes = 16;
-    HIP_TRY(hipMalloc(p, bytes));
+    HIP_TRY(pool_malloc(p, bytes));
     d->device_bytes += (long long) bytes;
     if (sched) d->sched_allocs.push_back({*p, bytes});
     return SPMV_HIP_OK;
@@ -144,7 +233,7 @@ static void sched_free(spmv_dev *d, void *p)
         if (d->sched_allocs[i].first == p) {
             d->device_bytes -= (long long) d->sched_allocs[i].second;
             d->sched_allocs.erase(d->sched_allocs.begin() + (long) i);
-            (void) hipFree(p);
+            (void) pool_free(p);
             return;
         }
 }
@@ -165,7 +254,7 @@ static void reset_tile_fields(spmv_dev *d)
 
 static void free_schedule(spmv_dev *d)
 {
-    for (auto &a : d->sched_allocs) { (void) hipFree(a.first); d->device_bytes -= (long long) a.second; }
+    for (auto &a : d->sched_allocs) { (void) pool_free(a.first); d->device_bytes -= (long long) a.second; }
     d->sched_allocs.clear();
     reset_tile_fields(d);
     d->blk_on = false; d->blk_slots = 0; d->blk_start = d->blk_end = nullptr; d->blk_val = nullptr; d->blk_col = nullptr; d->blk_row = nullptr;
@@ -176,7 +265,7 @@ static void free_schedule(spmv_dev *d)
 // `count` schedule allocations), keep the blocked streams.
 static void drop_tile_schedule(spmv_dev *d, size_t count)
 {
-    for (size_t i = 0; i < count && i < d->sched_allocs.size(); ++i) { (void) hipFree(d->sched_allocs[i].first); d->device_bytes -= (long long) d->sched_allocs[i].second; }
+    for (size_t i = 0; i < count && i < d->sched_allocs.size(); ++i) { (void) pool_free(d->sched_allocs[i].first); d->device_bytes -= (long long) d->sched_allocs[i].second; }
     d->sched_allocs.erase(d->sched_allocs.begin(), d->sched_allocs.begin() + (long) (count < d->sched_allocs.size() ? count : d->sched_allocs.size()));
     reset_tile_fields(d);
 }

@@ -54,6 +54,7 @@ int spmv_hip_last_error(void) { return g_err_code; }
 const char *spmv_hip_last_error_string(void) { return g_err_text; }
 void spmv_hip_clear_error(void) { g_err_code = 0; g_err_text[0] = 0; }
 int spmv_hip_device_count(void) { return spmv_shim_device_count(); }
+void spmv_hip_trim_pool(void) { spmv_shim_trim_pool(); }
 
 /* ---------------------------------------------------------------- handle life-cycle */
 static void handle_reset(spmv_Handle_t h) /* common.c:18-29 */

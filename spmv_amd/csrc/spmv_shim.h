@@ -75,6 +75,8 @@ double spmv_shim_time_self(spmv_dev *d, int iters);
 void spmv_shim_matrix_destroy(spmv_dev *d);
 /* memcpy that accepts a host or a device source (the reordering inspector works on host copies) */
 int spmv_shim_copy_to_host(void *dst, const void *src, size_t bytes);
+/* release the device blocks the library keeps for re-use between handles (shim/state.hpp "device-memory pool") */
+void spmv_shim_trim_pool(void);
 /* 1 if a kernel can use the pointer as is (device or managed memory), else 0 (also without any device) */
 int spmv_shim_is_device_ptr(const void *p);
 /* New values (host or device, nnz entries in CSR order) behind the same pattern: copied to HBM and

@@ -18,6 +18,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <algorithm>
+#include <mutex>
 #include <vector>
 
 #include "spmv_shim.h"
@@ -69,14 +70,14 @@ extern "C" int spmv_shim_matrix_create(spmv_dev **out, int m, int n, const int *
     // row statistics (also validates RowPtr)
     DevStats hs{0, INT_MAX, 0, 0, 0, 0};
     DevStats *ds = nullptr;
-    if (hipMalloc((void **) &ds, sizeof(DevStats)) != hipSuccess) return bail(fail(SPMV_HIP_E_ALLOC, "hipMalloc(stats)"));
+    if (pool_malloc((void **) &ds, sizeof(DevStats)) != hipSuccess) return bail(fail(SPMV_HIP_E_ALLOC, "pool_malloc(stats)"));
     (void) hipMemcpy(ds, &hs, sizeof hs, hipMemcpyHostToDevice);
     if (m > 0) {
         stats_kernel<<<grid_for(m, kBlock, d->cus * 8), kBlock>>>(m, d->rowptr, ds);
-        if (hipGetLastError() != hipSuccess) { (void) hipFree(ds); return bail(fail(SPMV_HIP_E_RUNTIME, "stats kernel launch failed")); }
+        if (hipGetLastError() != hipSuccess) { (void) pool_free(ds); return bail(fail(SPMV_HIP_E_RUNTIME, "stats kernel launch failed")); }
     }
     hipError_t e = hipMemcpy(&hs, ds, sizeof hs, hipMemcpyDeviceToHost);
-    (void) hipFree(ds);
+    (void) pool_free(ds);
     if (e != hipSuccess) return bail(fail(SPMV_HIP_E_RUNTIME, "stats kernel: %s", hipGetErrorString(e)));
     if (m > 0 && (hs.bad || hs.first != 0 || hs.last < 0))
         return bail(fail(SPMV_HIP_E_ARG, "RowPtr must start at 0 and be non-decreasing (RowPtr[0]=%d)", hs.first));
@@ -108,11 +109,11 @@ extern "C" int spmv_shim_matrix_create(spmv_dev **out, int m, int n, const int *
         // every column index must address x: the reference would read out of bounds, a GPU would fault
         int host2[2] = {INT_MAX, INT_MIN};
         int *mnmx = nullptr;
-        if (hipMalloc((void **) &mnmx, sizeof host2) != hipSuccess) return bail(fail(SPMV_HIP_E_ALLOC, "hipMalloc(colidx range)"));
+        if (pool_malloc((void **) &mnmx, sizeof host2) != hipSuccess) return bail(fail(SPMV_HIP_E_ALLOC, "pool_malloc(colidx range)"));
         (void) hipMemcpy(mnmx, host2, sizeof host2, hipMemcpyHostToDevice);
         colidx_range_kernel<<<grid_for(d->nnz, kBlock * 16, d->cus * 8), kBlock>>>(d->nnz, d->colidx, mnmx);
         const hipError_t e2 = hipMemcpy(host2, mnmx, sizeof host2, hipMemcpyDeviceToHost);
-        (void) hipFree(mnmx);
+        (void) pool_free(mnmx);
         if (e2 != hipSuccess) return bail(fail(SPMV_HIP_E_RUNTIME, "colidx range kernel: %s", hipGetErrorString(e2)));
         if (host2[0] < 0 || host2[1] >= n)
             return bail(fail(SPMV_HIP_E_ARG, "ColIdx out of range: min %d, max %d, n = %d", host2[0], host2[1], n));
@@ -140,12 +141,12 @@ extern "C" void spmv_shim_matrix_destroy(spmv_dev *d)
 {
     if (!d) return;
     free_schedule(d);
-    if (d->rowptr) (void) hipFree(d->rowptr);
-    if (d->colidx) (void) hipFree(d->colidx);
-    if (d->val) (void) hipFree(d->val);
-    if (d->x_stage) (void) hipFree(d->x_stage);
-    if (d->y_stage) (void) hipFree(d->y_stage);
-    if (d->scratch8) (void) hipFree(d->scratch8);
+    if (d->rowptr) (void) pool_free(d->rowptr);
+    if (d->colidx) (void) pool_free(d->colidx);
+    if (d->val) (void) pool_free(d->val);
+    if (d->x_stage) (void) pool_free(d->x_stage);
+    if (d->y_stage) (void) pool_free(d->y_stage);
+    if (d->scratch8) (void) pool_free(d->scratch8);
     delete d;
 }
 
@@ -391,9 +392,9 @@ extern "C" double spmv_shim_time_self(spmv_dev *d, int iters)
 {
     if (!d || !d->built || iters <= 0 || iters > 64) { fail(SPMV_HIP_E_ARG, "time_self: bad arguments"); return -1.0; }
     void *x = nullptr, *y = nullptr;
-    if (hipMalloc(&x, d->vsize * (size_t) (d->n > 0 ? d->n : 1)) != hipSuccess || hipMalloc(&y, d->vsize * (size_t) (d->m > 0 ? d->m : 1)) != hipSuccess) {
+    if (pool_malloc(&x, d->vsize * (size_t) (d->n > 0 ? d->n : 1)) != hipSuccess || pool_malloc(&y, d->vsize * (size_t) (d->m > 0 ? d->m : 1)) != hipSuccess) {
         (void) hipGetLastError();
-        if (x) (void) hipFree(x);
+        if (x) (void) pool_free(x);
         fail(SPMV_HIP_E_ALLOC, "time_self: scratch vectors");
         return -1.0;
     }
@@ -401,8 +402,8 @@ extern "C" double spmv_shim_time_self(spmv_dev *d, int iters)
     else fill_value_kernel<float><<<grid_for(d->n, kBlock, d->cus * 8), kBlock, 0, d->stream>>>(d->n, (float *) x, 1.0f);
     float ms[64];
     const double mean = spmv_shim_time(d, x, y, 2, iters, ms);
-    (void) hipFree(x);
-    (void) hipFree(y);
+    (void) pool_free(x);
+    (void) pool_free(y);
     if (mean < 0) return -1.0;
     float best = ms[0];
     for (int i = 1; i < iters; ++i) best = ms[i] < best ? ms[i] : best;

@@ -1,7 +1,15 @@
 #!/usr/bin/env python3
-"""Measure every BASELINE.json config shape (and the stand-ins SURVEY 8d lists) with the schedule the
-config names, plus the other schedules for comparison; write gpurun_out/configs_<tag>.json.
-Run on the GPU box:  python tools/measure_configs.py r01   (then copy the file to profiles/)."""
+"""Measure every BASELINE.json config shape (and the stand-ins SURVEY 8d lists) with the schedule the config names,
+plus the other schedules for comparison; write gpurun_out/configs_<tag>.json (copy it to profiles/).
+
+    python tools/measure_configs.py r02 [config ...]
+
+Per (config, method): min / mean launch time over 20 launches after 5 warm-ups (hipEvents on the launch stream), create
+time, and three byte counts over the min time as fractions of 8 TB/s:
+  frac_moved   spmv_hip_info.stream_bytes -- what the schedule's storage format makes one launch move (physical)
+  frac_alg     SURVEY 8d's algorithmic bytes B_alg = 4(m+1) + nnz(4+s) + s n + s m (effective rate; can exceed the
+               physical one when a 2 B/nnz slot stream replaces the 4 B/nnz ColIdx)
+"""
 import json
 import os
 import sys
@@ -9,57 +17,56 @@ import time
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tools"))
 import torch  # noqa: E402
-from spmv_amd import api, build, synth  # noqa: E402
+from spmv_amd import api, build  # noqa: E402
+import run_config as rc  # noqa: E402
 
-tag = sys.argv[1] if len(sys.argv) > 1 else "r01"
-build.build()
-dev = "cuda:0"
 M = api.SPMV_METHODS
-out = {"tag": tag, "device": torch.cuda.get_device_name(0), "note": "min over 20 launches after 5 warm-up, hipEvents on the launch stream; "
-       "GB/s = B_alg / t with B_alg = 4(m+1) + nnz(4+s) + s n + s m; frac = GB/s / 8000", "configs": []}
-
-
-def run(name, m, n, rp, ci, va, methods, iters=20):
+tag = sys.argv[1] if len(sys.argv) > 1 else "r02"
+wanted = sys.argv[2:] or ["2", "2r", "3w", "3w-uniform", "3o", "3o-uniform", "4", "5shard"]
+METHODS = {
+    "2": [M.Method_Parallel, M.Method_Balanced, M.Method_Balanced_Yid, M.Method_SellCSigma, M.Method_CSR5SPMV],
+    "2r": [M.Method_Parallel, M.Method_Balanced2, M.Method_CSR5SPMV, M.Method_SellCSigma],
+    "3w": [M.Method_Balanced2, M.Method_CSR5SPMV, M.Method_Parallel, M.Method_SellCSigma],
+    "3w-uniform": [M.Method_Balanced2, M.Method_CSR5SPMV, M.Method_Parallel],
+    "3o": [M.Method_Balanced2, M.Method_CSR5SPMV, M.Method_Parallel],
+    "3o-uniform": [M.Method_Balanced2, M.Method_CSR5SPMV],
+    "4": [M.Method_SellCSigma, M.Method_CSR5SPMV, M.Method_Balanced2, M.Method_Parallel],
+    "5shard": [M.Method_Parallel],
+}
+build.build()
+api.load()
+dev = "cuda:0"
+out = {"tag": tag, "device": torch.cuda.get_device_name(0),
+       "note": "min over 20 launches after 5 warm-up, hipEvents on the launch stream; frac_moved = stream_bytes / t / 8 TB/s (physical), "
+               "frac_alg = B_alg / t / 8 TB/s (SURVEY 8d algorithmic bytes, effective)", "configs": []}
+for cfg in wanted:
+    name, _ = rc.CONFIGS[cfg]
+    m, n, rp, ci, va = rc.make(cfg, dev)
     x = torch.rand(n, dtype=va.dtype, device=dev) * 2 - 1
     y = torch.empty(m, dtype=va.dtype, device=dev)
     rows = []
-    for meth in methods:
+    for meth in METHODS[cfg]:
         t0 = time.time()
         h = api.Handle(m, n, rp, ci, va, meth)
         create_s = time.time() - t0
         info = h.info()
-        mean, ms = api.time_launches(h.h, x, y, 5, iters)
+        mean, ms = api.time_launches(h.h, x, y, 5, 20)
+        used = h.method.name
         h.close()
-        gb = info["alg_bytes"] / 1e9
-        rows.append({"method": M(meth).name, "schedule": info["schedule_name"], "kernel": info["kernel_name"],
-                     "ms_min": round(float(ms.min()), 4), "ms_mean": round(float(mean), 4),
-                     "gbps_alg": round(gb / (float(ms.min()) / 1e3), 1), "frac_of_8TBs": round(gb / (float(ms.min()) / 1e3) / 8000, 3),
-                     "gflops": round(2 * info["nnz"] / float(ms.min()) / 1e6, 1), "create_s": round(create_s, 3),
+        t = float(ms.min()) / 1e3
+        rows.append({"method": M(meth).name, "method_used": used, "schedule": info["schedule_name"], "kernel": info["kernel_name"],
+                     "cache_blocked": info["cache_blocked"], "ms_min": round(t * 1e3, 4), "ms_mean": round(float(mean), 4),
+                     "gflops": round(2 * info["nnz"] / t / 1e9, 1),
+                     "stream_bytes": info["stream_bytes"], "alg_bytes": info["alg_bytes"],
+                     "frac_moved": round(info["stream_bytes"] / t / 8e12, 4), "frac_alg": round(info["alg_bytes"] / t / 8e12, 4),
+                     "create_s": round(create_s, 3), "inspect_ms": round(info["inspect_ms"], 1),
                      "stored_over_nnz": round(info["stored_nnz"] / max(info["nnz"], 1), 3)})
-        print(name, rows[-1], flush=True)
-    out["configs"].append({"name": name, "m": m, "n": n, "nnz": int(rp[-1].item()), "dtype": str(va.dtype), "results": rows})
-
-
-ALL = [M.Method_Parallel, M.Method_Balanced, M.Method_Balanced_Yid, M.Method_SellCSigma, M.Method_CSR5SPMV]
-_, _, rp, ci, va = synth.banded_device(10_000_000, 10_000_000, 32, "uniform", torch.float64, dev, 1)
-run("config 2: 1e7 x 1e7, 32 nnz/row banded, fp64 (named schedule: CSR-vector)", 10_000_000, 10_000_000, rp, ci, va, ALL)
-_, _, rp, ci, va = synth.uniform_k_device(10_000_000, 10_000_000, 32, "uniform", torch.float64, dev, 1)
-run("config 2 variant (ii): uniformly random columns", 10_000_000, 10_000_000, rp, ci, va, [M.Method_Balanced_Yid, M.Method_Balanced, M.Method_Parallel, M.Method_CSR5SPMV], 5)
-lens = synth.powerlaw_lengths_device(1_000_000, 3.1, 4700, 1.6, dev, 1)
-_, _, rp, ci, va = synth.from_row_lengths_device(lens, 1_000_000, "uniform", torch.float64, dev, 1)
-run("config 3 stand-in webbase-1M-style (named schedule: Balanced2 nnz-split)", 1_000_000, 1_000_000, rp, ci, va,
-    [M.Method_Balanced2, M.Method_CSR5SPMV, M.Method_Parallel, M.Method_SellCSigma])
-lens = synth.powerlaw_lengths_device(3_070_000, 76, 33000, 1.5, dev, 1)
-_, _, rp, ci, va = synth.from_row_lengths_device(lens, 3_070_000, "uniform", torch.float64, dev, 1)
-run("config 3 stand-in com-Orkut-style (random columns)", 3_070_000, 3_070_000, rp, ci, va, [M.Method_Balanced2, M.Method_CSR5SPMV], 5)
-lens = synth.skewed_lengths_device(10_000_000, dev, 1)
-_, _, rp, ci, va = synth.from_row_lengths_device(lens, 10_000_000, "uniform", torch.float32, dev, 1, local=4096)
-run("config 4: 1e7 rows skewed nnz, fp32, columns within +-4096 (named schedule: SELL C=64 sigma=1024)", 10_000_000, 10_000_000, rp, ci, va,
-    [M.Method_SellCSigma, M.Method_CSR5SPMV, M.Method_Balanced2, M.Method_Parallel], 10)
-_, _, rp, ci, va = synth.banded_device(10_000_000, 80_000_000, 32, "uniform", torch.float64, dev, 1, row0=30_000_000)
-run("config 5 shard: 1e7 of 8e7 rows, global columns (one rank of the 8-GPU case, no exchange)", 10_000_000, 80_000_000, rp, ci, va,
-    [M.Method_Parallel])
+        print(cfg, rows[-1], flush=True)
+    out["configs"].append({"config": cfg, "name": name, "m": m, "n": n, "nnz": int(rp[-1].item()), "dtype": str(va.dtype), "results": rows})
+    del rp, ci, va, x, y
+    torch.cuda.empty_cache()
 os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
 with open(os.path.join(ROOT, "gpurun_out", f"configs_{tag}.json"), "w") as f:
     json.dump(out, f, indent=1)
