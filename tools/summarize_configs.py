@@ -3,7 +3,8 @@
 
   profiles/<tag>_configs_pmc.json     per config: the run's own JSON (shape, kernel, model bytes, ms), rocprofv3 kernel stats
                                       (calls, avg / min ns) and per-launch FETCH_SIZE / WRITE_SIZE / TCC_HIT / TCC_MISS of every spmv::
-                                      kernel of the multiply, with the corrected HBM bytes and the fractions of 8 TB/s that follow
+                                      kernel of ONE multiply (SELL = slab kernel + long-row CSR5 kernel + carry fix-up), their sum
+                                      ("multiply"), the corrected HBM bytes and the fractions of 8 TB/s that follow
   profiles/<tag>_<config>_kernel_stats.csv   the --stats table (our kernels + the top of the rest)
   profiles/<tag>_bench_kernel_stats.csv      the same for `python3 bench.py`
   profiles/traffic_<tag>.json         what bench.py reads for roofline.traffic: entries keyed by (kernel, m, nnz, dtype)
@@ -65,6 +66,7 @@ def stats_table(base, out_csv):
              "min_ns": float(r["MinNs"]), "max_ns": float(r["MaxNs"])} for r in ours]
 
 
+STATS_ITERS, STATS_WARMUP = 20, 3   # tools/profile_configs.sh: run_config.py --iters 20 (warm-up 3) in the stats pass
 MULTIPLY = ("csr_vector_tile_kernel", "csr_vector_pipe_kernel", "csr_vector_rows_kernel", "csr_scalar_kernel", "nat_group_kernel", "nat_kernel",
             "csr5_group_kernel", "csr5_kernel", "csr5_fixup_kernel", "sell_window_kernel", "sell_kernel", "blk_kernel", "fill_zero_kernel")
 summary = {"tag": tag, "units": "FETCH_SIZE / WRITE_SIZE in KiB (rocprofv3) -> bytes = KiB x 1024; hbm_bytes = 2 x FETCH + WRITE (gfx950 wide-read "
@@ -83,38 +85,48 @@ for log in sorted(glob.glob(os.path.join(src, "*.stats.log"))):
         continue
     ks = stats_table(os.path.join(src, cfg, "stats"), os.path.join(dst, f"{tag}_{cfg}_kernel_stats.csv"))
     fetch, write, hit = (counters(os.path.join(src, cfg, sub)) for sub in ("fetch", "write", "hit"))
+    # The kernels of ONE multiply: those launched at least once per timed launch of the stats pass (20 timed + 3 warm-up;
+    # autotune candidates and inspector kernels run fewer times).  Matched by their full (template-instantiated) name.
+    n_mul = STATS_ITERS + STATS_WARMUP
+    avg = lambda v: (sum(v) / len(v)) if v else None   # noqa: E731
     kernels = {}
-    for name in sorted(set(fetch) | set(write) | set(hit)):
-        sn = short(name)
-        if "spmv::" not in name or sn not in MULTIPLY:
+    tot_ns = tot_bytes = tot_raw = 0.0
+    for st in ks:
+        if st["short"] not in MULTIPLY or st["calls"] < n_mul:
             continue
-        fv = fetch.get(name, {}).get("FETCH_SIZE", [])
-        wv = write.get(name, {}).get("WRITE_SIZE", [])
-        hv = hit.get(name, {}).get("TCC_HIT_sum", [])
-        mv = hit.get(name, {}).get("TCC_MISS_sum", [])
-        avg = lambda v: (sum(v) / len(v)) if v else None   # noqa: E731
+        name = next((nm for nm in set(fetch) | set(write) | set(hit) if nm[:110] == st["name"]), None)
+        fv = fetch.get(name, {}).get("FETCH_SIZE", []) if name else []
+        wv = write.get(name, {}).get("WRITE_SIZE", []) if name else []
+        hv = hit.get(name, {}).get("TCC_HIT_sum", []) if name else []
+        mv = hit.get(name, {}).get("TCC_MISS_sum", []) if name else []
         f_raw = avg(fv) * 1024.0 if fv else None
         w_raw = avg(wv) * 1024.0 if wv else None
-        st = next((k for k in ks if k["name"][:100] == name[:100]), None) or next((k for k in ks if k["short"] == sn), None)
-        k = {"launches_counted": len(fv) or len(wv) or len(hv), "fetch_bytes_raw": f_raw, "write_bytes": w_raw,
+        per_mul = max(1, st["calls"] // n_mul)   # create-time autotune launches the chosen form a few extra times
+        k = {"full_name": st["name"], "calls": st["calls"], "launches_per_multiply": per_mul, "avg_ns": st["avg_ns"], "min_ns": st["min_ns"],
+             "launches_counted": len(fv) or len(wv) or len(hv), "fetch_bytes_raw": f_raw, "write_bytes": w_raw,
              "hbm_bytes_per_launch": (2.0 * f_raw if f_raw is not None else 0.0) + (w_raw or 0.0),
              "hbm_bytes_per_launch_raw_fetch": (f_raw or 0.0) + (w_raw or 0.0),
              "tcc_hit": avg(hv), "tcc_miss": avg(mv),
              "l2_hit_rate": (avg(hv) / (avg(hv) + avg(mv))) if hv and mv and (avg(hv) + avg(mv)) > 0 else None}
-        if st:
-            k.update(calls=st["calls"], avg_ns=st["avg_ns"], min_ns=st["min_ns"])
-            k["hbm_gbps_at_avg"] = k["hbm_bytes_per_launch"] / st["avg_ns"]
-            k["frac_of_8TBs_at_avg"] = k["hbm_bytes_per_launch"] / st["avg_ns"] / 8000.0
-        kernels.setdefault(sn, k)
+        k["hbm_gbps_at_avg"] = k["hbm_bytes_per_launch"] / st["avg_ns"]
+        k["frac_of_8TBs_at_avg"] = k["hbm_bytes_per_launch"] / st["avg_ns"] / 8000.0
+        kernels[st["short"] + ("" if st["short"] not in kernels else "#" + str(len(kernels)))] = k
+        tot_ns += st["avg_ns"] * per_mul
+        tot_bytes += k["hbm_bytes_per_launch"] * per_mul
+        tot_raw += k["hbm_bytes_per_launch_raw_fetch"] * per_mul
     dom = run["kernel"]
     d = kernels.get(dom)
     cfg_out = {"run": run, "kernels": kernels}
-    if d and d.get("avg_ns"):
-        cfg_out["dominant"] = {
-            "kernel": dom, "avg_ms_rocprof": d["avg_ns"] / 1e6, "model_stream_bytes": run["stream_bytes"], "alg_bytes": run["alg_bytes"],
-            "pmc_hbm_bytes": d["hbm_bytes_per_launch"], "model_over_pmc": run["stream_bytes"] / d["hbm_bytes_per_launch"] if d["hbm_bytes_per_launch"] else None,
-            "frac_pmc_bytes": d["hbm_bytes_per_launch"] / d["avg_ns"] / 8000.0, "frac_model_bytes": run["stream_bytes"] / d["avg_ns"] / 8000.0,
-            "frac_alg_bytes": run["alg_bytes"] / d["avg_ns"] / 8000.0, "l2_hit_rate": d["l2_hit_rate"]}
+    if tot_ns > 0:
+        cfg_out["multiply"] = {
+            "kernels": sorted(kernels), "ms_rocprof_sum_of_kernels": tot_ns / 1e6, "ms_hip_events_min": run["ms_min"],
+            "model_stream_bytes": run["stream_bytes"], "alg_bytes": run["alg_bytes"],
+            "pmc_hbm_bytes_2xfetch_plus_write": tot_bytes, "pmc_hbm_bytes_1xfetch_plus_write": tot_raw,
+            "model_over_pmc": run["stream_bytes"] / tot_bytes if tot_bytes else None,
+            "frac_pmc_bytes": tot_bytes / tot_ns / 8000.0, "frac_model_bytes": run["stream_bytes"] / tot_ns / 8000.0,
+            "frac_alg_bytes": run["alg_bytes"] / tot_ns / 8000.0,
+            "l2_hit_rate_dominant": d["l2_hit_rate"] if d else None}
+    if d and len(kernels) == 1:
         entries.append({"config": cfg, "kernel_short": dom, "m": run["m"], "nnz": run["nnz"], "dtype": run["dtype"],
                         "hbm_bytes_per_launch": d["hbm_bytes_per_launch"], "fetch_bytes_raw": d["fetch_bytes_raw"], "write_bytes": d["write_bytes"],
                         "source": f"profiles/{tag}_configs_pmc.json#{cfg}"})
@@ -139,4 +151,4 @@ with open(os.path.join(dst, f"traffic_{tag}.json"), "w") as f:
     json.dump({"tag": tag, "correction": "2 x FETCH_SIZE (gfx950 wide-read under-count) + WRITE_SIZE, KiB -> bytes; separate --pmc passes",
                "entries": entries}, f, indent=1)
 for cfg, c in summary["configs"].items():
-    print(cfg, json.dumps(c.get("dominant", c.get("error")), indent=None)[:600])
+    print(cfg, json.dumps(c.get("multiply", c.get("error")), indent=None)[:700])
