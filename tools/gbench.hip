@@ -117,6 +117,28 @@ __global__ __launch_bounds__(64) void stream_gather(const double *__restrict__ t
     if (acc == 1.2345) out[gid] = acc;
 }
 
+// pure streams: what do 16-byte-per-lane reads, writes and a read+write copy sustain?
+__global__ __launch_bounds__(256) void stream_rw(const double *__restrict__ src, double *__restrict__ dst, size_t n2, int mode, int nt)
+{
+    typedef double d2_t __attribute__((ext_vector_type(2)));
+    const size_t i = (size_t) blockIdx.x * 256 * 4 + threadIdx.x;
+    d2_t acc = {0, 0};
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+        const size_t p = i + (size_t) u * 256;
+        if (p >= n2) break;
+        if (mode != 1) { // read
+            const d2_t v = nt ? __builtin_nontemporal_load(reinterpret_cast<const d2_t *>(src) + p) : reinterpret_cast<const d2_t *>(src)[p];
+            acc += v;
+            if (mode == 2) { if (nt) __builtin_nontemporal_store(v, reinterpret_cast<d2_t *>(dst) + p); else reinterpret_cast<d2_t *>(dst)[p] = v; }
+        } else {
+            const d2_t v = {(double) p, 1.0};
+            if (nt) __builtin_nontemporal_store(v, reinterpret_cast<d2_t *>(dst) + p); else reinterpret_cast<d2_t *>(dst)[p] = v;
+        }
+    }
+    if (mode == 0 && acc.x == 1.2345) dst[i] = acc.y;
+}
+
 template <typename F> static float time_ms(F f, int reps)
 {
     hipEvent_t a, b;
@@ -144,7 +166,7 @@ int main()
     CK(hipMalloc(&out, 64u << 20));
     const int steps = 64;
     constexpr int U = 16;
-    for (int wpc : {2, 8}) {              // waves per CU
+    for (int wpc : {8}) {              // waves per CU
         const int grid = 256 * wpc;
         const double lanes = (double) grid * 64 * steps * U;
         for (size_t bytes : {(size_t) 1 << 20, (size_t) 2 << 20, (size_t) 64 << 20}) {
@@ -165,6 +187,21 @@ int main()
             }
             printf("\n");
         }
+    }
+    { // pure 16-byte-per-lane streams over 2.56 GB
+        const size_t n2 = (size_t) 160 << 20; // 16-byte elements
+        double *a, *b;
+        CK(hipMalloc(&a, n2 * 16)); CK(hipMalloc(&b, n2 * 16));
+        CK(hipMemset(a, 0, n2 * 16)); CK(hipMemset(b, 0, n2 * 16));
+        const int grid = (int) ((n2 + 1023) / 1024);
+        const char *names[3] = {"read", "write", "copy"};
+        for (int mode = 0; mode < 3; ++mode)
+            for (int nt = 0; nt < 2; ++nt) {
+                float t = time_ms([&] { stream_rw<<<grid, 256>>>(a, b, n2, mode, nt); }, 5);
+                printf("stream %-5s %s: %.3f ms for %.2f GB -> %.0f GB/s\n", names[mode], nt ? "nt   " : "plain", t, n2 * 16 * (mode == 2 ? 2 : 1) / 1e9,
+                       n2 * 16 * (mode == 2 ? 2 : 1) / t / 1e6);
+            }
+        CK(hipFree(a)); CK(hipFree(b));
     }
     { // stream + gather: is the sum of the two what the chip does, or the max?
         const int wpc = 2, grid = 256 * wpc, st = 256;
