@@ -485,7 +485,9 @@ static bool wants_blocked(const spmv_dev *d, int staged_groups)
 {
     if (d->plan.cache_block == 2) return d->nnz > 0;
     if (d->plan.variant == 3) return false; // A/B: the tile executors with global gathers
-    return d->plan.cache_block == 1 && staged_groups == 0 && d->nnz >= (1ll << 21) && (long long) d->n * (long long) d->vsize >= (6ll << 20);
+    // x of a few L2 sizes still gathers well enough from L2 / the Infinity Cache: 8 MB of x (1e6 rows, power-law, 2.6e6 nnz)
+    // ran 26.6 us on the tile kernel against 31.4 us blocked (R-MAT columns) and 39.2 against 39.4 (uniform columns)
+    return d->plan.cache_block == 1 && staged_groups == 0 && d->nnz >= (1ll << 21) && (long long) d->n * (long long) d->vsize >= (16ll << 20);
 }
 
 // ------------------------------------------------------------------------------------ traffic model

@@ -464,7 +464,7 @@ def test_matrix_without_column_locality_runs_the_blocked_executor_deterministica
     import torch
     dev = torch.device("cuda:0")
     tdt = torch.float64 if dtype == np.float64 else torch.float32
-    m = n = 1_600_000 if dtype == np.float64 else 2_400_000
+    m = n = 2_400_000 if dtype == np.float64 else 4_800_000          # x = 19 MB: several times an XCD's 4 MiB L2
     _, _, rp, ci, va = synth.uniform_k_device(m, n, 8, "uniform", tdt, dev, seed=11)
     g = torch.Generator(device=dev); g.manual_seed(5)
     x = torch.rand(n, generator=g, device=dev, dtype=tdt) * 2 - 1

@@ -1,0 +1,22 @@
+#!/bin/bash
+set -u
+cd "$GRAFT_REPO_ROOT"
+for C in 3w 3w-uniform; do
+  while IFS= read -r OPTS; do
+    timeout -k 10 200 python3 tools/run_config.py --config $C --iters 200 --warmup 20 $OPTS 2>&1 | grep "RUNCONFIG\|rror" | python3 -c "
+import sys,json
+for l in sys.stdin:
+    if not l.startswith('RUNCONFIG'): print(l.strip()[:300]); continue
+    d=json.loads(l[10:]); print(d['config'], d['options'], d['kernel'], 'ms_min', d['ms_min'], 'ms_mean', d['ms_mean'], 'frac_alg', d['frac_alg'])
+"
+  done <<'LIST'
+
+--opt block_rows=2048
+--opt block_rows=512
+--opt block_rows=256
+--opt block_rows=256 --opt variant=19
+--opt block_rows=512 --opt variant=21
+--opt cache_block=0
+--opt cache_block=0 --method 6
+LIST
+done
