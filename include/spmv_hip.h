@@ -89,7 +89,7 @@ int spmv_hip_update_values(spmv_Handle_t handle, const void *Matrix_Val);
  *                    plumbing case); never selected automatically -- without it a missing GPU is an error)
  *       "check_values" (0/1, default 0: see spmv_hip_update_values)
  *       "gpus" (0 = this handle lives on the current device; G > 0: row blocks over min(G, visible devices) GPUs
- *               of this process, see "multi-GPU" below)   "x_exchange" (multi-GPU: 0 allgather, 1 halo, 2 broadcast)
+ *               of this process, see "multi-GPU" below)   "x_exchange" (multi-GPU: 0 allgather, 1 range, 2 broadcast)
  * Each key can also be preset with the environment variable SPMV_HIP_<KEY IN CAPS>.
  * Returns 0, or SPMV_HIP_E_ARG for an unknown key / illegal value. */
 int spmv_hip_set_option(const char *key, long value);
@@ -134,7 +134,10 @@ int spmv_hip_get_info(spmv_Handle_t handle, spmv_hip_info *out);
  * per device, each with its own schedule, stream, full-length x buffer and y block (the GPU analogue of the reference's
  * NUMA experiment, src/samples/numa.c:277-304).  spmv() keeps its signature and meaning: X and Y are FULL vectors (host
  * or device pointers); per call X is distributed (option "x_exchange": 0 = every device receives its slice and the
- * slices are all-gathered over xGMI with RCCL, 2 = X goes to device 0 and is broadcast -- north_star's literal form),
+ * slices are all-gathered over xGMI with RCCL, 2 = X goes to device 0 and is broadcast -- north_star's literal form,
+ * 1 = "range": every device receives only the columns its row block references, x[min ColIdx .. max ColIdx] -- for a
+ * banded matrix its own slice and a few values either side; in the distributed step they are pulled from the
+ * neighbouring devices by peer copies, no collective),
  * every device multiplies its block, and the y blocks are collected into Y.
  * A solver loop keeps the vectors DISTRIBUTED instead: write this step's x into the devices' slices, call
  * spmv_hip_multi_step (exchange + multiply, nothing crosses PCIe), read y from the devices' blocks.

@@ -11,7 +11,11 @@
 //   x_exchange 0 "allgather"  every device receives ITS slice of the caller's X (host X: G partial H2D copies, one
 //                             per PCIe link; device X: G device-to-device copies), then the slices are all-gathered
 //                             over xGMI (ncclAllGather in place);
-//   x_exchange 2 "bcast"      north_star's literal form: X goes to device 0 once and is broadcast (ncclBroadcast).
+//   x_exchange 2 "bcast"      north_star's literal form: X goes to device 0 once and is broadcast (ncclBroadcast);
+//   x_exchange 1 "range"      every device receives only x[col_min .. col_max] of ITS shard (known from create-time
+//                             validation): for a banded matrix its own slice plus 16 values either side instead of
+//                             the whole vector -- from the caller's X directly in spmv(), from the neighbours'
+//                             slices by peer copies over xGMI in the distributed step.  No collective at all.
 // A solver-style caller keeps x and y DISTRIBUTED instead (spmv_hip_multi_x_slice / _y_slice / _step): the step is
 // then all-gather + multiply with nothing crossing PCIe -- the path the 6x-at-8-GPUs target is about.
 //
@@ -127,7 +131,7 @@ extern "C" int spmv_shim_multi_create(spmv_multi **out, int gpus, int xchg, int 
     for (int i = 0; i < m; ++i)
         if (rp[i] > rp[i + 1]) return fail(SPMV_HIP_E_ARG, "RowPtr must be non-decreasing (row %d)", i);
     spmv_multi *mt = new spmv_multi();
-    mt->G = G; mt->xchg = xchg == 2 ? 2 : 0; mt->m = m; mt->n = n;
+    mt->G = G; mt->xchg = xchg == 2 ? 2 : (xchg == 1 ? 1 : 0); mt->m = m; mt->n = n;
     mt->vsize = value_size == sizeof(double) ? sizeof(double) : sizeof(float);
     mt->slice = ((long long) n + G - 1) / G;
     mt->sh.resize((size_t) G);
@@ -231,6 +235,24 @@ static int multi_exchange(spmv_multi *mt)
     const int G = mt->G;
     if (G == 1 && !mt->rccl) return SPMV_HIP_OK;
     const size_t sb = mt->vsize * (size_t) mt->slice;
+    if (mt->xchg == 1) { // "range": pull the referenced columns that live in other devices' slices (peer copies, no collective)
+        for (int g = 0; g < G; ++g) {
+            MultiShard &s = mt->sh[(size_t) g];
+            const long long lo = s.dev->col_min, hi = (long long) s.dev->col_max + 1; // [lo, hi)
+            if (hi <= lo) continue;
+            (void) hipSetDevice(s.device);
+            for (int h = 0; h < G; ++h) {
+                if (h == g) continue;
+                const MultiShard &o = mt->sh[(size_t) h];
+                const long long a = std::max(lo, mt->slice * h), b = std::min(hi, std::min((long long) mt->n, mt->slice * (h + 1)));
+                if (b <= a) continue;
+                HIP_TRY(hipStreamWaitEvent(s.stream, o.ready, 0));
+                HIP_TRY(hipMemcpyPeerAsync((char *) s.x + mt->vsize * (size_t) a, s.device, (const char *) o.x + mt->vsize * (size_t) a, o.device,
+                                           mt->vsize * (size_t) (b - a), s.stream));
+            }
+        }
+        return SPMV_HIP_OK;
+    }
     if (mt->rccl) {
         RcclApi &R = rccl_api();
         int rc = R.GroupStart();
@@ -306,7 +328,10 @@ extern "C" int spmv_shim_multi_run(spmv_multi *mt, const void *x, void *y)
         MultiShard &s = mt->sh[(size_t) g];
         if (hipSetDevice(s.device) != hipSuccess) { (void) hipGetLastError(); return done(fail(SPMV_HIP_E_RUNTIME, "hipSetDevice(%d)", s.device)); }
         hipError_t e = hipSuccess;
-        if (mt->xchg == 2 || G == 1) { // bcast: the whole vector to device 0 only (G == 1: that is everything)
+        if (mt->xchg == 1) { // range: exactly the columns this shard references, straight from the caller's vector
+            const long long lo = s.dev->col_min, cnt = (long long) s.dev->col_max + 1 - lo;
+            if (cnt > 0) e = hipMemcpyAsync((char *) s.x + vs * (size_t) lo, (const char *) x + vs * (size_t) lo, vs * (size_t) cnt, hipMemcpyDefault, s.stream);
+        } else if (mt->xchg == 2 || G == 1) { // bcast: the whole vector to device 0 only (G == 1: that is everything)
             if (g == 0 && mt->n > 0) e = hipMemcpyAsync(s.x, x, vs * (size_t) mt->n, hipMemcpyDefault, s.stream);
         } else {
             const long long first = mt->slice * g, cnt = std::max(0ll, std::min((long long) mt->n, first + mt->slice) - first);
@@ -315,8 +340,9 @@ extern "C" int spmv_shim_multi_run(spmv_multi *mt, const void *x, void *y)
         if (e == hipSuccess) e = hipEventRecord(s.ready, s.stream);
         if (e != hipSuccess) { (void) hipGetLastError(); return done(fail(SPMV_HIP_E_RUNTIME, "multi: x upload to device %d: %s", s.device, hipGetErrorString(e))); }
     }
-    // 2. exchange over xGMI, 3. multiply everywhere, 4. y blocks back to the caller's vector
-    rc = multi_exchange(mt);
+    // 2. exchange over xGMI (range mode: every device already took what it needs from X), 3. multiply everywhere,
+    // 4. y blocks back to the caller's vector
+    if (mt->xchg != 1) rc = multi_exchange(mt);
     for (int g = 0; g < G && !rc; ++g) {
         MultiShard &s = mt->sh[(size_t) g];
         (void) hipSetDevice(s.device);

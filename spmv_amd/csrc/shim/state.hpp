@@ -159,6 +159,7 @@ struct spmv_dev {
     int m = 0, n = 0;
     long long nnz = 0;
     size_t vsize = 8;
+    int col_min = 0, col_max = -1; // range of ColIdx (create-time validation; the multi-GPU "range" exchange moves only x[col_min .. col_max])
     // resident CSR
     int *rowptr = nullptr, *colidx = nullptr;
     void *val = nullptr;

@@ -56,7 +56,7 @@ static opt_t g_opts[SPMV_N_OPTS] = {
     [SPMV_OPT_CHECK_VALUES] = {"check_values", 0, 0, 1, 0, 0},        /* 1: spmv() checksums Matrix_Val on every call and refreshes the resident
                                                                        * copy when it changed behind an unchanged pointer (common.c:286-298 semantics) */
     [SPMV_OPT_GPUS] = {"gpus", 0, 0, 64, 0, 0},                       /* > 0: row blocks over min(gpus, visible devices) GPUs in this one process (multi.hpp) */
-    [SPMV_OPT_X_EXCHANGE] = {"x_exchange", 0, 0, 2, 0, 0},            /* multi-GPU: 0 = allgather of the x slices, 1 = halo (referenced entries only), 2 = broadcast from device 0 */
+    [SPMV_OPT_X_EXCHANGE] = {"x_exchange", 0, 0, 2, 0, 0},            /* multi-GPU: 0 = allgather of the x slices, 1 = range (each device gets x[min col .. max col] of its block), 2 = broadcast from device 0 */
 };
 
 static pthread_mutex_t g_opt_lock = PTHREAD_MUTEX_INITIALIZER;

@@ -117,6 +117,8 @@ extern "C" int spmv_shim_matrix_create(spmv_dev **out, int m, int n, const int *
         if (e2 != hipSuccess) return bail(fail(SPMV_HIP_E_RUNTIME, "colidx range kernel: %s", hipGetErrorString(e2)));
         if (host2[0] < 0 || host2[1] >= n)
             return bail(fail(SPMV_HIP_E_ARG, "ColIdx out of range: min %d, max %d, n = %d", host2[0], host2[1], n));
+        d->col_min = host2[0];
+        d->col_max = host2[1];
     }
     *out = d;
     return SPMV_HIP_OK;

@@ -45,7 +45,7 @@ def _multi_handle(csr, method, gpus, xchg=0, arrays=None):
 @pytest.mark.parametrize("method", ALL_METHODS, ids=lambda m: m.name)
 @pytest.mark.parametrize("name", ["banded_f64_eighths", "powerlaw_f32_eighths", "skewed_f64_eighths", "empty_mix_f64_eighths",
                                   "dense_row0_f32_eighths", "single_long_f64_eighths", "tiny_f64_eighths"])
-@pytest.mark.parametrize("gpus,xchg", [(2, 0), (3, 2)])
+@pytest.mark.parametrize("gpus,xchg", [(2, 0), (3, 2), (3, 1)])
 def test_sharded_handle_matches_the_reference_bits(virtual, name, method, gpus, xchg):
     csr, x, y_ref = load_golden(name)
     h = _multi_handle(csr, method, gpus, xchg)
@@ -114,19 +114,23 @@ def test_rccl_entry_points_with_a_one_rank_communicator(monkeypatch):
             h.close()
 
 
-def test_distributed_vectors_step(virtual):
+@pytest.mark.parametrize("xchg", [0, 1, 2])
+def test_distributed_vectors_step(virtual, xchg):
     """Solver-style use: x lives in the devices' slices, spmv_hip_multi_step exchanges + multiplies, y is read from the
     devices' blocks -- nothing crosses PCIe per step."""
     hip = C.CDLL("libamdhip64.so")
     hip.hipMemcpy.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_int]
     csr, x, y_ref = load_golden("banded_wide_f64_eighths")
-    h = _multi_handle(csr, M.Method_Parallel, 3, 0)
+    h = _multi_handle(csr, M.Method_Parallel, 3, xchg)
     try:
         G = h.multi_gpus()
         for g in range(G):
             s = h.multi_slices(g)
-            part = np.ascontiguousarray(x[s["x_first"]: s["x_first"] + s["x_count"]])
-            assert hip.hipMemcpy(s["x_ptr"], part.ctypes.data, part.nbytes, 4) == 0
+            if xchg == 2 and g > 0:
+                continue                                    # broadcast: device 0 holds the whole vector
+            lo, cnt = (0, csr.n) if xchg == 2 else (s["x_first"], s["x_count"])
+            part = np.ascontiguousarray(x[lo: lo + cnt])
+            assert hip.hipMemcpy(s["x_ptr"] - 8 * (s["x_first"] - lo), part.ctypes.data, part.nbytes, 4) == 0
         h.multi_step()
         y = np.full(csr.m, np.nan)
         for g in range(G):

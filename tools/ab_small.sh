@@ -7,16 +7,19 @@ for C in 3w 3w-uniform; do
 import sys,json
 for l in sys.stdin:
     if not l.startswith('RUNCONFIG'): print(l.strip()[:300]); continue
-    d=json.loads(l[10:]); print(d['config'], d['options'], d['kernel'], 'ms_min', d['ms_min'], 'ms_mean', d['ms_mean'], 'frac_alg', d['frac_alg'])
+    d=json.loads(l[10:]); print(d['config'], d['method'], d['options'], d['kernel'], 'ms_min', d['ms_min'], 'ms_mean', d['ms_mean'], 'frac_alg', d['frac_alg'])
 "
   done <<'LIST'
-
---opt block_rows=2048
---opt block_rows=512
---opt block_rows=256
---opt block_rows=256 --opt variant=19
---opt block_rows=512 --opt variant=21
---opt cache_block=0
---opt cache_block=0 --method 6
+--method 3
+--method 3 --opt csr5_sigma=4
+--method 3 --opt csr5_sigma=16
+--method 6
+--method 6 --opt csr5_sigma=4
+--method 6 --opt csr5_sigma=16
+--method 1
+--method 1 --opt lanes_per_row=1
+--method 1 --opt lanes_per_row=2
+--method 5
+--method 0
 LIST
 done
