@@ -78,7 +78,7 @@ int spmv_hip_update_values(spmv_Handle_t handle, const void *Matrix_Val);
  *                      favour -- CSR-vector for regular rows, CSR5 otherwise -- and, if that schedule cannot
  *                      stage a single x window on a matrix whose x is far larger than an L2, by
  *                      Method_Balanced_Yid with the cache-blocked executor; the handle reports it)
- *       "cache_block" (0 never / 1 automatic (default) / 2 always: every schedule but CSR-scalar and SELL hands the
+ *       "cache_block" (0 never / 1 automatic (default) / 2 always: every schedule but the debug kernel CSR-scalar hands the
  *                      multiply to the row-block x column-slab executor when no x window of the matrix fits LDS,
  *                      nnz >= 2^21 and n * size >= 16 MiB (x several times an XCD's L2): ~3x faster on columns
  *                      without locality.  One wavefront owns a row block, so results are bit-reproducible.)

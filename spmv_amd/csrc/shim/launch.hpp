@@ -257,6 +257,7 @@ static int launch(spmv_dev *d, const T *x, T *y)
         launch_long_rows<T>(d, x, y);
         break;
     case SPMV_SCHED_SELL:
+        if (d->blk_on) { launch_blocked<T>(d, x, y); break; }
         // staged path when at least half of the windows fit their x span in LDS; the LDS request is
         // sized by the largest staged span actually present (rounded to 16 KiB) to keep occupancy
         if (d->sell_staged > 0)

@@ -43,7 +43,7 @@ static opt_t g_opts[SPMV_N_OPTS] = {
     [SPMV_OPT_CSR5_SIGMA] = {"csr5_sigma", 0, 0, 16, 0, 0},           /* CSR5 / nnz-split tiles of 64 x sigma entries: 0 = auto, else 4, 8, 16 */
     [SPMV_OPT_ROWBLOCK_NNZ] = {"rowblock_nnz", 0, 0, 1 << 20, 0, 0},  /* Balanced: equal-nnz share of one row block, 0 = 256 mean-length rows */
     [SPMV_OPT_CACHE_BLOCK] = {"cache_block", 1, 0, 2, 0, 0},          /* row-block x column-slab executor when no x window can be staged:
-                                                                       * 1 = automatic (every schedule but CSR-scalar and SELL), 2 = always, 0 = never */
+                                                                       * 1 = automatic (every schedule but CSR-scalar), 2 = always, 0 = never */
     [SPMV_OPT_SLAB_KIB] = {"slab_kib", 0, 0, 1 << 16, 1, 0},          /* ... KiB of x per column slab (0 = as narrow as the cell table allows) */
     [SPMV_OPT_BLOCK_ROWS] = {"block_rows", 0, 0, 32768, 1, 0},        /* ... rows per block (0 = 64 KiB of y) */
     [SPMV_OPT_VARIANT] = {"variant", 0, 0, 1 << 20, 0, 0},            /* kernel-form selector of the A/B harness and the variant tests, 0 = default */

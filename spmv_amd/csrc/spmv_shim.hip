@@ -192,7 +192,10 @@ extern "C" int spmv_shim_build(spmv_dev *d, const spmv_plan *plan)
         if (!rc) rc = f64 ? build_rowblock_tiles<double>(d) : build_rowblock_tiles<float>(d);
         staged = d->vt_staged;
         break;
-    case SPMV_SCHED_SELL: rc = f64 ? build_sell<double>(d) : build_sell<float>(d); break;
+    case SPMV_SCHED_SELL:
+        rc = f64 ? build_sell<double>(d) : build_sell<float>(d);
+        staged = d->plan.sell_lds_x ? d->sell_staged : -1; // sell_lds_x = 0: the caller asked for the plain slab kernel
+        break;
     case SPMV_SCHED_CSR5:
         rc = f64 ? build_csr5<double>(d, d->c5, d->m, d->nnz, d->rowptr, d->colidx, (const double *) d->val, d->stats.empty_rows, d->stats.mean_row_len, nullptr)
                  : build_csr5<float>(d, d->c5, d->m, d->nnz, d->rowptr, d->colidx, (const float *) d->val, d->stats.empty_rows, d->stats.mean_row_len, nullptr);
@@ -201,11 +204,11 @@ extern "C" int spmv_shim_build(spmv_dev *d, const spmv_plan *plan)
     }
     // Columns without locality (no tile group's x windows fit LDS) and x far larger than an L2: every gather of
     // the tile executors crosses the fabric -> row blocks x column slabs (kernels/blocked.hpp) take over the
-    // multiply, whatever the method (SELL keeps its format: it is what the caller asked to see; CSR-scalar is
-    // the debug kernel).  The tile schedule's products are released once the blocked streams exist.
+    // multiply, whatever the method (CSR-scalar, the debug kernel, excepted).  The tile schedule's products are
+    // released once the blocked streams exist.
     if (!rc && staged >= 0 && wants_blocked(d, staged)) {
         const size_t keep_from = d->sched_allocs.size();
-        d->x_groups_seen = plan->sched == SPMV_SCHED_NNZ_SPLIT ? d->ns.groups : (plan->sched == SPMV_SCHED_CSR5 ? d->c5.groups : d->vt_tiles);
+        d->x_groups_seen = plan->sched == SPMV_SCHED_NNZ_SPLIT ? d->ns.groups : (plan->sched == SPMV_SCHED_CSR5 ? d->c5.groups : (plan->sched == SPMV_SCHED_SELL ? d->sell_nwin : d->vt_tiles));
         rc = f64 ? build_blocked<double>(d) : build_blocked<float>(d);
         if (!rc && d->blk_on) drop_tile_schedule(d, keep_from);
     }

@@ -110,7 +110,7 @@ def test_random_columns_every_method_runs_cache_blocked_and_auto_finds_it():
     g = torch.Generator(device=DEV); g.manual_seed(15)
     x = torch.randint(0, 8, (n,), generator=g, device=DEV).double() * 0.125
     want = _definition_regular(m, k, ci, va, x)
-    for method in (M.Method_Parallel, M.Method_Balanced, M.Method_Balanced_Yid, M.Method_CSR5SPMV):
+    for method in (M.Method_Parallel, M.Method_Balanced, M.Method_Balanced_Yid, M.Method_SellCSigma, M.Method_CSR5SPMV):
         y = torch.full((m,), float("nan"), dtype=torch.float64, device=DEV)
         with api.Handle(m, n, rp, ci, va, method) as h:
             h.spmv(x, y)

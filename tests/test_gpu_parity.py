@@ -86,8 +86,8 @@ def test_golden_device_pointers(name, method):
     check(yd.cpu().numpy(), csr, x, y_ref, exact=name.endswith("eighths"))
 
 
-@pytest.mark.parametrize("method", [M.Method_Parallel, M.Method_Balanced, M.Method_Balanced2, M.Method_Balanced_Yid, M.Method_CSR5SPMV],
-                         ids=lambda m: m.name)
+@pytest.mark.parametrize("method", [M.Method_Parallel, M.Method_Balanced, M.Method_Balanced2, M.Method_Balanced_Yid, M.Method_SellCSigma,
+                                    M.Method_CSR5SPMV], ids=lambda m: m.name)
 @pytest.mark.parametrize("name", NAMES)
 def test_golden_row_block_column_slab_executor(name, method):
     """Option cache_block = 2 forces the executor that big matrices without column locality get
@@ -105,6 +105,13 @@ def test_golden_row_block_column_slab_executor(name, method):
         api.set_option("cache_block", 1)
         api.set_option("block_rows", 0)
     assert actual in (method, M.Method_Balanced2, M.Method_Balanced)
+    if csr.nnz > 0:
+        api.set_option("cache_block", 2)
+        try:
+            with api.Handle(csr.m, csr.n, csr.rowptr, csr.colidx, csr.val, method) as h:
+                assert h.info()["kernel_name"] == "blk_kernel"
+        finally:
+            api.set_option("cache_block", 1)
     check(y, csr, x, y_ref, exact=name.endswith("eighths"))
     check(y3, csr, x, y_ref, exact=name.endswith("eighths"))
     assert np.array_equal(y.view(np.uint8), y2.view(np.uint8))
@@ -499,7 +506,7 @@ def test_update_values_refreshes_every_private_layout(name, method, blocked):
     h = None
     try:
         h = api.Handle(csr.m, csr.n, csr.rowptr, csr.colidx, val, method)
-        assert h.info()["cache_blocked"] == (1 if blocked and method not in (M.Method_Serial, M.Method_SellCSigma) else 0)
+        assert h.info()["cache_blocked"] == (1 if blocked and method != M.Method_Serial else 0)
         y0 = h.spmv(x, np.full(csr.m, np.nan, dtype=val.dtype))
         assert np.array_equal(y0, run_host(csr, x, method)[0])
         stale = val.copy()
