@@ -221,6 +221,52 @@ static void choose_vector_shape(const spmv_stats *st, int *lanes_out, int *thr_o
     *thr_out = best_thr;
 }
 
+/*
+ * SELL-C-sigma: which rows stay in the slabs?  Rows are sorted by length inside a sigma window, so a chunk of 64 rows pads
+ * to its longest row: a length class with N rows per window spreads over N / 64 chunks and pads each row by about half
+ * the lengths one chunk spans, (range of the class) x min(1, 64 / N) / 2 -- negligible for the bulk of the rows, ruinous
+ * for a class with fewer than a chunk's worth of rows per window (config 4: 9 % of the rows hold 64..256 entries = 92
+ * rows per 1024-row window = 1.4 chunks, padded by ~40 %; the rule of round 1, "rows longer than max(64, 8 x mean)
+ * leave the slabs", kept them in: padded / stored = 1.30, 0.71 ms; with them on the long-row (CSR5) path: 0.65 ms).
+ * The threshold is chosen at a histogram bucket bound to minimise the estimated bytes: padded slab slots for the rows
+ * below it, nnz x 1.05 on the long-row path for the rows above it.  Returns 0 for "no row leaves the slabs".
+ */
+static int choose_sell_long_threshold(const spmv_stats *st, int sigma)
+{
+    const int NB = SPMV_LEN_BUCKETS;
+    double best_cost = -1.0;
+    int best_thr = 0, best_cand = SPMV_LEN_BUCKETS, cand, b;
+    if (st->m <= 0 || st->nnz <= 0) return 0;
+    for (cand = NB; cand >= 1; --cand) { /* buckets 0 .. cand-1 stay in the slabs; start from "all of them" */
+        double cost = 0.0;
+        for (b = 0; b < NB; ++b) {
+            const double rows = (double) st->hist_rows[b], nnz = (double) st->hist_nnz[b];
+            if (rows <= 0.0) continue;
+            if (b < cand) {
+                const double upper = b < NB - 1 ? (double) (4 << b) : (double) st->max_row_len;
+                const double lower = b == 0 ? 0.0 : (double) (4 << (b - 1));
+                const double per_window = rows * (double) sigma / (double) st->m;
+                double span = (upper - lower) * (per_window >= 64.0 ? 64.0 / per_window : 1.0);
+                if (per_window < 64.0) span += upper - nnz / rows; /* shares its chunk with longer rows: padded to the class bound at least */
+                cost += nnz + rows * span * 0.5;
+            } else {
+                cost += nnz * 1.05;
+            }
+        }
+        if (best_cost < 0.0 || cost < best_cost * 0.97) { /* rows leave the slabs only for a clear (3 %) gain */
+            best_cost = cost;
+            best_cand = cand;
+        }
+    }
+    /* a class right below the cut with less than one chunk's worth of rows per window would pad a chunk of shorter rows: out too */
+    while (best_cand < NB && best_cand > 1) {
+        const double per_window = (double) st->hist_rows[best_cand - 1] * (double) sigma / (double) st->m;
+        if (per_window > 0.0 && per_window < 64.0) --best_cand; else break;
+    }
+    best_thr = best_cand >= NB ? 0 : (4 << (best_cand - 1));
+    return best_thr;
+}
+
 void spmv_plan_choose(SPMV_METHODS requested, const spmv_stats *st, size_t value_size, const spmv_options *opt,
                       spmv_plan *plan, SPMV_METHODS *actual, int allow_auto)
 {
@@ -307,6 +353,12 @@ void spmv_plan_choose(SPMV_METHODS requested, const spmv_stats *st, size_t value
         break;
     case Method_SellCSigma:
         plan->sched = SPMV_SCHED_SELL;
+        if (plan->sell_long_thr == 0) { /* automatic: from the row-length histogram; never above the round-1 rule max(64, 8 x mean) */
+            const int t = choose_sell_long_threshold(st, plan->sell_sigma);
+            double cap = 8.0 * st->mean_row_len;
+            if (cap < 64.0) cap = 64.0;
+            if (t > 0 && (double) t < cap) plan->sell_long_thr = t;
+        }
         break;
     case Method_CSR5SPMV:
         plan->sched = SPMV_SCHED_CSR5;

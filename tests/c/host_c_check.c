@@ -116,6 +116,19 @@ static int check_plan(void)
     (spmv_options_snapshot(&op), spmv_plan_choose(Method_Serial, &st, 8, &op, &pl, &act, 0));
     if (act != Method_Serial) rc = 13;
     spmv_hip_set_option("auto_method", 0);
+    /* SELL: which rows leave the slabs for the long-row path -- config 4's shape: 90 % rows of 8..24, 9 % of 64..256, 1 % of 1000..4000 */
+    memset(&st, 0, sizeof st); st.min_row_len = 1 << 30; st.n = 10000000;
+    hist_put(&st, 8, 1000000); hist_put(&st, 12, 4000000); hist_put(&st, 20, 4000000);
+    hist_put(&st, 64, 5000); hist_put(&st, 100, 300000); hist_put(&st, 200, 595000);
+    hist_put(&st, 1500, 40000); hist_put(&st, 3000, 60000);
+    st.mean_row_len = (double) st.nnz / (double) st.m;
+    (spmv_options_snapshot(&op), spmv_plan_choose(Method_SellCSigma, &st, 4, &op, &pl, &act, 1));
+    printf("sell skewed: long_thr=%d\n", pl.sell_long_thr);
+    if (pl.sell_long_thr != 32) rc = 18;
+    memset(&st, 0, sizeof st); st.min_row_len = 1 << 30; st.n = 10000000;
+    hist_put(&st, 32, 10000000); st.mean_row_len = 32.0;
+    (spmv_options_snapshot(&op), spmv_plan_choose(Method_SellCSigma, &st, 8, &op, &pl, &act, 1));
+    if (pl.sell_long_thr != 0) rc = 19; /* equal rows: everything stays in the slabs */
     /* a thread-local override wins over the process-wide value for creates on this thread, and only there */
     if (spmv_hip_set_thread_option("lanes_per_row", 16) != 0) rc = 15;
     (spmv_options_snapshot(&op), spmv_plan_choose(Method_Parallel, &st, 8, &op, &pl, &act, 1));

@@ -96,10 +96,19 @@ def test_fuzz_every_schedule_matches_the_definition(seed):
             h = api.spmv_create_handle_all_in_one(csr.m, csr.n, csr.rowptr, csr.colidx, csr.val, 1, method,
                                                   csr.val.dtype.itemsize, api.VECTORIZED_WAY.VECTOR_HIP, "fuzz")
             api.spmv(h, csr.m, csr.rowptr, csr.colidx, csr.val, x, y)
+            # values changed in place (x 2: still exact), refreshed without re-inspection, multiplied again
+            y2 = np.full(csr.m, np.nan, dtype=csr.val.dtype)
+            csr.val *= 2
+            try:
+                api.update_values(h, csr.val)
+                api.spmv(h, csr.m, csr.rowptr, csr.colidx, csr.val, x, y2)
+            finally:
+                csr.val /= 2
             api.spmv_destory_handle(h)
             assert not np.isnan(y).any(), (seed, method, chosen)
             bad = np.nonzero(y != want)[0]
             assert bad.size == 0, (seed, method.name, chosen, csr.m, csr.n, int(bad[0]), float(y[bad[0]]), float(want[bad[0]]))
+            assert np.array_equal(y2, 2 * want), (seed, method.name, chosen, "update_values")
     finally:
         for k, v in defaults.items():
             api.set_option(k, v)
