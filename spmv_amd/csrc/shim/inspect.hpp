@@ -485,9 +485,13 @@ static bool wants_blocked(const spmv_dev *d, int staged_groups)
 {
     if (d->plan.cache_block == 2) return d->nnz > 0;
     if (d->plan.variant == 3) return false; // A/B: the tile executors with global gathers
-    // x of a few L2 sizes still gathers well enough from L2 / the Infinity Cache: 8 MB of x (1e6 rows, power-law, 2.6e6 nnz)
-    // ran 26.6 us on the tile kernel against 31.4 us blocked (R-MAT columns) and 39.2 against 39.4 (uniform columns)
-    return d->plan.cache_block == 1 && staged_groups == 0 && d->nnz >= (1ll << 21) && (long long) d->n * (long long) d->vsize >= (16ll << 20);
+    // From which x size on?  Uniformly random columns, 16 nnz/row (tools/ab_threshold.py): the blocked executor wins as
+    // soon as x reaches one XCD's L2 -- fp64, x = 4 / 8 / 16 / 32 MB: 49 / 94 / 180 / 352 us against 55-62 / 157-168 /
+    // 434-450 / 1030-1050 us on the tile kernels (all four of them); at 2 MB the tile kernels lead (45 vs 50 us).  With
+    // very short rows the per-row work of a block (zeroing and writing its y) weighs more: the 1e6-row power-law
+    // stand-in (2.6 nnz/row, x = 8 MB) ran 26.6 us on the tile kernel against 31.4 us blocked -> 16 MiB there.
+    const long long min_x = d->stats.mean_row_len >= 8.0 ? (4ll << 20) : (16ll << 20);
+    return d->plan.cache_block == 1 && staged_groups == 0 && d->nnz >= (1ll << 21) && (long long) d->n * (long long) d->vsize >= min_x;
 }
 
 // ------------------------------------------------------------------------------------ traffic model
