@@ -332,6 +332,8 @@ def run_rank(args):
                 "kernel": info["kernel_name"], "bytes_moved_per_launch": moved, "x_bytes_per_launch": int(info["x_bytes"]),
                 "alg_bytes_per_launch": alg_bytes, "achieved_alg": round(achieved_alg, 1),
                 "frac_alg_bytes": round(achieved_alg / HBM_PEAK_GBPS, 4),
+                # the reference's own bytes model, x counted once per non-zero (csr5_avx2/utils.h:10-14, numa.c:247-248): comparability only
+                "reference_model_gbps": round(((m_loc + 1 + head["nnz_k"]) * 4 + (2 * head["nnz_k"] + m_loc) * s) / (mul_ms * 1e-3) / 1e9, 1),
                 "launch_ms_mean": round(mul_ms, 5), "launches_timed": K if world == 1 else max(5, K // 4),
                 "note": "achieved = bytes the kernel moves (storage-format model spmv_hip_info.stream_bytes, checked against the "
                         "rocprofv3 counters in profiles/) / mean launch time from HIP events on the launch stream; achieved_alg "

@@ -27,7 +27,9 @@ enum {
     SPMV_HIP_E_NOSTATE = 5,    /* handle has no device state (create failed or handle was cleared) */
     SPMV_HIP_E_RANGE = 6       /* nnz or padded size does not fit the index type */
 };
-/* Code of the most recent failure on the calling thread (0 if none since the last clear). */
+/* Failures are also printed to stderr (env SPMV_HIP_QUIET silences that); env SPMV_HIP_ABORT_ON_ERROR makes the
+ * first failure abort() the process -- for drop-in callers that never look at the error channel.
+ * Code of the most recent failure on the calling thread (0 if none since the last clear). */
 int spmv_hip_last_error(void);
 /* Human-readable text for it ("" if none).  Valid until the next failing call on this thread. */
 const char *spmv_hip_last_error_string(void);

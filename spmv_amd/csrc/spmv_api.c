@@ -49,6 +49,9 @@ void spmv_set_error(int code, const char *where, const char *what)
     g_err_code = code;
     snprintf(g_err_text, sizeof g_err_text, "%s: %s", where, what ? what : "");
     if (!getenv("SPMV_HIP_QUIET")) fprintf(stderr, "[spmv_hip] error %d in %s\n", code, g_err_text);
+    /* the API is all-void like the reference's (which checks nothing, not even malloc): a caller that cannot poll
+     * spmv_hip_last_error() may ask for the process to stop at the first failure instead of computing on */
+    if (getenv("SPMV_HIP_ABORT_ON_ERROR")) abort();
 }
 int spmv_hip_last_error(void) { return g_err_code; }
 const char *spmv_hip_last_error_string(void) { return g_err_text; }
