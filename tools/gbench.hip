@@ -139,6 +139,21 @@ __global__ __launch_bounds__(256) void stream_rw(const double *__restrict__ src,
     if (mode == 0 && acc.x == 1.2345) dst[i] = acc.y;
 }
 
+// FETCH_SIZE calibration (tools/profile_configs.sh): a read of a KNOWN byte count with the 16-byte-per-lane nt loads the
+// library's streams use.  MI355X_MICROARCH.md "HBM": on gfx950 FETCH_SIZE reports half the bytes of such reads.
+__global__ __launch_bounds__(256) void calib_read(const double *__restrict__ src, size_t n2, double *__restrict__ out)
+{
+    typedef double d2_t __attribute__((ext_vector_type(2)));
+    const size_t i = (size_t) blockIdx.x * 256 * 4 + threadIdx.x;
+    d2_t acc = {0, 0};
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+        const size_t p = i + (size_t) u * 256;
+        if (p < n2) acc += __builtin_nontemporal_load(reinterpret_cast<const d2_t *>(src) + p);
+    }
+    if (acc.x == 1.2345) out[i] = acc.y;
+}
+
 template <typename F> static float time_ms(F f, int reps)
 {
     hipEvent_t a, b;
@@ -157,8 +172,18 @@ template <typename F> static float time_ms(F f, int reps)
     return best;
 }
 
-int main()
+int main(int argc, char **argv)
 {
+    if (argc > 1 && strcmp(argv[1], "calib") == 0) { // known-bytes read for the FETCH_SIZE calibration
+        const size_t n2 = (size_t) 240 << 20;       // 16-byte elements: 3.75 GiB, far beyond the 256 MiB Infinity Cache
+        double *a, *o;
+        CK(hipMalloc(&a, n2 * 16)); CK(hipMalloc(&o, 1 << 20));
+        CK(hipMemset(a, 0, n2 * 16));
+        for (int r = 0; r < 3; ++r) calib_read<<<(int) ((n2 + 1023) / 1024), 256>>>(a, n2, o);
+        CK(hipDeviceSynchronize());
+        printf("CALIB kernel=calib_read bytes=%zu launches=3\n", n2 * 16);
+        return 0;
+    }
     const size_t maxb = 256u << 20;
     double *tab, *out;
     CK(hipMalloc(&tab, maxb));

@@ -22,8 +22,8 @@ for C in $CONFIGS; do
 done
 echo "== bench.py"; date +%T
 timeout -k 10 280 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/bench/stats" -- python3 "$REPO/bench.py" --steps 30 --warmup 5 --no-cpu > "$OUT/bench.stats.log" 2>&1 || echo "bench stats pass failed"
-if [ -x "$REPO/build/kbench" ]; then
-  timeout -k 10 280 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d "$OUT/calib/fetch" -- "$REPO/build/kbench" 10000000 1 > "$OUT/calib.log" 2>&1 || echo "calib pass failed"
+if [ -x "$REPO/build/gbench" ]; then   # hipcc -O3 --offload-arch=gfx950 tools/gbench.hip -o build/gbench
+  timeout -k 10 280 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d "$OUT/calib/fetch" -- "$REPO/build/gbench" calib > "$OUT/calib.log" 2>&1 || echo "calib pass failed"
 fi
 cd "$REPO"
 python3 tools/summarize_configs.py "$TAG" || true
