@@ -45,7 +45,7 @@ int spmv_hip_set_stream(spmv_Handle_t handle, void *hip_stream);
  * Host x or y always synchronise. */
 int spmv_hip_set_async(spmv_Handle_t handle, int async);
 int spmv_hip_synchronize(spmv_Handle_t handle);
-/* Device blocks freed by destroy / clear / re-inspection are kept (up to SPMV_HIP_POOL_MB MiB, default 8192; 0 = keep
+/* Device blocks freed by destroy / clear / re-inspection are kept (up to SPMV_HIP_POOL_MB MiB, default an eighth of the device's memory; 0 = keep
  * nothing) and handed to the next create: on this runtime a hipMalloc that follows a large hipFree can take seconds.
  * This returns them to the driver now. */
 void spmv_hip_trim_pool(void);

@@ -33,8 +33,8 @@ extern "C" const char *spmv_shim_error_text(void) { return t_err; }
 // created right after another handle was destroyed took 3.2 s of which 16 ms were inspector kernels).  create() frees
 // and allocates in quick succession (re-inspection, auto_method = 2 building five schedules, the blocked executor
 // replacing a tile schedule), so freed blocks are kept in a small per-process pool and handed out again: same
-// device, at least the size asked for and at most 25 % more.  Cap: SPMV_HIP_POOL_MB (default 8192 MiB; 0 = no
-// pool); spmv_hip_trim_pool() releases everything; an allocation that fails trims the pool and retries.
+// device, at least the size asked for and at most 25 % more.  Cap: SPMV_HIP_POOL_MB (default: an eighth of the
+// device's memory; 0 = no pool); spmv_hip_trim_pool() releases everything; an allocation that fails trims the pool and retries.
 struct PoolBlock { void *p; size_t bytes; int device; };
 static std::mutex g_pool_lock;
 static std::vector<PoolBlock> g_pool;              // free blocks
@@ -46,7 +46,12 @@ static size_t pool_cap()
     static long long cap = -1;
     if (cap < 0) {
         const char *e = getenv("SPMV_HIP_POOL_MB");
-        cap = (e && *e ? atoll(e) : 8192ll) << 20;
+        if (e && *e) cap = atoll(e) << 20;
+        else { // default: an eighth of the device's memory (36 GB of 288): the blocks of one large handle
+            size_t free_b = 0, total_b = 0;
+            if (hipMemGetInfo(&free_b, &total_b) != hipSuccess) { (void) hipGetLastError(); total_b = (size_t) 64 << 30; }
+            cap = (long long) (total_b / 8);
+        }
         if (cap < 0) cap = 0;
     }
     return (size_t) cap;

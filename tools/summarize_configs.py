@@ -28,8 +28,10 @@ os.makedirs(dst, exist_ok=True)
 
 
 def find(base, suffix):
+    """newest match: rocprofv3 names its files by process id, and gpurun MERGES a run's output into gpurun_out/ without
+    deleting what an earlier run left there"""
     hits = glob.glob(os.path.join(base, "**", f"*{suffix}"), recursive=True)
-    return hits[0] if hits else None
+    return max(hits, key=os.path.getmtime) if hits else None
 
 
 def counters(base):
