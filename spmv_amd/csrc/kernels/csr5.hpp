@@ -221,16 +221,34 @@ __global__ __launch_bounds__(kBlock) void csr5_transpose_kernel(int nnz, int p, 
 // global columns with -1 = padding; v: values): gathers, per-lane segmented sums cut at the row-start
 // flags, cross-lane combine, y stores and the tile's carry.  Shared by the transposed (CSR5) and
 // the natural-layout (nnz-split) tile loaders.
+// Row map of a tile in LDS (matrices with empty rows: the tiles run over the compacted row space and y[row_map[r]] is
+// where a row's sum goes).  A tile writes rows r0 .. r1 = tile_ptr[t] .. tile_ptr[t + 1], at most 64 * SIGMA + 1 of
+// them; all of their row_map entries are fetched up front by unconditional, coalesced loads and parked in `rm`
+// ((SIGMA + 1) * 64 ints, private to the wavefront).  Before: every row start did "load row_map[seg_row] -> wait ->
+// store y" inside its branch, and since stores count in vmcnt on gfx9 each wait also drained the previous store --
+// up to SIGMA + 1 memory latencies per tile, the whole run time of the 1e6-row power-law stand-in (21 us).
+template <int SIGMA>
+__device__ __forceinline__ void csr5_stage_row_map(int lane, int r0, int r1, const int *__restrict__ row_map, int *__restrict__ rm)
+{
+    int tmp[SIGMA + 1];
+    const int span = r1 - r0;
+#pragma unroll
+    for (int j = 0; j <= SIGMA; ++j) {
+        const int k = j * kWave + lane;
+        tmp[j] = row_map[r0 + (k < span ? k : span)];
+    }
+#pragma unroll
+    for (int j = 0; j <= SIGMA; ++j) rm[j * kWave + lane] = tmp[j];
+    wave_lds_sync();
+}
+
 template <typename T, int SIGMA, bool MAPPED, bool STAGED>
 __device__ __forceinline__ void csr5_tile_compute(int t, int lane, const int (&c)[SIGMA], const T (&v)[SIGMA],
-                                                  const int *__restrict__ tile_ptr, const unsigned *__restrict__ desc,
-                                                  const int *__restrict__ row_map,
+                                                  unsigned d, int r0, const int *__restrict__ rm /* MAPPED: the tile's row map in LDS */,
                                                   const T *__restrict__ x, const T *__restrict__ xs,
                                                   T *__restrict__ y, T *__restrict__ carry)
 {
-    const unsigned d = desc[(long long) t * kWave + lane];
     const unsigned flags = d & kCsr5FlagMask;
-    const int r0 = tile_ptr[t];
     // row of the tile's first row start: r0 itself if the tile begins on a row boundary
     const unsigned f0 = (unsigned) __builtin_amdgcn_readfirstlane((int) flags);
     int seg_row = r0 + ((f0 & 1u) ? 0 : 1) + (int) (d >> kCsr5YoffShift);
@@ -247,7 +265,7 @@ __device__ __forceinline__ void csr5_tile_compute(int t, int lane, const int (&c
     for (int i = 0; i < SIGMA; ++i) {
         if (flags & (1u << i)) {
             if (started) {
-                y[MAPPED ? row_map[seg_row] : seg_row] = acc; // began and ended inside this lane
+                y[MAPPED ? rm[seg_row - r0] : seg_row] = acc; // began and ended inside this lane
                 ++seg_row;
             } else {
                 head = acc;
@@ -269,7 +287,7 @@ __device__ __forceinline__ void csr5_tile_compute(int t, int lane, const int (&c
     }
     T next = __shfl_down(B, 1, kWave);
     if (lane == kWave - 1) next = 0;
-    if (started) y[MAPPED ? row_map[seg_row] : seg_row] = acc + next;
+    if (started) y[MAPPED ? rm[seg_row - r0] : seg_row] = acc + next;
     if (lane == 0) carry[t] = B;
 }
 
@@ -281,12 +299,14 @@ template <typename T, int SIGMA, bool MAPPED, bool STAGED>
 __device__ __forceinline__ void csr5_tile(int t, int lane, const int *__restrict__ tile_ptr,
                                           const unsigned *__restrict__ desc, const int *__restrict__ tcol,
                                           const unsigned short *__restrict__ tcol16,
-                                          const T *__restrict__ tval, const int *__restrict__ row_map,
+                                          const T *__restrict__ tval, const int *__restrict__ row_map, int *__restrict__ rm,
                                           const T *__restrict__ x, const T *__restrict__ xs,
                                           T *__restrict__ y, T *__restrict__ carry)
 {
     constexpr int TN = kWave * SIGMA;
     const long long base = (long long) t * TN + lane;
+    const unsigned d = desc[(long long) t * kWave + lane]; // descriptor and row range first: nothing below waits for them
+    const int r0 = tile_ptr[t], r1 = MAPPED ? tile_ptr[t + 1] : 0;
     int c[SIGMA];
     T v[SIGMA];
     if (STAGED) {
@@ -305,7 +325,8 @@ __device__ __forceinline__ void csr5_tile(int t, int lane, const int *__restrict
     }
 #pragma unroll
     for (int i = 0; i < SIGMA; ++i) v[i] = ld_stream(tval + base + i * kWave);
-    csr5_tile_compute<T, SIGMA, MAPPED, STAGED>(t, lane, c, v, tile_ptr, desc, row_map, x, xs, y, carry);
+    if constexpr (MAPPED) csr5_stage_row_map<SIGMA>(lane, r0, r1, row_map, rm);
+    csr5_tile_compute<T, SIGMA, MAPPED, STAGED>(t, lane, c, v, d, r0, rm, x, xs, y, carry);
 }
 
 // y = 0 for the matrix's empty rows (they are outside the compacted row space the tiles write), spread
@@ -326,10 +347,11 @@ __global__ __launch_bounds__(kBlock) void csr5_kernel(int p, const int *__restri
                                                       T *__restrict__ carry, int n_empty, const int *__restrict__ empty_list)
 {
     if (MAPPED) zero_empty_rows(n_empty, empty_list, y);
+    __shared__ int rm_lds[MAPPED ? kBlock / kWave : 1][MAPPED ? (SIGMA + 1) * kWave : 1];
     const int lane = threadIdx.x & (kWave - 1);
     const int t = blockIdx.x * (kBlock / kWave) + threadIdx.x / kWave;
     if (t >= p) return;
-    csr5_tile<T, SIGMA, MAPPED, false>(t, lane, tile_ptr, desc, tcol, nullptr, tval, row_map, x, nullptr, y, carry);
+    csr5_tile<T, SIGMA, MAPPED, false>(t, lane, tile_ptr, desc, tcol, nullptr, tval, row_map, rm_lds[MAPPED ? threadIdx.x / kWave : 0], x, nullptr, y, carry);
 }
 
 // ---- LDS-staged x windows (xwindows.hpp) --------------------------------------------------------
@@ -359,13 +381,15 @@ __global__ __launch_bounds__(kBlock) void csr5_group_kernel(int group_tiles, int
         if (threadIdx.x == 0) xs[tw.total] = T(0); // the zero slot of padding entries
         __syncthreads();
     }
+    __shared__ int rm_lds[MAPPED ? kBlock / kWave : 1][MAPPED ? (SIGMA + 1) * kWave : 1];
+    int *rm = rm_lds[MAPPED ? threadIdx.x / kWave : 0];
     const int lane = threadIdx.x & (kWave - 1);
     const int t0 = blockIdx.x * group_tiles;
     for (int k = threadIdx.x / kWave; k < group_tiles; k += kBlock / kWave) {
         const int t = t0 + k;
         if (t >= p) break;
-        if (staged) csr5_tile<T, SIGMA, MAPPED, true>(t, lane, tile_ptr, desc, tcol, tcol16, tval, row_map, x, xs, y, carry);
-        else csr5_tile<T, SIGMA, MAPPED, false>(t, lane, tile_ptr, desc, tcol, tcol16, tval, row_map, x, xs, y, carry);
+        if (staged) csr5_tile<T, SIGMA, MAPPED, true>(t, lane, tile_ptr, desc, tcol, tcol16, tval, row_map, rm, x, xs, y, carry);
+        else csr5_tile<T, SIGMA, MAPPED, false>(t, lane, tile_ptr, desc, tcol, tcol16, tval, row_map, rm, x, xs, y, carry);
     }
 }
 
@@ -393,11 +417,13 @@ template <typename T, int SIGMA, bool MAPPED, bool STAGED, bool HALF>
 __device__ __forceinline__ void nat_tile(int t, int lane, int nnz, unsigned zslot, unsigned char *__restrict__ wl,
                                          const int *__restrict__ tile_ptr, const unsigned *__restrict__ desc,
                                          const int *__restrict__ colidx, const unsigned short *__restrict__ col16,
-                                         const T *__restrict__ val, const int *__restrict__ row_map,
+                                         const T *__restrict__ val, const int *__restrict__ row_map, int *__restrict__ rm,
                                          const T *__restrict__ x, const T *__restrict__ xs,
                                          T *__restrict__ y, T *__restrict__ carry)
 {
     using NL = NatLds<T, SIGMA, HALF>;
+    const unsigned d = desc[(long long) t * kWave + lane]; // descriptor and row range first: in flight with the tile itself
+    const int r0 = tile_ptr[t], r1 = MAPPED ? tile_ptr[t + 1] : 0;
     constexpr int TN = kWave * SIGMA;
     constexpr int EPL = 16 / (int) sizeof(T);              // values per 16-byte load
     constexpr int VL = SIGMA / EPL;                        // value loads per lane
@@ -505,7 +531,8 @@ __device__ __forceinline__ void nat_tile(int t, int lane, int nnz, unsigned zslo
         }
         wave_lds_sync(); // the buffer is free for the other half / the wave's next tile
     }
-    csr5_tile_compute<T, SIGMA, MAPPED, STAGED>(t, lane, c, v, tile_ptr, desc, row_map, x, xs, y, carry);
+    if constexpr (MAPPED) csr5_stage_row_map<SIGMA>(lane, r0, r1, row_map, rm);
+    csr5_tile_compute<T, SIGMA, MAPPED, STAGED>(t, lane, c, v, d, r0, rm, x, xs, y, carry);
 }
 
 template <typename T, int SIGMA, bool MAPPED>
@@ -517,10 +544,11 @@ __global__ __launch_bounds__(kBlock) void nat_kernel(int p, int nnz, const int *
 {
     if (MAPPED) zero_empty_rows(n_empty, empty_list, y);
     __shared__ __attribute__((aligned(16))) unsigned char nat_lds[kBlock / kWave][NatLds<T, SIGMA, false>::kBytes];
+    __shared__ int rm_lds[MAPPED ? kBlock / kWave : 1][MAPPED ? (SIGMA + 1) * kWave : 1];
     const int lane = threadIdx.x & (kWave - 1), wave = threadIdx.x / kWave;
     const int t = blockIdx.x * (kBlock / kWave) + wave;
     if (t >= p) return;
-    nat_tile<T, SIGMA, MAPPED, false, false>(t, lane, nnz, 0u, nat_lds[wave], tile_ptr, desc, colidx, nullptr, val, row_map, x, nullptr, y, carry);
+    nat_tile<T, SIGMA, MAPPED, false, false>(t, lane, nnz, 0u, nat_lds[wave], tile_ptr, desc, colidx, nullptr, val, row_map, rm_lds[MAPPED ? wave : 0], x, nullptr, y, carry);
 }
 
 // HALF: two-half hand-over (half the tile buffers, twice the wave syncs: ~8 % slower per tile) -- chosen by
@@ -538,6 +566,7 @@ __global__ __launch_bounds__(kBlock) void nat_group_kernel(int group_tiles, int 
     if (MAPPED) zero_empty_rows(n_empty, empty_list, y);
     extern __shared__ __attribute__((aligned(16))) unsigned char csr5_x_lds[];
     __shared__ __attribute__((aligned(16))) unsigned char nat_lds[kBlock / kWave][NatLds<T, SIGMA, HALF>::kBytes];
+    __shared__ int rm_lds[MAPPED ? kBlock / kWave : 1][MAPPED ? (SIGMA + 1) * kWave : 1];
     T *xs = reinterpret_cast<T *>(csr5_x_lds);
     const TileWindows &tw = wins[blockIdx.x];
     const bool staged = tw.nwin > 0;
@@ -551,8 +580,8 @@ __global__ __launch_bounds__(kBlock) void nat_group_kernel(int group_tiles, int 
     for (int k = wave; k < group_tiles; k += kBlock / kWave) {
         const int t = t0 + k;
         if (t >= p) break;
-        if (staged) nat_tile<T, SIGMA, MAPPED, true, HALF>(t, lane, nnz, (unsigned) tw.total, nat_lds[wave], tile_ptr, desc, colidx, col16, val, row_map, x, xs, y, carry);
-        else nat_tile<T, SIGMA, MAPPED, false, HALF>(t, lane, nnz, 0u, nat_lds[wave], tile_ptr, desc, colidx, col16, val, row_map, x, xs, y, carry);
+        if (staged) nat_tile<T, SIGMA, MAPPED, true, HALF>(t, lane, nnz, (unsigned) tw.total, nat_lds[wave], tile_ptr, desc, colidx, col16, val, row_map, rm_lds[MAPPED ? wave : 0], x, xs, y, carry);
+        else nat_tile<T, SIGMA, MAPPED, false, HALF>(t, lane, nnz, 0u, nat_lds[wave], tile_ptr, desc, colidx, col16, val, row_map, rm_lds[MAPPED ? wave : 0], x, xs, y, carry);
     }
 }
 

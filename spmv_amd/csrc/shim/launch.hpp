@@ -144,10 +144,11 @@ static void launch_csr5_form(spmv_dev *d, const Csr5Plan &P, const T *x, T *y)
         if (P.natural) {
             // the waves' tile buffers are static LDS next to the x windows: if the full-size buffers would leave
             // one workgroup per CU, hand the tiles over in two halves (half the buffers)
-            constexpr size_t full = (size_t) (kBlock / kWave) * NatLds<T, SIGMA, false>::kBytes;
+            constexpr size_t rmb = MAPPED ? (size_t) (kBlock / kWave) * (SIGMA + 1) * kWave * sizeof(int) : 0; // the tiles' row maps (matrices with empty rows)
+            constexpr size_t full = (size_t) (kBlock / kWave) * NatLds<T, SIGMA, false>::kBytes + rmb;
             const bool half = lds + full > 76 * 1024; // two workgroups no longer fit a CU's 160 KiB
             if (half) {
-                ensure_lds<nat_group_kernel<T, SIGMA, MAPPED, true>>(d, lds, (size_t) (kBlock / kWave) * NatLds<T, SIGMA, true>::kBytes);
+                ensure_lds<nat_group_kernel<T, SIGMA, MAPPED, true>>(d, lds, (size_t) (kBlock / kWave) * NatLds<T, SIGMA, true>::kBytes + rmb);
                 nat_group_kernel<T, SIGMA, MAPPED, true><<<P.groups, kBlock, lds, d->stream>>>(P.group_tiles, P.tiles, (int) P.nnz, P.tile_ptr, P.desc, P.col, P.col16,
                                                                                               (const T *) P.val, P.row_map, P.wins, x, y, (T *) P.carry, P.n_empty, P.empty_list);
             } else {
@@ -157,7 +158,7 @@ static void launch_csr5_form(spmv_dev *d, const Csr5Plan &P, const T *x, T *y)
             }
             return;
         }
-        ensure_lds<csr5_group_kernel<T, SIGMA, MAPPED>>(d, lds);
+        ensure_lds<csr5_group_kernel<T, SIGMA, MAPPED>>(d, lds, MAPPED ? (size_t) (kBlock / kWave) * (SIGMA + 1) * kWave * sizeof(int) : 0);
         csr5_group_kernel<T, SIGMA, MAPPED><<<P.groups, kBlock, lds, d->stream>>>(P.group_tiles, P.tiles, P.tile_ptr, P.desc, P.col, P.col16, (const T *) P.val, P.row_map, P.wins,
                                                                                  x, y, (T *) P.carry, P.n_empty, P.empty_list);
         return;
