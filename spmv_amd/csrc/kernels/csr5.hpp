@@ -596,8 +596,15 @@ __global__ __launch_bounds__(kBlock) void csr5_fixup_kernel(int p, const int *__
     const int n = run_len[t];
     if (n <= 0) return;
     T sum = 0;
-    for (int u = t; u < t + n; ++u) sum += carry[u];
     const int r = tile_ptr[t];
+    for (int u = t; u < t + n; u += 8) { // a row that spans many tiles: eight carries in flight, added in tile order as before
+        T c[8];
+#pragma unroll
+        for (int k = 0; k < 8; ++k) c[k] = carry[u + k < t + n ? u + k : t + n - 1];
+#pragma unroll
+        for (int k = 0; k < 8; ++k)
+            if (u + k < t + n) sum += c[k];
+    }
     y[MAPPED ? row_map[r] : r] += sum;
 }
 
