@@ -576,6 +576,41 @@ def test_options_are_per_handle_and_thread_local_overrides_do_not_leak():
         a.close(); b.close()
 
 
+def test_threads_create_differently_tuned_handles_concurrently():
+    """Options are resolved per handle (process-wide -> thread-local override -> snapshot): four threads create handles with
+    four lane widths at the same time, multiply, refresh values and destroy, without seeing each other's settings."""
+    import threading
+    csr, x, y_ref = load_golden("rowlen_sweep_f64_eighths")
+    out, errs = {}, []
+
+    def work(lanes):
+        try:
+            for _ in range(5):
+                api.set_thread_option("lanes_per_row", lanes)
+                val = csr.val.copy()
+                h = api.Handle(csr.m, csr.n, csr.rowptr, csr.colidx, val, M.Method_Parallel)
+                assert h.option("lanes_per_row") == lanes and h.info()["lanes_per_row"] == lanes
+                y = h.spmv(x, np.empty(csr.m))
+                val *= 2.0
+                h.update_values(val)
+                y2 = h.spmv(x, np.empty(csr.m))
+                h.close()
+                assert np.array_equal(y, y_ref) and np.array_equal(y2, 2.0 * y_ref)
+            out[lanes] = True
+        except Exception as e:                      # noqa: BLE001
+            errs.append((lanes, repr(e)))
+        finally:
+            api.clear_thread_options()
+
+    threads = [threading.Thread(target=work, args=(l,)) for l in (2, 8, 16, 64)]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join()
+    assert not errs, errs
+    assert sorted(out) == [2, 8, 16, 64] and api.get_option("lanes_per_row") == 0
+
+
 def test_stream_bytes_model_of_the_storage_format():
     """spmv_hip_info.stream_bytes: what one launch has to move given the format -- below alg_bytes when the 16-bit
     slot stream replaces ColIdx, above it for SELL's padding; x charged by the windows actually staged."""
