@@ -198,10 +198,21 @@ def run_rank(args):
     one_device = bool(os.environ.get("SPMV_BENCH_ONE_DEVICE"))      # rehearsal only: every rank on cuda:0
     dev_index = 0 if (one_device or world == 1) else local_rank
     assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE {world}"
+    backend_note = None
     if world > 1:
         torch.cuda.set_device(dev_index)
         if args.backend == "nccl":
-            dist.init_process_group("nccl", device_id=torch.device("cuda", dev_index))
+            try:        # RCCL over xGMI; every rank sees the same failure if the node's RCCL cannot come up
+                dist.init_process_group("nccl", device_id=torch.device("cuda", dev_index))
+                dist.barrier()
+            except Exception as e:      # noqa: BLE001 -- keep the scaling run alive and say so in the line
+                backend_note = f"nccl init failed ({type(e).__name__}: {str(e)[:120]}); fell back to gloo (host-staged exchange, NOT the judged path)"
+                sys.stderr.write("bench.py: " + backend_note + "\n")
+                if dist.is_initialized():
+                    dist.destroy_process_group()
+                os.environ["MASTER_PORT"] = str(int(os.environ.get("MASTER_PORT", "29500")) + 1)
+                args.backend = "gloo"
+                dist.init_process_group("gloo")
         else:
             dist.init_process_group("gloo")
         assert dist.get_world_size() == world
@@ -320,7 +331,7 @@ def run_rank(args):
                 "schedule": f"{api.SPMV_METHODS(args.method).name} -> {info['schedule_name']}"
                             + (f" L={info['lanes_per_row']}" if info['lanes_per_row'] else ""),
                 "x_exchange": head["xchg"], "rccl_ranks": (dist.get_world_size() if world > 1 else 1),
-                "backend": (args.backend if world > 1 else "none"),
+                "backend": (args.backend if world > 1 else "none"), "backend_note": backend_note,
                 "ghost_columns_rank0": first["ghost_columns_rank0"], "overlap_split": first["overlap_split"],
                 "boundary_rows_rank0": first["boundary_rows_rank0"], "vectors": "device-resident x, y",
                 "nnz_total": nnz_all, "create_seconds": round(first["create_s"], 3), "inspect_ms": round(info["inspect_ms"], 3),
