@@ -66,7 +66,8 @@ int spmv_hip_update_values(spmv_Handle_t handle, const void *Matrix_Val);
  * without racing -- and stored in the handle (spmv_hip_get_handle_option). */
 /* keys: "lanes_per_row" (CSR-vector, 0 = auto, else 1..64 power of two)
  *       "sell_c" (64)  "sell_sigma" (1024)  "sell_lds_x" (0/1: stage narrow x windows in LDS)
- *       "sell_long_thr" (rows longer than this stay out of the slabs, 0 = max(64, 8 x mean row length))
+ *       "sell_long_thr" (rows longer than this stay out of the slabs; 0 = from the row-length histogram: length classes with
+ *                        less than a chunk's worth of rows per sigma window leave, at most max(64, 8 x mean row length) stays)
  *       "csr5_sigma" (0 = auto)  "rowblock_nnz" (equal-nnz share of one Balanced row block, 0 = auto = 8192)
  *       "variant" (kernel variant selector used by the tuning harness, 0 = default)
  *       "autotune" (0/1, default 1: for matrices above 2^24 nnz create() times the applicable CSR-vector

@@ -39,7 +39,7 @@ static opt_t g_opts[SPMV_N_OPTS] = {
     [SPMV_OPT_SELL_C] = {"sell_c", 64, 64, 64, 1, 0},                 /* one wavefront per chunk: C is the wave width */
     [SPMV_OPT_SELL_SIGMA] = {"sell_sigma", 1024, 64, 1 << 20, 1, 0},
     [SPMV_OPT_SELL_LDS_X] = {"sell_lds_x", 1, 0, 1, 0, 0},            /* SELL: stage the x windows of the sigma windows in LDS */
-    [SPMV_OPT_SELL_LONG_THR] = {"sell_long_thr", 0, 0, 1 << 20, 0, 0},/* SELL: rows longer than this leave the slabs for the long-row path (0 = max(64, 8 x mean)) */
+    [SPMV_OPT_SELL_LONG_THR] = {"sell_long_thr", 0, 0, 1 << 20, 0, 0},/* SELL: rows longer than this leave the slabs for the long-row path (0 = from the histogram, choose_sell_long_threshold) */
     [SPMV_OPT_CSR5_SIGMA] = {"csr5_sigma", 0, 0, 16, 0, 0},           /* CSR5 / nnz-split tiles of 64 x sigma entries: 0 = auto, else 4, 8, 16 */
     [SPMV_OPT_ROWBLOCK_NNZ] = {"rowblock_nnz", 0, 0, 1 << 20, 0, 0},  /* Balanced: equal-nnz share of one row block, 0 = 256 mean-length rows */
     [SPMV_OPT_CACHE_BLOCK] = {"cache_block", 1, 0, 2, 0, 0},          /* row-block x column-slab executor when no x window can be staged:
