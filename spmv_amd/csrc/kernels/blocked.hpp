@@ -20,7 +20,7 @@
 //               16-bit row number inside the block; block regions start at multiples of 8 entries so
 //               every load is a 16-byte load.
 //   executor    ONE WAVEFRONT per row block (a 64-thread workgroup).  y of the block lives in LDS
-//               (R * sizeof(T) = 64 KiB: two blocks per CU -- more resident blocks drift apart in their
+//               (R doubles = 64 KiB, for fp32 values too -- see lds_add: two blocks per CU -- more resident blocks drift apart in their
 //               slab position and thrash L2), the wave walks the block's entries in stored order -- slab
 //               after slab; blocks are dispatched in order and hold similar work, so the blocks of an XCD
 //               gather from the same few slabs of x at a time, which therefore stay in L2 -- with 16
@@ -177,10 +177,13 @@ __global__ __launch_bounds__(kWave) void blk_fill_kernel(int m, int R, int K, in
 
 constexpr int kBlkPad = 65536; // zero entries behind the last block: two executor steps of the widest form (256 threads x 4 entries x 16 groups x 2)
 
-__device__ __forceinline__ void lds_add(float *p, float v) { (void) unsafeAtomicAdd(p, v); }
+// The block's y is accumulated in DOUBLE for both value types: ds_add_f32 runs at 2.0e11 adds/s over the chip whatever the
+// bank pattern, ds_add_f64 at 7-9e11/s (tools/gbench lds, profiles/r02_gbench.txt) -- with float accumulators every fp32
+// matrix ran at the LDS-atomic rate (0.51 ms for 9.6e7 entries, local columns or not).  fp32 products are rounded to
+// float first (as every other executor forms them) and summed in double, which is at least as accurate as a float sum.
 __device__ __forceinline__ void lds_add(double *p, double v) { (void) unsafeAtomicAdd(p, v); }
 
-// Executor.  Dynamic LDS: R * sizeof(T) bytes (the block's y).  NT = 64: one wavefront per block (deterministic);
+// Executor.  Dynamic LDS: R * 8 bytes (the block's y, in double).  NT = 64: one wavefront per block (deterministic);
 // UN load groups of 16 bytes of values in flight per lane, and the NEXT step's stream loads are issued before
 // this step's gathers are waited for.
 //
@@ -221,10 +224,10 @@ __global__ __launch_bounds__(NT) void blk_kernel(int m, int R, const long long *
                                                  const unsigned short *__restrict__ brow, const T *__restrict__ x, T *__restrict__ y)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char blk_y_lds[];
-    T *ys = reinterpret_cast<T *>(blk_y_lds);
+    double *ys = reinterpret_cast<double *>(blk_y_lds);
     constexpr int EPL = 16 / (int) sizeof(T); // entries per 16-byte value load
     constexpr int STEP = NT * EPL;            // entries one load group covers over the workgroup
-    for (int i = threadIdx.x; i < R; i += NT) ys[i] = T(0);
+    for (int i = threadIdx.x; i < R; i += NT) ys[i] = 0.0;
     __syncthreads();
     const long long s = start[blockIdx.x], e = end[blockIdx.x];
     const long long lane0 = s + (long long) threadIdx.x * EPL;
@@ -245,7 +248,7 @@ __global__ __launch_bounds__(NT) void blk_kernel(int m, int R, const long long *
             const long long p = lane0 + (it - s) + (long long) u * STEP;
 #pragma unroll
             for (int j = 0; j < EPL; ++j) // unconditional: a masked entry adds 0 to a row of this block (its row number is the next block's or padding's, < R) -- a branch here makes the compiler sink gathers into it and wait for the whole queue
-                lds_add(&ys[cur[u].r[j]], p + j < e ? cur[u].v[j] * xv[u][j] : T(0));
+                lds_add(&ys[cur[u].r[j]], p + j < e ? (double) (cur[u].v[j] * xv[u][j]) : 0.0);
         }
 #pragma unroll
         for (int u = 0; u < UN; ++u) cur[u] = nxt[u];
@@ -253,7 +256,7 @@ __global__ __launch_bounds__(NT) void blk_kernel(int m, int R, const long long *
     __syncthreads();
     const long long r0 = (long long) blockIdx.x * R;
     for (int i = threadIdx.x; i < R; i += NT)
-        if (r0 + i < m) y[r0 + i] = ys[i];
+        if (r0 + i < m) y[r0 + i] = (T) ys[i];
 }
 
 } // namespace spmv

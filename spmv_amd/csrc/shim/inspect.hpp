@@ -449,10 +449,10 @@ static int blocked_fill(spmv_dev *d, int wshift, bool values_only)
 template <typename T>
 static int build_blocked(spmv_dev *d)
 {
-    int R = d->plan.block_rows > 0 ? d->plan.block_rows : (int) (64 * 1024 / sizeof(T));
+    int R = d->plan.block_rows > 0 ? d->plan.block_rows : (int) (64 * 1024 / sizeof(double)); // double accumulators (blocked.hpp)
     if (d->plan.block_rows == 0) // small matrices: at least ~512 blocks (two single-wave blocks per CU), down to 1024 rows
         while (R > 1024 && (long long) d->m / R < 512) R >>= 1;
-    if ((size_t) R * sizeof(T) > 128 * 1024) R = (int) (128 * 1024 / sizeof(T));
+    if ((size_t) R * sizeof(double) > 128 * 1024) R = (int) (128 * 1024 / sizeof(double));
     // Slab width: as narrow as the cell table allows (2^25 cells: ~400 MB of inspector scratch), down to 32
     // columns.  Narrow slabs cost nothing in L2 locality (the sweep over x is the same) and put entries that
     // gather from the same cache line into neighbouring lanes, which the L1/TA path merges into one L2

@@ -118,7 +118,7 @@ static int autotune_vector(spmv_dev *d)
 template <typename T>
 static void launch_blocked(spmv_dev *d, const T *x, T *y)
 {
-    const size_t lds = (size_t) d->blk_R * sizeof(T);
+    const size_t lds = (size_t) d->blk_R * sizeof(double); // accumulators are double for both value types
 #define SPMV_BLK_LAUNCH(NT, UN)                                                                                                  \
     do {                                                                                                                         \
         ensure_lds<blk_kernel<T, NT, UN>>(d, lds);                                                                               \

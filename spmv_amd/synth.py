@@ -256,9 +256,15 @@ def from_row_lengths_device(lens, n, values="uniform", dtype=None, device="cuda"
         centre = row_of * n // max(m, 1)
         jitter = torch.randint(-local, local + 1, (nnz,), generator=g, device=device, dtype=torch.int64)
         colidx = (centre + jitter).clamp_(0, n - 1).to(torch.int32)
-    elif cols == "rmat":
+    elif cols in ("rmat", "web"):
         row_of = torch.repeat_interleave(torch.arange(m, device=device, dtype=torch.int64), lens)
         colidx = rmat_columns_device(row_of, m, n, device, seed)
+        if cols == "web":   # web-graph-like: 90 % of a row's links stay near its own position ("same host"), 10 % follow the R-MAT hubs
+            centre = row_of * n // max(m, 1)
+            near = (centre + torch.randint(-2000, 2001, (nnz,), generator=g, device=device, dtype=torch.int64)).clamp_(0, n - 1)
+            keep = torch.rand(nnz, generator=g, device=device) < 0.1
+            colidx = torch.where(keep, colidx.to(torch.int64), near).to(torch.int32)
+            del centre, near, keep
         key = (row_of << 32) | colidx.to(torch.int64)                   # sort columns inside every row
         del row_of
         colidx = (torch.sort(key).values & 0xFFFFFFFF).to(torch.int32)

@@ -154,6 +154,34 @@ __global__ __launch_bounds__(256) void calib_read(const double *__restrict__ src
     if (acc.x == 1.2345) out[i] = acc.y;
 }
 
+
+// LDS float atomics from ONE wavefront per workgroup (the blocked executor's accumulation): U adds per step per lane into a
+// region of `words` elements.  pattern 0: lane-consecutive (no bank conflict), 1: hashed (random banks), 2: ascending with a
+// random stride (what a cell sorted by row looks like).
+template <typename T, int U>
+__global__ __launch_bounds__(64) void lds_atomics(int words, int steps, int pattern, T *__restrict__ out)
+{
+    extern __shared__ unsigned char raw[];
+    T *ys = reinterpret_cast<T *>(raw);
+    for (int i = threadIdx.x; i < words; i += 64) ys[i] = 0;
+    __syncthreads();
+    unsigned h = blockIdx.x * 64u + threadIdx.x;
+    for (int s = 0; s < steps; ++s) {
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            unsigned idx;
+            if (pattern == 0) idx = (threadIdx.x + (s * U + u) * 64u);
+            else if (pattern == 1) { h = h * 1664525u + 1013904223u; idx = h >> 8; }
+            else { h = h * 1664525u + 1013904223u; idx = (s * U + u) * 37u + threadIdx.x * 6u + ((h >> 20) & 3u); }
+            unsafeAtomicAdd(&ys[idx & (unsigned) (words - 1)], (T) 1);
+        }
+    }
+    __syncthreads();
+    T acc = 0;
+    for (int i = threadIdx.x; i < words; i += 64) acc += ys[i];
+    if (acc == (T) 1.2345) out[blockIdx.x] = acc;
+}
+
 template <typename F> static float time_ms(F f, int reps)
 {
     hipEvent_t a, b;
@@ -182,6 +210,19 @@ int main(int argc, char **argv)
         for (int r = 0; r < 3; ++r) calib_read<<<(int) ((n2 + 1023) / 1024), 256>>>(a, n2, o);
         CK(hipDeviceSynchronize());
         printf("CALIB kernel=calib_read bytes=%zu launches=3\n", n2 * 16);
+        return 0;
+    }
+    if (argc > 1 && strcmp(argv[1], "lds") == 0) { // LDS atomic-add rate, one wavefront per workgroup
+        double *o; CK(hipMalloc(&o, 1 << 20));
+        const int steps = 256; constexpr int U = 16;
+        for (int grid : {1024, 2048, 4096})
+            for (int pattern = 0; pattern < 3; ++pattern) {
+                const double adds = (double) grid * 64 * steps * U;
+                float t8 = time_ms([&] { lds_atomics<double, U><<<grid, 64, 4096 * 8>>>(4096, steps, pattern, o); }, 3);
+                float t4 = time_ms([&] { lds_atomics<float, U><<<grid, 64, 4096 * 4>>>(4096, steps, pattern, (float *) o); }, 3);
+                float t4b = time_ms([&] { lds_atomics<float, U><<<grid, 64, 8192 * 4>>>(8192, steps, pattern, (float *) o); }, 3);
+                printf("lds_atomics grid %d pattern %d: f64 %.3g/s  f32 %.3g/s  f32(32 KiB) %.3g/s\n", grid, pattern, adds / t8 * 1e3, adds / t4 * 1e3, adds / t4b * 1e3);
+            }
         return 0;
     }
     const size_t maxb = 256u << 20;

@@ -24,12 +24,13 @@ import run_config as rc  # noqa: E402
 
 M = api.SPMV_METHODS
 tag = sys.argv[1] if len(sys.argv) > 1 else "r02"
-wanted = sys.argv[2:] or ["2", "2r", "3w", "3w-uniform", "3o", "3o-uniform", "4", "5shard"]
+wanted = sys.argv[2:] or ["2", "2r", "3w", "3w-uniform", "3w-web", "3o", "3o-uniform", "4", "5shard"]
 METHODS = {
     "2": [M.Method_Parallel, M.Method_Balanced, M.Method_Balanced_Yid, M.Method_SellCSigma, M.Method_CSR5SPMV],
     "2r": [M.Method_Parallel, M.Method_Balanced2, M.Method_CSR5SPMV, M.Method_SellCSigma],
     "3w": [M.Method_Balanced2, M.Method_CSR5SPMV, M.Method_Parallel, M.Method_SellCSigma],
     "3w-uniform": [M.Method_Balanced2, M.Method_CSR5SPMV, M.Method_Parallel],
+    "3w-web": [M.Method_Balanced2, M.Method_CSR5SPMV, M.Method_Parallel, M.Method_SellCSigma],
     "3o": [M.Method_Balanced2, M.Method_CSR5SPMV, M.Method_Parallel],
     "3o-uniform": [M.Method_Balanced2, M.Method_CSR5SPMV],
     "4": [M.Method_SellCSigma, M.Method_CSR5SPMV, M.Method_Balanced2, M.Method_Parallel],

@@ -22,6 +22,7 @@ CONFIGS = {
     "2r": ("config 2 variant (ii): uniformly random columns, fp64", M.Method_Parallel),
     "3w": ("config 3 stand-in webbase-1M-style: 1e6 rows, mean 3.1, max 4.7k, R-MAT columns, fp64", M.Method_Balanced2),
     "3w-uniform": ("config 3 stand-in webbase-1M-style, uniform columns, fp64", M.Method_Balanced2),
+    "3w-web": ("config 3 stand-in webbase-1M-style, web-like columns (90 % within +-2000 of the row, 10 % R-MAT hubs), fp64", M.Method_Balanced2),
     "3o": ("config 3 stand-in com-Orkut-style: 3.07e6 rows, ~2.3e8 nnz, R-MAT columns, fp64", M.Method_Balanced2),
     "3o-uniform": ("config 3 stand-in com-Orkut-style, uniform columns, fp64", M.Method_Balanced2),
     "4": ("config 4: 1e7 rows skewed nnz, fp32, columns within +-4096", M.Method_SellCSigma),
@@ -35,9 +36,9 @@ def make(config, dev):
         return synth.banded_device(10_000_000, 10_000_000, 32, "uniform", f64, dev, 1)
     if config == "2r":
         return synth.uniform_k_device(10_000_000, 10_000_000, 32, "uniform", f64, dev, 1)
-    if config in ("3w", "3w-uniform"):
+    if config in ("3w", "3w-uniform", "3w-web"):
         lens = synth.powerlaw_lengths_device(1_000_000, 3.1, 4700, 1.6, dev, 1)
-        return synth.from_row_lengths_device(lens, 1_000_000, "uniform", f64, dev, 1, cols="rmat" if config == "3w" else "uniform")
+        return synth.from_row_lengths_device(lens, 1_000_000, "uniform", f64, dev, 1, cols={"3w": "rmat", "3w-uniform": "uniform", "3w-web": "web"}[config])
     if config in ("3o", "3o-uniform"):
         lens = synth.powerlaw_lengths_device(3_070_000, 76, 33000, 1.5, dev, 1)
         return synth.from_row_lengths_device(lens, 3_070_000, "uniform", f64, dev, 1, cols="rmat" if config == "3o" else "uniform")
