@@ -172,7 +172,12 @@ __global__ __launch_bounds__(64) void lds_atomics(int words, int steps, int patt
             unsigned idx;
             if (pattern == 0) idx = (threadIdx.x + (s * U + u) * 64u);
             else if (pattern == 1) { h = h * 1664525u + 1013904223u; idx = h >> 8; }
-            else { h = h * 1664525u + 1013904223u; idx = (s * U + u) * 37u + threadIdx.x * 6u + ((h >> 20) & 3u); }
+            else if (pattern == 2) { h = h * 1664525u + 1013904223u; idx = (s * U + u) * 37u + threadIdx.x * 6u + ((h >> 20) & 3u); }
+            else if (pattern == 3) idx = (s * U + u) * 37u;                       // all 64 lanes on one address
+            else if (pattern == 4) idx = (s * U + u) * 37u + (threadIdx.x >> 3);  // runs of 8 lanes per address
+            else idx = (threadIdx.x + (s * U + u) * 64u);                         // 5, 6: lane-consecutive, a quarter / one lane active
+            if (pattern == 5 && (threadIdx.x & 3)) continue;
+            if (pattern == 6 && threadIdx.x) continue;
             unsafeAtomicAdd(&ys[idx & (unsigned) (words - 1)], (T) 1);
         }
     }
@@ -215,8 +220,8 @@ int main(int argc, char **argv)
     if (argc > 1 && strcmp(argv[1], "lds") == 0) { // LDS atomic-add rate, one wavefront per workgroup
         double *o; CK(hipMalloc(&o, 1 << 20));
         const int steps = 256; constexpr int U = 16;
-        for (int grid : {1024, 2048, 4096})
-            for (int pattern = 0; pattern < 3; ++pattern) {
+        for (int grid : {1024, 4096})
+            for (int pattern = 0; pattern < 7; ++pattern) {
                 const double adds = (double) grid * 64 * steps * U;
                 float t8 = time_ms([&] { lds_atomics<double, U><<<grid, 64, 4096 * 8>>>(4096, steps, pattern, o); }, 3);
                 float t4 = time_ms([&] { lds_atomics<float, U><<<grid, 64, 4096 * 4>>>(4096, steps, pattern, (float *) o); }, 3);
