@@ -149,6 +149,19 @@ __global__ __launch_bounds__(kBlock) void csr5_tile_ptr_kernel(int m2, int nnz, 
     tile_ptr[t] = r;
 }
 
+// out[0] = max over the tiles of tile_ptr[t + 1] - tile_ptr[t] (out zeroed by the caller): sizes the waves' row-map buffers.
+__global__ __launch_bounds__(kBlock) void csr5_tile_rows_max_kernel(int p, const int *__restrict__ tile_ptr, int *__restrict__ out)
+{
+    const int t = blockIdx.x * kBlock + threadIdx.x;
+    int v = t < p ? tile_ptr[t + 1] - tile_ptr[t] : 0;
+#pragma unroll
+    for (int d = 1; d < kWave; d <<= 1) {
+        const int o = __shfl_xor(v, d, kWave);
+        v = o > v ? o : v;
+    }
+    if ((threadIdx.x & (kWave - 1)) == 0 && v > 0) atomicMax(out, v);
+}
+
 // One wavefront per tile: bit flags of the row starts inside each lane's SIGMA elements, y_offset =
 // exclusive count of starts over the lanes.  Also the run length of the row open at the tile start.
 template <int SIGMA>
@@ -227,18 +240,33 @@ __global__ __launch_bounds__(kBlock) void csr5_transpose_kernel(int nnz, int p, 
 // ((SIGMA + 1) * 64 ints, private to the wavefront).  Before: every row start did "load row_map[seg_row] -> wait ->
 // store y" inside its branch, and since stores count in vmcnt on gfx9 each wait also drained the previous store --
 // up to SIGMA + 1 memory latencies per tile, the whole run time of the 1e6-row power-law stand-in (21 us).
+// The calling wave's row-map buffer inside the workgroup's dynamic LDS.  rm_stride (ints per wave) is kWave when no tile of
+// the plan holds kWave row starts or more -- the long-row sub-matrix of SELL / CSR-vector -- and (SIGMA + 1) * kWave otherwise
+// (launch_csr5_form): 1 KiB instead of 17 KiB per workgroup next to the x windows.
+__device__ __forceinline__ int *wave_row_map(unsigned char *dyn_lds, int rm_off, int rm_stride)
+{
+    return reinterpret_cast<int *>(dyn_lds + rm_off) + (threadIdx.x / kWave) * rm_stride;
+}
+
 template <int SIGMA>
 __device__ __forceinline__ void csr5_stage_row_map(int lane, int r0, int r1, const int *__restrict__ row_map, int *__restrict__ rm)
 {
-    int tmp[SIGMA + 1];
-    const int span = r1 - r0;
+    // Tiles of long rows hold fewer than 64 row starts (the long-row sub-matrix of SELL: at most 32 per tile of 1024):
+    // one load covers them; the other SIGMA sit behind ONE wave-uniform branch (config 4 through SELL: 0.63 ms, 0.72-0.75
+    // with all SIGMA + 1 loads issued for every tile).
+    const int span = __builtin_amdgcn_readfirstlane(r1 - r0);
+    const int first = row_map[r0 + (lane < span ? lane : span)];
+    if (span >= kWave) {
+        int tmp[SIGMA];
 #pragma unroll
-    for (int j = 0; j <= SIGMA; ++j) {
-        const int k = j * kWave + lane;
-        tmp[j] = row_map[r0 + (k < span ? k : span)];
+        for (int j = 1; j <= SIGMA; ++j) {
+            const int k = j * kWave + lane;
+            tmp[j - 1] = row_map[r0 + (k < span ? k : span)];
+        }
+#pragma unroll
+        for (int j = 1; j <= SIGMA; ++j) rm[j * kWave + lane] = tmp[j - 1];
     }
-#pragma unroll
-    for (int j = 0; j <= SIGMA; ++j) rm[j * kWave + lane] = tmp[j];
+    rm[lane] = first;
     wave_lds_sync();
 }
 
@@ -344,14 +372,14 @@ __global__ __launch_bounds__(kBlock) void csr5_kernel(int p, const int *__restri
                                                       const int *__restrict__ tcol, const T *__restrict__ tval,
                                                       const int *__restrict__ row_map,
                                                       const T *__restrict__ x, T *__restrict__ y,
-                                                      T *__restrict__ carry, int n_empty, const int *__restrict__ empty_list)
+                                                      T *__restrict__ carry, int n_empty, const int *__restrict__ empty_list, int rm_stride)
 {
     if (MAPPED) zero_empty_rows(n_empty, empty_list, y);
-    __shared__ int rm_lds[MAPPED ? kBlock / kWave : 1][MAPPED ? (SIGMA + 1) * kWave : 1];
+    extern __shared__ __attribute__((aligned(16))) unsigned char csr5_x_lds[]; // MAPPED: the waves' row maps (rm_stride ints each)
     const int lane = threadIdx.x & (kWave - 1);
     const int t = blockIdx.x * (kBlock / kWave) + threadIdx.x / kWave;
     if (t >= p) return;
-    csr5_tile<T, SIGMA, MAPPED, false>(t, lane, tile_ptr, desc, tcol, nullptr, tval, row_map, rm_lds[MAPPED ? threadIdx.x / kWave : 0], x, nullptr, y, carry);
+    csr5_tile<T, SIGMA, MAPPED, false>(t, lane, tile_ptr, desc, tcol, nullptr, tval, row_map, wave_row_map(csr5_x_lds, 0, rm_stride), x, nullptr, y, carry);
 }
 
 // ---- LDS-staged x windows (xwindows.hpp) --------------------------------------------------------
@@ -369,10 +397,10 @@ __global__ __launch_bounds__(kBlock) void csr5_group_kernel(int group_tiles, int
                                                             const int *__restrict__ row_map,
                                                             const TileWindows *__restrict__ wins,
                                                             const T *__restrict__ x, T *__restrict__ y,
-                                                            T *__restrict__ carry, int n_empty, const int *__restrict__ empty_list)
+                                                            T *__restrict__ carry, int n_empty, const int *__restrict__ empty_list, int rm_off, int rm_stride)
 {
     if (MAPPED) zero_empty_rows(n_empty, empty_list, y);
-    extern __shared__ __attribute__((aligned(16))) unsigned char csr5_x_lds[];
+    extern __shared__ __attribute__((aligned(16))) unsigned char csr5_x_lds[]; // x windows, then (MAPPED) the waves' row maps at byte rm_off
     T *xs = reinterpret_cast<T *>(csr5_x_lds);
     const TileWindows &tw = wins[blockIdx.x];
     const bool staged = tw.nwin > 0;
@@ -381,8 +409,7 @@ __global__ __launch_bounds__(kBlock) void csr5_group_kernel(int group_tiles, int
         if (threadIdx.x == 0) xs[tw.total] = T(0); // the zero slot of padding entries
         __syncthreads();
     }
-    __shared__ int rm_lds[MAPPED ? kBlock / kWave : 1][MAPPED ? (SIGMA + 1) * kWave : 1];
-    int *rm = rm_lds[MAPPED ? threadIdx.x / kWave : 0];
+    int *rm = wave_row_map(csr5_x_lds, rm_off, rm_stride);
     const int lane = threadIdx.x & (kWave - 1);
     const int t0 = blockIdx.x * group_tiles;
     for (int k = threadIdx.x / kWave; k < group_tiles; k += kBlock / kWave) {
@@ -540,15 +567,16 @@ __global__ __launch_bounds__(kBlock) void nat_kernel(int p, int nnz, const int *
                                                      const unsigned *__restrict__ desc,
                                                      const int *__restrict__ colidx, const T *__restrict__ val,
                                                      const int *__restrict__ row_map,
-                                                     const T *__restrict__ x, T *__restrict__ y, T *__restrict__ carry, int n_empty, const int *__restrict__ empty_list)
+                                                     const T *__restrict__ x, T *__restrict__ y, T *__restrict__ carry, int n_empty, const int *__restrict__ empty_list,
+                                                     int rm_stride)
 {
     if (MAPPED) zero_empty_rows(n_empty, empty_list, y);
+    extern __shared__ __attribute__((aligned(16))) unsigned char csr5_x_lds[]; // MAPPED: the waves' row maps (rm_stride ints each)
     __shared__ __attribute__((aligned(16))) unsigned char nat_lds[kBlock / kWave][NatLds<T, SIGMA, false>::kBytes];
-    __shared__ int rm_lds[MAPPED ? kBlock / kWave : 1][MAPPED ? (SIGMA + 1) * kWave : 1];
     const int lane = threadIdx.x & (kWave - 1), wave = threadIdx.x / kWave;
     const int t = blockIdx.x * (kBlock / kWave) + wave;
     if (t >= p) return;
-    nat_tile<T, SIGMA, MAPPED, false, false>(t, lane, nnz, 0u, nat_lds[wave], tile_ptr, desc, colidx, nullptr, val, row_map, rm_lds[MAPPED ? wave : 0], x, nullptr, y, carry);
+    nat_tile<T, SIGMA, MAPPED, false, false>(t, lane, nnz, 0u, nat_lds[wave], tile_ptr, desc, colidx, nullptr, val, row_map, wave_row_map(csr5_x_lds, 0, rm_stride), x, nullptr, y, carry);
 }
 
 // HALF: two-half hand-over (half the tile buffers, twice the wave syncs: ~8 % slower per tile) -- chosen by
@@ -561,12 +589,12 @@ __global__ __launch_bounds__(kBlock) void nat_group_kernel(int group_tiles, int 
                                                            const int *__restrict__ row_map,
                                                            const TileWindows *__restrict__ wins,
                                                            const T *__restrict__ x, T *__restrict__ y,
-                                                           T *__restrict__ carry, int n_empty, const int *__restrict__ empty_list)
+                                                           T *__restrict__ carry, int n_empty, const int *__restrict__ empty_list, int rm_off, int rm_stride)
 {
     if (MAPPED) zero_empty_rows(n_empty, empty_list, y);
-    extern __shared__ __attribute__((aligned(16))) unsigned char csr5_x_lds[];
+    extern __shared__ __attribute__((aligned(16))) unsigned char csr5_x_lds[]; // x windows, then (MAPPED) the waves' row maps at byte rm_off
     __shared__ __attribute__((aligned(16))) unsigned char nat_lds[kBlock / kWave][NatLds<T, SIGMA, HALF>::kBytes];
-    __shared__ int rm_lds[MAPPED ? kBlock / kWave : 1][MAPPED ? (SIGMA + 1) * kWave : 1];
+    int *rm = wave_row_map(csr5_x_lds, rm_off, rm_stride);
     T *xs = reinterpret_cast<T *>(csr5_x_lds);
     const TileWindows &tw = wins[blockIdx.x];
     const bool staged = tw.nwin > 0;
@@ -580,8 +608,8 @@ __global__ __launch_bounds__(kBlock) void nat_group_kernel(int group_tiles, int 
     for (int k = wave; k < group_tiles; k += kBlock / kWave) {
         const int t = t0 + k;
         if (t >= p) break;
-        if (staged) nat_tile<T, SIGMA, MAPPED, true, HALF>(t, lane, nnz, (unsigned) tw.total, nat_lds[wave], tile_ptr, desc, colidx, col16, val, row_map, rm_lds[MAPPED ? wave : 0], x, xs, y, carry);
-        else nat_tile<T, SIGMA, MAPPED, false, HALF>(t, lane, nnz, 0u, nat_lds[wave], tile_ptr, desc, colidx, col16, val, row_map, rm_lds[MAPPED ? wave : 0], x, xs, y, carry);
+        if (staged) nat_tile<T, SIGMA, MAPPED, true, HALF>(t, lane, nnz, (unsigned) tw.total, nat_lds[wave], tile_ptr, desc, colidx, col16, val, row_map, rm, x, xs, y, carry);
+        else nat_tile<T, SIGMA, MAPPED, false, HALF>(t, lane, nnz, 0u, nat_lds[wave], tile_ptr, desc, colidx, col16, val, row_map, rm, x, xs, y, carry);
     }
 }
 

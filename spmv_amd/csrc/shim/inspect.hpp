@@ -280,10 +280,12 @@ static int build_csr5_sigma(spmv_dev *d, Csr5Plan &P, const int *rp, int m2, con
         ALLOC_TRY(d, &P.col, sizeof(int) * (size_t) p * TN, true);
         ALLOC_TRY(d, &P.val, sizeof(T) * (size_t) p * TN, true);
     }
-    int *flag = nullptr;
-    ALLOC_TRY(d, &flag, sizeof(int), true);
-    HIP_TRY(hipMemsetAsync(flag, 0, sizeof(int), d->stream));
+    int *flag = nullptr; // [0] some tile carries into an earlier tile's row, [1] max rows of a tile
+    ALLOC_TRY(d, &flag, 2 * sizeof(int), true);
+    HIP_TRY(hipMemsetAsync(flag, 0, 2 * sizeof(int), d->stream));
     csr5_tile_ptr_kernel<<<grid_for((long long) p + 1, kBlock, INT_MAX), kBlock, 0, d->stream>>>(m2, (int) P.nnz, p, TN, rp, P.tile_ptr);
+    HIP_TRY(hipGetLastError());
+    csr5_tile_rows_max_kernel<<<grid_for(p, kBlock, INT_MAX), kBlock, 0, d->stream>>>(p, P.tile_ptr, flag + 1);
     HIP_TRY(hipGetLastError());
     csr5_desc_kernel<SIGMA><<<grid_for(p, kBlock / kWave, INT_MAX), kBlock, 0, d->stream>>>(m2, (int) P.nnz, p, rp, P.tile_ptr, P.desc, P.run_len, flag);
     HIP_TRY(hipGetLastError());
@@ -291,8 +293,11 @@ static int build_csr5_sigma(spmv_dev *d, Csr5Plan &P, const int *rp, int m2, con
         csr5_transpose_kernel<T, SIGMA><<<grid_for(p, kBlock / kWave, INT_MAX), kBlock, 0, d->stream>>>((int) P.nnz, p, colidx, val, P.col, (T *) P.val);
         HIP_TRY(hipGetLastError());
     }
-    HIP_TRY(hipMemcpyAsync(&P.fixup, flag, sizeof(int), hipMemcpyDeviceToHost, d->stream));
+    int flags_h[2] = {0, 0};
+    HIP_TRY(hipMemcpyAsync(flags_h, flag, 2 * sizeof(int), hipMemcpyDeviceToHost, d->stream));
     HIP_TRY(hipStreamSynchronize(d->stream));
+    P.fixup = flags_h[0];
+    P.max_tile_rows = flags_h[1];
     // x windows of every group of consecutive tiles -> the 16-bit slot stream (xwindows.hpp).  Group size:
     // 16 tiles (natural layout: 32) unless staging the windows costs more than 15 % of the bytes the group
     // streams -- wide windows, e.g. columns scattered +-4096 around the diagonal -- then 32 and 64 tiles are

@@ -139,35 +139,42 @@ static void launch_blocked(spmv_dev *d, const T *x, T *y)
 template <typename T, int SIGMA, bool MAPPED>
 static void launch_csr5_form(spmv_dev *d, const Csr5Plan &P, const T *x, T *y)
 {
+    // MAPPED (matrices with empty rows, long-row sub-matrices): every wave stages its tile's row map in LDS, behind the x
+    // windows in the dynamic segment.  A tile of long rows holds few row starts: kWave ints per wave then (csr5.hpp)
+    const int rm_stride = MAPPED ? (P.max_tile_rows < kWave ? kWave : (SIGMA + 1) * kWave) : 0;
+    const size_t rmb = (size_t) (kBlock / kWave) * rm_stride * sizeof(int);
     if (P.staged > 0) { // the inspector staged (at least half of) the groups: their column stream is the 16-bit slot array
         const size_t lds = ((((size_t) P.maxspan + 1) * sizeof(T)) + 1023) & ~(size_t) 1023; // + the zero slot
         if (P.natural) {
             // the waves' tile buffers are static LDS next to the x windows: if the full-size buffers would leave
             // one workgroup per CU, hand the tiles over in two halves (half the buffers)
-            constexpr size_t rmb = MAPPED ? (size_t) (kBlock / kWave) * (SIGMA + 1) * kWave * sizeof(int) : 0; // the tiles' row maps (matrices with empty rows)
-            constexpr size_t full = (size_t) (kBlock / kWave) * NatLds<T, SIGMA, false>::kBytes + rmb;
-            const bool half = lds + full > 76 * 1024; // two workgroups no longer fit a CU's 160 KiB
+            constexpr size_t full = (size_t) (kBlock / kWave) * NatLds<T, SIGMA, false>::kBytes;
+            const bool half = lds + rmb + full > 76 * 1024; // two workgroups no longer fit a CU's 160 KiB
             if (half) {
-                ensure_lds<nat_group_kernel<T, SIGMA, MAPPED, true>>(d, lds, (size_t) (kBlock / kWave) * NatLds<T, SIGMA, true>::kBytes + rmb);
-                nat_group_kernel<T, SIGMA, MAPPED, true><<<P.groups, kBlock, lds, d->stream>>>(P.group_tiles, P.tiles, (int) P.nnz, P.tile_ptr, P.desc, P.col, P.col16,
-                                                                                              (const T *) P.val, P.row_map, P.wins, x, y, (T *) P.carry, P.n_empty, P.empty_list);
+                ensure_lds<nat_group_kernel<T, SIGMA, MAPPED, true>>(d, lds + rmb, (size_t) (kBlock / kWave) * NatLds<T, SIGMA, true>::kBytes);
+                nat_group_kernel<T, SIGMA, MAPPED, true><<<P.groups, kBlock, lds + rmb, d->stream>>>(P.group_tiles, P.tiles, (int) P.nnz, P.tile_ptr, P.desc, P.col, P.col16,
+                                                                                                    (const T *) P.val, P.row_map, P.wins, x, y, (T *) P.carry, P.n_empty, P.empty_list,
+                                                                                                    (int) lds, rm_stride);
             } else {
-                ensure_lds<nat_group_kernel<T, SIGMA, MAPPED, false>>(d, lds, full);
-                nat_group_kernel<T, SIGMA, MAPPED, false><<<P.groups, kBlock, lds, d->stream>>>(P.group_tiles, P.tiles, (int) P.nnz, P.tile_ptr, P.desc, P.col, P.col16,
-                                                                                               (const T *) P.val, P.row_map, P.wins, x, y, (T *) P.carry, P.n_empty, P.empty_list);
+                ensure_lds<nat_group_kernel<T, SIGMA, MAPPED, false>>(d, lds + rmb, full);
+                nat_group_kernel<T, SIGMA, MAPPED, false><<<P.groups, kBlock, lds + rmb, d->stream>>>(P.group_tiles, P.tiles, (int) P.nnz, P.tile_ptr, P.desc, P.col, P.col16,
+                                                                                                     (const T *) P.val, P.row_map, P.wins, x, y, (T *) P.carry, P.n_empty, P.empty_list,
+                                                                                                     (int) lds, rm_stride);
             }
             return;
         }
-        ensure_lds<csr5_group_kernel<T, SIGMA, MAPPED>>(d, lds, MAPPED ? (size_t) (kBlock / kWave) * (SIGMA + 1) * kWave * sizeof(int) : 0);
-        csr5_group_kernel<T, SIGMA, MAPPED><<<P.groups, kBlock, lds, d->stream>>>(P.group_tiles, P.tiles, P.tile_ptr, P.desc, P.col, P.col16, (const T *) P.val, P.row_map, P.wins,
-                                                                                 x, y, (T *) P.carry, P.n_empty, P.empty_list);
+        ensure_lds<csr5_group_kernel<T, SIGMA, MAPPED>>(d, lds + rmb);
+        csr5_group_kernel<T, SIGMA, MAPPED><<<P.groups, kBlock, lds + rmb, d->stream>>>(P.group_tiles, P.tiles, P.tile_ptr, P.desc, P.col, P.col16, (const T *) P.val, P.row_map, P.wins,
+                                                                                       x, y, (T *) P.carry, P.n_empty, P.empty_list, (int) lds, rm_stride);
         return;
     }
     const int grid = grid_for(P.tiles, kBlock / kWave, INT_MAX);
     if (P.natural)
-        nat_kernel<T, SIGMA, MAPPED><<<grid, kBlock, 0, d->stream>>>(P.tiles, (int) P.nnz, P.tile_ptr, P.desc, P.col, (const T *) P.val, P.row_map, x, y, (T *) P.carry, P.n_empty, P.empty_list);
+        nat_kernel<T, SIGMA, MAPPED><<<grid, kBlock, rmb, d->stream>>>(P.tiles, (int) P.nnz, P.tile_ptr, P.desc, P.col, (const T *) P.val, P.row_map, x, y, (T *) P.carry, P.n_empty,
+                                                                      P.empty_list, rm_stride);
     else
-        csr5_kernel<T, SIGMA, MAPPED><<<grid, kBlock, 0, d->stream>>>(P.tiles, P.tile_ptr, P.desc, P.col, (const T *) P.val, P.row_map, x, y, (T *) P.carry, P.n_empty, P.empty_list);
+        csr5_kernel<T, SIGMA, MAPPED><<<grid, kBlock, rmb, d->stream>>>(P.tiles, P.tile_ptr, P.desc, P.col, (const T *) P.val, P.row_map, x, y, (T *) P.carry, P.n_empty, P.empty_list,
+                                                                       rm_stride);
 }
 
 template <typename T, int SIGMA>

@@ -145,6 +145,7 @@ struct DevStats {
 struct Csr5Plan {
     int sigma = 0, tiles = 0, m2 = 0, fixup = 0, groups = 0, staged = 0, maxspan = 0, group_tiles = kCsr5GroupTiles;
     long long nnz = 0;
+    int max_tile_rows = 0;        // max over the tiles of tile_ptr[t + 1] - tile_ptr[t]: below kWave the waves' row maps need kWave ints, not (sigma + 1) * kWave
     int n_empty = 0;              // empty rows (outside row_map): the tile kernel zeroes y for them
     const int *empty_list = nullptr;
     bool natural = false;         // nnz-split: no transposed copies, col/val are the matrix's own arrays (kernels/csr5.hpp, nat_tile)

@@ -82,12 +82,14 @@ class ShardedSpMV:
     """
 
     def __init__(self, rowptr, colidx, val, n_global, xchg="halo", method=api.SPMV_METHODS.Method_Parallel,
-                 group=None, compute=None, overlap=True):
+                 group=None, compute=None, overlap=True, force_exchange=False):
+        """force_exchange: keep the exchange mode in a group of ONE rank (the collectives then run over a single
+        member) -- how the GPU test drives every RCCL call of this file on a one-GPU box."""
         assert xchg in ("halo", "allgather", "bcast", "none")
         self.group = group
         self.world = dist.get_world_size(group) if dist.is_initialized() else 1
         self.rank = dist.get_rank(group) if dist.is_initialized() else 0
-        self.xchg = xchg if self.world > 1 else "none"
+        self.xchg = xchg if (self.world > 1 or (force_exchange and dist.is_initialized())) else "none"
         self.n_global = int(n_global)
         self.m_local = int(rowptr.shape[0] - 1)
         self.c0, self.c1 = slice_bounds(self.n_global, self.world, self.rank)

@@ -66,3 +66,49 @@ def test_two_ranks_one_gpu(xchg, method, kind):
     out = mp.Manager().dict()
     mp.spawn(_worker, args=(world, _free_port(), kind, xchg, method, out), nprocs=world, join=True)
     assert all(out[r] for r in range(world)), dict(out)
+
+
+def _rccl_worker(rank, world, port, out):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    torch.cuda.set_device(0)
+    dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", 0))
+    try:
+        dev = torch.device("cuda:0")
+        m = n = 20011
+        A = synth.powerlaw(m, n, 8.0, 3000, 1.5, "eighths", np.float64, seed=5)
+        x = synth.fill_x(n, "eighths", np.float64, 7)
+        want = oracle.spmv_serial(A, x)
+        rp, ci, va = (torch.from_numpy(a).to(dev) for a in (A.rowptr, A.colidx, A.val))
+        xt = torch.from_numpy(x).to(dev)
+        got = {}
+        for xchg in ("halo", "allgather", "bcast"):
+            sh = ShardedSpMV(rp, ci, va, n, xchg=xchg, method=4, force_exchange=True)
+            assert sh.xchg == xchg and dist.get_backend() == "nccl"
+            if xchg == "bcast":
+                sh.set_full_x(xt)
+            xl = sh.x_local_view()
+            xl.copy_(xt)
+            y = torch.full((m,), float("nan"), dtype=torch.float64, device=dev)
+            for _ in range(3):
+                sh.step(xl, y)
+            sh.exchange_only(xl)
+            torch.cuda.synchronize()
+            got[xchg] = bool(np.array_equal(y.cpu().numpy(), want))
+            sh.close()
+        # the reductions bench.py makes over the group, on device tensors
+        t = torch.tensor([1.5], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dist.barrier()
+        got["all_reduce"] = float(t.item()) == 1.5
+        out.update(got)
+    finally:
+        dist.destroy_process_group()
+
+
+def test_rccl_collectives_of_every_exchange_mode_with_one_rank():
+    """RCCL refuses two ranks on one device, so the one-GPU box cannot run world 2 over it; but every collective
+    spmv_amd.dist issues (all_to_all_single with split sizes, in-place all_gather_into_tensor, broadcast, all_reduce,
+    barrier) can run through backend "nccl" (= RCCL) in a group of one, on device tensors and on the handle's stream."""
+    out = mp.Manager().dict()
+    mp.spawn(_rccl_worker, args=(1, _free_port(), out), nprocs=1, join=True)
+    assert dict(out) == {"halo": True, "allgather": True, "bcast": True, "all_reduce": True}, dict(out)
