@@ -372,12 +372,12 @@ __global__ __launch_bounds__(kBlock) void csr5_kernel(int p, const int *__restri
                                                       const int *__restrict__ tcol, const T *__restrict__ tval,
                                                       const int *__restrict__ row_map,
                                                       const T *__restrict__ x, T *__restrict__ y,
-                                                      T *__restrict__ carry, int n_empty, const int *__restrict__ empty_list, int rm_stride)
+                                                      T *__restrict__ carry, int n_empty, const int *__restrict__ empty_list, int rm_stride, int xcd)
 {
     if (MAPPED) zero_empty_rows(n_empty, empty_list, y);
     extern __shared__ __attribute__((aligned(16))) unsigned char csr5_x_lds[]; // MAPPED: the waves' row maps (rm_stride ints each)
     const int lane = threadIdx.x & (kWave - 1);
-    const int t = blockIdx.x * (kBlock / kWave) + threadIdx.x / kWave;
+    const int t = (xcd ? xcd_block(blockIdx.x, gridDim.x) : (int) blockIdx.x) * (kBlock / kWave) + threadIdx.x / kWave;
     if (t >= p) return;
     csr5_tile<T, SIGMA, MAPPED, false>(t, lane, tile_ptr, desc, tcol, nullptr, tval, row_map, wave_row_map(csr5_x_lds, 0, rm_stride), x, nullptr, y, carry);
 }
@@ -568,13 +568,13 @@ __global__ __launch_bounds__(kBlock) void nat_kernel(int p, int nnz, const int *
                                                      const int *__restrict__ colidx, const T *__restrict__ val,
                                                      const int *__restrict__ row_map,
                                                      const T *__restrict__ x, T *__restrict__ y, T *__restrict__ carry, int n_empty, const int *__restrict__ empty_list,
-                                                     int rm_stride)
+                                                     int rm_stride, int xcd)
 {
     if (MAPPED) zero_empty_rows(n_empty, empty_list, y);
     extern __shared__ __attribute__((aligned(16))) unsigned char csr5_x_lds[]; // MAPPED: the waves' row maps (rm_stride ints each)
     __shared__ __attribute__((aligned(16))) unsigned char nat_lds[kBlock / kWave][NatLds<T, SIGMA, false>::kBytes];
     const int lane = threadIdx.x & (kWave - 1), wave = threadIdx.x / kWave;
-    const int t = blockIdx.x * (kBlock / kWave) + wave;
+    const int t = (xcd ? xcd_block(blockIdx.x, gridDim.x) : (int) blockIdx.x) * (kBlock / kWave) + wave;
     if (t >= p) return;
     nat_tile<T, SIGMA, MAPPED, false, false>(t, lane, nnz, 0u, nat_lds[wave], tile_ptr, desc, colidx, nullptr, val, row_map, wave_row_map(csr5_x_lds, 0, rm_stride), x, nullptr, y, carry);
 }

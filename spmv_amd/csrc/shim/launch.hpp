@@ -169,12 +169,13 @@ static void launch_csr5_form(spmv_dev *d, const Csr5Plan &P, const T *x, T *y)
         return;
     }
     const int grid = grid_for(P.tiles, kBlock / kWave, INT_MAX);
+    const int xcd = d->plan.variant == 30 ? 0 : 1; // XCD-aware block order (common.hpp: xcd_block); variant 30 = dispatch order, for A/B
     if (P.natural)
         nat_kernel<T, SIGMA, MAPPED><<<grid, kBlock, rmb, d->stream>>>(P.tiles, (int) P.nnz, P.tile_ptr, P.desc, P.col, (const T *) P.val, P.row_map, x, y, (T *) P.carry, P.n_empty,
-                                                                      P.empty_list, rm_stride);
+                                                                      P.empty_list, rm_stride, xcd);
     else
         csr5_kernel<T, SIGMA, MAPPED><<<grid, kBlock, rmb, d->stream>>>(P.tiles, P.tile_ptr, P.desc, P.col, (const T *) P.val, P.row_map, x, y, (T *) P.carry, P.n_empty, P.empty_list,
-                                                                       rm_stride);
+                                                                       rm_stride, xcd);
 }
 
 template <typename T, int SIGMA>
