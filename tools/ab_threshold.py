@@ -9,7 +9,7 @@ from spmv_amd import api, build, synth
 build.build(); api.load()
 dev = "cuda:0"
 for dt in (torch.float64, torch.float32):
-    for n in (500_000, 1_000_000, 1_500_000, 2_000_000, 3_000_000, 4_000_000):
+    for n in ((250_000, 500_000, 1_000_000, 2_000_000, 4_000_000) if dt == torch.float64 else (500_000, 1_000_000, 2_000_000, 4_000_000, 8_000_000)):
         m, _, rp, ci, va = synth.uniform_k_device(n, n, 16, "uniform", dt, dev, seed=3)
         x = torch.rand(n, dtype=dt, device=dev); y = torch.empty(m, dtype=dt, device=dev)
         row = []
