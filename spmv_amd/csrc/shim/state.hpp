@@ -259,8 +259,18 @@ static void reset_tile_fields(spmv_dev *d)
     d->lsub_rowptr = d->lsub_colidx = nullptr; d->lsub_val = nullptr; d->lsub_nnz = 0;
 }
 
+// Blocks returned to the pool may be handed to another handle at once (hipFree would have waited for the device): no
+// launch of this handle may still be reading them.  In async mode (spmv_hip_set_async) a multiply can be in flight when
+// the caller destroys or rebuilds the handle.
+static void quiesce(spmv_dev *d)
+{
+    DeviceGuard guard(d->device);
+    if (hipStreamSynchronize(d->stream) != hipSuccess) (void) hipGetLastError();
+}
+
 static void free_schedule(spmv_dev *d)
 {
+    if (!d->sched_allocs.empty()) quiesce(d);
     for (auto &a : d->sched_allocs) { (void) pool_free(a.first); d->device_bytes -= (long long) a.second; }
     d->sched_allocs.clear();
     reset_tile_fields(d);
@@ -272,6 +282,7 @@ static void free_schedule(spmv_dev *d)
 // `count` schedule allocations), keep the blocked streams.
 static void drop_tile_schedule(spmv_dev *d, size_t count)
 {
+    quiesce(d);
     for (size_t i = 0; i < count && i < d->sched_allocs.size(); ++i) { (void) pool_free(d->sched_allocs[i].first); d->device_bytes -= (long long) d->sched_allocs[i].second; }
     d->sched_allocs.erase(d->sched_allocs.begin(), d->sched_allocs.begin() + (long) (count < d->sched_allocs.size() ? count : d->sched_allocs.size()));
     reset_tile_fields(d);

@@ -142,6 +142,7 @@ extern "C" int spmv_shim_matrix_stats(const spmv_dev *d, spmv_stats *out)
 extern "C" void spmv_shim_matrix_destroy(spmv_dev *d)
 {
     if (!d) return;
+    quiesce(d); // an asynchronous multiply may still read the arrays that go back to the pool below
     free_schedule(d);
     if (d->rowptr) (void) pool_free(d->rowptr);
     if (d->colidx) (void) pool_free(d->colidx);
