@@ -39,12 +39,9 @@ struct RcclApi {
     bool ok = false;
 };
 
-static RcclApi &rccl_api()
+static RcclApi rccl_load()
 {
-    static RcclApi a;
-    static bool tried = false;
-    if (tried) return a;
-    tried = true;
+    RcclApi a;
     if (getenv("SPMV_HIP_NO_RCCL")) return a;
     a.lib = dlopen("librccl.so", RTLD_NOW | RTLD_LOCAL);
     if (!a.lib) a.lib = dlopen("librccl.so.1", RTLD_NOW | RTLD_LOCAL);
@@ -57,6 +54,12 @@ static RcclApi &rccl_api()
     a.GroupEnd = (decltype(a.GroupEnd)) dlsym(a.lib, "ncclGroupEnd");
     a.GetErrorString = (decltype(a.GetErrorString)) dlsym(a.lib, "ncclGetErrorString");
     a.ok = a.CommInitAll && a.CommDestroy && a.AllGather && a.Broadcast && a.GroupStart && a.GroupEnd;
+    return a;
+}
+
+static RcclApi &rccl_api()
+{
+    static RcclApi a = rccl_load(); // initialised once, also when several threads create multi-GPU handles at the same time
     return a;
 }
 

@@ -2,6 +2,7 @@
 // error channel, the device-side state of a handle (spmv_dev), allocation bookkeeping and the small
 // utility kernels (row statistics, ColIdx validation, fills).
 #pragma once
+#include <atomic>
 
 // ------------------------------------------------------------------------------------ errors
 static thread_local char t_err[400] = "";
@@ -394,13 +395,17 @@ __global__ __launch_bounds__(kBlock) void fill_zero_kernel(long long n, T *y)
 
 // Dynamic LDS above the 64 KiB default needs hipFuncAttributeMaxDynamicSharedMemorySize raised once per kernel
 // instantiation (and per device): remembered here, so that launches do not pay the call every time.
+static std::mutex g_lds_attr_lock;
+
 template <auto Kernel>
 static void ensure_lds(const spmv_dev *d, size_t bytes, size_t static_bytes = 0)
 {
-    static size_t granted[64]; // per device ordinal; zero-initialised = the 64 KiB default
+    static std::atomic<size_t> granted[64]; // per device ordinal; zero-initialised = the 64 KiB default
     const int dev = d->device >= 0 && d->device < 64 ? d->device : 0;
-    if (bytes + static_bytes <= 64 * 1024 || bytes <= granted[dev]) return;
-    if (hipFuncSetAttribute((const void *) Kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int) bytes) == hipSuccess) granted[dev] = bytes;
+    if (bytes + static_bytes <= 64 * 1024 || bytes <= granted[dev].load(std::memory_order_acquire)) return;
+    std::lock_guard<std::mutex> g(g_lds_attr_lock); // the attribute only ever grows: a second thread must not set a smaller value after a larger one
+    if (bytes <= granted[dev].load(std::memory_order_relaxed)) return;
+    if (hipFuncSetAttribute((const void *) Kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int) bytes) == hipSuccess) granted[dev].store(bytes, std::memory_order_release);
     else (void) hipGetLastError();
 }
 
