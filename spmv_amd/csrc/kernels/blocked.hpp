@@ -259,4 +259,71 @@ __global__ __launch_bounds__(NT) void blk_kernel(int m, int R, const long long *
         if (r0 + i < m) y[r0 + i] = (T) ys[i];
 }
 
+// Three-stage form of the executor (the default): in step t the wave ISSUES the stream loads of step t + 2, ISSUES the
+// gathers of step t + 1 (whose columns arrived during step t - 1 .. t) and ADDS step t (whose x values were gathered during
+// step t - 1).  Nothing is waited for in the step that issued it: blk_kernel above gathers and adds in the same step and
+// copies cur = nxt at its end, i.e. every step costs a gather round trip plus the rest of a stream round trip for 512
+// entries per wave -- with two or three waves per CU that, not a bandwidth, was its rate.  Three stream register sets
+// and two x sets are used in rotation (the loop body is written out for six consecutive steps), so no loaded register is
+// ever copied.  Same additions in the same order as blk_kernel: bit-identical results.
+template <typename T, int UN = 4>
+__global__ __launch_bounds__(kWave) void blk_kernel3(int m, int R, const long long *__restrict__ start, const long long *__restrict__ end,
+                                                     const T *__restrict__ bval, const int *__restrict__ bcol,
+                                                     const unsigned short *__restrict__ brow, const T *__restrict__ x, T *__restrict__ y)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char blk_y_lds[];
+    double *ys = reinterpret_cast<double *>(blk_y_lds);
+    constexpr int EPL = 16 / (int) sizeof(T);
+    constexpr int STEP = kWave * EPL;
+    constexpr long long S = (long long) STEP * UN; // entries per step
+    for (int i = threadIdx.x; i < R; i += kWave) ys[i] = 0.0;
+    __syncthreads();
+    const long long s = start[blockIdx.x], e = end[blockIdx.x];
+    const long long lane0 = s + (long long) threadIdx.x * EPL;
+    const int nsteps = (int) ((e - s + S - 1) / S); // wave-uniform
+    BlkGroup<T, EPL> g0[UN], g1[UN], g2[UN];
+    T x0[UN][EPL], x1[UN][EPL];
+    auto load = [&](int t, BlkGroup<T, EPL>(&g)[UN]) { // stream of step t (padded: in bounds up to three steps past the last block)
+#pragma unroll
+        for (int u = 0; u < UN; ++u) blk_load<T, EPL>(lane0 + (long long) t * S + (long long) u * STEP, bval, bcol, brow, g[u]);
+    };
+    auto gather = [&](const BlkGroup<T, EPL>(&g)[UN], T(&xv)[UN][EPL]) { // columns past this block's end are the next block's or padding's: valid
+#pragma unroll
+        for (int u = 0; u < UN; ++u)
+#pragma unroll
+            for (int j = 0; j < EPL; ++j) xv[u][j] = x[g[u].c[j]];
+    };
+    auto add = [&](int t, const BlkGroup<T, EPL>(&g)[UN], const T(&xv)[UN][EPL]) {
+#pragma unroll
+        for (int u = 0; u < UN; ++u) {
+            const long long p = lane0 + (long long) t * S + (long long) u * STEP;
+#pragma unroll
+            for (int j = 0; j < EPL; ++j) lds_add(&ys[g[u].r[j]], p + j < e ? (double) (g[u].v[j] * xv[u][j]) : 0.0);
+        }
+    };
+    if (nsteps > 0) {
+        load(0, g0);
+        load(1, g1);
+        gather(g0, x0);
+#define SPMV_BLK_PHASE(ga, gb, gc, xa, xb)                                                                              \
+        load(t + 2, gc);                                                                                                \
+        gather(gb, xb);                                                                                                 \
+        add(t, ga, xa);                                                                                                 \
+        if (++t >= nsteps) break;
+        for (int t = 0;;) {
+            SPMV_BLK_PHASE(g0, g1, g2, x0, x1)
+            SPMV_BLK_PHASE(g1, g2, g0, x1, x0)
+            SPMV_BLK_PHASE(g2, g0, g1, x0, x1)
+            SPMV_BLK_PHASE(g0, g1, g2, x1, x0)
+            SPMV_BLK_PHASE(g1, g2, g0, x0, x1)
+            SPMV_BLK_PHASE(g2, g0, g1, x1, x0)
+        }
+#undef SPMV_BLK_PHASE
+    }
+    __syncthreads();
+    const long long r0 = (long long) blockIdx.x * R;
+    for (int i = threadIdx.x; i < R; i += kWave)
+        if (r0 + i < m) y[r0 + i] = (T) ys[i];
+}
+
 } // namespace spmv

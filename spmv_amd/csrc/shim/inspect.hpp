@@ -40,6 +40,7 @@ template <typename T>
 static int build_csr5(spmv_dev *d, Csr5Plan &P, int m, long long nnz, const int *rowptr, const int *colidx, const T *val, int empty_rows,
                       double mean_row_len, const int *out_rows, bool natural = false);
 template <typename T> static int autotune_vector(spmv_dev *d);
+template <typename T> static int autotune_blocked(spmv_dev *d);
 template <typename T> static int build_tile_windows(spmv_dev *d, int tiles, const int *split, int rows_per_tile = kVecTileRows, bool wide = false);
 constexpr size_t kVecWideXTileBytes = 96 * 1024; // budget of the wide form (slot indices; two workgroups per CU)
 

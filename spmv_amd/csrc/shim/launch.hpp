@@ -125,15 +125,72 @@ static void launch_blocked(spmv_dev *d, const T *x, T *y)
         blk_kernel<T, NT, UN><<<d->blk_B, NT, lds, d->stream>>>(d->m, d->blk_R, d->blk_start, d->blk_end, (const T *) d->blk_val, \
                                                                 d->blk_col, d->blk_row, x, y);                                   \
     } while (0)
+#define SPMV_BLK3_LAUNCH(UN)                                                                                                     \
+    do {                                                                                                                         \
+        ensure_lds<blk_kernel3<T, UN>>(d, lds);                                                                                  \
+        blk_kernel3<T, UN><<<d->blk_B, kWave, lds, d->stream>>>(d->m, d->blk_R, d->blk_start, d->blk_end, (const T *) d->blk_val, \
+                                                                d->blk_col, d->blk_row, x, y);                                   \
+    } while (0)
     switch (d->plan.variant) {
     case 19: SPMV_BLK_LAUNCH(kWave, 2); break;
     case 20: SPMV_BLK_LAUNCH(kWave, 4); break;
     case 21: SPMV_BLK_LAUNCH(kWave, 8); break;
     case 22: SPMV_BLK_LAUNCH(kWave, 16); break;
     case 23: SPMV_BLK_LAUNCH(256, 4); break;
-    default: SPMV_BLK_LAUNCH(kWave, 4); break;
+    case 29: SPMV_BLK_LAUNCH(kWave, 4); break; // the forms autotune_blocked chooses from, forced: two-stage x 4,
+    case 35: SPMV_BLK3_LAUNCH(8); break;       // three-stage x 8,
+    case 37: SPMV_BLK3_LAUNCH(12); break;      // three-stage x 12
+    case 34: SPMV_BLK3_LAUNCH(4); break;       // A/B only: three-stage x 4
+    default:
+        if (d->blk_form == 0) SPMV_BLK_LAUNCH(kWave, 4);
+        else if (d->blk_form == 2) SPMV_BLK3_LAUNCH(12);
+        else SPMV_BLK3_LAUNCH(8);
+        break;
     }
+#undef SPMV_BLK3_LAUNCH
 #undef SPMV_BLK_LAUNCH
+}
+
+// Time the three executor forms on the resident streams (x = 1: the gather pattern does not depend on the values) and keep
+// the fastest: the three-stage forms win where the gathers dominate (config 2-ii 2.00 -> 1.75 ms, Orkut-style 0.85 -> 0.73 /
+// 1.26 -> 1.05), the two-stage form where the stream does (web-like 4e6 x 24: 0.257 vs 0.27).
+template <typename T>
+static int autotune_blocked(spmv_dev *d)
+{
+    d->blk_form = 1;
+    if (!d->blk_on || !d->plan.autotune || d->plan.variant != 0) return SPMV_HIP_OK;
+    T *x = nullptr, *y = nullptr;
+    if (pool_malloc((void **) &x, sizeof(T) * (size_t) d->n) != hipSuccess || pool_malloc((void **) &y, sizeof(T) * (size_t) d->m) != hipSuccess) {
+        (void) hipGetLastError();
+        if (x) (void) pool_free(x);
+        return SPMV_HIP_OK; // no room to tune: keep the default
+    }
+    fill_value_kernel<T><<<grid_for(d->n, kBlock, d->cus * 8), kBlock, 0, d->stream>>>(d->n, x, T(1));
+    hipEvent_t e0, e1;
+    (void) hipEventCreate(&e0);
+    (void) hipEventCreate(&e1);
+    float tmin[3] = {1e30f, 1e30f, 1e30f};
+    for (int f = 0; f < 3; ++f) { d->blk_form = f; launch_blocked<T>(d, x, y); } // warm every form once
+    for (int round = 0; round < 3; ++round) // interleaved rounds: min per form
+        for (int f = 0; f < 3; ++f) {
+            d->blk_form = f;
+            (void) hipEventRecord(e0, d->stream);
+            launch_blocked<T>(d, x, y);
+            (void) hipEventRecord(e1, d->stream);
+            (void) hipEventSynchronize(e1);
+            float ms = 0;
+            (void) hipEventElapsedTime(&ms, e0, e1);
+            if (ms < tmin[f]) tmin[f] = ms;
+        }
+    int best = 1;
+    for (int f = 0; f < 3; ++f) { d->blk_tune_ms[f] = tmin[f]; if (tmin[f] < tmin[best]) best = f; }
+    d->blk_form = best;
+    (void) hipEventDestroy(e0);
+    (void) hipEventDestroy(e1);
+    (void) pool_free(x);
+    (void) pool_free(y);
+    if (hipGetLastError() != hipSuccess) d->blk_form = 1;
+    return SPMV_HIP_OK;
 }
 
 template <typename T, int SIGMA, bool MAPPED>

@@ -201,6 +201,8 @@ struct spmv_dev {
     // row blocks x column slabs (kernels/blocked.hpp): the nnz-split executor for columns without locality
     bool blk_on = false;
     int blk_R = 0, blk_K = 0, blk_B = 0, blk_wshift = 0;
+    int blk_form = 1;             // executor form: 0 two-stage x 4 load groups, 1 / 2 three-stage x 8 / 12 (launch_blocked; chosen by autotune_blocked)
+    float blk_tune_ms[3] = {0, 0, 0};
     long long blk_slots = 0;
     long long *blk_start = nullptr, *blk_end = nullptr;
     void *blk_val = nullptr;

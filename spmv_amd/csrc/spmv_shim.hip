@@ -212,6 +212,7 @@ extern "C" int spmv_shim_build(spmv_dev *d, const spmv_plan *plan)
         d->x_groups_seen = plan->sched == SPMV_SCHED_NNZ_SPLIT ? d->ns.groups : (plan->sched == SPMV_SCHED_CSR5 ? d->c5.groups : (plan->sched == SPMV_SCHED_SELL ? d->sell_nwin : d->vt_tiles));
         rc = f64 ? build_blocked<double>(d) : build_blocked<float>(d);
         if (!rc && d->blk_on) drop_tile_schedule(d, keep_from);
+        if (!rc && d->blk_on) rc = f64 ? autotune_blocked<double>(d) : autotune_blocked<float>(d);
     }
     if (!rc) rc = account_stream_bytes(d);
     if (rc) { free_schedule(d); return rc; }
