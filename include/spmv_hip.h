@@ -118,8 +118,9 @@ typedef struct spmv_hip_info {
     double inspect_ms;          /* wall time of the inspector inside create */
     const char *schedule_name;
     const char *kernel_name;    /* symbol of the dominant kernel (as rocprofv3 shows it) */
-    int tuned_choice;           /* csr-vector autotune: 0 none, 10/11 tile 4-deep, 5/12 tile 2-deep, 4 pipe */
-    float tune_ms[3];           /* measured ms of {tile/4-deep, tile/2-deep, pipe} at create (0 if not tuned) */
+    int tuned_choice;           /* csr-vector autotune: 0 none, 10/11 tile 4-deep, 5/12 tile 2-deep, 4 pipe; cache_blocked: 100 + form */
+    float tune_ms[3];           /* measured ms of {tile/4-deep, tile/2-deep, pipe} at create (0 if not tuned); cache_blocked: of the
+                                   row-block executor's {two-stage x 4, three-stage x 8, three-stage x 12} forms */
     int x_groups;               /* tiles / tile groups / sigma windows the inspector analysed for x windows */
     int x_groups_staged;        /* ... of which have their x windows staged in LDS (0: every gather goes to L1/L2) */
     int cache_blocked;          /* 1: the row-block x column-slab executor runs (option "cache_block") */

@@ -444,8 +444,8 @@ extern "C" int spmv_shim_info(const spmv_dev *d, spmv_hip_info *o)
     const long long s = (long long) d->vsize;
     o->alg_bytes = 4ll * ((long long) d->m + 1) + d->nnz * (4 + s) + s * d->n + s * d->m;
     o->inspect_ms = d->inspect_ms;
-    o->tuned_choice = d->vec_choice;
-    for (int k = 0; k < 3; ++k) o->tune_ms[k] = d->tune_ms[k];
+    o->tuned_choice = d->blk_on ? 100 + d->blk_form : d->vec_choice; // cache_blocked: 100 two-stage x 4, 101 / 102 three-stage x 8 / x 12
+    for (int k = 0; k < 3; ++k) o->tune_ms[k] = d->blk_on ? d->blk_tune_ms[k] : d->tune_ms[k];
     o->schedule_name = kSchedNames[d->plan.sched];
     o->kernel_name = kKernelNames[d->plan.sched];
     if (d->plan.sched == SPMV_SCHED_CSR_VECTOR && d->vt_tiles > 0 && d->vec_choice != VEC_PIPE &&

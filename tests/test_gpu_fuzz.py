@@ -74,7 +74,7 @@ def _definition(csr, x):
 
 
 OPTIONS = {"csr5_sigma": [0, 4, 8, 16], "sell_sigma": [64, 1024], "rowblock_nnz": [0, 64, 700], "lanes_per_row": [0, 1, 4, 64],
-           "cache_block": [1, 2], "variant": [0, 0, 0, 3, 20, 22, 30]}
+           "cache_block": [1, 2], "variant": [0, 0, 0, 3, 20, 22, 30, 34, 37]}
 
 
 # SPMV_FUZZ_FIRST / SPMV_FUZZ_SEEDS widen the sweep (348 seeds were run once on the final kernels)

@@ -493,6 +493,43 @@ def test_matrix_without_column_locality_runs_the_blocked_executor_deterministica
     assert bool(((ys[0].double() - want).abs() <= TOL[np.dtype(dtype)] * scale).all())
 
 
+@pytest.mark.parametrize("dtype", [np.float64, np.float32])
+def test_blocked_executor_forms_give_the_same_bits_and_create_picks_one_by_timing(dtype):
+    """The row-block executor has a two-stage and two three-stage pipelined forms (blocked.hpp: blk_kernel, blk_kernel3);
+    create() times them and keeps the fastest (info.tuned_choice 100 / 101 / 102, info.tune_ms).  They issue the same
+    additions in the same order, so on inexact data every form -- and hence whichever one a handle happened to pick --
+    gives the same bits; power-law rows with hubs make blocks of very different lengths (partial last steps)."""
+    import torch
+    dev = torch.device("cuda:0")
+    tdt = torch.float64 if dtype == np.float64 else torch.float32
+    m = n = 1_300_000
+    lens = synth.powerlaw_lengths_device(m, 12.0, 20000, 1.6, dev, 3)
+    _, _, rp, ci, va = synth.from_row_lengths_device(lens, n, "uniform", tdt, dev, 3, cols="rmat")
+    g = torch.Generator(device=dev); g.manual_seed(9)
+    x = torch.rand(n, generator=g, device=dev, dtype=tdt) * 2 - 1
+    keep = {k: api.get_option(k) for k in ("cache_block", "variant")}
+    ys = {}
+    try:
+        api.set_option("cache_block", 2)
+        for variant in (0, 29, 34, 35, 37):
+            api.set_option("variant", variant)
+            y = torch.full((m,), float("nan"), dtype=tdt, device=dev)
+            with api.Handle(m, n, rp, ci, va, M.Method_Balanced2) as h:
+                info = h.info()
+                assert info["cache_blocked"] == 1 and info["kernel_name"] == "blk_kernel", info
+                if variant == 0:
+                    assert info["tuned_choice"] in (100, 101, 102) and min(info["tune_ms"]) > 0, info
+                h.spmv(x, y)
+            torch.cuda.synchronize()
+            assert not bool(torch.isnan(y).any())
+            ys[variant] = y
+    finally:
+        for k, v in keep.items():
+            api.set_option(k, v)
+    for variant, y in ys.items():
+        assert torch.equal(y, ys[0]), f"variant {variant} differs from the tuned default"
+
+
 @pytest.mark.parametrize("method", ALL_METHODS, ids=lambda m: m.name)
 @pytest.mark.parametrize("name", ["skewed_f64_uniform", "skewed_f32_uniform", "empty_mix_f64_uniform", "banded_wide_f32_uniform"])
 @pytest.mark.parametrize("blocked", [0, 1])

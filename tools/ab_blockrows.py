@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""Blocked executor: rows per block (option block_rows; 0 = default rule) x load groups in flight (variant 0 / 21) on the
+"""Blocked executor: rows per block (option block_rows; 0 = default rule; BLOCK_ROWS=...) x executor form (VARIANTS=0,29,37: tuned / two-stage / three-stage x 12) on the
 run_config shapes:  python tools/ab_blockrows.py 3o 3o-uniform 2r"""
 import os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -13,9 +13,9 @@ api.set_option("cache_block", 2)
 for cfg in sys.argv[1:] or ["3o"]:
     m, n, rp, ci, va = rc.make(cfg, dev)
     x = torch.rand(n, dtype=va.dtype, device=dev); y = torch.empty(m, dtype=va.dtype, device=dev)
-    for br in (0, 1024, 2048, 4096, 8192):
+    for br in [int(v) for v in os.environ.get("BLOCK_ROWS", "0,2048,4096,8192,16384").split(",")]:
         row = []
-        for var in (0, 21, 19):
+        for var in [int(v) for v in os.environ.get("VARIANTS", "0,29,37").split(",")]:
             api.set_option("variant", var); api.set_option("block_rows", br)
             h = api.Handle(m, n, rp, ci, va, 4)
             _, ms = api.time_launches(h.h, x, y, 5, 20)
