@@ -83,7 +83,7 @@ int spmv_hip_update_values(spmv_Handle_t handle, const void *Matrix_Val);
  *                      Method_Balanced_Yid with the cache-blocked executor; the handle reports it)
  *       "cache_block" (0 never / 1 automatic (default) / 2 always: every schedule but the debug kernel CSR-scalar hands the
  *                      multiply to the row-block x column-slab executor when no x window of the matrix fits LDS,
- *                      nnz >= 2^21 and n * size >= 4 MiB (x as large as an XCD's L2; 16 MiB when rows average fewer than 8 entries): ~3x faster on columns
+ *                      nnz >= 2^21 and n * size >= 4 MiB (x as large as an XCD's L2; 12 MiB when rows average fewer than 8 entries): ~3x faster on columns
  *                      without locality.  One wavefront owns a row block, so results are bit-reproducible.)
  *       "slab_kib" (KiB of x per column slab, 0 = as narrow as the cell table allows)
  *       "block_rows" (rows per block, 0 = 64 KiB of y)

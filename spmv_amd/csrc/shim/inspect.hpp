@@ -495,8 +495,10 @@ static bool wants_blocked(const spmv_dev *d, int staged_groups)
     // soon as x reaches one XCD's L2 -- fp64, x = 4 / 8 / 16 / 32 MB: 49 / 94 / 180 / 352 us against 55-62 / 157-168 /
     // 434-450 / 1030-1050 us on the tile kernels (all four of them); at 2 MB the tile kernels lead (45 vs 50 us).  With
     // very short rows the per-row work of a block (zeroing and writing its y) weighs more: the 1e6-row power-law
-    // stand-in (2.6 nnz/row, x = 8 MB) ran 26.6 us on the tile kernel against 31.4 us blocked -> 16 MiB there.
-    const long long min_x = d->stats.mean_row_len >= 8.0 ? (4ll << 20) : (16ll << 20);
+    // stand-in (2.6 nnz/row) at x = 8 / 16 / 32 MB (tools/ab_short_rows.py, three-stage executor forms): tile 26.8 / 50.4 / 98.4 us
+    // against blocked 28.0 / 46.9 / 77.4 (R-MAT columns), 21.9 / 41.3 / 76.1 against 25.0 / 36.2 / 58.2 (web-like), 38.2 / 90.9 /
+    // 201 against 37.2 / 64.5 / 121 (uniform) -> 12 MiB there.
+    const long long min_x = d->stats.mean_row_len >= 8.0 ? (4ll << 20) : (12ll << 20);
     return d->plan.cache_block == 1 && staged_groups == 0 && d->nnz >= (1ll << 21) && (long long) d->n * (long long) d->vsize >= min_x;
 }
 

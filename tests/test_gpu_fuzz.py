@@ -77,7 +77,7 @@ OPTIONS = {"csr5_sigma": [0, 4, 8, 16], "sell_sigma": [64, 1024], "rowblock_nnz"
            "cache_block": [1, 2], "variant": [0, 0, 0, 3, 20, 22, 30, 34, 37]}
 
 
-# SPMV_FUZZ_FIRST / SPMV_FUZZ_SEEDS widen the sweep (348 seeds were run once on the final kernels)
+# SPMV_FUZZ_FIRST / SPMV_FUZZ_SEEDS widen the sweep (seeds 48..847 were run once on the final kernels of round 2)
 _FIRST, _COUNT = int(os.environ.get("SPMV_FUZZ_FIRST", "0")), int(os.environ.get("SPMV_FUZZ_SEEDS", "48"))
 
 
