@@ -247,9 +247,17 @@ __global__ __launch_bounds__(kSellWinThreads) void sell_window_kernel(int chunks
         __syncthreads();
     }
     const int lane = threadIdx.x & (kWave - 1);
-    for (int k = threadIdx.x / kWave; k < chunks_per_win; k += kSellWinThreads / kWave) {
+    // Chunks are sorted by width inside a sigma window (widest first): handing them to the 8 waves round-robin gives wave 0 the
+    // widest chunk of every pass and wave 7 the narrowest, and the workgroup -- its x windows in LDS -- lasts as long as wave 0
+    // (config 4's slabs: 38 columns per sigma window for wave 0, 23 for wave 7).  Every second pass therefore runs the other way:
+    // wave v takes chunks v and 15 - v of each group of 16.
+    constexpr int kWaves = kSellWinThreads / kWave;
+    const int wave = threadIdx.x / kWave;
+    const bool mirror = (chunks_per_win % (2 * kWaves)) == 0;
+    for (int i = 0; i * kWaves < chunks_per_win; ++i) {
+        const int k = i * kWaves + ((mirror && (i & 1)) ? kWaves - 1 - wave : wave);
         const long long c = (long long) w * chunks_per_win + k;
-        if (c >= nchunks) break;
+        if (k >= chunks_per_win || c >= nchunks) continue; // a short last pass / last window group: other waves may still hold valid chunks
         const long long c0 = chunk_ptr[c];
         const int width = (int) (chunk_ptr[c + 1] - c0);
         const int *pc = scol + (size_t) c0 * kSellC + lane;
