@@ -452,12 +452,35 @@ static int blocked_fill(spmv_dev *d, int wshift, bool values_only)
     return SPMV_HIP_OK;
 }
 
-template <typename T>
-static int build_blocked(spmv_dev *d)
+// Rows per block.  rule 0 (first choice): FULL ROUNDS of fat blocks -- two blocks are resident per CU (2 x 78 KiB of its 160 KiB
+// of LDS), so the block count is made a multiple of 2 * CUs and R = ceil(m / blocks) <= 9984: the grid then runs in whole
+// rounds.  With 8192-row blocks config 2-ii has 1221 blocks = 2.4 rounds of 512 and pays for three (1.75 ms); with 9766-row
+// blocks exactly two (1.54 ms); 9728 rows = 1028 blocks: 2.02 ms, the four stragglers cost a round.  Orkut-style uniform:
+// 512 blocks of 5997 rows 0.79 ms vs 750 blocks of 4096 rows 1.02; R-MAT 0.69 vs 0.70.  rule 1: at least 512 blocks of at
+// most 8192 rows (a power of two) -- more, thinner blocks = more waves per CU, what a STREAM-bound matrix wants (web-like
+// 4e6 x 24: 977 blocks of 4096 rows 0.245 ms vs 512 blocks of 7813 rows 0.275); spmv_shim_build tries it when rule 0 turns out
+// stream-bound and keeps the faster set.
+static int blocked_rows_per_block(const spmv_dev *d, int rule)
 {
-    int R = d->plan.block_rows > 0 ? d->plan.block_rows : (int) (64 * 1024 / sizeof(double)); // double accumulators (blocked.hpp)
-    if (d->plan.block_rows == 0) // small matrices: at least ~512 blocks (two single-wave blocks per CU), down to 1024 rows
-        while (R > 1024 && (long long) d->m / R < 512) R >>= 1;
+    if (d->plan.block_rows > 0) return d->plan.block_rows;
+    int R;
+    if (rule == 0) {
+        const long long slots = 2ll * (d->cus > 0 ? d->cus : 256), rmax = 9984;
+        const long long rounds = ((long long) d->m + slots * rmax - 1) / (slots * rmax);
+        const long long B = slots * (rounds > 0 ? rounds : 1);
+        R = (int) (((long long) d->m + B - 1) / B);
+        if (R < 1024) R = 1024;
+    } else {
+        R = (int) (64 * 1024 / sizeof(double));
+        while (R > 1024 && (long long) d->m / R < 512) R >>= 1; // small matrices: at least ~512 blocks, down to 1024 rows
+    }
+    return R;
+}
+
+template <typename T>
+static int build_blocked(spmv_dev *d, int rule)
+{
+    int R = blocked_rows_per_block(d, rule); // double accumulators (blocked.hpp)
     if ((size_t) R * sizeof(double) > 128 * 1024) R = (int) (128 * 1024 / sizeof(double));
     // Slab width: as narrow as the cell table allows (2^25 cells: ~400 MB of inspector scratch), down to 32
     // columns.  Narrow slabs cost nothing in L2 locality (the sweep over x is the same) and put entries that

@@ -171,7 +171,7 @@ static int autotune_blocked(spmv_dev *d)
     (void) hipEventCreate(&e1);
     float tmin[3] = {1e30f, 1e30f, 1e30f};
     for (int f = 0; f < 3; ++f) { d->blk_form = f; launch_blocked<T>(d, x, y); } // warm every form once
-    for (int round = 0; round < 3; ++round) // interleaved rounds: min per form
+    for (int round = 0; round < 5; ++round) // interleaved rounds: min per form (three rounds once picked the slow form on config 2-ii)
         for (int f = 0; f < 3; ++f) {
             d->blk_form = f;
             (void) hipEventRecord(e0, d->stream);

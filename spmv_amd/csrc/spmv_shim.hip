@@ -210,9 +210,48 @@ extern "C" int spmv_shim_build(spmv_dev *d, const spmv_plan *plan)
     if (!rc && staged >= 0 && wants_blocked(d, staged)) {
         const size_t keep_from = d->sched_allocs.size();
         d->x_groups_seen = plan->sched == SPMV_SCHED_NNZ_SPLIT ? d->ns.groups : (plan->sched == SPMV_SCHED_CSR5 ? d->c5.groups : (plan->sched == SPMV_SCHED_SELL ? d->sell_nwin : d->vt_tiles));
-        rc = f64 ? build_blocked<double>(d) : build_blocked<float>(d);
+        rc = f64 ? build_blocked<double>(d, 0) : build_blocked<float>(d, 0);
         if (!rc && d->blk_on) drop_tile_schedule(d, keep_from);
         if (!rc && d->blk_on) rc = f64 ? autotune_blocked<double>(d) : autotune_blocked<float>(d);
+        // Stream-bound under rule 0 (the three streams alone move >= 3.6 TB/s; web-like 4e6 x 24 in fp32 sits at 4.2)?  Then thinner blocks may do better: build the
+        // rule-1 set next to this one, time it, keep the faster (one more inspector pass, only for such matrices).
+        if (!rc && d->blk_on && plan->autotune && plan->variant == 0 && plan->block_rows == 0 && d->nnz >= (1ll << 22) &&
+            blocked_rows_per_block(d, 1) != d->blk_R) {
+            float best0 = d->blk_tune_ms[0];
+            for (int f = 1; f < 3; ++f) best0 = d->blk_tune_ms[f] < best0 ? d->blk_tune_ms[f] : best0;
+            const double rate = best0 > 0 ? (double) d->nnz * ((double) d->vsize + 6.0) / ((double) best0 * 1e-3) : 0.0;
+            if (rate >= 3.6e12) {
+                struct BlkSet { long long *start, *end; void *val; int *col; unsigned short *row; int R, K, B, wshift, form; long long slots; float tune[3]; };
+                auto take = [&]() { return BlkSet{d->blk_start, d->blk_end, d->blk_val, d->blk_col, d->blk_row, d->blk_R, d->blk_K, d->blk_B, d->blk_wshift, d->blk_form,
+                                                  d->blk_slots, {d->blk_tune_ms[0], d->blk_tune_ms[1], d->blk_tune_ms[2]}}; };
+                auto put = [&](const BlkSet &b) {
+                    d->blk_start = b.start; d->blk_end = b.end; d->blk_val = b.val; d->blk_col = b.col; d->blk_row = b.row;
+                    d->blk_R = b.R; d->blk_K = b.K; d->blk_B = b.B; d->blk_wshift = b.wshift; d->blk_form = b.form; d->blk_slots = b.slots;
+                    for (int f = 0; f < 3; ++f) d->blk_tune_ms[f] = b.tune[f];
+                };
+                auto release = [&](const BlkSet &b) {
+                    quiesce(d);
+                    sched_free(d, b.start); sched_free(d, b.end); sched_free(d, b.val); sched_free(d, b.col); sched_free(d, b.row);
+                };
+                const BlkSet first = take();
+                d->blk_on = false;
+                const int rc2 = f64 ? build_blocked<double>(d, 1) : build_blocked<float>(d, 1);
+                if (!rc2 && d->blk_on) {
+                    (void) (f64 ? autotune_blocked<double>(d) : autotune_blocked<float>(d));
+                    float best1 = d->blk_tune_ms[0];
+                    for (int f = 1; f < 3; ++f) best1 = d->blk_tune_ms[f] < best1 ? d->blk_tune_ms[f] : best1;
+                    const BlkSet second = take();
+                    if (best1 > 0 && best1 < 0.97f * best0) release(first);
+                    else { release(second); put(first); }
+                } else { // the second set could not be built (memory): keep the first
+                    const BlkSet partial = take();
+                    if (partial.start != first.start) { if (partial.start) sched_free(d, partial.start); if (partial.end && partial.end != first.end) sched_free(d, partial.end); }
+                    put(first);
+                    (void) hipGetLastError();
+                }
+                d->blk_on = true;
+            }
+        }
     }
     if (!rc) rc = account_stream_bytes(d);
     if (rc) { free_schedule(d); return rc; }

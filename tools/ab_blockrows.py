@@ -11,7 +11,14 @@ build.build(); api.load()
 dev = "cuda:0"
 api.set_option("cache_block", 2)
 for cfg in sys.argv[1:] or ["3o"]:
-    m, n, rp, ci, va = rc.make(cfg, dev)
+    if cfg.startswith("web24"):   # 4e6 x 24 web-like, fp64 / fp32 (web24f)
+        from spmv_amd import synth
+        dt = torch.float32 if cfg.endswith("f") else torch.float64
+        m = n = 4_000_000
+        lens = torch.full((m,), 24, dtype=torch.int64, device=dev)
+        _, _, rp, ci, va = synth.from_row_lengths_device(lens, m, "uniform", dt, dev, 1, cols="web")
+    else:
+        m, n, rp, ci, va = rc.make(cfg, dev)
     x = torch.rand(n, dtype=va.dtype, device=dev); y = torch.empty(m, dtype=va.dtype, device=dev)
     for br in [int(v) for v in os.environ.get("BLOCK_ROWS", "0,2048,4096,8192,16384").split(",")]:
         row = []
