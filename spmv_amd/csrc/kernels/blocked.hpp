@@ -41,15 +41,69 @@
 namespace spmv {
 
 
-// cell histogram: cnt[(r / R) * K + (c >> wshift)] += 1 for every entry; 16 lanes sweep a row
-__global__ __launch_bounds__(kBlock) void blk_count_kernel(int m, int R, int K, int wshift, const int *__restrict__ rowptr,
+// Row blocks of EQUAL WORK: block b holds rows [row0[b], row0[b + 1]).  All blocks of a round are resident together and the
+// round lasts as long as its heaviest block (Orkut-style stand-in, fixed 5997-row blocks: heaviest / mean = 1.18; 4e6 rows of
+// 2.6 entries: 1.40), so the cut points follow the entries, not the rows: work(r) = RowPtr[r] + c r (c entries of fixed cost per
+// row, so that stretches of empty rows still end a block), each block takes 1 / (blocks left) of the work left, never more than
+// rcap rows (its accumulators live in LDS).  One thread: B binary searches over RowPtr.  out[0] = blocks made (>= btarget when
+// the row cap cut some short), out[1] = most rows in a block.
+__global__ __launch_bounds__(kBlock) void blk_partition_kernel(int m, const int *__restrict__ rowptr, int btarget, int rcap, long long c,
+                                                               int *__restrict__ cut /* [btarget + 1] scratch */, int *__restrict__ row0, int *__restrict__ out)
+{
+    // one workgroup.  Cut points of equal work, found independently: cut[b] = first row whose work reaches b / btarget of the total
+    const long long total = (long long) rowptr[m] + c * m;
+    for (int b = threadIdx.x; b <= btarget; b += kBlock) {
+        const long long target = b == btarget ? total : (total / btarget) * b + ((total % btarget) * b) / btarget;
+        int lo = 0, hi = m; // smallest r in [0, m] with work(r) >= target
+        while (lo < hi) {
+            const int mid = lo + ((hi - lo) >> 1);
+            if ((long long) rowptr[mid] + c * mid >= target) hi = mid; else lo = mid + 1;
+        }
+        cut[b] = b == 0 ? 0 : (b == btarget ? m : lo);
+    }
+    __syncthreads();
+    if (threadIdx.x != 0) return;
+    // one thread: drop empty blocks (a single row heavier than a share), split blocks above the row cap
+    int nb = 0, maxr = 0;
+    for (int b = 0; b < btarget; ++b) {
+        int start = cut[b];
+        const int end = cut[b + 1];
+        while (end - start > rcap) {
+            row0[nb++] = start;
+            maxr = rcap;
+            start += rcap;
+        }
+        if (end > start) {
+            row0[nb++] = start;
+            maxr = end - start > maxr ? end - start : maxr;
+        }
+    }
+    row0[nb] = m;
+    out[0] = nb;
+    out[1] = maxr;
+}
+
+// block of row r: the last b with row0[b] <= r
+__device__ __forceinline__ int blk_of_row(const int *__restrict__ row0, int B, int r)
+{
+    int lo = 0, hi = B; // row0[lo] <= r < row0[hi]
+    while (hi - lo > 1) {
+        const int mid = (lo + hi) >> 1;
+        if (row0[mid] <= r) lo = mid; else hi = mid;
+    }
+    return lo;
+}
+
+// cell histogram: cnt[block(r) * K + (c >> wshift)] += 1 for every entry; 16 lanes sweep a row
+__global__ __launch_bounds__(kBlock) void blk_count_kernel(int m, int B, const int *__restrict__ row0, int K, int wshift, const int *__restrict__ rowptr,
                                                            const int *__restrict__ colidx, int *__restrict__ cnt)
 {
     const int sub = threadIdx.x / 16, l = threadIdx.x % 16;
     const long long stride = (long long) gridDim.x * (kBlock / 16);
     for (long long r = (long long) blockIdx.x * (kBlock / 16) + sub; r < m; r += stride) {
         const int p0 = rowptr[r], p1 = rowptr[r + 1];
-        const long long cell0 = (r / R) * K;
+        if (p0 == p1) continue;
+        const long long cell0 = (long long) blk_of_row(row0, B, (int) r) * K;
         for (int p = p0 + l; p < p1; p += 16) atomicAdd(&cnt[cell0 + (colidx[p] >> wshift)], 1);
     }
 }
@@ -138,7 +192,7 @@ __device__ __forceinline__ int row_of_position(const int *rp, int nr, int row, i
 // The L1/TA path merges lanes of an instruction that hit the same line wherever they sit in the wave, and a cell
 // is only a few lines wide.)
 template <typename T, bool VALUES_ONLY>
-__global__ __launch_bounds__(kWave) void blk_fill_kernel(int m, int R, int K, int wshift, const int *__restrict__ rowptr,
+__global__ __launch_bounds__(kWave) void blk_fill_kernel(const int *__restrict__ row0, int K, int wshift, const int *__restrict__ rowptr,
                                                          const int *__restrict__ colidx, const T *__restrict__ val,
                                                          unsigned long long *__restrict__ cursor, T *__restrict__ bval,
                                                          int *__restrict__ bcol, unsigned short *__restrict__ brow)
@@ -146,8 +200,8 @@ __global__ __launch_bounds__(kWave) void blk_fill_kernel(int m, int R, int K, in
     extern __shared__ __attribute__((aligned(16))) unsigned char blk_fill_lds[];
     int *rp = reinterpret_cast<int *>(blk_fill_lds);
     const int lane = threadIdx.x;
-    const long long r0 = (long long) blockIdx.x * R;
-    const int nr = (int) (r0 + R <= m ? R : m - r0);
+    const long long r0 = row0[blockIdx.x];
+    const int nr = row0[blockIdx.x + 1] - (int) r0;
     for (int i = lane; i <= nr; i += kWave) rp[i] = rowptr[r0 + i];
     __syncthreads();
     const int p0 = rp[0], p1 = rp[nr];
@@ -219,7 +273,7 @@ __device__ __forceinline__ void blk_load(long long p, const T *__restrict__ bval
 }
 
 template <typename T, int NT = kWave, int UN = 4>
-__global__ __launch_bounds__(NT) void blk_kernel(int m, int R, const long long *__restrict__ start, const long long *__restrict__ end,
+__global__ __launch_bounds__(NT) void blk_kernel(const int *__restrict__ row0, int R, const long long *__restrict__ start, const long long *__restrict__ end,
                                                  const T *__restrict__ bval, const int *__restrict__ bcol,
                                                  const unsigned short *__restrict__ brow, const T *__restrict__ x, T *__restrict__ y)
 {
@@ -227,7 +281,7 @@ __global__ __launch_bounds__(NT) void blk_kernel(int m, int R, const long long *
     double *ys = reinterpret_cast<double *>(blk_y_lds);
     constexpr int EPL = 16 / (int) sizeof(T); // entries per 16-byte value load
     constexpr int STEP = NT * EPL;            // entries one load group covers over the workgroup
-    for (int i = threadIdx.x; i < R; i += NT) ys[i] = 0.0;
+    for (int i = threadIdx.x; i < R; i += NT) ys[i] = 0.0; // R = the most rows of any block: masked entries of the next block may add 0 anywhere below it
     __syncthreads();
     const long long s = start[blockIdx.x], e = end[blockIdx.x];
     const long long lane0 = s + (long long) threadIdx.x * EPL;
@@ -254,9 +308,9 @@ __global__ __launch_bounds__(NT) void blk_kernel(int m, int R, const long long *
         for (int u = 0; u < UN; ++u) cur[u] = nxt[u];
     }
     __syncthreads();
-    const long long r0 = (long long) blockIdx.x * R;
-    for (int i = threadIdx.x; i < R; i += NT)
-        if (r0 + i < m) y[r0 + i] = (T) ys[i];
+    const long long r0 = row0[blockIdx.x];
+    const int nr = row0[blockIdx.x + 1] - (int) r0;
+    for (int i = threadIdx.x; i < nr; i += NT) y[r0 + i] = (T) ys[i];
 }
 
 // Three-stage form of the executor (the default): in step t the wave ISSUES the stream loads of step t + 2, ISSUES the
@@ -267,7 +321,7 @@ __global__ __launch_bounds__(NT) void blk_kernel(int m, int R, const long long *
 // and two x sets are used in rotation (the loop body is written out for six consecutive steps), so no loaded register is
 // ever copied.  Same additions in the same order as blk_kernel: bit-identical results.
 template <typename T, int UN = 4>
-__global__ __launch_bounds__(kWave) void blk_kernel3(int m, int R, const long long *__restrict__ start, const long long *__restrict__ end,
+__global__ __launch_bounds__(kWave) void blk_kernel3(const int *__restrict__ row0, int R, const long long *__restrict__ start, const long long *__restrict__ end,
                                                      const T *__restrict__ bval, const int *__restrict__ bcol,
                                                      const unsigned short *__restrict__ brow, const T *__restrict__ x, T *__restrict__ y)
 {
@@ -321,9 +375,9 @@ __global__ __launch_bounds__(kWave) void blk_kernel3(int m, int R, const long lo
 #undef SPMV_BLK_PHASE
     }
     __syncthreads();
-    const long long r0 = (long long) blockIdx.x * R;
-    for (int i = threadIdx.x; i < R; i += kWave)
-        if (r0 + i < m) y[r0 + i] = (T) ys[i];
+    const long long r0 = row0[blockIdx.x];
+    const int nr = row0[blockIdx.x + 1] - (int) r0;
+    for (int i = threadIdx.x; i < nr; i += kWave) y[r0 + i] = (T) ys[i];
 }
 
 } // namespace spmv

@@ -413,7 +413,7 @@ static int blocked_fill(spmv_dev *d, int wshift, bool values_only)
         return fail(SPMV_HIP_E_ALLOC, "pool_malloc(block cells)");
     }
     hipError_t e = hipMemsetAsync(cnt, 0, sizeof(int) * cells, d->stream);
-    blk_count_kernel<<<grid_for(d->m, kBlock / 16, d->cus * 16), kBlock, 0, d->stream>>>(d->m, R, K, wshift, d->rowptr, d->colidx, cnt);
+    blk_count_kernel<<<grid_for(d->m, kBlock / 16, d->cus * 16), kBlock, 0, d->stream>>>(d->m, B, d->blk_row0, K, wshift, d->rowptr, d->colidx, cnt);
     if (!values_only) {
         blk_totals_kernel<<<B, kWave, 0, d->stream>>>(B, K, cnt, tot);
         scan_i32_to_i64_kernel<<<1, kBlock, 0, d->stream>>>(B, tot, d->blk_start);
@@ -438,11 +438,11 @@ static int blocked_fill(spmv_dev *d, int wshift, bool values_only)
     const size_t lds = sizeof(int) * ((size_t) R + 1);
     if (values_only) {
         ensure_lds<blk_fill_kernel<T, true>>(d, lds);
-        blk_fill_kernel<T, true><<<B, kWave, lds, d->stream>>>(d->m, R, K, wshift, d->rowptr, d->colidx, (const T *) d->val,
+        blk_fill_kernel<T, true><<<B, kWave, lds, d->stream>>>(d->blk_row0, K, wshift, d->rowptr, d->colidx, (const T *) d->val,
                                                              (unsigned long long *) cursor, (T *) d->blk_val, d->blk_col, d->blk_row);
     } else {
         ensure_lds<blk_fill_kernel<T, false>>(d, lds);
-        blk_fill_kernel<T, false><<<B, kWave, lds, d->stream>>>(d->m, R, K, wshift, d->rowptr, d->colidx, (const T *) d->val,
+        blk_fill_kernel<T, false><<<B, kWave, lds, d->stream>>>(d->blk_row0, K, wshift, d->rowptr, d->colidx, (const T *) d->val,
                                                               (unsigned long long *) cursor, (T *) d->blk_val, d->blk_col, d->blk_row);
     }
     if (e == hipSuccess) e = hipGetLastError();
@@ -452,43 +452,81 @@ static int blocked_fill(spmv_dev *d, int wshift, bool values_only)
     return SPMV_HIP_OK;
 }
 
-// Rows per block.  rule 0 (first choice): FULL ROUNDS of fat blocks -- two blocks are resident per CU (2 x 78 KiB of its 160 KiB
-// of LDS), so the block count is made a multiple of 2 * CUs and R = ceil(m / blocks) <= 9984: the grid then runs in whole
-// rounds.  With 8192-row blocks config 2-ii has 1221 blocks = 2.4 rounds of 512 and pays for three (1.75 ms); with 9766-row
-// blocks exactly two (1.54 ms); 9728 rows = 1028 blocks: 2.02 ms, the four stragglers cost a round.  Orkut-style uniform:
-// 512 blocks of 5997 rows 0.79 ms vs 750 blocks of 4096 rows 1.02; R-MAT 0.69 vs 0.70.  rule 1: at least 512 blocks of at
-// most 8192 rows (a power of two) -- more, thinner blocks = more waves per CU, what a STREAM-bound matrix wants (web-like
-// 4e6 x 24: 977 blocks of 4096 rows 0.245 ms vs 512 blocks of 7813 rows 0.275); spmv_shim_build tries it when rule 0 turns out
-// stream-bound and keeps the faster set.
-static int blocked_rows_per_block(const spmv_dev *d, int rule)
+// How many row blocks, and how many rows at most in one.  rule 0 (first choice): FULL ROUNDS of fat blocks -- two blocks are
+// resident per CU (2 x 78 KiB of its 160 KiB of LDS), so the block count is a multiple of 2 * CUs with at most 9984 rows each:
+// the grid then runs in whole rounds.  With 8192-row blocks config 2-ii has 1221 blocks = 2.4 rounds of 512 and pays for three
+// (1.75 ms); with 1024 blocks exactly two (1.54 ms); 1028 blocks: 2.02 ms, the four stragglers cost a round.  Orkut-style uniform:
+// 512 blocks 0.79 ms vs 750 blocks of 4096 rows 1.02; R-MAT 0.69 vs 0.70.  rule 1: at least 512 blocks of at most 8192 rows (a
+// power of two) -- more, thinner blocks = more waves per CU, what a STREAM-bound matrix wants (web-like 4e6 x 24: 977 blocks
+// 0.245 ms vs 512 blocks 0.275); spmv_shim_build tries it when rule 0 turns out stream-bound and keeps the faster set.  The cut
+// points themselves follow the work, not the row count (blk_partition_kernel).  Option block_rows: uniform blocks of that many rows.
+static void blocked_block_rule(const spmv_dev *d, int rule, int *btarget, int *rcap)
 {
-    if (d->plan.block_rows > 0) return d->plan.block_rows;
-    int R;
+    if (d->plan.block_rows > 0) {
+        *rcap = d->plan.block_rows;
+        *btarget = (int) (((long long) d->m + *rcap - 1) / *rcap);
+        return;
+    }
     if (rule == 0) {
         const long long slots = 2ll * (d->cus > 0 ? d->cus : 256), rmax = 9984;
         const long long rounds = ((long long) d->m + slots * rmax - 1) / (slots * rmax);
-        const long long B = slots * (rounds > 0 ? rounds : 1);
-        R = (int) (((long long) d->m + B - 1) / B);
-        if (R < 1024) R = 1024;
+        long long B = slots * (rounds > 0 ? rounds : 1);
+        if ((long long) d->m / B < 1024) B = ((long long) d->m + 1023) / 1024; // small matrices: blocks of about 1024 rows
+        *btarget = (int) (B > 0 ? B : 1);
+        *rcap = (int) rmax;
     } else {
-        R = (int) (64 * 1024 / sizeof(double));
+        int R = (int) (64 * 1024 / sizeof(double));
         while (R > 1024 && (long long) d->m / R < 512) R >>= 1; // small matrices: at least ~512 blocks, down to 1024 rows
+        *btarget = (int) (((long long) d->m + R - 1) / R);
+        *rcap = R + R / 4; // equal-work cut points may stretch a block of light rows
+        if (*rcap > 9984) *rcap = 9984;
     }
-    return R;
+}
+
+// would rule 1 cut the rows differently from rule 0?
+static bool blocked_differs(const spmv_dev *d)
+{
+    int b0, r0, b1, r1;
+    blocked_block_rule(d, 0, &b0, &r0);
+    blocked_block_rule(d, 1, &b1, &r1);
+    return b0 != b1;
 }
 
 template <typename T>
 static int build_blocked(spmv_dev *d, int rule)
 {
-    int R = blocked_rows_per_block(d, rule); // double accumulators (blocked.hpp)
-    if ((size_t) R * sizeof(double) > 128 * 1024) R = (int) (128 * 1024 / sizeof(double));
+    int btarget = 1, rcap = 1024;
+    blocked_block_rule(d, rule, &btarget, &rcap);
+    if (rcap > 16384) rcap = 16384; // 128 KiB of double accumulators; row numbers inside a block are 16-bit
+    // cut points: uniform for option block_rows, equal work otherwise
+    const size_t cap_blocks = (size_t) btarget + (size_t) (d->m / rcap) + 2;
+    int rc = dev_alloc(d, (void **) &d->blk_row0, sizeof(int) * (cap_blocks + 1), true);
+    if (rc) return rc;
+    int B = btarget, R = rcap;
+    if (d->plan.block_rows > 0) {
+        std::vector<int> h((size_t) B + 1);
+        for (int b = 0; b <= B; ++b) h[(size_t) b] = (int) std::min<long long>((long long) b * rcap, d->m);
+        HIP_TRY(hipMemcpyAsync(d->blk_row0, h.data(), sizeof(int) * ((size_t) B + 1), hipMemcpyHostToDevice, d->stream));
+        HIP_TRY(hipStreamSynchronize(d->stream));
+    } else {
+        int *out = nullptr, hout[2] = {0, 0}; // [0..1] results, [2 ..] the kernel's cut-point scratch
+        HIP_TRY(pool_malloc((void **) &out, sizeof(int) * ((size_t) btarget + 3)));
+        const long long c = std::max<long long>(1, (long long) (d->stats.mean_row_len / 8.0)); // fixed cost of a row, in entries
+        blk_partition_kernel<<<1, kBlock, 0, d->stream>>>(d->m, d->rowptr, btarget, rcap, c, out + 2, d->blk_row0, out);
+        hipError_t e = hipGetLastError();
+        if (e == hipSuccess) e = hipMemcpyAsync(hout, out, sizeof hout, hipMemcpyDeviceToHost, d->stream);
+        if (e == hipSuccess) e = hipStreamSynchronize(d->stream);
+        (void) pool_free(out);
+        if (e != hipSuccess) return fail(SPMV_HIP_E_RUNTIME, "block partition: %s", hipGetErrorString(e));
+        B = hout[0];
+        R = hout[1] > 0 ? hout[1] : 1;
+        if (B < 1 || (size_t) B > cap_blocks) return fail(SPMV_HIP_E_RUNTIME, "block partition produced %d blocks", B);
+    }
     // Slab width: as narrow as the cell table allows (2^25 cells: ~400 MB of inspector scratch), down to 32
     // columns.  Narrow slabs cost nothing in L2 locality (the sweep over x is the same) and put entries that
     // gather from the same cache line into neighbouring lanes, which the L1/TA path merges into one L2
-    // request -- the executor is bound by the L2's request rate (Orkut-style stand-in, 74 nnz/row over 3e6
-    // columns: 2.05 -> 1.13 ms; 32 nnz/row over 1e7 columns is too sparse for that, 0.4 entries per line and
-    // block: 2.1 -> 2.0 ms).
-    const int B = (int) (((long long) d->m + R - 1) / R);
+    // request (Orkut-style stand-in, 74 nnz/row over 3e6 columns: 2.05 -> 1.13 ms; 32 nnz/row over 1e7 columns is
+    // too sparse for that, 0.4 entries per line and block: 2.1 -> 2.0 ms).
     int wshift = 5;
     if (d->plan.slab_kib > 0) {
         wshift = 0;
@@ -498,7 +536,7 @@ static int build_blocked(spmv_dev *d, int rule)
     }
     const int K = (int) ((((long long) d->n - 1) >> wshift) + 1);
     if ((long long) B * K > (1ll << 26)) return SPMV_HIP_OK; // cell table too large: keep the tile executor
-    int rc = dev_alloc(d, (void **) &d->blk_start, sizeof(long long) * ((size_t) B + 1), true);
+    rc = dev_alloc(d, (void **) &d->blk_start, sizeof(long long) * ((size_t) B + 1), true);
     if (!rc) rc = dev_alloc(d, (void **) &d->blk_end, sizeof(long long) * (size_t) B, true);
     if (rc) return rc;
     d->blk_R = R; d->blk_K = K; d->blk_B = B; d->blk_wshift = wshift;

@@ -122,13 +122,13 @@ static void launch_blocked(spmv_dev *d, const T *x, T *y)
 #define SPMV_BLK_LAUNCH(NT, UN)                                                                                                  \
     do {                                                                                                                         \
         ensure_lds<blk_kernel<T, NT, UN>>(d, lds);                                                                               \
-        blk_kernel<T, NT, UN><<<d->blk_B, NT, lds, d->stream>>>(d->m, d->blk_R, d->blk_start, d->blk_end, (const T *) d->blk_val, \
+        blk_kernel<T, NT, UN><<<d->blk_B, NT, lds, d->stream>>>(d->blk_row0, d->blk_R, d->blk_start, d->blk_end, (const T *) d->blk_val, \
                                                                 d->blk_col, d->blk_row, x, y);                                   \
     } while (0)
 #define SPMV_BLK3_LAUNCH(UN)                                                                                                     \
     do {                                                                                                                         \
         ensure_lds<blk_kernel3<T, UN>>(d, lds);                                                                                  \
-        blk_kernel3<T, UN><<<d->blk_B, kWave, lds, d->stream>>>(d->m, d->blk_R, d->blk_start, d->blk_end, (const T *) d->blk_val, \
+        blk_kernel3<T, UN><<<d->blk_B, kWave, lds, d->stream>>>(d->blk_row0, d->blk_R, d->blk_start, d->blk_end, (const T *) d->blk_val, \
                                                                 d->blk_col, d->blk_row, x, y);                                   \
     } while (0)
     switch (d->plan.variant) {

@@ -205,6 +205,7 @@ struct spmv_dev {
     float blk_tune_ms[3] = {0, 0, 0};
     long long blk_slots = 0;
     long long *blk_start = nullptr, *blk_end = nullptr;
+    int *blk_row0 = nullptr;      // [blk_B + 1] first row of every block (equal-work cut points, blocked.hpp: blk_partition_kernel)
     void *blk_val = nullptr;
     int *blk_col = nullptr;
     unsigned short *blk_row = nullptr;
@@ -277,7 +278,7 @@ static void free_schedule(spmv_dev *d)
     for (auto &a : d->sched_allocs) { (void) pool_free(a.first); d->device_bytes -= (long long) a.second; }
     d->sched_allocs.clear();
     reset_tile_fields(d);
-    d->blk_on = false; d->blk_slots = 0; d->blk_start = d->blk_end = nullptr; d->blk_val = nullptr; d->blk_col = nullptr; d->blk_row = nullptr;
+    d->blk_on = false; d->blk_slots = 0; d->blk_start = d->blk_end = nullptr; d->blk_row0 = nullptr; d->blk_val = nullptr; d->blk_col = nullptr; d->blk_row = nullptr;
     d->built = false;
 }
 

@@ -216,22 +216,22 @@ extern "C" int spmv_shim_build(spmv_dev *d, const spmv_plan *plan)
         // Stream-bound under rule 0 (the three streams alone move >= 3.6 TB/s; web-like 4e6 x 24 in fp32 sits at 4.2)?  Then thinner blocks may do better: build the
         // rule-1 set next to this one, time it, keep the faster (one more inspector pass, only for such matrices).
         if (!rc && d->blk_on && plan->autotune && plan->variant == 0 && plan->block_rows == 0 && d->nnz >= (1ll << 22) &&
-            blocked_rows_per_block(d, 1) != d->blk_R) {
+            blocked_differs(d)) {
             float best0 = d->blk_tune_ms[0];
             for (int f = 1; f < 3; ++f) best0 = d->blk_tune_ms[f] < best0 ? d->blk_tune_ms[f] : best0;
             const double rate = best0 > 0 ? (double) d->nnz * ((double) d->vsize + 6.0) / ((double) best0 * 1e-3) : 0.0;
             if (rate >= 3.6e12) {
-                struct BlkSet { long long *start, *end; void *val; int *col; unsigned short *row; int R, K, B, wshift, form; long long slots; float tune[3]; };
-                auto take = [&]() { return BlkSet{d->blk_start, d->blk_end, d->blk_val, d->blk_col, d->blk_row, d->blk_R, d->blk_K, d->blk_B, d->blk_wshift, d->blk_form,
+                struct BlkSet { int *row0; long long *start, *end; void *val; int *col; unsigned short *row; int R, K, B, wshift, form; long long slots; float tune[3]; };
+                auto take = [&]() { return BlkSet{d->blk_row0, d->blk_start, d->blk_end, d->blk_val, d->blk_col, d->blk_row, d->blk_R, d->blk_K, d->blk_B, d->blk_wshift, d->blk_form,
                                                   d->blk_slots, {d->blk_tune_ms[0], d->blk_tune_ms[1], d->blk_tune_ms[2]}}; };
                 auto put = [&](const BlkSet &b) {
-                    d->blk_start = b.start; d->blk_end = b.end; d->blk_val = b.val; d->blk_col = b.col; d->blk_row = b.row;
+                    d->blk_row0 = b.row0; d->blk_start = b.start; d->blk_end = b.end; d->blk_val = b.val; d->blk_col = b.col; d->blk_row = b.row;
                     d->blk_R = b.R; d->blk_K = b.K; d->blk_B = b.B; d->blk_wshift = b.wshift; d->blk_form = b.form; d->blk_slots = b.slots;
                     for (int f = 0; f < 3; ++f) d->blk_tune_ms[f] = b.tune[f];
                 };
                 auto release = [&](const BlkSet &b) {
                     quiesce(d);
-                    sched_free(d, b.start); sched_free(d, b.end); sched_free(d, b.val); sched_free(d, b.col); sched_free(d, b.row);
+                    sched_free(d, b.row0); sched_free(d, b.start); sched_free(d, b.end); sched_free(d, b.val); sched_free(d, b.col); sched_free(d, b.row);
                 };
                 const BlkSet first = take();
                 d->blk_on = false;
@@ -245,7 +245,9 @@ extern "C" int spmv_shim_build(spmv_dev *d, const spmv_plan *plan)
                     else { release(second); put(first); }
                 } else { // the second set could not be built (memory): keep the first
                     const BlkSet partial = take();
-                    if (partial.start != first.start) { if (partial.start) sched_free(d, partial.start); if (partial.end && partial.end != first.end) sched_free(d, partial.end); }
+                    if (partial.row0 && partial.row0 != first.row0) sched_free(d, partial.row0);
+                    if (partial.start && partial.start != first.start) sched_free(d, partial.start);
+                    if (partial.end && partial.end != first.end) sched_free(d, partial.end);
                     put(first);
                     (void) hipGetLastError();
                 }
