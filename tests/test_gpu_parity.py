@@ -493,6 +493,43 @@ def test_matrix_without_column_locality_runs_the_blocked_executor_deterministica
     assert bool(((ys[0].double() - want).abs() <= TOL[np.dtype(dtype)] * scale).all())
 
 
+@pytest.mark.parametrize("method", [M.Method_Parallel, M.Method_Balanced2, M.Method_SellCSigma], ids=lambda m: m.name)
+def test_blocked_executor_equal_work_cut_points_on_a_lopsided_matrix(method):
+    """The row blocks of the blocked executor are cut by work (blocked.hpp: blk_partition_kernel).  One row that outweighs
+    every share (several cut points collapse onto it: empty blocks are dropped), light rows whose share would span more
+    rows than the LDS accumulators hold (blocks are split at the row cap) and a long stretch of empty rows: exact data,
+    so the result must equal the definition bit for bit, and spmv_hip_update_values must hit the same positions."""
+    import torch
+    dev = torch.device("cuda:0")
+    m, n = 120_000, 500_000
+    g = torch.Generator(device=dev); g.manual_seed(21)
+    lens = torch.randint(0, 4, (m,), generator=g, device=dev, dtype=torch.int64)
+    lens[5] = 400_000
+    lens[60_000:100_000] = 0
+    lens[m - 1] = 17
+    _, _, rp, ci, va = synth.from_row_lengths_device(lens, n, "eighths", torch.float64, dev, seed=4)
+    x = (torch.randint(-8, 9, (n,), generator=g, device=dev) * 0.125).to(torch.float64)
+    prod = va * x[ci.long()]
+    cs = torch.cat([torch.zeros(1, dtype=torch.float64, device=dev), torch.cumsum(prod, 0)])
+    want = cs[rp[1:].long()] - cs[rp[:-1].long()]
+    keep = api.get_option("cache_block")
+    try:
+        api.set_option("cache_block", 2)
+        y = torch.full((m,), float("nan"), dtype=torch.float64, device=dev)
+        with api.Handle(m, n, rp, ci, va, method) as h:
+            assert h.info()["cache_blocked"] == 1
+            h.spmv(x, y)
+            torch.cuda.synchronize()
+            assert torch.equal(y, want)
+            va2 = va * 2
+            h.update_values(va2)
+            h.spmv(x, y)
+            torch.cuda.synchronize()
+            assert torch.equal(y, 2 * want)
+    finally:
+        api.set_option("cache_block", keep)
+
+
 @pytest.mark.parametrize("dtype", [np.float64, np.float32])
 def test_blocked_executor_forms_give_the_same_bits_and_create_picks_one_by_timing(dtype):
     """The row-block executor has a two-stage and two three-stage pipelined forms (blocked.hpp: blk_kernel, blk_kernel3);
