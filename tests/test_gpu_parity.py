@@ -501,10 +501,10 @@ def test_blocked_executor_equal_work_cut_points_on_a_lopsided_matrix(method):
     so the result must equal the definition bit for bit, and spmv_hip_update_values must hit the same positions."""
     import torch
     dev = torch.device("cuda:0")
-    m, n = 120_000, 500_000
+    m, n = 120_000, 4_000_000
     g = torch.Generator(device=dev); g.manual_seed(21)
     lens = torch.randint(0, 4, (m,), generator=g, device=dev, dtype=torch.int64)
-    lens[5] = 400_000
+    lens[5] = 3_500_000     # 118 shares of ~31 k work each: ~110 cut points fall on this row, and a share of light rows (work 1-3 each) spans more than the 9984-row cap
     lens[60_000:100_000] = 0
     lens[m - 1] = 17
     _, _, rp, ci, va = synth.from_row_lengths_device(lens, n, "eighths", torch.float64, dev, seed=4)
