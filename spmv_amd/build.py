@@ -56,6 +56,25 @@ def _run(cmd):
         sys.stderr.write(r.stderr)
 
 
+def build_debug(defines, name="libspmv_hip_dbg.so", verbose=False):
+    """A/B build for tools/ (never loaded by the package): the same sources with extra -D defines -> spmv_amd/lib/<name>."""
+    os.makedirs(LIBDIR, exist_ok=True)
+    os.makedirs(OBJDIR, exist_ok=True)
+    objs = []
+    for src in C_SOURCES:
+        obj = os.path.join(OBJDIR, "dbg_" + src.replace(os.sep, "_") + ".o")
+        _run([CC, *C_FLAGS, f"-I{INC}", f"-I{CSRC}", "-c", os.path.join(CSRC, src), "-o", obj])
+        objs.append(obj)
+    for src in HIP_SOURCES:
+        obj = os.path.join(OBJDIR, "dbg_" + src + ".o")
+        _run([HIPCC, *HIP_FLAGS, *[f"-D{d}" for d in defines], f"-I{INC}", f"-I{CSRC}", "-c", os.path.join(CSRC, src), "-o", obj])
+        objs.append(obj)
+    gomp = subprocess.run([CC, "-print-file-name=libgomp.so"], capture_output=True, text=True).stdout.strip()
+    out = os.path.join(LIBDIR, name)
+    _run([HIPCC, "-shared", "-fPIC", f"--offload-arch={ARCH}", "-o", out, *objs, gomp, "-lpthread", "-lm"])
+    return out
+
+
 def build(force=False, verbose=False):
     os.makedirs(LIBDIR, exist_ok=True)
     os.makedirs(OBJDIR, exist_ok=True)
@@ -98,4 +117,7 @@ def build(force=False, verbose=False):
 
 
 if __name__ == "__main__":
-    print(build(force="--force" in sys.argv, verbose=True))
+    if "--debug" in sys.argv:   # python -m spmv_amd.build --debug SPMV_BLK_DEBUG_FORMS [...]
+        print(build_debug(sys.argv[sys.argv.index("--debug") + 1:]))
+    else:
+        print(build(force="--force" in sys.argv, verbose=True))

@@ -1,56 +1,74 @@
 // blocked.hpp -- row blocks x column slabs: the executor for matrices whose columns have NO locality
 // (uniformly random / social-graph structure), whatever the method asked for.
 //
-// Why.  When no x window of a tile group fits LDS (xwindows.hpp), every gather of x is a scattered
-// 8-byte read.  x itself stays resident in the 256 MiB Infinity Cache, but each gather pulls a whole
-// line across the fabric into an XCD's L2: 3.2e8 gathers = ~21 GB of line traffic, ~6 ms for a
-// matrix whose own stream is 3.8 GB.  The reference meets the same wall on the CPU
-// and does nothing about it; its Balanced2 workers own consecutive non-zeros
-// (parallel_balanced2_spmv.c:41-53) and gather x wherever the columns point.
+// Why.  When no x window of a tile group fits LDS (xwindows.hpp), every gather of x is a scattered read.  x itself
+// stays resident in the 256 MiB Infinity Cache, but each gather pulls a whole line across the fabric into an XCD's
+// L2: 3.2e8 gathers = ~21 GB of line traffic, ~6 ms for a matrix whose own stream is 3.8 GB.  The
+// reference meets the same wall on the CPU and does nothing about it; its Balanced2 workers own consecutive
+// non-zeros (parallel_balanced2_spmv.c:41-53) and gather x wherever the columns point.
 //
-// Here, for that case only:
-//   inspector   rows are cut into blocks of R rows, columns into slabs of W columns -- as narrow as a
-//               table of 2^25 (block, slab) cells allows, down to 32 columns: the sweep over x is what
-//               keeps x in L2, and narrow slabs additionally put gathers from one cache line into
-//               neighbouring lanes, which merge into one L2 request.  The entries of a row block are
-//               stored sorted by SLAB, and inside a (block, slab) cell in CSR order -- a STABLE counting
-//               sort, done by ONE wavefront per block that walks the block's entries in CSR order and
-//               ranks the 64 entries of a batch against each other with ballots (blk_fill_kernel), so the
-//               stored order is a function of the matrix alone.  Three streams: value, global column,
-//               16-bit row number inside the block; block regions start at multiples of 8 entries so
-//               every load is a 16-byte load.
-//   executor    ONE WAVEFRONT per row block (a 64-thread workgroup).  y of the block lives in LDS
-//               (R doubles = 64 KiB, for fp32 values too -- see lds_add: two blocks per CU -- more resident blocks drift apart in their
-//               slab position and thrash L2), the wave walks the block's entries in stored order -- slab
-//               after slab; blocks are dispatched in order and hold similar work, so the blocks of an XCD
-//               gather from the same few slabs of x at a time, which therefore stay in L2 -- with 16
-//               gathers in flight per lane, and adds every product into y's LDS copy (ds_add).  At the end
-//               the block's y is written once, coalesced: no partial sums, no carries, no read-modify-write
-//               of y in HBM.
-//   determinism every row is touched by exactly one wavefront, whose additions happen in program order
-//               over a stream whose order is fixed by the inspector: the result is reproducible bit for
-//               bit, run to run and handle to handle (the first version of this executor used a
-//               256-thread workgroup per block, whose four waves raced on the rows: kept as variant 23).
-//
-// What bounds it is the L2's rate of random requests (one request per gather that is not merged with a
-// neighbour's; ~1.4-1.7e11/s over the chip), not HBM: DESIGN.md 3.7 has the counters.
+// Here, for that case only (format of round 3; DESIGN.md 3.7 has the measurements):
+//   layout      rows are cut into blocks of at most R rows of EQUAL WORK (blk_partition_kernel), columns into slabs of
+//               2^wshift columns (128 unless that would make more than 32768 slabs).  The entries of a row block are
+//               stored sorted by slab, in GROUPS of 64 lanes x 16 bytes of values (128 fp64 / 256 fp32 entries), as two
+//               streams: the value and a 32-bit word (16-bit column offset | 16-bit row inside the block) -- 12 bytes per
+//               fp64 entry, the bytes of plain CSR.  A block's region has two parts:
+//                 dense   the (block, slab) cells with at least one group's worth of entries, back to back.  A group
+//                         touches at most two cells, so its header names two slabs (A: the slab of its first entry, B:
+//                         the next dense slab); the executor reads both slabs of x with COALESCED loads into LDS and
+//                         the entries pick their x there -- the column field is (A or B, offset in the slab).  No
+//                         scattered load at all: a scattered load occupies the CU's vector-memory path lane by lane
+//                         and the matrix stream queues behind it, a coalesced one for a few cycles.
+//                 sparse  everything else, super-slab (65536 columns) after super-slab, each super-slab's run padded
+//                         to whole groups, so that a group lies in ONE super-slab: its header is the super-slab's
+//                         first column (wave-uniform: a scalar load, the gather is base + 16-bit offset) and x is
+//                         gathered through L2 as before -- the sweep over the slabs, in step over the blocks of an XCD,
+//                         is what keeps x in L2.
+//   inspector   (device) one 1024-thread workgroup per block counts the block's cells in LDS (blk_count_kernel); a
+//               layout pass turns counts into part offsets; then the fill (blk_fill_kernel): the cells of a block are
+//               split into up to 16 column ranges and ONE WAVEFRONT per (block, range) scans the block's entries in CSR
+//               order, keeps those of its range (compacted through a small LDS queue, order kept) and gives each the
+//               next position of its cell from a cursor in LDS.  Only that wave touches those cursors and it does so in
+//               CSR order, so the stored order -- (part, slab, CSR order) -- is a function of the matrix alone.
+//   executor    ONE WAVEFRONT per row block (a 64-thread workgroup, two blocks per CU).  y of the block lives in LDS
+//               as doubles (for fp32 values too -- see lds_add); the wave walks first the dense groups, then the sparse
+//               ones, three steps in flight (stream loads of step t + 2, x of step t + 1, additions of step t), and
+//               adds every product into y's LDS copy (ds_add_f64).  At the end the block's y is written once,
+//               coalesced: no partial sums, no carries, no read-modify-write of y in HBM.  No load sits behind a
+//               branch: groups past a part's end are read (the streams are padded) and their products go to a junk
+//               accumulator.
+//   determinism every row is touched by exactly one wavefront, whose additions happen in program order over a stream
+//               whose order is fixed by the inspector: the result is reproducible bit for bit, run to run and handle
+//               to handle.
 #pragma once
 #include <climits>
 #include "common.hpp"
 
 namespace spmv {
 
+constexpr int kBlkSlabShift = 7;     // dense cells: slabs of 128 columns (1 KiB of fp64 x, two 512-byte load instructions)
+constexpr int kBlkSuperShift = 16;   // sparse entries: 16-bit column offsets inside super-slabs of 65536 columns
+constexpr int kBlkMaxCells = 32768;  // cells of one row block at most (the count kernel's histogram: 128 KiB of LDS)
+constexpr int kBlkParts = 16;        // column ranges the fill of one block is split over (one wavefront each)
+constexpr int kBlkCountThreads = 1024;
+constexpr int kBlkPadGroups = 128;   // zero groups behind the last block: three executor steps of the widest form, and header loads reach 64 groups ahead
+constexpr int kBlkDenseUn = 8;       // groups per step of the dense loop (LDS: 2 slabs x 128 columns each)
+
+struct BlkDir {      // one row block's region: groups [g0, g0 + nd) dense, [g0 + nd, g0 + nd + ns) sparse
+    long long g0;
+    int nd, ns;
+};
 
 // Row blocks of EQUAL WORK: block b holds rows [row0[b], row0[b + 1]).  All blocks of a round are resident together and the
 // round lasts as long as its heaviest block (Orkut-style stand-in, fixed 5997-row blocks: heaviest / mean = 1.18; 4e6 rows of
 // 2.6 entries: 1.40), so the cut points follow the entries, not the rows: work(r) = RowPtr[r] + c r (c entries of fixed cost per
 // row, so that stretches of empty rows still end a block), each block takes 1 / (blocks left) of the work left, never more than
-// rcap rows (its accumulators live in LDS).  One thread: B binary searches over RowPtr.  out[0] = blocks made (>= btarget when
+// rcap rows (its accumulators live in LDS).  One workgroup: B binary searches over RowPtr.  out[0] = blocks made (>= btarget when
 // the row cap cut some short), out[1] = most rows in a block.
 __global__ __launch_bounds__(kBlock) void blk_partition_kernel(int m, const int *__restrict__ rowptr, int btarget, int rcap, long long c,
                                                                int *__restrict__ cut /* [btarget + 1] scratch */, int *__restrict__ row0, int *__restrict__ out)
 {
-    // one workgroup.  Cut points of equal work, found independently: cut[b] = first row whose work reaches b / btarget of the total
+    // cut points of equal work, found independently: cut[b] = first row whose work reaches b / btarget of the total
     const long long total = (long long) rowptr[m] + c * m;
     for (int b = threadIdx.x; b <= btarget; b += kBlock) {
         const long long target = b == btarget ? total : (total / btarget) * b + ((total % btarget) * b) / btarget;
@@ -83,153 +101,221 @@ __global__ __launch_bounds__(kBlock) void blk_partition_kernel(int m, const int 
     out[1] = maxr;
 }
 
-// block of row r: the last b with row0[b] <= r
-__device__ __forceinline__ int blk_of_row(const int *__restrict__ row0, int B, int r)
+// Sum over the wavefront, every lane gets the total.
+__device__ __forceinline__ int wave_sum(int v)
 {
-    int lo = 0, hi = B; // row0[lo] <= r < row0[hi]
-    while (hi - lo > 1) {
-        const int mid = (lo + hi) >> 1;
-        if (row0[mid] <= r) lo = mid; else hi = mid;
-    }
-    return lo;
-}
-
-// cell histogram: cnt[block(r) * K + (c >> wshift)] += 1 for every entry; 16 lanes sweep a row
-__global__ __launch_bounds__(kBlock) void blk_count_kernel(int m, int B, const int *__restrict__ row0, int K, int wshift, const int *__restrict__ rowptr,
-                                                           const int *__restrict__ colidx, int *__restrict__ cnt)
-{
-    const int sub = threadIdx.x / 16, l = threadIdx.x % 16;
-    const long long stride = (long long) gridDim.x * (kBlock / 16);
-    for (long long r = (long long) blockIdx.x * (kBlock / 16) + sub; r < m; r += stride) {
-        const int p0 = rowptr[r], p1 = rowptr[r + 1];
-        if (p0 == p1) continue;
-        const long long cell0 = (long long) blk_of_row(row0, B, (int) r) * K;
-        for (int p = p0 + l; p < p1; p += 16) atomicAdd(&cnt[cell0 + (colidx[p] >> wshift)], 1);
-    }
+#pragma unroll
+    for (int o = kWave / 2; o > 0; o >>= 1) v += __shfl_xor(v, o, kWave);
+    return v;
 }
 
 // exclusive prefix sum of one value per lane over the wavefront
-__device__ __forceinline__ long long wave_excl_scan(long long v, int lane, long long *total)
+__device__ __forceinline__ int wave_excl_scan(int v, int lane, int *total)
 {
-    long long inc = v;
+    int inc = v;
 #pragma unroll
     for (int o = 1; o < kWave; o <<= 1) {
-        const long long t = __shfl_up(inc, o, kWave);
+        const int t = __shfl_up(inc, o, kWave);
         if (lane >= o) inc += t;
     }
     *total = __shfl(inc, kWave - 1, kWave);
     return inc - v;
 }
 
-// tot[b] = entries of block b, rounded up to 8 (block regions start 16-byte aligned in every stream); one wave per block
-__global__ __launch_bounds__(kWave) void blk_totals_kernel(int B, int K, const int *__restrict__ cnt, int *__restrict__ tot)
+// super-slabs [s0, s1) of column range `part` out of `nparts` (S super-slabs in all)
+__device__ __forceinline__ void blk_part_range(int S, int nparts, int part, int &s0, int &s1)
 {
-    const int b = blockIdx.x, lane = threadIdx.x;
-    long long s = 0;
-    for (int k = lane; k < K; k += kWave) s += cnt[(long long) b * K + k];
-#pragma unroll
-    for (int o = kWave / 2; o > 0; o >>= 1) s += __shfl_xor(s, o, kWave);
-    if (lane == 0) tot[b] = (int) ((s + 7) & ~7ll);
+    s0 = (int) (((long long) S * part) / nparts);
+    s1 = (int) (((long long) S * (part + 1)) / nparts);
 }
 
-// cursor[b][k] = first position of cell (b, k); end[b] = one past the block's last real entry; one wave per block,
-// every lane owns a contiguous run of cells
-__global__ __launch_bounds__(kWave) void blk_cells_kernel(int B, int K, const int *__restrict__ cnt, const long long *__restrict__ start,
-                                                          long long *__restrict__ cursor, long long *__restrict__ end)
+// Inspector pass 1: the cells of row block blockIdx.x, counted in LDS (K counters), written to cnt[b][K]; and per
+// column range (part) of the block the entries in dense cells (count >= dense_min) and the entries in sparse cells,
+// the latter with every super-slab's run rounded up to whole groups of 2^ge entries -- parts[b][part] = (dense, sparse).
+__global__ __launch_bounds__(kBlkCountThreads) void blk_count_kernel(const int *__restrict__ row0, int K, int wshift, int dense_min, int ge, int nparts,
+                                                                     int S, const int *__restrict__ rowptr, const int *__restrict__ colidx,
+                                                                     int *__restrict__ cnt, i32x2 *__restrict__ parts)
 {
-    const int b = blockIdx.x, lane = threadIdx.x;
-    const int per = (K + kWave - 1) / kWave, k0 = lane * per, k1 = k0 + per < K ? k0 + per : K;
-    long long mine = 0, total;
-    for (int k = k0; k < k1; ++k) mine += cnt[(long long) b * K + k];
-    long long p = start[b] + wave_excl_scan(mine, lane, &total);
-    for (int k = k0; k < k1; ++k) {
-        cursor[(long long) b * K + k] = p;
-        p += cnt[(long long) b * K + k];
-    }
-    if (lane == 0) end[b] = start[b] + total;
-}
-
-// Stable rank of the 64 entries of a batch among the entries with the same key: rank = number of lower lanes with
-// my key, cnt = lanes with my key, leader = the lowest of them.  One pass per distinct key of the batch.
-__device__ __forceinline__ void batch_rank(bool valid, int key, int lane, int &rank, int &cnt, int &leader)
-{
-    unsigned long long todo = __ballot(valid);
-    rank = 0; cnt = 0; leader = lane;
-    while (todo) {
-        const int l0 = __ffsll((long long) todo) - 1;
-        const int k0 = __shfl(key, l0, kWave);
-        const bool mine = valid && key == k0;
-        const unsigned long long mk = __ballot(mine);
-        if (mine) {
-            rank = __popcll(mk & ((1ull << lane) - 1ull));
-            cnt = __popcll(mk);
-            leader = l0;
+    extern __shared__ __attribute__((aligned(16))) unsigned char blk_count_lds[];
+    unsigned *cells = reinterpret_cast<unsigned *>(blk_count_lds);
+    const int b = blockIdx.x;
+    for (int i = threadIdx.x; i < K; i += kBlkCountThreads) cells[i] = 0u;
+    __syncthreads();
+    const int p0 = rowptr[row0[b]], p1 = rowptr[row0[b + 1]];
+    for (int p = p0 + (int) threadIdx.x; p < p1; p += kBlkCountThreads) atomicAdd(&cells[ld_stream(colidx + p) >> wshift], 1u);
+    __syncthreads();
+    const int wave = threadIdx.x / kWave, lane = threadIdx.x % kWave;
+    const int cs = kBlkSuperShift - wshift; // cells per super-slab = 2^cs
+    int *out = cnt + (long long) b * K;
+    for (int part = wave; part < nparts; part += kBlkCountThreads / kWave) {
+        int s0, s1;
+        blk_part_range(S, nparts, part, s0, s1);
+        int dsum = 0, spad = 0;
+        for (int s = s0; s < s1; ++s) {
+            const int ka = s << cs, kb = min((s + 1) << cs, K);
+            int d = 0, sp = 0;
+            for (int k = ka + lane; k < kb; k += kWave) {
+                const int c = (int) cells[k];
+                out[k] = c;
+                if (c >= dense_min) d += c; else sp += c;
+            }
+            dsum += wave_sum(d);
+            spad += ((wave_sum(sp) + (1 << ge) - 1) >> ge) << ge;
         }
-        todo &= ~mk;
+        if (lane == 0) parts[(long long) b * kBlkParts + part] = i32x2{dsum, spad};
     }
 }
 
-// row of CSR position p inside the block whose row pointers are rp[0..nr]: the largest r with rp[r] <= p, searched
-// upwards from `row` (p only grows along a lane)
-__device__ __forceinline__ int row_of_position(const int *rp, int nr, int row, int p)
+// Inspector pass 2: per block, where each part's dense and sparse entries start inside the block's region (in entries:
+// dense parts back to back from 0, the dense total rounded up to a whole group, then the sparse parts), and the block's
+// group counts.  One thread per block.
+__global__ __launch_bounds__(kBlock) void blk_layout_kernel(int B, int nparts, int ge, const i32x2 *__restrict__ parts, i32x2 *__restrict__ part_off,
+                                                            int *__restrict__ groups, int *__restrict__ dense_groups)
 {
-    int lo = row, hi = nr; // rp[lo] <= p < rp[hi]
-    while (hi - lo > 1) {
-        const int mid = (lo + hi) >> 1;
-        if (rp[mid] <= p) lo = mid; else hi = mid;
+    const int b = blockIdx.x * kBlock + threadIdx.x;
+    if (b >= B) return;
+    int d = 0;
+    for (int w = 0; w < nparts; ++w) {
+        part_off[(long long) b * kBlkParts + w].x = d;
+        d += parts[(long long) b * kBlkParts + w].x;
     }
-    return lo;
+    const int dp = ((d + (1 << ge) - 1) >> ge) << ge;
+    int s = dp;
+    for (int w = 0; w < nparts; ++w) {
+        part_off[(long long) b * kBlkParts + w].y = s;
+        s += parts[(long long) b * kBlkParts + w].y;
+    }
+    groups[b] = s >> ge;
+    dense_groups[b] = dp >> ge;
 }
 
-// Stable scatter: ONE wavefront per row block walks the block's entries in CSR order, 64 at a time.  Inside a
-// batch, entries of the same cell are ranked by lane (batch_rank); the first of each cell advances the cell's
-// cursor by the cell's count in this batch.  Only this wave touches the cursors of its block and it does so batch
-// after batch, so position = cell start + number of earlier entries (CSR order) of the same cell: the stored order
-// does not depend on timing.  VALUES_ONLY: re-permute new values into the same positions
-// (spmv_hip_update_values).  Dynamic LDS: (R + 1) ints, the block's row pointers.
-// (Tried and dropped: a pre-pass that sorts the entries of a cell by x cache line, so that neighbouring lanes
-// gather from the same line -- no change on any shape: 2.32 vs 2.31 ms, 1.178 vs 1.176 ms, +40 ms of inspector.
-// The L1/TA path merges lanes of an instruction that hit the same line wherever they sit in the wave, and a cell
-// is only a few lines wide.)
+// Inspector pass 3, the stable fill: ONE wavefront per (row block, column range).  It turns the range's cell counts into
+// cursors (LDS) and group headers, then scans the block's entries in CSR order, 8 batches of 64 per round, appends the
+// entries of its range to a small LDS queue (ballot + popcount: order kept) and, whenever 64 are queued, hands each the next
+// position of its cell (LDS atomic with return: one wave, one instruction at a time, so positions follow the queue order
+// batch after batch; inside a batch the LDS unit serialises the lanes that hit one cursor in a fixed order) and stores
+// value and (column field | row << 16) there.  VALUES_ONLY: re-permute new values into the same positions
+// (spmv_hip_update_values).  Dynamic LDS: 2 x (most cells of a range) + 128 ints.
 template <typename T, bool VALUES_ONLY>
-__global__ __launch_bounds__(kWave) void blk_fill_kernel(const int *__restrict__ row0, int K, int wshift, const int *__restrict__ rowptr,
-                                                         const int *__restrict__ colidx, const T *__restrict__ val,
-                                                         unsigned long long *__restrict__ cursor, T *__restrict__ bval,
-                                                         int *__restrict__ bcol, unsigned short *__restrict__ brow)
+__global__ __launch_bounds__(kWave) void blk_fill_kernel(const int *__restrict__ row0, int K, int wshift, int dense_min, int ge, int nparts, int S, int range_cells,
+                                                         const int *__restrict__ rowptr, const int *__restrict__ colidx, const T *__restrict__ val,
+                                                         const int *__restrict__ cnt, const i32x2 *__restrict__ part_off, const long long *__restrict__ gstart,
+                                                         const int *__restrict__ dense_groups, T *__restrict__ bval, unsigned *__restrict__ bmeta,
+                                                         int *__restrict__ hdr_a, int *__restrict__ hdr_b, BlkDir *__restrict__ dir)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char blk_fill_lds[];
-    int *rp = reinterpret_cast<int *>(blk_fill_lds);
+    unsigned *cur = reinterpret_cast<unsigned *>(blk_fill_lds); // next position of every cell of the range (entries from the block region's start)
+    unsigned *cst = cur + range_cells;                          // the cell's first position | dense << 31
+    int *queue = reinterpret_cast<int *>(cst + range_cells);    // ring of 128 CSR positions
     const int lane = threadIdx.x;
-    const long long r0 = row0[blockIdx.x];
-    const int nr = row0[blockIdx.x + 1] - (int) r0;
-    for (int i = lane; i <= nr; i += kWave) rp[i] = rowptr[r0 + i];
+    const int b = blockIdx.x / nparts, part = blockIdx.x % nparts;
+    const int cs = kBlkSuperShift - wshift, gsize = 1 << ge;
+    int s0, s1;
+    blk_part_range(S, nparts, part, s0, s1);
+    const int k0 = s0 << cs, k1 = min(s1 << cs, K);
+    const long long g0 = gstart[b];
+    if (!VALUES_ONLY && part == 0 && lane == 0) dir[b] = BlkDir{g0, dense_groups[b], (int) (gstart[b + 1] - g0) - dense_groups[b]};
+    const int *mycnt = cnt + (long long) b * K;
+    { // cursors and headers of this range: super-slab after super-slab, every lane a contiguous run of the super-slab's cells
+        const i32x2 off = part_off[(long long) b * kBlkParts + part];
+        int doff = off.x, soff = off.y;
+        for (int s = s0; s < s1; ++s) {
+            const int ka = s << cs, kb = min((s + 1) << cs, K);
+            const int per = (kb - ka + kWave - 1) / kWave;
+            const int a = min(ka + lane * per, kb), e = min(a + per, kb);
+            int d = 0, sp = 0;
+            for (int k = a; k < e; ++k) {
+                const int c = mycnt[k];
+                if (c >= dense_min) d += c; else sp += c;
+            }
+            int dtot, stot;
+            int dpos = doff + wave_excl_scan(d, lane, &dtot), spos = soff + wave_excl_scan(sp, lane, &stot);
+            for (int k = a; k < e; ++k) {
+                const int c = mycnt[k];
+                if (c >= dense_min) {
+                    cur[k - k0] = (unsigned) dpos;
+                    cst[k - k0] = (unsigned) dpos | 0x80000000u;
+                    if (!VALUES_ONLY) { // this cell is slab A of every group that STARTS inside it, slab B of the group it starts inside of
+                        for (int g = (dpos + gsize - 1) >> ge; g <= (dpos + c - 1) >> ge; ++g) hdr_a[g0 + g] = k;
+                        if (dpos & (gsize - 1)) hdr_b[g0 + (dpos >> ge)] = k;
+                    }
+                    dpos += c;
+                } else {
+                    cur[k - k0] = (unsigned) spos;
+                    cst[k - k0] = (unsigned) spos;
+                    spos += c;
+                }
+            }
+            doff += dtot;
+            const int send = ((soff + stot + gsize - 1) >> ge) << ge; // the super-slab's run, in whole groups
+            if (!VALUES_ONLY)
+                for (int g = (soff >> ge) + lane; g < (send >> ge); g += kWave) hdr_a[g0 + g] = s << kBlkSuperShift; // first column of the super-slab
+            soff = send;
+        }
+    }
     __syncthreads();
-    const int p0 = rp[0], p1 = rp[nr];
-    unsigned long long *cur = cursor + (long long) blockIdx.x * K;
-    int row = 0;
-    for (int q = p0; q < p1; q += kWave) {
-        const int p = q + lane;
-        const bool valid = p < p1;
-        const int c = valid ? colidx[p] : 0;
-        const int cell = c >> wshift;
-        if (valid) row = row_of_position(rp, nr, row, p);
-        int rank, cnt, leader;
-        batch_rank(valid, cell, lane, rank, cnt, leader);
-        unsigned long long base = 0;
-        if (valid && rank == 0) base = atomicAdd(&cur[cell], (unsigned long long) cnt); // L2 atomic: coherent batch to batch
-        base = __shfl(base, leader, kWave);
-        if (valid) {
-            const unsigned long long pos = base + (unsigned long long) rank;
-            bval[pos] = val[p];
+    const int r0 = row0[b], nr = row0[b + 1] - r0;
+    const int p0 = rowptr[r0], p1 = rowptr[r0 + nr];
+    const long long e0 = g0 << ge; // first entry of the block's region
+    int qh = 0, qn = 0;            // queue head, entries queued (wave-uniform)
+    auto drain = [&](int count) {  // the first `count` (<= 64) queued entries, in queue order
+        const bool on = lane < count;
+        const int p = on ? queue[(qh + lane) & 127] : p0;
+        const int c = colidx[p];
+        const T v = val[p];
+        if (on) {
+            const int kk = (c >> wshift) - k0;
+            const unsigned pos = atomicAdd(&cur[kk], 1u);
+            // lane l of the executor loads 16 bytes = the entries l, 64 + l (fp32: .., 128 + l, 192 + l) of the group's sorted order, so that ONE gather
+            // instruction covers 64 CONSECUTIVE entries of that order: the entries of a cell then sit in one instruction and their lanes merge per cache line
+            const unsigned epl = 16u / (unsigned) sizeof(T), gi = pos & ((1u << ge) - 1u);
+            const long long spos = e0 + (long long) (pos - gi) + (long long) ((gi & (kWave - 1)) * epl + (gi >> 6));
+            bval[spos] = v;
             if constexpr (!VALUES_ONLY) {
-                bcol[pos] = c;
-                brow[pos] = (unsigned short) row;
+                const unsigned st = cst[kk];
+                int lo = 0, hi = nr; // row of CSR position p inside the block: rowptr[r0 + lo] <= p < rowptr[r0 + hi]
+                while (hi - lo > 1) {
+                    const int mid = (lo + hi) >> 1;
+                    if (rowptr[r0 + mid] <= p) lo = mid; else hi = mid;
+                }
+                unsigned col;
+                if (st >> 31) { // dense: slab A of my group if my cell started at or before the group's first entry
+                    const unsigned gfirst = (pos >> ge) << ge;
+                    col = ((st & 0x7fffffffu) > gfirst ? 1u << kBlkSlabShift : 0u) | ((unsigned) c & ((1u << kBlkSlabShift) - 1u));
+                } else {
+                    col = (unsigned) c & ((1u << kBlkSuperShift) - 1u);
+                }
+                bmeta[spos] = col | ((unsigned) lo << 16);
+            }
+        }
+        qh = (qh + count) & 127;
+        qn -= count;
+    };
+    constexpr int NB = 8; // batches of 64 entries loaded per round
+    for (int q = p0; q < p1; q += NB * kWave) {
+        int c[NB];
+#pragma unroll
+        for (int i = 0; i < NB; ++i) { // padded ColIdx: in bounds
+            const int p = q + i * kWave + lane;
+            c[i] = p < p1 ? ld_stream(colidx + p) : -1;
+        }
+#pragma unroll
+        for (int i = 0; i < NB; ++i) {
+            const int k = c[i] >> wshift; // -1 for lanes past the block's end
+            const bool mine = k >= k0 && k < k1;
+            const unsigned long long mk = __ballot(mine);
+            if (mine) queue[(qh + qn + __popcll(mk & ((1ull << lane) - 1ull))) & 127] = q + i * kWave + lane;
+            qn += __popcll(mk);
+            if (qn >= kWave) {
+                __syncthreads();
+                drain(kWave);
+                __syncthreads();
             }
         }
     }
+    __syncthreads();
+    if (qn > 0) drain(qn);
 }
-
-constexpr int kBlkPad = 65536; // zero entries behind the last block: two executor steps of the widest form (256 threads x 4 entries x 16 groups x 2)
 
 // The block's y is accumulated in DOUBLE for both value types: ds_add_f32 runs at 2.0e11 adds/s over the chip whatever the
 // bank pattern, ds_add_f64 at 7-9e11/s (tools/gbench lds, profiles/r02_gbench.txt) -- with float accumulators every fp32
@@ -237,132 +323,157 @@ constexpr int kBlkPad = 65536; // zero entries behind the last block: two execut
 // float first (as every other executor forms them) and summed in double, which is at least as accurate as a float sum.
 __device__ __forceinline__ void lds_add(double *p, double v) { (void) unsafeAtomicAdd(p, v); }
 
-// Executor.  Dynamic LDS: R * 8 bytes (the block's y, in double).  NT = 64: one wavefront per block (deterministic);
-// UN load groups of 16 bytes of values in flight per lane, and the NEXT step's stream loads are issued before
-// this step's gathers are waited for.
-//
-// No load sits behind a branch: the streams are padded past the last block (blocked_fill) and a load group that
-// starts past this block's end simply reads the next block's entries, whose products are masked at the LDS add.
-// With "if (p < e) load" the compiler had put a wait after every load -- one gather in flight per wave, 0.8 us
-// per 64 entries, and the kernel looked "L2-request bound" at a rate that was really one memory latency per
-// instruction (round 1: 2.0 ms on config 2 with random columns).
-template <typename T, int EPL>
-struct BlkGroup {
-    T v[EPL];
-    int c[EPL];
-    unsigned r[EPL];
+template <typename T, int UN>
+struct BlkStep { // the stream of one step: UN groups, per lane 16 bytes of values and their (column field | row << 16) words ...
+    T v[UN][16 / sizeof(T)];
+    unsigned w[UN][16 / sizeof(T)];
+    int ha, hb;  // ... and, in lane u < UN, the header words of group u of some step (see the loops: which step)
 };
 
-template <typename T, int EPL>
-__device__ __forceinline__ void blk_load(long long p, const T *__restrict__ bval, const int *__restrict__ bcol,
-                                         const unsigned short *__restrict__ brow, BlkGroup<T, EPL> &g)
+// stream of the UN groups from group g on, header words of the groups from hg on (all relative to the block's region)
+template <typename T, int UN, bool DENSE>
+__device__ __forceinline__ void blk_load_step(int g, int hg, int lane, const T *__restrict__ bv, const unsigned *__restrict__ bm, const int *__restrict__ ha,
+                                              const int *__restrict__ hb, BlkStep<T, UN> &s)
 {
-    if constexpr (EPL == 2) {
-        const f64x2 q = __builtin_nontemporal_load(reinterpret_cast<const f64x2 *>(bval + p));
-        const i32x2 cc = __builtin_nontemporal_load(reinterpret_cast<const i32x2 *>(bcol + p));
-        const unsigned w = (unsigned) __builtin_nontemporal_load(reinterpret_cast<const int *>(brow + p));
-        g.v[0] = q.x; g.v[1] = q.y; g.c[0] = cc.x; g.c[1] = cc.y; g.r[0] = w & 0xffffu; g.r[1] = w >> 16;
-    } else {
-        const f32x4 q = __builtin_nontemporal_load(reinterpret_cast<const f32x4 *>(bval + p));
-        const i32x4 cc = __builtin_nontemporal_load(reinterpret_cast<const i32x4 *>(bcol + p));
-        const i32x2 w = __builtin_nontemporal_load(reinterpret_cast<const i32x2 *>(brow + p));
-        g.v[0] = q.x; g.v[1] = q.y; g.v[2] = q.z; g.v[3] = q.w;
-        g.c[0] = cc.x; g.c[1] = cc.y; g.c[2] = cc.z; g.c[3] = cc.w;
-        g.r[0] = (unsigned) w.x & 0xffffu; g.r[1] = (unsigned) w.x >> 16; g.r[2] = (unsigned) w.y & 0xffffu; g.r[3] = (unsigned) w.y >> 16;
-    }
-}
-
-template <typename T, int NT = kWave, int UN = 4>
-__global__ __launch_bounds__(NT) void blk_kernel(const int *__restrict__ row0, int R, const long long *__restrict__ start, const long long *__restrict__ end,
-                                                 const T *__restrict__ bval, const int *__restrict__ bcol,
-                                                 const unsigned short *__restrict__ brow, const T *__restrict__ x, T *__restrict__ y)
-{
-    extern __shared__ __attribute__((aligned(16))) unsigned char blk_y_lds[];
-    double *ys = reinterpret_cast<double *>(blk_y_lds);
-    constexpr int EPL = 16 / (int) sizeof(T); // entries per 16-byte value load
-    constexpr int STEP = NT * EPL;            // entries one load group covers over the workgroup
-    for (int i = threadIdx.x; i < R; i += NT) ys[i] = 0.0; // R = the most rows of any block: masked entries of the next block may add 0 anywhere below it
-    __syncthreads();
-    const long long s = start[blockIdx.x], e = end[blockIdx.x];
-    const long long lane0 = s + (long long) threadIdx.x * EPL;
-    BlkGroup<T, EPL> cur[UN], nxt[UN];
-#pragma unroll
-    for (int u = 0; u < UN; ++u) blk_load<T, EPL>(lane0 + (long long) u * STEP, bval, bcol, brow, cur[u]);
-    for (long long it = s; it < e; it += (long long) STEP * UN) { // wave-uniform trip count
-        T xv[UN][EPL];
-#pragma unroll
-        for (int u = 0; u < UN; ++u)
-#pragma unroll
-            for (int j = 0; j < EPL; ++j) xv[u][j] = x[cur[u].c[j]]; // cached loads: the slab stays in L2
-        const long long pn = lane0 + (it - s) + (long long) STEP * UN;
-#pragma unroll
-        for (int u = 0; u < UN; ++u) blk_load<T, EPL>(pn + (long long) u * STEP, bval, bcol, brow, nxt[u]); // next step's stream (padded: always in bounds)
-#pragma unroll
-        for (int u = 0; u < UN; ++u) {
-            const long long p = lane0 + (it - s) + (long long) u * STEP;
-#pragma unroll
-            for (int j = 0; j < EPL; ++j) // unconditional: a masked entry adds 0 to a row of this block (its row number is the next block's or padding's, < R) -- a branch here makes the compiler sink gathers into it and wait for the whole queue
-                lds_add(&ys[cur[u].r[j]], p + j < e ? (double) (cur[u].v[j] * xv[u][j]) : 0.0);
-        }
-#pragma unroll
-        for (int u = 0; u < UN; ++u) cur[u] = nxt[u];
-    }
-    __syncthreads();
-    const long long r0 = row0[blockIdx.x];
-    const int nr = row0[blockIdx.x + 1] - (int) r0;
-    for (int i = threadIdx.x; i < nr; i += NT) y[r0 + i] = (T) ys[i];
-}
-
-// Three-stage form of the executor (the default): in step t the wave ISSUES the stream loads of step t + 2, ISSUES the
-// gathers of step t + 1 (whose columns arrived during step t - 1 .. t) and ADDS step t (whose x values were gathered during
-// step t - 1).  Nothing is waited for in the step that issued it: blk_kernel above gathers and adds in the same step and
-// copies cur = nxt at its end, i.e. every step costs a gather round trip plus the rest of a stream round trip for 512
-// entries per wave -- with two or three waves per CU that, not a bandwidth, was its rate.  Three stream register sets
-// and two x sets are used in rotation (the loop body is written out for six consecutive steps), so no loaded register is
-// ever copied.  Same additions in the same order as blk_kernel: bit-identical results.
-template <typename T, int UN = 4>
-__global__ __launch_bounds__(kWave) void blk_kernel3(const int *__restrict__ row0, int R, const long long *__restrict__ start, const long long *__restrict__ end,
-                                                     const T *__restrict__ bval, const int *__restrict__ bcol,
-                                                     const unsigned short *__restrict__ brow, const T *__restrict__ x, T *__restrict__ y)
-{
-    extern __shared__ __attribute__((aligned(16))) unsigned char blk_y_lds[];
-    double *ys = reinterpret_cast<double *>(blk_y_lds);
     constexpr int EPL = 16 / (int) sizeof(T);
-    constexpr int STEP = kWave * EPL;
-    constexpr long long S = (long long) STEP * UN; // entries per step
-    for (int i = threadIdx.x; i < R; i += kWave) ys[i] = 0.0;
-    __syncthreads();
-    const long long s = start[blockIdx.x], e = end[blockIdx.x];
-    const long long lane0 = s + (long long) threadIdx.x * EPL;
-    const int nsteps = (int) ((e - s + S - 1) / S); // wave-uniform
-    BlkGroup<T, EPL> g0[UN], g1[UN], g2[UN];
-    T x0[UN][EPL], x1[UN][EPL];
-    auto load = [&](int t, BlkGroup<T, EPL>(&g)[UN]) { // stream of step t (padded: in bounds up to three steps past the last block)
+    s.ha = ha[hg + lane]; // one coalesced load for all groups of a step (the arrays are padded by kBlkPadGroups); a scalar load per group would have
+    if constexpr (DENSE) s.hb = hb[hg + lane]; // to be waited for with lgkmcnt(0), i.e. together with every LDS operation in flight
 #pragma unroll
-        for (int u = 0; u < UN; ++u) blk_load<T, EPL>(lane0 + (long long) t * S + (long long) u * STEP, bval, bcol, brow, g[u]);
-    };
-    auto gather = [&](const BlkGroup<T, EPL>(&g)[UN], T(&xv)[UN][EPL]) { // columns past this block's end are the next block's or padding's: valid
-#pragma unroll
-        for (int u = 0; u < UN; ++u)
-#pragma unroll
-            for (int j = 0; j < EPL; ++j) xv[u][j] = x[g[u].c[j]];
-    };
-    auto add = [&](int t, const BlkGroup<T, EPL>(&g)[UN], const T(&xv)[UN][EPL]) {
-#pragma unroll
-        for (int u = 0; u < UN; ++u) {
-            const long long p = lane0 + (long long) t * S + (long long) u * STEP;
-#pragma unroll
-            for (int j = 0; j < EPL; ++j) lds_add(&ys[g[u].r[j]], p + j < e ? (double) (g[u].v[j] * xv[u][j]) : 0.0);
+    for (int u = 0; u < UN; ++u) {
+        const int p = ((g + u) * kWave + lane) * EPL;
+        if constexpr (EPL == 2) {
+            const f64x2 q = __builtin_nontemporal_load(reinterpret_cast<const f64x2 *>(bv + p));
+            const i32x2 cc = __builtin_nontemporal_load(reinterpret_cast<const i32x2 *>(bm + p));
+            s.v[u][0] = q.x; s.v[u][1] = q.y;
+            s.w[u][0] = (unsigned) cc.x; s.w[u][1] = (unsigned) cc.y;
+        } else {
+            const f32x4 q = __builtin_nontemporal_load(reinterpret_cast<const f32x4 *>(bv + p));
+            const i32x4 cc = __builtin_nontemporal_load(reinterpret_cast<const i32x4 *>(bm + p));
+            s.v[u][0] = q.x; s.v[u][1] = q.y; s.v[u][2] = q.z; s.v[u][3] = q.w;
+            s.w[u][0] = (unsigned) cc.x; s.w[u][1] = (unsigned) cc.y; s.w[u][2] = (unsigned) cc.z; s.w[u][3] = (unsigned) cc.w;
         }
-    };
-    if (nsteps > 0) {
-        load(0, g0);
-        load(1, g1);
-        gather(g0, x0);
-#define SPMV_BLK_PHASE(ga, gb, gc, xa, xb)                                                                              \
-        load(t + 2, gc);                                                                                                \
-        gather(gb, xb);                                                                                                 \
-        add(t, ga, xa);                                                                                                 \
+    }
+}
+
+// Executor.  Dynamic LDS: (R + 2) doubles (the block's y; slot R takes the products of padding entries and of groups past a
+// part's end), then -- only when some block has dense groups -- kBlkDenseUn x 256 values of x (two slabs per group of a step).
+// UN = groups per step of the sparse loop (8 or 12 loads of values in flight per lane and step).
+//
+// Both loops run three steps deep: in step t the wave ISSUES the stream loads of step t + 2, brings in the x of step t + 1
+// (dense: writes the slabs loaded during step t - 1 to LDS and issues the slab loads of step t + 2; sparse: issues the gathers,
+// whose columns arrived during step t - 1 .. t) and ADDS step t.  Nothing is waited for in the step that issued it.  Three
+// stream register sets (and two x sets in the sparse loop) are used in rotation -- the loop bodies are written out for
+// three / six consecutive steps -- so no loaded register is ever copied.  Group headers travel with the stream sets as ONE
+// vector load per step (lane u = group u) and are broadcast with v_readlane when needed, a step after they were loaded.
+template <typename T, int UN, int DBG = 0> // DBG (tools only, wrong results): 1 = coalesced x reads instead of gathers, 2 = no LDS adds, 3 = both
+__global__ __launch_bounds__(kWave) void blk_kernel(const int *__restrict__ row0, int R, const BlkDir *__restrict__ dir, const T *__restrict__ bval,
+                                                    const unsigned *__restrict__ bmeta, const int *__restrict__ hdr_a, const int *__restrict__ hdr_b,
+                                                    const T *__restrict__ x, int n, T *__restrict__ y)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char blk_y_lds[];
+    double *ys = reinterpret_cast<double *>(blk_y_lds);
+    T *xb = reinterpret_cast<T *>(ys + ((R + 2) & ~1)); // slab buffers of the dense loop
+    constexpr int EPL = 16 / (int) sizeof(T);
+    constexpr int DU = kBlkDenseUn;
+    constexpr int SLAB = 1 << kBlkSlabShift;
+    const int lane = threadIdx.x;
+    for (int i = lane; i <= R; i += kWave) ys[i] = 0.0;
+    __syncthreads();
+    const BlkDir d = dir[blockIdx.x];
+    const unsigned junk = (unsigned) R;
+    const long long e0 = d.g0 * (long long) (kWave * EPL);
+    const T *__restrict__ bv = bval + e0;           // the block's region: groups [0, nd) dense, [nd, nd + ns) sparse
+    const unsigned *__restrict__ bm = bmeta + e0;
+    const int *__restrict__ ha = hdr_a + d.g0, *__restrict__ hb = hdr_b + d.g0;
+
+    if (d.nd > 0) { // ------------------------------------------------------------------ dense groups: x through LDS
+        const int nd = d.nd, nsteps = (nd + DU - 1) / DU;
+        BlkStep<T, DU> g0, g1, g2; // the set of step s carries the headers of step s + 1
+        T sl[DU][4];               // the two slabs of every group of a step: A[lane], A[64 + lane], B[lane], B[64 + lane]
+        auto load_slabs = [&](int s, int hva, int hvb) { // slabs of step s, whose header words are in (hva, hvb)
+#pragma unroll
+            for (int u = 0; u < DU; ++u) {
+                const bool ok = s * DU + u < nd; // wave-uniform
+                int a = __builtin_amdgcn_readlane(hva, u), bb = __builtin_amdgcn_readlane(hvb, u);
+                a = ok ? a : 0;
+                bb = ok && bb >= 0 ? bb : a;     // no second cell in this group: stage slab A twice
+                const int ca = a << kBlkSlabShift, cb = bb << kBlkSlabShift;
+                sl[u][0] = x[min(ca + lane, n - 1)];
+                sl[u][1] = x[min(ca + kWave + lane, n - 1)];
+                sl[u][2] = x[min(cb + lane, n - 1)];
+                sl[u][3] = x[min(cb + kWave + lane, n - 1)];
+            }
+        };
+        auto write_slabs = [&]() {
+#pragma unroll
+            for (int u = 0; u < DU; ++u) {
+                xb[u * 2 * SLAB + lane] = sl[u][0];
+                xb[u * 2 * SLAB + kWave + lane] = sl[u][1];
+                xb[u * 2 * SLAB + SLAB + lane] = sl[u][2];
+                xb[u * 2 * SLAB + SLAB + kWave + lane] = sl[u][3];
+            }
+        };
+        load_slabs(0, ha[lane], hb[lane]);
+        blk_load_step<T, DU, true>(0, DU, lane, bv, bm, ha, hb, g0);
+        blk_load_step<T, DU, true>(DU, 2 * DU, lane, bv, bm, ha, hb, g1);
+        write_slabs();  // slabs of step 0
+        load_slabs(1, g0.ha, g0.hb);
+#define SPMV_BLK_DENSE_PHASE(ga, gb, gc)                                                                                   \
+        {                                                                                                                   \
+            blk_load_step<T, DU, true>((t + 2) * DU, (t + 3) * DU, lane, bv, bm, ha, hb, gc);                               \
+            T xv[DU][EPL];                                                                                                  \
+            _Pragma("unroll") for (int u = 0; u < DU; ++u)                                                                  \
+                _Pragma("unroll") for (int j = 0; j < EPL; ++j) xv[u][j] = xb[u * 2 * SLAB + (ga.w[u][j] & (2 * SLAB - 1))]; \
+            write_slabs();     /* slabs of step t + 1, loaded during step t - 1 .. t; DS operations of a wave execute in order: the reads above come first */ \
+            load_slabs(t + 2, gb.ha, gb.hb);                                                                                \
+            _Pragma("unroll") for (int u = 0; u < DU; ++u) {                                                                \
+                const bool ok = t * DU + u < nd;                                                                            \
+                _Pragma("unroll") for (int j = 0; j < EPL; ++j)                                                             \
+                    lds_add(&ys[ok ? ga.w[u][j] >> 16 : junk], (double) (ga.v[u][j] * xv[u][j]));                           \
+            }                                                                                                               \
+            if (++t >= nsteps) break;                                                                                       \
+        }
+        for (int t = 0;;) {
+            SPMV_BLK_DENSE_PHASE(g0, g1, g2)
+            SPMV_BLK_DENSE_PHASE(g1, g2, g0)
+            SPMV_BLK_DENSE_PHASE(g2, g0, g1)
+        }
+#undef SPMV_BLK_DENSE_PHASE
+    }
+
+    if (d.ns > 0) { // ------------------------------------------------------------------ sparse groups: x gathered through L2
+        const int gs = d.nd, ns = d.ns, nsteps = (ns + UN - 1) / UN;
+        BlkStep<T, UN> g0, g1, g2; // the set of step s carries the headers of step s
+        T x0[UN][EPL], x1[UN][EPL];
+        auto gather = [&](int s, const BlkStep<T, UN> &g, T(&xv)[UN][EPL]) {
+#pragma unroll
+            for (int u = 0; u < UN; ++u) {
+                int base = __builtin_amdgcn_readlane(g.ha, u);
+                base = s * UN + u < ns ? base : 0; // wave-uniform; a group past the part's end gathers x[16-bit offset]: in bounds (offset < min(n, 65536))
+                const T *__restrict__ xs = x + base;
+#pragma unroll
+                for (int j = 0; j < EPL; ++j) xv[u][j] = (DBG & 1) ? x[lane * EPL + j + u * kWave * EPL] : xs[g.w[u][j] & 0xffffu];
+            }
+        };
+        double dbg_acc = 0.0;
+        auto add = [&](int s, const BlkStep<T, UN> &g, const T(&xv)[UN][EPL]) {
+#pragma unroll
+            for (int u = 0; u < UN; ++u) {
+                const bool ok = s * UN + u < ns;
+#pragma unroll
+                for (int j = 0; j < EPL; ++j) {
+                    if constexpr (DBG & 2) dbg_acc += (double) (g.v[u][j] * xv[u][j]) * (double) (ok ? g.w[u][j] >> 16 : junk);
+                    else lds_add(&ys[ok ? g.w[u][j] >> 16 : junk], (double) (g.v[u][j] * xv[u][j]));
+                }
+            }
+        };
+        blk_load_step<T, UN, false>(gs, gs, lane, bv, bm, ha, hb, g0);
+        blk_load_step<T, UN, false>(gs + UN, gs + UN, lane, bv, bm, ha, hb, g1);
+        gather(0, g0, x0);
+#define SPMV_BLK_PHASE(ga, gb, gc, xa, xbb)                                                                                \
+        blk_load_step<T, UN, false>(gs + (t + 2) * UN, gs + (t + 2) * UN, lane, bv, bm, ha, hb, gc);                       \
+        gather(t + 1, gb, xbb);                                                                                            \
+        add(t, ga, xa);                                                                                                    \
         if (++t >= nsteps) break;
         for (int t = 0;;) {
             SPMV_BLK_PHASE(g0, g1, g2, x0, x1)
@@ -373,11 +484,12 @@ __global__ __launch_bounds__(kWave) void blk_kernel3(const int *__restrict__ row
             SPMV_BLK_PHASE(g2, g0, g1, x1, x0)
         }
 #undef SPMV_BLK_PHASE
+        if constexpr (DBG & 2) ys[lane] = dbg_acc;
     }
     __syncthreads();
     const long long r0 = row0[blockIdx.x];
     const int nr = row0[blockIdx.x + 1] - (int) r0;
-    for (int i = threadIdx.x; i < nr; i += kWave) y[r0 + i] = (T) ys[i];
+    for (int i = lane; i < nr; i += kWave) y[r0 + i] = (T) ys[i];
 }
 
 } // namespace spmv

@@ -395,91 +395,121 @@ static int build_csr5(spmv_dev *d, Csr5Plan &P, int m, long long nnz, const int 
     }
 }
 
-// Row blocks x column slabs (kernels/blocked.hpp).  R rows per block: y of a block = 64 KiB of LDS, one
-// wavefront per block; W columns per slab: see below.  blocked_fill does the stable counting sort (also for
-// spmv_hip_update_values: same positions, new values).
+// Row blocks x column slabs (kernels/blocked.hpp): count the cells of every block, lay the parts out, fill.
+// blocked_fill runs the three inspector passes; values_only re-permutes new values into the positions of the existing
+// layout (spmv_hip_update_values): the counts are taken again (3 ms) rather than kept (up to 128 MB).
 template <typename T>
-static int blocked_fill(spmv_dev *d, int wshift, bool values_only)
+static int blocked_fill(spmv_dev *d, bool values_only)
 {
-    const int R = d->blk_R, K = d->blk_K, B = d->blk_B;
-    int *cnt = nullptr, *tot = nullptr;
-    long long *cursor = nullptr;
-    const size_t cells = (size_t) B * K;
-    HIP_TRY(pool_malloc((void **) &cnt, sizeof(int) * cells));
-    auto cleanup = [&]() { (void) pool_free(cnt); if (tot) (void) pool_free(tot); if (cursor) (void) pool_free(cursor); };
-    if (pool_malloc((void **) &tot, sizeof(int) * (size_t) B) != hipSuccess || pool_malloc((void **) &cursor, sizeof(long long) * cells) != hipSuccess) {
+    BlkSet &S = d->blk;
+    const int B = S.B, K = S.K;
+    int *cnt = nullptr, *groups = nullptr;
+    i32x2 *parts = nullptr, *part_off = nullptr;
+    auto cleanup = [&]() { if (cnt) (void) pool_free(cnt); if (groups) (void) pool_free(groups); if (parts) (void) pool_free(parts); if (part_off) (void) pool_free(part_off); };
+    if (pool_malloc((void **) &cnt, sizeof(int) * (size_t) B * K) != hipSuccess || pool_malloc((void **) &groups, sizeof(int) * (size_t) B) != hipSuccess ||
+        pool_malloc((void **) &parts, sizeof(i32x2) * (size_t) B * kBlkParts) != hipSuccess || pool_malloc((void **) &part_off, sizeof(i32x2) * (size_t) B * kBlkParts) != hipSuccess) {
         (void) hipGetLastError();
         cleanup();
         return fail(SPMV_HIP_E_ALLOC, "pool_malloc(block cells)");
     }
-    hipError_t e = hipMemsetAsync(cnt, 0, sizeof(int) * cells, d->stream);
-    blk_count_kernel<<<grid_for(d->m, kBlock / 16, d->cus * 16), kBlock, 0, d->stream>>>(d->m, B, d->blk_row0, K, wshift, d->rowptr, d->colidx, cnt);
+    ensure_lds<blk_count_kernel>(d, sizeof(unsigned) * (size_t) K);
+    blk_count_kernel<<<B, kBlkCountThreads, sizeof(unsigned) * (size_t) K, d->stream>>>(S.row0, K, S.wshift, S.dense_min, S.ge, S.nparts, S.S, d->rowptr, d->colidx, cnt, parts);
+    hipError_t e = hipGetLastError();
     if (!values_only) {
-        blk_totals_kernel<<<B, kWave, 0, d->stream>>>(B, K, cnt, tot);
-        scan_i32_to_i64_kernel<<<1, kBlock, 0, d->stream>>>(B, tot, d->blk_start);
+        int rc = dev_alloc(d, (void **) &S.gstart, sizeof(long long) * ((size_t) B + 1), true);
+        if (!rc) rc = dev_alloc(d, (void **) &S.dgroups, sizeof(int) * (size_t) B, true);
+        if (!rc) rc = dev_alloc(d, (void **) &S.dir, sizeof(BlkDir) * (size_t) B, true);
+        if (rc) { cleanup(); return rc; }
     }
-    blk_cells_kernel<<<B, kWave, 0, d->stream>>>(B, K, cnt, d->blk_start, cursor, d->blk_end);
+    int *dg_scratch = nullptr; // values_only: the block directory exists; the layout pass only has to reproduce the part offsets
+    if (values_only && pool_malloc((void **) &dg_scratch, sizeof(int) * (size_t) B) != hipSuccess) { (void) hipGetLastError(); cleanup(); return fail(SPMV_HIP_E_ALLOC, "pool_malloc(block layout)"); }
+    blk_layout_kernel<<<grid_for(B, kBlock, INT_MAX), kBlock, 0, d->stream>>>(B, S.nparts, S.ge, parts, part_off, groups, values_only ? dg_scratch : S.dgroups);
     if (e == hipSuccess) e = hipGetLastError();
     if (!values_only) {
+        scan_i32_to_i64_kernel<<<1, kBlock, 0, d->stream>>>(B, groups, S.gstart);
         long long total = 0;
-        if (e == hipSuccess) e = hipMemcpyAsync(&total, d->blk_start + B, sizeof(long long), hipMemcpyDeviceToHost, d->stream);
+        std::vector<int> dg((size_t) B);
+        if (e == hipSuccess) e = hipGetLastError();
+        if (e == hipSuccess) e = hipMemcpyAsync(&total, S.gstart + B, sizeof(long long), hipMemcpyDeviceToHost, d->stream);
+        if (e == hipSuccess) e = hipMemcpyAsync(dg.data(), S.dgroups, sizeof(int) * (size_t) B, hipMemcpyDeviceToHost, d->stream);
         if (e == hipSuccess) e = hipStreamSynchronize(d->stream);
         if (e != hipSuccess) { cleanup(); return fail(SPMV_HIP_E_RUNTIME, "block inspector: %s", hipGetErrorString(e)); }
-        const size_t slots = (size_t) total + kBlkPad; // the executor loads up to two steps past a block's end, unguarded: keep that in bounds
-        int rc = dev_alloc(d, &d->blk_val, sizeof(T) * slots, true);
-        if (!rc) rc = dev_alloc(d, (void **) &d->blk_col, sizeof(int) * slots, true);
-        if (!rc) rc = dev_alloc(d, (void **) &d->blk_row, sizeof(unsigned short) * slots, true);
+        S.groups = total;
+        S.dense_groups = 0;
+        for (int v : dg) S.dense_groups += v;
+        if ((total + kBlkPadGroups) >> (31 - S.ge) > 0) { cleanup(); return fail(SPMV_HIP_E_RANGE, "blocked layout: %lld groups exceed 32-bit positions", total); }
+        const size_t ng = (size_t) total + kBlkPadGroups, slots = ng << S.ge; // the executor loads up to three steps past a block's end, unguarded: keep that in bounds
+        int rc = dev_alloc(d, &S.val, sizeof(T) * slots, true);
+        if (!rc) rc = dev_alloc(d, (void **) &S.meta, sizeof(unsigned) * slots, true);
+        if (!rc) rc = dev_alloc(d, (void **) &S.hdr_a, sizeof(int) * ng, true);
+        if (!rc) rc = dev_alloc(d, (void **) &S.hdr_b, sizeof(int) * ng, true);
         if (rc) { cleanup(); return rc; }
-        d->blk_slots = (long long) slots;
-        (void) hipMemsetAsync(d->blk_val, 0, sizeof(T) * slots, d->stream); // padding entries: 0 * x[0]
-        (void) hipMemsetAsync(d->blk_col, 0, sizeof(int) * slots, d->stream);
-        (void) hipMemsetAsync(d->blk_row, 0, sizeof(unsigned short) * slots, d->stream);
+        (void) hipMemsetAsync(S.val, 0, sizeof(T) * slots, d->stream);      // padding entries: value 0, column field 0,
+        fill_value_kernel<unsigned><<<grid_for((long long) slots, kBlock * 4, d->cus * 16), kBlock, 0, d->stream>>>((long long) slots, S.meta, (unsigned) S.R << 16); // row = the junk accumulator
+        (void) hipMemsetAsync(S.hdr_a, 0, sizeof(int) * ng, d->stream);
+        (void) hipMemsetAsync(S.hdr_b, 0xff, sizeof(int) * ng, d->stream);  // -1: the group has no second slab
     }
-    const size_t lds = sizeof(int) * ((size_t) R + 1);
+    const size_t lds = sizeof(unsigned) * (2 * (size_t) S.range_cells + 128);
     if (values_only) {
         ensure_lds<blk_fill_kernel<T, true>>(d, lds);
-        blk_fill_kernel<T, true><<<B, kWave, lds, d->stream>>>(d->blk_row0, K, wshift, d->rowptr, d->colidx, (const T *) d->val,
-                                                             (unsigned long long *) cursor, (T *) d->blk_val, d->blk_col, d->blk_row);
+        blk_fill_kernel<T, true><<<B * S.nparts, kWave, lds, d->stream>>>(S.row0, K, S.wshift, S.dense_min, S.ge, S.nparts, S.S, S.range_cells, d->rowptr, d->colidx, (const T *) d->val,
+                                                                        cnt, part_off, S.gstart, S.dgroups, (T *) S.val, S.meta, S.hdr_a, S.hdr_b, S.dir);
     } else {
         ensure_lds<blk_fill_kernel<T, false>>(d, lds);
-        blk_fill_kernel<T, false><<<B, kWave, lds, d->stream>>>(d->blk_row0, K, wshift, d->rowptr, d->colidx, (const T *) d->val,
-                                                              (unsigned long long *) cursor, (T *) d->blk_val, d->blk_col, d->blk_row);
+        blk_fill_kernel<T, false><<<B * S.nparts, kWave, lds, d->stream>>>(S.row0, K, S.wshift, S.dense_min, S.ge, S.nparts, S.S, S.range_cells, d->rowptr, d->colidx, (const T *) d->val,
+                                                                         cnt, part_off, S.gstart, S.dgroups, (T *) S.val, S.meta, S.hdr_a, S.hdr_b, S.dir);
     }
     if (e == hipSuccess) e = hipGetLastError();
     if (e == hipSuccess) e = hipStreamSynchronize(d->stream);
     cleanup();
+    if (dg_scratch) (void) pool_free(dg_scratch);
     if (e != hipSuccess) return fail(SPMV_HIP_E_RUNTIME, "block fill: %s", hipGetErrorString(e));
     return SPMV_HIP_OK;
 }
 
+// LDS of one executor workgroup: the block's accumulators (+ junk slot), and the slab buffers when the set has dense groups
+template <typename T>
+static size_t blocked_lds_bytes(const BlkSet &S)
+{
+    return sizeof(double) * (size_t) ((S.R + 2) & ~1) + (S.dense_groups > 0 ? sizeof(T) * (size_t) kBlkDenseUn * (2u << kBlkSlabShift) : 0);
+}
+
+// most rows of a block such that TWO blocks fit a CU's 160 KiB of LDS (78 KiB each), with / without slab buffers
+template <typename T>
+static int blocked_row_cap(bool dense)
+{
+    const size_t budget = 78 * 1024 - (dense ? sizeof(T) * (size_t) kBlkDenseUn * (2u << kBlkSlabShift) : 0);
+    return (int) (budget / sizeof(double)) - 2;
+}
+
 // How many row blocks, and how many rows at most in one.  rule 0 (first choice): FULL ROUNDS of fat blocks -- two blocks are
-// resident per CU (2 x 78 KiB of its 160 KiB of LDS), so the block count is a multiple of 2 * CUs with at most 9984 rows each:
+// resident per CU (2 x 78 KiB of its 160 KiB of LDS), so the block count is a multiple of 2 * CUs with at most rmax rows each:
 // the grid then runs in whole rounds.  With 8192-row blocks config 2-ii has 1221 blocks = 2.4 rounds of 512 and pays for three
 // (1.75 ms); with 1024 blocks exactly two (1.54 ms); 1028 blocks: 2.02 ms, the four stragglers cost a round.  Orkut-style uniform:
 // 512 blocks 0.79 ms vs 750 blocks of 4096 rows 1.02; R-MAT 0.69 vs 0.70.  rule 1: at least 512 blocks of at most 8192 rows (a
 // power of two) -- more, thinner blocks = more waves per CU, what a STREAM-bound matrix wants (web-like 4e6 x 24: 977 blocks
 // 0.245 ms vs 512 blocks 0.275); spmv_shim_build tries it when rule 0 turns out stream-bound and keeps the faster set.  The cut
 // points themselves follow the work, not the row count (blk_partition_kernel).  Option block_rows: uniform blocks of that many rows.
-static void blocked_block_rule(const spmv_dev *d, int rule, int *btarget, int *rcap)
+static void blocked_block_rule(const spmv_dev *d, int rule, int rmax, int *btarget, int *rcap)
 {
     if (d->plan.block_rows > 0) {
-        *rcap = d->plan.block_rows;
+        *rcap = d->plan.block_rows < 16384 ? d->plan.block_rows : 16384; // 128 KiB of double accumulators; row numbers inside a block are 16-bit
         *btarget = (int) (((long long) d->m + *rcap - 1) / *rcap);
         return;
     }
     if (rule == 0) {
-        const long long slots = 2ll * (d->cus > 0 ? d->cus : 256), rmax = 9984;
+        const long long slots = 2ll * (d->cus > 0 ? d->cus : 256);
         const long long rounds = ((long long) d->m + slots * rmax - 1) / (slots * rmax);
         long long B = slots * (rounds > 0 ? rounds : 1);
         if ((long long) d->m / B < 1024) B = ((long long) d->m + 1023) / 1024; // small matrices: blocks of about 1024 rows
         *btarget = (int) (B > 0 ? B : 1);
-        *rcap = (int) rmax;
+        *rcap = rmax;
     } else {
         int R = (int) (64 * 1024 / sizeof(double));
         while (R > 1024 && (long long) d->m / R < 512) R >>= 1; // small matrices: at least ~512 blocks, down to 1024 rows
         *btarget = (int) (((long long) d->m + R - 1) / R);
         *rcap = R + R / 4; // equal-work cut points may stretch a block of light rows
-        if (*rcap > 9984) *rcap = 9984;
+        if (*rcap > rmax) *rcap = rmax;
     }
 }
 
@@ -487,32 +517,30 @@ static void blocked_block_rule(const spmv_dev *d, int rule, int *btarget, int *r
 static bool blocked_differs(const spmv_dev *d)
 {
     int b0, r0, b1, r1;
-    blocked_block_rule(d, 0, &b0, &r0);
-    blocked_block_rule(d, 1, &b1, &r1);
+    blocked_block_rule(d, 0, 9982, &b0, &r0);
+    blocked_block_rule(d, 1, 9982, &b1, &r1);
     return b0 != b1;
 }
 
-template <typename T>
-static int build_blocked(spmv_dev *d, int rule)
+// cut points of the row blocks: uniform for option block_rows, equal work otherwise
+static int blocked_partition(spmv_dev *d, int btarget, int rcap)
 {
-    int btarget = 1, rcap = 1024;
-    blocked_block_rule(d, rule, &btarget, &rcap);
-    if (rcap > 16384) rcap = 16384; // 128 KiB of double accumulators; row numbers inside a block are 16-bit
-    // cut points: uniform for option block_rows, equal work otherwise
+    BlkSet &S = d->blk;
     const size_t cap_blocks = (size_t) btarget + (size_t) (d->m / rcap) + 2;
-    int rc = dev_alloc(d, (void **) &d->blk_row0, sizeof(int) * (cap_blocks + 1), true);
+    if (S.row0) sched_free(d, S.row0);
+    int rc = dev_alloc(d, (void **) &S.row0, sizeof(int) * (cap_blocks + 1), true);
     if (rc) return rc;
     int B = btarget, R = rcap;
     if (d->plan.block_rows > 0) {
         std::vector<int> h((size_t) B + 1);
         for (int b = 0; b <= B; ++b) h[(size_t) b] = (int) std::min<long long>((long long) b * rcap, d->m);
-        HIP_TRY(hipMemcpyAsync(d->blk_row0, h.data(), sizeof(int) * ((size_t) B + 1), hipMemcpyHostToDevice, d->stream));
+        HIP_TRY(hipMemcpyAsync(S.row0, h.data(), sizeof(int) * ((size_t) B + 1), hipMemcpyHostToDevice, d->stream));
         HIP_TRY(hipStreamSynchronize(d->stream));
     } else {
         int *out = nullptr, hout[2] = {0, 0}; // [0..1] results, [2 ..] the kernel's cut-point scratch
         HIP_TRY(pool_malloc((void **) &out, sizeof(int) * ((size_t) btarget + 3)));
         const long long c = std::max<long long>(1, (long long) (d->stats.mean_row_len / 8.0)); // fixed cost of a row, in entries
-        blk_partition_kernel<<<1, kBlock, 0, d->stream>>>(d->m, d->rowptr, btarget, rcap, c, out + 2, d->blk_row0, out);
+        blk_partition_kernel<<<1, kBlock, 0, d->stream>>>(d->m, d->rowptr, btarget, rcap, c, out + 2, S.row0, out);
         hipError_t e = hipGetLastError();
         if (e == hipSuccess) e = hipMemcpyAsync(hout, out, sizeof hout, hipMemcpyDeviceToHost, d->stream);
         if (e == hipSuccess) e = hipStreamSynchronize(d->stream);
@@ -522,26 +550,52 @@ static int build_blocked(spmv_dev *d, int rule)
         R = hout[1] > 0 ? hout[1] : 1;
         if (B < 1 || (size_t) B > cap_blocks) return fail(SPMV_HIP_E_RUNTIME, "block partition produced %d blocks", B);
     }
-    // Slab width: as narrow as the cell table allows (2^25 cells: ~400 MB of inspector scratch), down to 32
-    // columns.  Narrow slabs cost nothing in L2 locality (the sweep over x is the same) and put entries that
-    // gather from the same cache line into neighbouring lanes, which the L1/TA path merges into one L2
-    // request (Orkut-style stand-in, 74 nnz/row over 3e6 columns: 2.05 -> 1.13 ms; 32 nnz/row over 1e7 columns is
-    // too sparse for that, 0.4 entries per line and block: 2.1 -> 2.0 ms).
-    int wshift = 5;
+    S.B = B;
+    S.R = R;
+    return SPMV_HIP_OK;
+}
+
+template <typename T>
+static int build_blocked(spmv_dev *d, int rule)
+{
+    BlkSet &S = d->blk;
+    S = BlkSet();
+    // Slab width: 128 columns (the unit the dense part stages in LDS; narrow slabs also put entries that gather from the
+    // same cache line into neighbouring lanes, which the L1/TA path merges into one L2 request), wider only when a block
+    // would have more than 32768 cells (the count kernel's LDS histogram), or by option slab_kib.
+    int wshift = kBlkSlabShift;
     if (d->plan.slab_kib > 0) {
         wshift = 0;
         while ((sizeof(T) << wshift) < ((size_t) d->plan.slab_kib << 10)) ++wshift;
-    } else {
-        while ((long long) B * ((((long long) d->n - 1) >> wshift) + 1) > (1ll << 25)) ++wshift;
     }
-    const int K = (int) ((((long long) d->n - 1) >> wshift) + 1);
-    if ((long long) B * K > (1ll << 26)) return SPMV_HIP_OK; // cell table too large: keep the tile executor
-    rc = dev_alloc(d, (void **) &d->blk_start, sizeof(long long) * ((size_t) B + 1), true);
-    if (!rc) rc = dev_alloc(d, (void **) &d->blk_end, sizeof(long long) * (size_t) B, true);
-    if (rc) return rc;
-    d->blk_R = R; d->blk_K = K; d->blk_B = B; d->blk_wshift = wshift;
-    rc = blocked_fill<T>(d, wshift, false);
-    if (rc) return rc;
+    while (wshift < kBlkSuperShift && ((((long long) d->n - 1) >> wshift) + 1) > kBlkMaxCells) ++wshift;
+    if (wshift > kBlkSuperShift) wshift = kBlkSuperShift;
+    S.wshift = wshift;
+    S.K = (int) ((((long long) d->n - 1) >> wshift) + 1);
+    S.S = (int) ((((long long) d->n - 1) >> kBlkSuperShift) + 1);
+    S.nparts = S.S < kBlkParts ? S.S : kBlkParts;
+    S.ge = sizeof(T) == 8 ? 7 : 8; // 64 lanes x 16 bytes of values
+    // dense cells: at least one group's worth of entries in 128 columns (option dense_cells = 0: none, > 1: that many)
+    S.dense_min = INT_MAX;
+    if (wshift == kBlkSlabShift && d->n >= 512 && d->plan.dense_cells != 0)
+        S.dense_min = d->plan.dense_cells > (1 << S.ge) ? d->plan.dense_cells : 1 << S.ge;
+    S.range_cells = std::min(S.K, ((S.S + S.nparts - 1) / S.nparts) << (kBlkSuperShift - wshift));
+    int rc = SPMV_HIP_OK;
+    for (int pass = 0; pass < 2; ++pass) {
+        // pass 0 assumes no dense groups (fattest blocks); if dense groups turn up and the blocks are too fat to leave room
+        // for the slab buffers, the rows are cut again under the smaller cap
+        int btarget = 1, rcap = 1024;
+        blocked_block_rule(d, rule, blocked_row_cap<T>(pass == 1), &btarget, &rcap);
+        rc = blocked_partition(d, btarget, rcap);
+        if (rc) return rc;
+        if (pass == 1) { // drop the first pass's streams
+            for (void *p : {(void *) S.gstart, (void *) S.dgroups, (void *) S.dir, S.val, (void *) S.meta, (void *) S.hdr_a, (void *) S.hdr_b}) if (p) sched_free(d, p);
+            S.gstart = nullptr; S.dgroups = nullptr; S.dir = nullptr; S.val = nullptr; S.meta = nullptr; S.hdr_a = S.hdr_b = nullptr;
+        }
+        rc = blocked_fill<T>(d, false);
+        if (rc) return rc;
+        if (S.dense_groups == 0 || blocked_lds_bytes<T>(S) <= 80 * 1024 || d->plan.block_rows > 0) break;
+    }
     d->blk_on = true;
     return SPMV_HIP_OK;
 }
@@ -621,8 +675,8 @@ static int account_stream_bytes(spmv_dev *d)
     const long long s = (long long) d->vsize, m = d->m, n = d->n;
     Traffic t;
     int rc = SPMV_HIP_OK;
-    if (d->blk_on) {
-        t.bytes = (d->blk_slots - kBlkPad) * (s + 4 + 2) + 16ll * d->blk_B + s * m;
+    if (d->blk_on) { // value + (column | row) word per stored entry, the group headers (dense: two), the block directory, y once
+        t.bytes = (d->blk.groups << d->blk.ge) * (s + 4) + 4ll * (d->blk.groups + d->blk.dense_groups) + (long long) (sizeof(BlkDir) + 8) * d->blk.B + s * m;
         t.gathers_global = true;
     } else {
         switch (d->plan.sched) {

@@ -110,44 +110,34 @@ static int autotune_vector(spmv_dev *d)
     return SPMV_HIP_OK;
 }
 
-// Row blocks x column slabs (kernels/blocked.hpp): one single-wave workgroup per row block.  Variants for A/B
-// runs: 19 / 21 / 22 = 2 / 8 / 16 load groups in flight per lane (default 4: 2.14 vs 2.33 ms on config 2 with random
-// columns, 0.83 vs 0.94 ms on the Orkut-style R-MAT stand-in; 8 wins by 6 % on Orkut-style with uniform columns);
-// 23 = the first-round 256-thread workgroup per block, whose waves race on the rows (not bit-reproducible on
-// inexact data).
+// Row blocks x column slabs (kernels/blocked.hpp): one single-wave workgroup per row block.  Forms = groups per step of
+// the sparse loop: 4 / 8 / 12 (d->blk.form 0 / 1 / 2, chosen by autotune_blocked; option variant 29 / 35 / 37 forces one --
+// all three add the same products in the same order: tests compare their bits).
 template <typename T>
 static void launch_blocked(spmv_dev *d, const T *x, T *y)
 {
-    const size_t lds = (size_t) d->blk_R * sizeof(double); // accumulators are double for both value types
-#define SPMV_BLK_LAUNCH(NT, UN)                                                                                                  \
-    do {                                                                                                                         \
-        ensure_lds<blk_kernel<T, NT, UN>>(d, lds);                                                                               \
-        blk_kernel<T, NT, UN><<<d->blk_B, NT, lds, d->stream>>>(d->blk_row0, d->blk_R, d->blk_start, d->blk_end, (const T *) d->blk_val, \
-                                                                d->blk_col, d->blk_row, x, y);                                   \
+    const BlkSet &S = d->blk;
+    const size_t lds = blocked_lds_bytes<T>(S);
+#define SPMV_BLK_LAUNCH(UN)                                                                                                       \
+    do {                                                                                                                          \
+        ensure_lds<blk_kernel<T, UN>>(d, lds);                                                                                    \
+        blk_kernel<T, UN><<<S.B, kWave, lds, d->stream>>>(S.row0, S.R, S.dir, (const T *) S.val, S.meta, S.hdr_a, S.hdr_b, x, d->n, y); \
     } while (0)
-#define SPMV_BLK3_LAUNCH(UN)                                                                                                     \
-    do {                                                                                                                         \
-        ensure_lds<blk_kernel3<T, UN>>(d, lds);                                                                                  \
-        blk_kernel3<T, UN><<<d->blk_B, kWave, lds, d->stream>>>(d->blk_row0, d->blk_R, d->blk_start, d->blk_end, (const T *) d->blk_val, \
-                                                                d->blk_col, d->blk_row, x, y);                                   \
+#ifdef SPMV_BLK_DEBUG_FORMS // A/B builds of tools/ only (wrong results): variant 51 / 52 / 53 = no gathers / no LDS adds / neither, 8 groups per step
+#define SPMV_BLK_DBG_LAUNCH(DBG)                                                                                                  \
+    do {                                                                                                                          \
+        ensure_lds<blk_kernel<T, 8, DBG>>(d, lds);                                                                                \
+        blk_kernel<T, 8, DBG><<<S.B, kWave, lds, d->stream>>>(S.row0, S.R, S.dir, (const T *) S.val, S.meta, S.hdr_a, S.hdr_b, x, d->n, y); \
     } while (0)
-    switch (d->plan.variant) {
-    case 19: SPMV_BLK_LAUNCH(kWave, 2); break;
-    case 20: SPMV_BLK_LAUNCH(kWave, 4); break;
-    case 21: SPMV_BLK_LAUNCH(kWave, 8); break;
-    case 22: SPMV_BLK_LAUNCH(kWave, 16); break;
-    case 23: SPMV_BLK_LAUNCH(256, 4); break;
-    case 29: SPMV_BLK_LAUNCH(kWave, 4); break; // the forms autotune_blocked chooses from, forced: two-stage x 4,
-    case 35: SPMV_BLK3_LAUNCH(8); break;       // three-stage x 8,
-    case 37: SPMV_BLK3_LAUNCH(12); break;      // three-stage x 12
-    case 34: SPMV_BLK3_LAUNCH(4); break;       // A/B only: three-stage x 4
-    default:
-        if (d->blk_form == 0) SPMV_BLK_LAUNCH(kWave, 4);
-        else if (d->blk_form == 2) SPMV_BLK3_LAUNCH(12);
-        else SPMV_BLK3_LAUNCH(8);
-        break;
-    }
-#undef SPMV_BLK3_LAUNCH
+    if (d->plan.variant == 51) { SPMV_BLK_DBG_LAUNCH(1); return; }
+    if (d->plan.variant == 52) { SPMV_BLK_DBG_LAUNCH(2); return; }
+    if (d->plan.variant == 53) { SPMV_BLK_DBG_LAUNCH(3); return; }
+#undef SPMV_BLK_DBG_LAUNCH
+#endif
+    const int form = d->plan.variant == 29 ? 0 : (d->plan.variant == 35 ? 1 : (d->plan.variant == 37 ? 2 : S.form));
+    if (form == 0) SPMV_BLK_LAUNCH(4);
+    else if (form == 2) SPMV_BLK_LAUNCH(12);
+    else SPMV_BLK_LAUNCH(8);
 #undef SPMV_BLK_LAUNCH
 }
 
@@ -157,7 +147,7 @@ static void launch_blocked(spmv_dev *d, const T *x, T *y)
 template <typename T>
 static int autotune_blocked(spmv_dev *d)
 {
-    d->blk_form = 1;
+    d->blk.form = 1;
     if (!d->blk_on || !d->plan.autotune || d->plan.variant != 0) return SPMV_HIP_OK;
     T *x = nullptr, *y = nullptr;
     if (pool_malloc((void **) &x, sizeof(T) * (size_t) d->n) != hipSuccess || pool_malloc((void **) &y, sizeof(T) * (size_t) d->m) != hipSuccess) {
@@ -170,10 +160,10 @@ static int autotune_blocked(spmv_dev *d)
     (void) hipEventCreate(&e0);
     (void) hipEventCreate(&e1);
     float tmin[3] = {1e30f, 1e30f, 1e30f};
-    for (int f = 0; f < 3; ++f) { d->blk_form = f; launch_blocked<T>(d, x, y); } // warm every form once
+    for (int f = 0; f < 3; ++f) { d->blk.form = f; launch_blocked<T>(d, x, y); } // warm every form once
     for (int round = 0; round < 5; ++round) // interleaved rounds: min per form (three rounds once picked the slow form on config 2-ii)
         for (int f = 0; f < 3; ++f) {
-            d->blk_form = f;
+            d->blk.form = f;
             (void) hipEventRecord(e0, d->stream);
             launch_blocked<T>(d, x, y);
             (void) hipEventRecord(e1, d->stream);
@@ -183,13 +173,13 @@ static int autotune_blocked(spmv_dev *d)
             if (ms < tmin[f]) tmin[f] = ms;
         }
     int best = 1;
-    for (int f = 0; f < 3; ++f) { d->blk_tune_ms[f] = tmin[f]; if (tmin[f] < tmin[best]) best = f; }
-    d->blk_form = best;
+    for (int f = 0; f < 3; ++f) { d->blk.tune_ms[f] = tmin[f]; if (tmin[f] < tmin[best]) best = f; }
+    d->blk.form = best;
     (void) hipEventDestroy(e0);
     (void) hipEventDestroy(e1);
     (void) pool_free(x);
     (void) pool_free(y);
-    if (hipGetLastError() != hipSuccess) d->blk_form = 1;
+    if (hipGetLastError() != hipSuccess) d->blk.form = 1;
     return SPMV_HIP_OK;
 }
 

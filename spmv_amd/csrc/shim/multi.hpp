@@ -119,7 +119,7 @@ extern "C" int spmv_shim_multi_create(spmv_multi **out, int gpus, int xchg, int 
     int G = gpus < 1 ? 1 : gpus;
     if (!virt && G > ndev) G = ndev;
     if (G > 64) G = 64;
-    if (m > 0 && G > m) G = m;
+    if (G > m) G = m; // never more shards than rows; an empty matrix is one (empty) shard
     if (G < 1) G = 1;
     int cur = -1;
     if (hipGetDevice(&cur) != hipSuccess) { (void) hipGetLastError(); cur = 0; }
@@ -185,7 +185,7 @@ extern "C" int spmv_shim_multi_create(spmv_multi **out, int gpus, int xchg, int 
             for (int g = 0; g < G; ++g) mt->sh[(size_t) g].comm = comms[(size_t) g];
             mt->rccl = true;
         }
-    } else if (G == 1 && rccl_api().ok && getenv("SPMV_HIP_RCCL_SINGLE")) { // exercise the RCCL calls with one rank (test hook)
+    } else if (G == 1 && getenv("SPMV_HIP_RCCL_SINGLE") && rccl_api().ok) { // exercise the RCCL calls with one rank (test hook)
         int dv = mt->sh[0].device;
         ncclComm_t_ c = nullptr;
         if (rccl_api().CommInitAll(&c, 1, &dv) == 0) { mt->sh[0].comm = c; mt->rccl = true; }

@@ -158,6 +158,22 @@ struct Csr5Plan {
     void *val = nullptr, *carry = nullptr;
 };
 
+// One row-block x column-slab layout (kernels/blocked.hpp; built by build_blocked).
+struct BlkSet {
+    int R = 0, K = 0, B = 0, wshift = kBlkSlabShift; // most rows of a block (= the junk accumulator's slot), slabs, blocks, log2(columns per slab)
+    int S = 1, nparts = 1, ge = 7, dense_min = INT_MAX, range_cells = 0; // super-slabs, column ranges of the fill, log2(entries per group), dense-cell threshold
+    int form = 1;                 // executor form: groups per step of the sparse loop 4 / 8 / 12 (launch_blocked; chosen by autotune_blocked)
+    float tune_ms[3] = {0, 0, 0};
+    long long groups = 0, dense_groups = 0; // groups stored (without the padding behind the last block), of which dense
+    int *row0 = nullptr;          // [B + 1] first row of every block (equal-work cut points, blk_partition_kernel)
+    long long *gstart = nullptr;  // [B + 1] first group of every block
+    int *dgroups = nullptr;       // [B] dense groups of every block
+    BlkDir *dir = nullptr;        // [B] what the executor reads
+    void *val = nullptr;
+    unsigned *meta = nullptr;     // 16-bit column field | 16-bit row in the block
+    int *hdr_a = nullptr, *hdr_b = nullptr; // per group: dense: slabs A and B (B < 0: none); sparse: first column of the super-slab
+};
+
 struct spmv_dev {
     int device = 0;
     int cus = 256;
@@ -198,17 +214,9 @@ struct spmv_dev {
     void *sval = nullptr;
     // csr5
     Csr5Plan c5, c5_long, ns; // ns: the natural-layout plan of the nnz-split schedule
-    // row blocks x column slabs (kernels/blocked.hpp): the nnz-split executor for columns without locality
+    // row blocks x column slabs (kernels/blocked.hpp): the executor for columns without locality
     bool blk_on = false;
-    int blk_R = 0, blk_K = 0, blk_B = 0, blk_wshift = 0;
-    int blk_form = 1;             // executor form: 0 two-stage x 4 load groups, 1 / 2 three-stage x 8 / 12 (launch_blocked; chosen by autotune_blocked)
-    float blk_tune_ms[3] = {0, 0, 0};
-    long long blk_slots = 0;
-    long long *blk_start = nullptr, *blk_end = nullptr;
-    int *blk_row0 = nullptr;      // [blk_B + 1] first row of every block (equal-work cut points, blocked.hpp: blk_partition_kernel)
-    void *blk_val = nullptr;
-    int *blk_col = nullptr;
-    unsigned short *blk_row = nullptr;
+    BlkSet blk;
     // long-row sub-matrix (rows longer than long_thr, in row order), the input of c5_long
     int *lsub_rowptr = nullptr, *lsub_colidx = nullptr;
     void *lsub_val = nullptr;
@@ -278,7 +286,8 @@ static void free_schedule(spmv_dev *d)
     for (auto &a : d->sched_allocs) { (void) pool_free(a.first); d->device_bytes -= (long long) a.second; }
     d->sched_allocs.clear();
     reset_tile_fields(d);
-    d->blk_on = false; d->blk_slots = 0; d->blk_start = d->blk_end = nullptr; d->blk_row0 = nullptr; d->blk_val = nullptr; d->blk_col = nullptr; d->blk_row = nullptr;
+    d->blk_on = false;
+    d->blk = BlkSet();
     d->built = false;
 }
 

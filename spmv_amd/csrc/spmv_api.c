@@ -361,9 +361,16 @@ void spmv(const spmv_Handle_t handle, BASIC_INT_TYPE m, const BASIC_INT_TYPE *Ro
          * the resident copies (no re-inspection: the pattern is the same). */
         unsigned long long sum = 0;
         if (spmv_shim_checksum(st->dev, Matrix_Val, &sum) == SPMV_HIP_OK && sum != st->val_sum) {
-            rc = spmv_shim_update_values(st->dev, Matrix_Val);
-            if (rc) { spmv_set_error(rc, "spmv/refresh values", spmv_shim_error_text()); return; }
-            st->val_sum = sum;
+            if (handle->Level_3_opt_used) {
+                /* option "reorder": the resident matrix is P A P^T, whose value order is not the caller's -- the values
+                 * cannot be refreshed in place; upload, reorder and inspect the caller's matrix again (state_build
+                 * takes a new checksum) */
+                if (state_build(handle, st, m, st->n, RowPtr, ColIdx, Matrix_Val) != SPMV_HIP_OK) return;
+            } else {
+                rc = spmv_shim_update_values(st->dev, Matrix_Val);
+                if (rc) { spmv_set_error(rc, "spmv/refresh values", spmv_shim_error_text()); return; }
+                st->val_sum = sum;
+            }
         }
     }
     rc = st->multi ? spmv_shim_multi_run(st->multi, X, Y) : spmv_shim_run(st->dev, X, Y);
@@ -474,9 +481,31 @@ int spmv_hip_get_info(spmv_Handle_t h, spmv_hip_info *out)
         out->kernel_name = "spmv_host_rows";
         return SPMV_HIP_OK;
     }
-    if (st && st->multi && out) { /* shard 0 speaks for the handle; the totals are the whole matrix's */
-        int rc = spmv_shim_info(spmv_shim_multi_shard(st->multi, 0), out);
-        if (rc == SPMV_HIP_OK) { out->m = st->m; out->n = st->n; out->nnz = spmv_shim_multi_nnz(st->multi); }
+    if (st && st->multi && out) { /* shard 0 names the schedule; sizes, byte counts and stored entries are summed over the
+                                   * shards (inspect_ms: the slowest shard), so that rates derived from the struct are the whole matrix's */
+        int rc = spmv_shim_info(spmv_shim_multi_shard(st->multi, 0), out), g;
+        const int G = spmv_shim_multi_count(st->multi);
+        for (g = 1; g < G && rc == SPMV_HIP_OK; ++g) {
+            spmv_hip_info o;
+            rc = spmv_shim_info(spmv_shim_multi_shard(st->multi, g), &o);
+            if (rc != SPMV_HIP_OK) break;
+            out->stream_bytes += o.stream_bytes;
+            out->x_bytes += o.x_bytes;
+            out->stored_nnz += o.stored_nnz;
+            out->device_bytes += o.device_bytes;
+            out->empty_rows += o.empty_rows;
+            out->x_groups += o.x_groups;
+            out->x_groups_staged += o.x_groups_staged;
+            if (o.inspect_ms > out->inspect_ms) out->inspect_ms = o.inspect_ms;
+            if (o.max_row_len > out->max_row_len) out->max_row_len = o.max_row_len;
+            if (o.min_row_len < out->min_row_len) out->min_row_len = o.min_row_len;
+        }
+        if (rc == SPMV_HIP_OK) {
+            const long long s = h->data_size == sizeof(double) ? 8 : 4;
+            out->m = st->m; out->n = st->n; out->nnz = spmv_shim_multi_nnz(st->multi);
+            out->mean_row_len = st->m > 0 ? (double) out->nnz / st->m : 0.0;
+            out->alg_bytes = 4ll * ((long long) st->m + 1) + out->nnz * (4 + s) + s * st->n + s * st->m;
+        }
         return rc;
     }
     st = state_of(h, "get_info");

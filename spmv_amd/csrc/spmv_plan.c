@@ -45,7 +45,9 @@ static opt_t g_opts[SPMV_N_OPTS] = {
     [SPMV_OPT_CACHE_BLOCK] = {"cache_block", 1, 0, 2, 0, 0},          /* row-block x column-slab executor when no x window can be staged:
                                                                        * 1 = automatic (every schedule but CSR-scalar), 2 = always, 0 = never */
     [SPMV_OPT_SLAB_KIB] = {"slab_kib", 0, 0, 1 << 16, 1, 0},          /* ... KiB of x per column slab (0 = as narrow as the cell table allows) */
-    [SPMV_OPT_BLOCK_ROWS] = {"block_rows", 0, 0, 32768, 1, 0},        /* ... rows per block (0 = 64 KiB of y) */
+    [SPMV_OPT_BLOCK_ROWS] = {"block_rows", 0, 0, 16384, 1, 0},        /* ... uniform blocks of that many rows (0 = equal-work blocks, two per CU) */
+    [SPMV_OPT_DENSE_CELLS] = {"dense_cells", 1, 0, 1 << 20, 0, 0},    /* ... (block, 128-column slab) cells with at least one group's worth of entries read x
+                                                                       * through LDS: 1 = yes (default), 0 = no, > 1 = at least that many entries */
     [SPMV_OPT_VARIANT] = {"variant", 0, 0, 1 << 20, 0, 0},            /* kernel-form selector of the A/B harness and the variant tests, 0 = default */
     [SPMV_OPT_AUTO_METHOD] = {"auto_method", 0, 0, 2, 0, 0},          /* 1: create() picks the schedule from the matrix by rules (two stages, spmv_api.c);
                                                                        * 2: ... by building the candidate schedules and timing them */
@@ -282,6 +284,7 @@ void spmv_plan_choose(SPMV_METHODS requested, const spmv_stats *st, size_t value
     plan->cache_block = (int) opt->v[SPMV_OPT_CACHE_BLOCK];
     plan->slab_kib = (int) opt->v[SPMV_OPT_SLAB_KIB];
     plan->block_rows = (int) opt->v[SPMV_OPT_BLOCK_ROWS];
+    plan->dense_cells = (int) opt->v[SPMV_OPT_DENSE_CELLS];
     plan->csr5_sigma = (int) opt->v[SPMV_OPT_CSR5_SIGMA];
     /* one workgroup's equal-nnz share (Method_Balanced): the non-zeros of 256 mean-length rows, so that a
      * block is about one 256-row slab of the CSR-vector wave program (8192 for config 2; a share that is

@@ -213,42 +213,29 @@ extern "C" int spmv_shim_build(spmv_dev *d, const spmv_plan *plan)
         rc = f64 ? build_blocked<double>(d, 0) : build_blocked<float>(d, 0);
         if (!rc && d->blk_on) drop_tile_schedule(d, keep_from);
         if (!rc && d->blk_on) rc = f64 ? autotune_blocked<double>(d) : autotune_blocked<float>(d);
-        // Stream-bound under rule 0 (the three streams alone move >= 3.6 TB/s; web-like 4e6 x 24 in fp32 sits at 4.2)?  Then thinner blocks may do better: build the
+        // Stream-bound under rule 0 (the streams alone move >= 3.6 TB/s; web-like 4e6 x 24 in fp32 sits at 4.2)?  Then thinner blocks may do better: build the
         // rule-1 set next to this one, time it, keep the faster (one more inspector pass, only for such matrices).
         if (!rc && d->blk_on && plan->autotune && plan->variant == 0 && plan->block_rows == 0 && d->nnz >= (1ll << 22) &&
             blocked_differs(d)) {
-            float best0 = d->blk_tune_ms[0];
-            for (int f = 1; f < 3; ++f) best0 = d->blk_tune_ms[f] < best0 ? d->blk_tune_ms[f] : best0;
-            const double rate = best0 > 0 ? (double) d->nnz * ((double) d->vsize + 6.0) / ((double) best0 * 1e-3) : 0.0;
+            auto best_of = [](const BlkSet &b) { float t = b.tune_ms[0]; for (int f = 1; f < 3; ++f) t = b.tune_ms[f] < t ? b.tune_ms[f] : t; return t; };
+            const float best0 = best_of(d->blk);
+            const double rate = best0 > 0 ? (double) d->nnz * ((double) d->vsize + 4.0) / ((double) best0 * 1e-3) : 0.0;
             if (rate >= 3.6e12) {
-                struct BlkSet { int *row0; long long *start, *end; void *val; int *col; unsigned short *row; int R, K, B, wshift, form; long long slots; float tune[3]; };
-                auto take = [&]() { return BlkSet{d->blk_row0, d->blk_start, d->blk_end, d->blk_val, d->blk_col, d->blk_row, d->blk_R, d->blk_K, d->blk_B, d->blk_wshift, d->blk_form,
-                                                  d->blk_slots, {d->blk_tune_ms[0], d->blk_tune_ms[1], d->blk_tune_ms[2]}}; };
-                auto put = [&](const BlkSet &b) {
-                    d->blk_row0 = b.row0; d->blk_start = b.start; d->blk_end = b.end; d->blk_val = b.val; d->blk_col = b.col; d->blk_row = b.row;
-                    d->blk_R = b.R; d->blk_K = b.K; d->blk_B = b.B; d->blk_wshift = b.wshift; d->blk_form = b.form; d->blk_slots = b.slots;
-                    for (int f = 0; f < 3; ++f) d->blk_tune_ms[f] = b.tune[f];
-                };
                 auto release = [&](const BlkSet &b) {
                     quiesce(d);
-                    sched_free(d, b.row0); sched_free(d, b.start); sched_free(d, b.end); sched_free(d, b.val); sched_free(d, b.col); sched_free(d, b.row);
+                    for (void *p : {(void *) b.row0, (void *) b.gstart, (void *) b.dgroups, (void *) b.dir, b.val, (void *) b.meta, (void *) b.hdr_a, (void *) b.hdr_b}) if (p) sched_free(d, p);
                 };
-                const BlkSet first = take();
+                const BlkSet first = d->blk;
                 d->blk_on = false;
                 const int rc2 = f64 ? build_blocked<double>(d, 1) : build_blocked<float>(d, 1);
                 if (!rc2 && d->blk_on) {
                     (void) (f64 ? autotune_blocked<double>(d) : autotune_blocked<float>(d));
-                    float best1 = d->blk_tune_ms[0];
-                    for (int f = 1; f < 3; ++f) best1 = d->blk_tune_ms[f] < best1 ? d->blk_tune_ms[f] : best1;
-                    const BlkSet second = take();
+                    const float best1 = best_of(d->blk);
                     if (best1 > 0 && best1 < 0.97f * best0) release(first);
-                    else { release(second); put(first); }
+                    else { release(d->blk); d->blk = first; }
                 } else { // the second set could not be built (memory): keep the first
-                    const BlkSet partial = take();
-                    if (partial.row0 && partial.row0 != first.row0) sched_free(d, partial.row0);
-                    if (partial.start && partial.start != first.start) sched_free(d, partial.start);
-                    if (partial.end && partial.end != first.end) sched_free(d, partial.end);
-                    put(first);
+                    release(d->blk);
+                    d->blk = first;
                     (void) hipGetLastError();
                 }
                 d->blk_on = true;
@@ -285,7 +272,7 @@ static int update_values(spmv_dev *d, const void *val)
     const T *v = (const T *) d->val;
     int rc = SPMV_HIP_OK;
     if (d->blk_on) { // the blocked streams are the only copy the executor reads
-        rc = blocked_fill<T>(d, d->blk_wshift, true);
+        rc = blocked_fill<T>(d, true);
     } else {
         if (d->nlong > 0 && d->lsub_val) { // long-row sub-matrix, then its CSR5 tiles
             long_rows_gather_kernel<T><<<d->nlong, kBlock, 0, d->stream>>>(d->long_rows, d->rowptr, nullptr, v, d->lsub_rowptr, nullptr, (T *) d->lsub_val);
@@ -314,14 +301,22 @@ extern "C" int spmv_shim_update_values(spmv_dev *d, const void *val)
     return d->vsize == sizeof(double) ? update_values<double>(d, val) : update_values<float>(d, val);
 }
 
+// Checksum of the value array (option "check_values"): the sum over the 32-bit words of word * (odd multiplier of its
+// position) modulo 2^64.  Position-weighted, so swapped or permuted values and changes whose plain word sums cancel are
+// seen too; still a commutative sum, so host loop and device reduction agree whatever their order.
+__host__ __device__ static inline unsigned long long checksum_term(unsigned w, long long i)
+{
+    return ((unsigned long long) w + 0x9E3779B97F4A7C15ull) * (2ull * (unsigned long long) i + 1ull);
+}
+
 __global__ __launch_bounds__(kBlock) void checksum_kernel(long long words, const unsigned *__restrict__ w, unsigned long long *__restrict__ out)
 {
     unsigned long long s = 0;
     const long long stride = (long long) gridDim.x * kBlock;
-    for (long long i = (long long) blockIdx.x * kBlock + threadIdx.x; i < words; i += stride) s += w[i];
+    for (long long i = (long long) blockIdx.x * kBlock + threadIdx.x; i < words; i += stride) s += checksum_term(w[i], i);
 #pragma unroll
     for (int o = kWave / 2; o > 0; o >>= 1) s += __shfl_xor(s, o, kWave);
-    if ((threadIdx.x & (kWave - 1)) == 0 && s) atomicAdd(out, s);
+    if ((threadIdx.x & (kWave - 1)) == 0) atomicAdd(out, s);
 }
 
 extern "C" int spmv_shim_checksum(spmv_dev *d, const void *val, unsigned long long *out)
@@ -334,7 +329,7 @@ extern "C" int spmv_shim_checksum(spmv_dev *d, const void *val, unsigned long lo
     if (!is_device_ptr(val)) { // host array: summed where it lives
         const unsigned *w = (const unsigned *) val;
         unsigned long long s = 0;
-        for (long long i = 0; i < words; ++i) s += w[i];
+        for (long long i = 0; i < words; ++i) s += checksum_term(w[i], i);
         *out = s;
         return SPMV_HIP_OK;
     }
@@ -485,8 +480,8 @@ extern "C" int spmv_shim_info(const spmv_dev *d, spmv_hip_info *o)
     const long long s = (long long) d->vsize;
     o->alg_bytes = 4ll * ((long long) d->m + 1) + d->nnz * (4 + s) + s * d->n + s * d->m;
     o->inspect_ms = d->inspect_ms;
-    o->tuned_choice = d->blk_on ? 100 + d->blk_form : d->vec_choice; // cache_blocked: 100 two-stage x 4, 101 / 102 three-stage x 8 / x 12
-    for (int k = 0; k < 3; ++k) o->tune_ms[k] = d->blk_on ? d->blk_tune_ms[k] : d->tune_ms[k];
+    o->tuned_choice = d->blk_on ? 100 + d->blk.form : d->vec_choice; // cache_blocked: 100 / 101 / 102 = 4 / 8 / 12 groups per step
+    for (int k = 0; k < 3; ++k) o->tune_ms[k] = d->blk_on ? d->blk.tune_ms[k] : d->tune_ms[k];
     o->schedule_name = kSchedNames[d->plan.sched];
     o->kernel_name = kKernelNames[d->plan.sched];
     if (d->plan.sched == SPMV_SCHED_CSR_VECTOR && d->vt_tiles > 0 && d->vec_choice != VEC_PIPE &&
@@ -496,7 +491,7 @@ extern "C" int spmv_shim_info(const spmv_dev *d, spmv_hip_info *o)
     o->cache_blocked = d->blk_on ? 1 : 0;
     o->stream_bytes = d->stream_bytes;
     o->x_bytes = d->x_bytes;
-    if (d->blk_on) { o->stored_nnz = d->blk_slots - kBlkPad; o->x_groups = d->x_groups_seen; o->x_groups_staged = 0; }
+    if (d->blk_on) { o->stored_nnz = d->blk.groups << d->blk.ge; o->x_groups = d->x_groups_seen; o->x_groups_staged = 0; }
     if (!d->blk_on) switch (d->plan.sched) {
     case SPMV_SCHED_CSR_VECTOR:
     case SPMV_SCHED_ROWBLOCK: o->x_groups = d->vt_tiles; o->x_groups_staged = d->vt_staged; break;
