@@ -118,9 +118,10 @@ typedef struct spmv_hip_info {
     double inspect_ms;          /* wall time of the inspector inside create */
     const char *schedule_name;
     const char *kernel_name;    /* symbol of the dominant kernel (as rocprofv3 shows it) */
-    int tuned_choice;           /* csr-vector autotune: 0 none, 10/11 tile 4-deep, 5/12 tile 2-deep, 4 pipe; cache_blocked: 100 + form */
+    int tuned_choice;           /* csr-vector autotune: 0 none, 10/11 tile 4-deep, 5/12 tile 2-deep, 4 pipe; cache_blocked: 100 / 101 =
+                                   8 / 12 groups per pipeline step */
     float tune_ms[3];           /* measured ms of {tile/4-deep, tile/2-deep, pipe} at create (0 if not tuned); cache_blocked: of the
-                                   row-block executor's {two-stage x 4, three-stage x 8, three-stage x 12} forms */
+                                   row-block executor's {8, 12} groups-per-step forms ([2] unused) */
     int x_groups;               /* tiles / tile groups / sigma windows the inspector analysed for x windows */
     int x_groups_staged;        /* ... of which have their x windows staged in LDS (0: every gather goes to L1/L2) */
     int cache_blocked;          /* 1: the row-block x column-slab executor runs (option "cache_block") */
@@ -130,6 +131,9 @@ typedef struct spmv_hip_info {
                                  * once where x is gathered through L2), y written once, carries.  This -- not alg_bytes --
                                  * is what divides by the launch time to give the HBM rate actually sustained. */
     long long x_bytes;          /* the part of stream_bytes charged for reading x */
+    float route_ms[2];          /* only when part of the tile groups stage their x windows and part do not: create() builds the tile
+                                 * schedule AND the row-block x column-slab executor, times both -- [0] tile schedule, [1] blocked
+                                 * executor, ms -- and keeps the faster (0, 0: the choice needed no measurement) */
 } spmv_hip_info;
 int spmv_hip_get_info(spmv_Handle_t handle, spmv_hip_info *out);
 

@@ -10,53 +10,54 @@
 // Here, for that case only (format of round 3; DESIGN.md 3.7 has the measurements):
 //   layout      rows are cut into blocks of at most R rows of EQUAL WORK (blk_partition_kernel), columns into slabs of
 //               2^wshift columns (128 unless that would make more than 32768 slabs).  The entries of a row block are
-//               stored sorted by slab, in GROUPS of 64 lanes x 16 bytes of values (128 fp64 / 256 fp32 entries), as two
-//               streams: the value and a 32-bit word (16-bit column offset | 16-bit row inside the block) -- 12 bytes per
-//               fp64 entry, the bytes of plain CSR.  A block's region has two parts:
-//                 dense   the (block, slab) cells with at least one group's worth of entries, back to back.  A group
-//                         touches at most two cells, so its header names two slabs (A: the slab of its first entry, B:
-//                         the next dense slab); the executor reads both slabs of x with COALESCED loads into LDS and
-//                         the entries pick their x there -- the column field is (A or B, offset in the slab).  No
-//                         scattered load at all: a scattered load occupies the CU's vector-memory path lane by lane
-//                         and the matrix stream queues behind it, a coalesced one for a few cycles.
-//                 sparse  everything else, super-slab (65536 columns) after super-slab, each super-slab's run padded
-//                         to whole groups, so that a group lies in ONE super-slab: its header is the super-slab's
-//                         first column (wave-uniform: a scalar load, the gather is base + 16-bit offset) and x is
-//                         gathered through L2 as before -- the sweep over the slabs, in step over the blocks of an XCD,
-//                         is what keeps x in L2.
-//   inspector   (device) one 1024-thread workgroup per block counts the block's cells in LDS (blk_count_kernel); a
-//               layout pass turns counts into part offsets; then the fill (blk_fill_kernel): the cells of a block are
-//               split into up to 16 column ranges and ONE WAVEFRONT per (block, range) scans the block's entries in CSR
-//               order, keeps those of its range (compacted through a small LDS queue, order kept) and gives each the
-//               next position of its cell from a cursor in LDS.  Only that wave touches those cursors and it does so in
-//               CSR order, so the stored order -- (part, slab, CSR order) -- is a function of the matrix alone.
+//               stored sorted by slab -- the sweep over the slabs, in step over the blocks of an XCD, is what keeps x in L2 --
+//               in GROUPS of 64 lanes x 16 bytes of values (128 fp64 / 256 fp32 entries), as two streams: the value and a
+//               32-bit word (16-bit column offset | 16-bit row inside the block) -- 12 bytes per fp64 entry, the bytes of
+//               plain CSR.  16-bit column offsets count from the first column of a SUPER-SLAB of 65536 columns; every
+//               super-slab's run of a block is padded to whole groups, so a group lies in ONE super-slab and its header is
+//               that super-slab's first column (wave-uniform; the gather is base + offset).  Inside a group the sorted order
+//               is dealt to the lanes so that ONE gather instruction covers 64 CONSECUTIVE entries of it (lane l holds
+//               entries l and 64 + l): the entries of a (block, slab) cell then sit in one instruction and the lanes that
+//               hit the same cache line merge into one L2 request (with lane l holding 2l and 2l + 1 a cell was split over
+//               two instructions: 0.63 instead of ~0.45 L2 requests per entry on uniformly random columns).
+//   inspector   (device, three kernels over the resident CSR) blk_rows_kernel: the row-in-block of every entry;
+//               blk_count_kernel: one 1024-thread workgroup per block counts the block's cells in LDS and reports the
+//               block's group count; blk_fill_kernel: the same workgroup counts again, one wave turns the counts into cell
+//               cursors (LDS) and writes the group headers, then the 16 waves walk the block's entries in CSR order, 4096
+//               per round, wave w owning entries [256 w, 256 w + 256) of the round, and take TURNS (a barrier apiece) at
+//               advancing the cursors with LDS atomics: cursor updates therefore happen in CSR order, wave after wave,
+//               instruction after instruction (inside one instruction the LDS unit serialises the lanes that hit one
+//               cursor in a fixed order), so the stored order -- (slab, CSR order) -- is a function of the matrix alone.
 //   executor    ONE WAVEFRONT per row block (a 64-thread workgroup, two blocks per CU).  y of the block lives in LDS
-//               as doubles (for fp32 values too -- see lds_add); the wave walks first the dense groups, then the sparse
-//               ones, three steps in flight (stream loads of step t + 2, x of step t + 1, additions of step t), and
-//               adds every product into y's LDS copy (ds_add_f64).  At the end the block's y is written once,
-//               coalesced: no partial sums, no carries, no read-modify-write of y in HBM.  No load sits behind a
-//               branch: groups past a part's end are read (the streams are padded) and their products go to a junk
-//               accumulator.
+//               as doubles (for fp32 values too -- see lds_add); the wave walks the block's groups three steps deep
+//               (stream loads of step t + 2, gathers of step t + 1, additions of step t) and adds every product into y's
+//               LDS copy (ds_add_f64).  At the end the block's y is written once, coalesced: no partial sums, no
+//               carries, no read-modify-write of y in HBM.  No load sits behind a branch: groups past the block's end are
+//               read (the streams are padded) and their products go to a junk accumulator.
 //   determinism every row is touched by exactly one wavefront, whose additions happen in program order over a stream
 //               whose order is fixed by the inspector: the result is reproducible bit for bit, run to run and handle
 //               to handle.
+//   not here    DENSE (block, slab) cells read through LDS (two coalesced slabs of x per group, the column field naming
+//               slab and offset): built and measured in round 3 (commit "dense cells through LDS as an experiment") --
+//               slower on every shape (Orkut-style R-MAT 0.65 vs 0.57 ms, web-like 4e6 x 24 0.31 vs 0.24): the cells that
+//               qualify are exactly those whose gathers already merge into a handful of L2 requests or hit L1, and the
+//               slab traffic (2 KiB per 128 entries through the vector-memory path and LDS) costs more than it saves.
 #pragma once
 #include <climits>
 #include "common.hpp"
 
 namespace spmv {
 
-constexpr int kBlkSlabShift = 7;     // dense cells: slabs of 128 columns (1 KiB of fp64 x, two 512-byte load instructions)
-constexpr int kBlkSuperShift = 16;   // sparse entries: 16-bit column offsets inside super-slabs of 65536 columns
-constexpr int kBlkMaxCells = 32768;  // cells of one row block at most (the count kernel's histogram: 128 KiB of LDS)
-constexpr int kBlkParts = 16;        // column ranges the fill of one block is split over (one wavefront each)
-constexpr int kBlkCountThreads = 1024;
+constexpr int kBlkSlabShift = 7;     // slabs of 128 columns unless that makes too many cells
+constexpr int kBlkSuperShift = 16;   // 16-bit column offsets inside super-slabs of 65536 columns
+constexpr int kBlkMaxCells = 32768;  // cells of one row block at most (the inspector's cursors: 128 KiB of LDS)
+constexpr int kBlkThreads = 1024;    // inspector workgroups: 16 waves per row block
+constexpr int kBlkTurn = 4;          // batches of 64 entries a wave places per turn
 constexpr int kBlkPadGroups = 128;   // zero groups behind the last block: three executor steps of the widest form, and header loads reach 64 groups ahead
-constexpr int kBlkDenseUn = 8;       // groups per step of the dense loop (LDS: 2 slabs x 128 columns each)
 
-struct BlkDir {      // one row block's region: groups [g0, g0 + nd) dense, [g0 + nd, g0 + nd + ns) sparse
+struct BlkDir {      // one row block's region: groups [g0, g0 + ns)
     long long g0;
-    int nd, ns;
+    int ns, pad;
 };
 
 // Row blocks of EQUAL WORK: block b holds rows [row0[b], row0[b + 1]).  All blocks of a round are resident together and the
@@ -122,199 +123,138 @@ __device__ __forceinline__ int wave_excl_scan(int v, int lane, int *total)
     return inc - v;
 }
 
-// super-slabs [s0, s1) of column range `part` out of `nparts` (S super-slabs in all)
-__device__ __forceinline__ void blk_part_range(int S, int nparts, int part, int &s0, int &s1)
+// rowin[p] = row of entry p inside its row block, for every entry of block blockIdx.x: the block's row pointers in LDS
+// ((R + 1) ints), one binary search per entry.
+__global__ __launch_bounds__(kBlkThreads) void blk_rows_kernel(const int *__restrict__ row0, const int *__restrict__ rowptr, unsigned short *__restrict__ rowin)
 {
-    s0 = (int) (((long long) S * part) / nparts);
-    s1 = (int) (((long long) S * (part + 1)) / nparts);
+    extern __shared__ __attribute__((aligned(16))) unsigned char blk_rows_lds[];
+    int *rp = reinterpret_cast<int *>(blk_rows_lds);
+    const int r0 = row0[blockIdx.x], nr = row0[blockIdx.x + 1] - r0;
+    for (int i = threadIdx.x; i <= nr; i += kBlkThreads) rp[i] = rowptr[r0 + i];
+    __syncthreads();
+    const int p0 = rp[0], p1 = rp[nr];
+    for (int p = p0 + (int) threadIdx.x; p < p1; p += kBlkThreads) {
+        int lo = 0, hi = nr; // rp[lo] <= p < rp[hi]
+        while (hi - lo > 1) {
+            const int mid = (lo + hi) >> 1;
+            if (rp[mid] <= p) lo = mid; else hi = mid;
+        }
+        rowin[p] = (unsigned short) lo;
+    }
 }
 
-// Inspector pass 1: the cells of row block blockIdx.x, counted in LDS (K counters), written to cnt[b][K]; and per
-// column range (part) of the block the entries in dense cells (count >= dense_min) and the entries in sparse cells,
-// the latter with every super-slab's run rounded up to whole groups of 2^ge entries -- parts[b][part] = (dense, sparse).
-__global__ __launch_bounds__(kBlkCountThreads) void blk_count_kernel(const int *__restrict__ row0, int K, int wshift, int dense_min, int ge, int nparts,
-                                                                     int S, const int *__restrict__ rowptr, const int *__restrict__ colidx,
-                                                                     int *__restrict__ cnt, i32x2 *__restrict__ parts)
+// cells[k] = entries of row block b in slab k (LDS histogram, all threads of the workgroup)
+__device__ __forceinline__ void blk_count_cells(unsigned *cells, int K, int wshift, int p0, int p1, const int *__restrict__ colidx)
+{
+    for (int i = threadIdx.x; i < K; i += kBlkThreads) cells[i] = 0u;
+    __syncthreads();
+    for (int p = p0 + (int) threadIdx.x; p < p1; p += kBlkThreads) atomicAdd(&cells[ld_stream(colidx + p) >> wshift], 1u);
+    __syncthreads();
+}
+
+// Inspector pass 1: groups[b] = groups of 2^ge entries row block b needs -- its cells counted in LDS (K counters), every
+// super-slab's run rounded up to whole groups.
+__global__ __launch_bounds__(kBlkThreads) void blk_count_kernel(const int *__restrict__ row0, int K, int wshift, int ge, const int *__restrict__ rowptr,
+                                                                const int *__restrict__ colidx, int *__restrict__ groups)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char blk_count_lds[];
     unsigned *cells = reinterpret_cast<unsigned *>(blk_count_lds);
+    __shared__ int total;
     const int b = blockIdx.x;
-    for (int i = threadIdx.x; i < K; i += kBlkCountThreads) cells[i] = 0u;
-    __syncthreads();
-    const int p0 = rowptr[row0[b]], p1 = rowptr[row0[b + 1]];
-    for (int p = p0 + (int) threadIdx.x; p < p1; p += kBlkCountThreads) atomicAdd(&cells[ld_stream(colidx + p) >> wshift], 1u);
-    __syncthreads();
+    if (threadIdx.x == 0) total = 0;
+    blk_count_cells(cells, K, wshift, rowptr[row0[b]], rowptr[row0[b + 1]], colidx);
     const int wave = threadIdx.x / kWave, lane = threadIdx.x % kWave;
-    const int cs = kBlkSuperShift - wshift; // cells per super-slab = 2^cs
-    int *out = cnt + (long long) b * K;
-    for (int part = wave; part < nparts; part += kBlkCountThreads / kWave) {
-        int s0, s1;
-        blk_part_range(S, nparts, part, s0, s1);
-        int dsum = 0, spad = 0;
-        for (int s = s0; s < s1; ++s) {
-            const int ka = s << cs, kb = min((s + 1) << cs, K);
-            int d = 0, sp = 0;
-            for (int k = ka + lane; k < kb; k += kWave) {
-                const int c = (int) cells[k];
-                out[k] = c;
-                if (c >= dense_min) d += c; else sp += c;
-            }
-            dsum += wave_sum(d);
-            spad += ((wave_sum(sp) + (1 << ge) - 1) >> ge) << ge;
-        }
-        if (lane == 0) parts[(long long) b * kBlkParts + part] = i32x2{dsum, spad};
+    const int cs = kBlkSuperShift - wshift, S = (K + (1 << cs) - 1) >> cs; // cells per super-slab = 2^cs
+    int mine = 0;
+    for (int s = wave; s < S; s += kBlkThreads / kWave) {
+        const int ka = s << cs, kb = min((s + 1) << cs, K);
+        int c = 0;
+        for (int k = ka + lane; k < kb; k += kWave) c += (int) cells[k];
+        mine += (wave_sum(c) + (1 << ge) - 1) >> ge;
     }
+    if (lane == 0 && mine) atomicAdd(&total, mine);
+    __syncthreads();
+    if (threadIdx.x == 0) groups[b] = total;
 }
 
-// Inspector pass 2: per block, where each part's dense and sparse entries start inside the block's region (in entries:
-// dense parts back to back from 0, the dense total rounded up to a whole group, then the sparse parts), and the block's
-// group counts.  One thread per block.
-__global__ __launch_bounds__(kBlock) void blk_layout_kernel(int B, int nparts, int ge, const i32x2 *__restrict__ parts, i32x2 *__restrict__ part_off,
-                                                            int *__restrict__ groups, int *__restrict__ dense_groups)
+// position of entry i of a group's sorted order inside the group's 2^ge stored entries: lane (i mod 64) holds it as its
+// (i / 64)-th entry, and a lane's EPL entries are consecutive in memory (one 16-byte load)
+__device__ __forceinline__ unsigned blk_stored_pos(unsigned pos, int ge, unsigned epl)
 {
-    const int b = blockIdx.x * kBlock + threadIdx.x;
-    if (b >= B) return;
-    int d = 0;
-    for (int w = 0; w < nparts; ++w) {
-        part_off[(long long) b * kBlkParts + w].x = d;
-        d += parts[(long long) b * kBlkParts + w].x;
-    }
-    const int dp = ((d + (1 << ge) - 1) >> ge) << ge;
-    int s = dp;
-    for (int w = 0; w < nparts; ++w) {
-        part_off[(long long) b * kBlkParts + w].y = s;
-        s += parts[(long long) b * kBlkParts + w].y;
-    }
-    groups[b] = s >> ge;
-    dense_groups[b] = dp >> ge;
+    const unsigned gi = pos & ((1u << ge) - 1u);
+    return (pos - gi) + (gi & (kWave - 1)) * epl + (gi >> 6);
 }
 
-// Inspector pass 3, the stable fill: ONE wavefront per (row block, column range).  It turns the range's cell counts into
-// cursors (LDS) and group headers, then scans the block's entries in CSR order, 8 batches of 64 per round, appends the
-// entries of its range to a small LDS queue (ballot + popcount: order kept) and, whenever 64 are queued, hands each the next
-// position of its cell (LDS atomic with return: one wave, one instruction at a time, so positions follow the queue order
-// batch after batch; inside a batch the LDS unit serialises the lanes that hit one cursor in a fixed order) and stores
-// value and (column field | row << 16) there.  VALUES_ONLY: re-permute new values into the same positions
-// (spmv_hip_update_values).  Dynamic LDS: 2 x (most cells of a range) + 128 ints.
+// Inspector pass 2, the stable fill (see the header).  Dynamic LDS: K cursors.  VALUES_ONLY: re-permute new values into the
+// same positions (spmv_hip_update_values).
 template <typename T, bool VALUES_ONLY>
-__global__ __launch_bounds__(kWave) void blk_fill_kernel(const int *__restrict__ row0, int K, int wshift, int dense_min, int ge, int nparts, int S, int range_cells,
-                                                         const int *__restrict__ rowptr, const int *__restrict__ colidx, const T *__restrict__ val,
-                                                         const int *__restrict__ cnt, const i32x2 *__restrict__ part_off, const long long *__restrict__ gstart,
-                                                         const int *__restrict__ dense_groups, T *__restrict__ bval, unsigned *__restrict__ bmeta,
-                                                         int *__restrict__ hdr_a, int *__restrict__ hdr_b, BlkDir *__restrict__ dir)
+__global__ __launch_bounds__(kBlkThreads) void blk_fill_kernel(const int *__restrict__ row0, int K, int wshift, int ge, const int *__restrict__ rowptr,
+                                                               const int *__restrict__ colidx, const T *__restrict__ val, const unsigned short *__restrict__ rowin,
+                                                               const long long *__restrict__ gstart, T *__restrict__ bval, unsigned *__restrict__ bmeta,
+                                                               int *__restrict__ hdr, BlkDir *__restrict__ dir)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char blk_fill_lds[];
-    unsigned *cur = reinterpret_cast<unsigned *>(blk_fill_lds); // next position of every cell of the range (entries from the block region's start)
-    unsigned *cst = cur + range_cells;                          // the cell's first position | dense << 31
-    int *queue = reinterpret_cast<int *>(cst + range_cells);    // ring of 128 CSR positions
-    const int lane = threadIdx.x;
-    const int b = blockIdx.x / nparts, part = blockIdx.x % nparts;
-    const int cs = kBlkSuperShift - wshift, gsize = 1 << ge;
-    int s0, s1;
-    blk_part_range(S, nparts, part, s0, s1);
-    const int k0 = s0 << cs, k1 = min(s1 << cs, K);
+    unsigned *cur = reinterpret_cast<unsigned *>(blk_fill_lds); // counts, then the next position of every cell (entries from the block region's start)
+    const int b = blockIdx.x;
+    const int wave = threadIdx.x / kWave, lane = threadIdx.x % kWave;
+    const int p0 = rowptr[row0[b]], p1 = rowptr[row0[b + 1]];
     const long long g0 = gstart[b];
-    if (!VALUES_ONLY && part == 0 && lane == 0) dir[b] = BlkDir{g0, dense_groups[b], (int) (gstart[b + 1] - g0) - dense_groups[b]};
-    const int *mycnt = cnt + (long long) b * K;
-    { // cursors and headers of this range: super-slab after super-slab, every lane a contiguous run of the super-slab's cells
-        const i32x2 off = part_off[(long long) b * kBlkParts + part];
-        int doff = off.x, soff = off.y;
-        for (int s = s0; s < s1; ++s) {
+    blk_count_cells(cur, K, wshift, p0, p1, colidx);
+    if (wave == 0) { // counts -> cursors, super-slab after super-slab (every lane a contiguous run of the super-slab's cells); group headers
+        const int cs = kBlkSuperShift - wshift, S = (K + (1 << cs) - 1) >> cs, gsize = 1 << ge;
+        int off = 0;
+        for (int s = 0; s < S; ++s) {
             const int ka = s << cs, kb = min((s + 1) << cs, K);
             const int per = (kb - ka + kWave - 1) / kWave;
             const int a = min(ka + lane * per, kb), e = min(a + per, kb);
-            int d = 0, sp = 0;
+            int c = 0;
+            for (int k = a; k < e; ++k) c += (int) cur[k];
+            int tot;
+            int pos = off + wave_excl_scan(c, lane, &tot);
             for (int k = a; k < e; ++k) {
-                const int c = mycnt[k];
-                if (c >= dense_min) d += c; else sp += c;
+                const int ck = (int) cur[k];
+                cur[k] = (unsigned) pos;
+                pos += ck;
             }
-            int dtot, stot;
-            int dpos = doff + wave_excl_scan(d, lane, &dtot), spos = soff + wave_excl_scan(sp, lane, &stot);
-            for (int k = a; k < e; ++k) {
-                const int c = mycnt[k];
-                if (c >= dense_min) {
-                    cur[k - k0] = (unsigned) dpos;
-                    cst[k - k0] = (unsigned) dpos | 0x80000000u;
-                    if (!VALUES_ONLY) { // this cell is slab A of every group that STARTS inside it, slab B of the group it starts inside of
-                        for (int g = (dpos + gsize - 1) >> ge; g <= (dpos + c - 1) >> ge; ++g) hdr_a[g0 + g] = k;
-                        if (dpos & (gsize - 1)) hdr_b[g0 + (dpos >> ge)] = k;
-                    }
-                    dpos += c;
-                } else {
-                    cur[k - k0] = (unsigned) spos;
-                    cst[k - k0] = (unsigned) spos;
-                    spos += c;
-                }
-            }
-            doff += dtot;
-            const int send = ((soff + stot + gsize - 1) >> ge) << ge; // the super-slab's run, in whole groups
+            const int end = ((off + tot + gsize - 1) >> ge) << ge; // the super-slab's run, in whole groups
             if (!VALUES_ONLY)
-                for (int g = (soff >> ge) + lane; g < (send >> ge); g += kWave) hdr_a[g0 + g] = s << kBlkSuperShift; // first column of the super-slab
-            soff = send;
+                for (int g = (off >> ge) + lane; g < (end >> ge); g += kWave) hdr[g0 + g] = s << kBlkSuperShift; // first column of the super-slab
+            off = end;
         }
+        if (!VALUES_ONLY && lane == 0) dir[b] = BlkDir{g0, off >> ge, 0};
     }
     __syncthreads();
-    const int r0 = row0[b], nr = row0[b + 1] - r0;
-    const int p0 = rowptr[r0], p1 = rowptr[r0 + nr];
     const long long e0 = g0 << ge; // first entry of the block's region
-    int qh = 0, qn = 0;            // queue head, entries queued (wave-uniform)
-    auto drain = [&](int count) {  // the first `count` (<= 64) queued entries, in queue order
-        const bool on = lane < count;
-        const int p = on ? queue[(qh + lane) & 127] : p0;
-        const int c = colidx[p];
-        const T v = val[p];
-        if (on) {
-            const int kk = (c >> wshift) - k0;
-            const unsigned pos = atomicAdd(&cur[kk], 1u);
-            // lane l of the executor loads 16 bytes = the entries l, 64 + l (fp32: .., 128 + l, 192 + l) of the group's sorted order, so that ONE gather
-            // instruction covers 64 CONSECUTIVE entries of that order: the entries of a cell then sit in one instruction and their lanes merge per cache line
-            const unsigned epl = 16u / (unsigned) sizeof(T), gi = pos & ((1u << ge) - 1u);
-            const long long spos = e0 + (long long) (pos - gi) + (long long) ((gi & (kWave - 1)) * epl + (gi >> 6));
-            bval[spos] = v;
-            if constexpr (!VALUES_ONLY) {
-                const unsigned st = cst[kk];
-                int lo = 0, hi = nr; // row of CSR position p inside the block: rowptr[r0 + lo] <= p < rowptr[r0 + hi]
-                while (hi - lo > 1) {
-                    const int mid = (lo + hi) >> 1;
-                    if (rowptr[r0 + mid] <= p) lo = mid; else hi = mid;
-                }
-                unsigned col;
-                if (st >> 31) { // dense: slab A of my group if my cell started at or before the group's first entry
-                    const unsigned gfirst = (pos >> ge) << ge;
-                    col = ((st & 0x7fffffffu) > gfirst ? 1u << kBlkSlabShift : 0u) | ((unsigned) c & ((1u << kBlkSlabShift) - 1u));
-                } else {
-                    col = (unsigned) c & ((1u << kBlkSuperShift) - 1u);
-                }
-                bmeta[spos] = col | ((unsigned) lo << 16);
-            }
-        }
-        qh = (qh + count) & 127;
-        qn -= count;
-    };
-    constexpr int NB = 8; // batches of 64 entries loaded per round
-    for (int q = p0; q < p1; q += NB * kWave) {
-        int c[NB];
+    constexpr unsigned EPL = 16u / (unsigned) sizeof(T);
+    constexpr int ROUND = kBlkThreads * kBlkTurn; // entries per round; wave w owns [w * 64 * kBlkTurn, ...) of it: turns in wave order = CSR order
+    for (int q = p0; q < p1; q += ROUND) {
+        int c[kBlkTurn], r[kBlkTurn];
+        T v[kBlkTurn];
+        unsigned pos[kBlkTurn];
 #pragma unroll
-        for (int i = 0; i < NB; ++i) { // padded ColIdx: in bounds
-            const int p = q + i * kWave + lane;
-            c[i] = p < p1 ? ld_stream(colidx + p) : -1;
+        for (int i = 0; i < kBlkTurn; ++i) { // padded ColIdx / Val: reads up to kStreamPad past nnz stay in bounds only for the last block -- guard by position
+            const int p = q + (wave * kBlkTurn + i) * kWave + lane;
+            const bool on = p < p1;
+            c[i] = on ? ld_stream(colidx + p) : -1;
+            v[i] = on ? ld_stream(val + p) : T(0);
+            if constexpr (!VALUES_ONLY) r[i] = on ? (int) ld_stream(rowin + p) : 0;
+        }
+        for (int turn = 0; turn < kBlkThreads / kWave; ++turn) {
+            if (wave == turn) {
+#pragma unroll
+                for (int i = 0; i < kBlkTurn; ++i)
+                    if (c[i] >= 0) pos[i] = atomicAdd(&cur[c[i] >> wshift], 1u);
+            }
+            __syncthreads();
         }
 #pragma unroll
-        for (int i = 0; i < NB; ++i) {
-            const int k = c[i] >> wshift; // -1 for lanes past the block's end
-            const bool mine = k >= k0 && k < k1;
-            const unsigned long long mk = __ballot(mine);
-            if (mine) queue[(qh + qn + __popcll(mk & ((1ull << lane) - 1ull))) & 127] = q + i * kWave + lane;
-            qn += __popcll(mk);
-            if (qn >= kWave) {
-                __syncthreads();
-                drain(kWave);
-                __syncthreads();
+        for (int i = 0; i < kBlkTurn; ++i)
+            if (c[i] >= 0) {
+                const long long sp = e0 + blk_stored_pos(pos[i], ge, EPL);
+                bval[sp] = v[i];
+                if constexpr (!VALUES_ONLY) bmeta[sp] = ((unsigned) c[i] & ((1u << kBlkSuperShift) - 1u)) | ((unsigned) r[i] << 16);
             }
-        }
     }
-    __syncthreads();
-    if (qn > 0) drain(qn);
 }
 
 // The block's y is accumulated in DOUBLE for both value types: ds_add_f32 runs at 2.0e11 adds/s over the chip whatever the
@@ -324,20 +264,19 @@ __global__ __launch_bounds__(kWave) void blk_fill_kernel(const int *__restrict__
 __device__ __forceinline__ void lds_add(double *p, double v) { (void) unsafeAtomicAdd(p, v); }
 
 template <typename T, int UN>
-struct BlkStep { // the stream of one step: UN groups, per lane 16 bytes of values and their (column field | row << 16) words ...
+struct BlkStep { // the stream of one step: UN groups, per lane 16 bytes of values and their (column offset | row << 16) words ...
     T v[UN][16 / sizeof(T)];
     unsigned w[UN][16 / sizeof(T)];
-    int ha, hb;  // ... and, in lane u < UN, the header words of group u of some step (see the loops: which step)
+    int h;       // ... and, in lane u < UN, the header (first column of the super-slab) of group u of the step
 };
 
-// stream of the UN groups from group g on, header words of the groups from hg on (all relative to the block's region)
-template <typename T, int UN, bool DENSE>
-__device__ __forceinline__ void blk_load_step(int g, int hg, int lane, const T *__restrict__ bv, const unsigned *__restrict__ bm, const int *__restrict__ ha,
-                                              const int *__restrict__ hb, BlkStep<T, UN> &s)
+// stream and headers of the UN groups from group g on (relative to the block's region)
+template <typename T, int UN>
+__device__ __forceinline__ void blk_load_step(int g, int lane, const T *__restrict__ bv, const unsigned *__restrict__ bm, const int *__restrict__ hd, BlkStep<T, UN> &s)
 {
     constexpr int EPL = 16 / (int) sizeof(T);
-    s.ha = ha[hg + lane]; // one coalesced load for all groups of a step (the arrays are padded by kBlkPadGroups); a scalar load per group would have
-    if constexpr (DENSE) s.hb = hb[hg + lane]; // to be waited for with lgkmcnt(0), i.e. together with every LDS operation in flight
+    s.h = hd[g + lane]; // one coalesced load for all groups of a step (the array is padded by kBlkPadGroups); a scalar load per group would have to be
+                        // waited for with lgkmcnt(0), i.e. together with every LDS operation in flight
 #pragma unroll
     for (int u = 0; u < UN; ++u) {
         const int p = ((g + u) * kWave + lane) * EPL;
@@ -355,101 +294,40 @@ __device__ __forceinline__ void blk_load_step(int g, int hg, int lane, const T *
     }
 }
 
-// Executor.  Dynamic LDS: (R + 2) doubles (the block's y; slot R takes the products of padding entries and of groups past a
-// part's end), then -- only when some block has dense groups -- kBlkDenseUn x 256 values of x (two slabs per group of a step).
-// UN = groups per step of the sparse loop (8 or 12 loads of values in flight per lane and step).
+// Executor.  Dynamic LDS: (R + 2) doubles (the block's y; slot R takes the products of padding entries and of groups past the
+// block's end).  UN = groups per step (8 / 12 loads of values in flight per lane and step).
 //
-// Both loops run three steps deep: in step t the wave ISSUES the stream loads of step t + 2, brings in the x of step t + 1
-// (dense: writes the slabs loaded during step t - 1 to LDS and issues the slab loads of step t + 2; sparse: issues the gathers,
-// whose columns arrived during step t - 1 .. t) and ADDS step t.  Nothing is waited for in the step that issued it.  Three
-// stream register sets (and two x sets in the sparse loop) are used in rotation -- the loop bodies are written out for
-// three / six consecutive steps -- so no loaded register is ever copied.  Group headers travel with the stream sets as ONE
-// vector load per step (lane u = group u) and are broadcast with v_readlane when needed, a step after they were loaded.
+// Three steps deep: in step t the wave ISSUES the stream loads of step t + 2, ISSUES the gathers of step t + 1 (whose columns
+// arrived during step t - 1 .. t) and ADDS step t (whose x values were gathered during step t - 1).  Nothing is waited for in
+// the step that issued it.  Three stream register sets and two x sets are used in rotation (the loop body is written out for
+// six consecutive steps), so no loaded register is ever copied.  Group headers travel with the stream sets as ONE vector load
+// per step (lane u = group u) and are broadcast with v_readlane when the gathers are issued, a step after they were loaded.
 template <typename T, int UN, int DBG = 0> // DBG (tools only, wrong results): 1 = coalesced x reads instead of gathers, 2 = no LDS adds, 3 = both
 __global__ __launch_bounds__(kWave) void blk_kernel(const int *__restrict__ row0, int R, const BlkDir *__restrict__ dir, const T *__restrict__ bval,
-                                                    const unsigned *__restrict__ bmeta, const int *__restrict__ hdr_a, const int *__restrict__ hdr_b,
-                                                    const T *__restrict__ x, int n, T *__restrict__ y)
+                                                    const unsigned *__restrict__ bmeta, const int *__restrict__ hdr, const T *__restrict__ x, T *__restrict__ y)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char blk_y_lds[];
     double *ys = reinterpret_cast<double *>(blk_y_lds);
-    T *xb = reinterpret_cast<T *>(ys + ((R + 2) & ~1)); // slab buffers of the dense loop
     constexpr int EPL = 16 / (int) sizeof(T);
-    constexpr int DU = kBlkDenseUn;
-    constexpr int SLAB = 1 << kBlkSlabShift;
     const int lane = threadIdx.x;
+    const int blk = blockIdx.x;
     for (int i = lane; i <= R; i += kWave) ys[i] = 0.0;
     __syncthreads();
-    const BlkDir d = dir[blockIdx.x];
+    const BlkDir d = dir[blk];
     const unsigned junk = (unsigned) R;
     const long long e0 = d.g0 * (long long) (kWave * EPL);
-    const T *__restrict__ bv = bval + e0;           // the block's region: groups [0, nd) dense, [nd, nd + ns) sparse
+    const T *__restrict__ bv = bval + e0;           // the block's region: groups [0, ns)
     const unsigned *__restrict__ bm = bmeta + e0;
-    const int *__restrict__ ha = hdr_a + d.g0, *__restrict__ hb = hdr_b + d.g0;
-
-    if (d.nd > 0) { // ------------------------------------------------------------------ dense groups: x through LDS
-        const int nd = d.nd, nsteps = (nd + DU - 1) / DU;
-        BlkStep<T, DU> g0, g1, g2; // the set of step s carries the headers of step s + 1
-        T sl[DU][4];               // the two slabs of every group of a step: A[lane], A[64 + lane], B[lane], B[64 + lane]
-        auto load_slabs = [&](int s, int hva, int hvb) { // slabs of step s, whose header words are in (hva, hvb)
-#pragma unroll
-            for (int u = 0; u < DU; ++u) {
-                const bool ok = s * DU + u < nd; // wave-uniform
-                int a = __builtin_amdgcn_readlane(hva, u), bb = __builtin_amdgcn_readlane(hvb, u);
-                a = ok ? a : 0;
-                bb = ok && bb >= 0 ? bb : a;     // no second cell in this group: stage slab A twice
-                const int ca = a << kBlkSlabShift, cb = bb << kBlkSlabShift;
-                sl[u][0] = x[min(ca + lane, n - 1)];
-                sl[u][1] = x[min(ca + kWave + lane, n - 1)];
-                sl[u][2] = x[min(cb + lane, n - 1)];
-                sl[u][3] = x[min(cb + kWave + lane, n - 1)];
-            }
-        };
-        auto write_slabs = [&]() {
-#pragma unroll
-            for (int u = 0; u < DU; ++u) {
-                xb[u * 2 * SLAB + lane] = sl[u][0];
-                xb[u * 2 * SLAB + kWave + lane] = sl[u][1];
-                xb[u * 2 * SLAB + SLAB + lane] = sl[u][2];
-                xb[u * 2 * SLAB + SLAB + kWave + lane] = sl[u][3];
-            }
-        };
-        load_slabs(0, ha[lane], hb[lane]);
-        blk_load_step<T, DU, true>(0, DU, lane, bv, bm, ha, hb, g0);
-        blk_load_step<T, DU, true>(DU, 2 * DU, lane, bv, bm, ha, hb, g1);
-        write_slabs();  // slabs of step 0
-        load_slabs(1, g0.ha, g0.hb);
-#define SPMV_BLK_DENSE_PHASE(ga, gb, gc)                                                                                   \
-        {                                                                                                                   \
-            blk_load_step<T, DU, true>((t + 2) * DU, (t + 3) * DU, lane, bv, bm, ha, hb, gc);                               \
-            T xv[DU][EPL];                                                                                                  \
-            _Pragma("unroll") for (int u = 0; u < DU; ++u)                                                                  \
-                _Pragma("unroll") for (int j = 0; j < EPL; ++j) xv[u][j] = xb[u * 2 * SLAB + (ga.w[u][j] & (2 * SLAB - 1))]; \
-            write_slabs();     /* slabs of step t + 1, loaded during step t - 1 .. t; DS operations of a wave execute in order: the reads above come first */ \
-            load_slabs(t + 2, gb.ha, gb.hb);                                                                                \
-            _Pragma("unroll") for (int u = 0; u < DU; ++u) {                                                                \
-                const bool ok = t * DU + u < nd;                                                                            \
-                _Pragma("unroll") for (int j = 0; j < EPL; ++j)                                                             \
-                    lds_add(&ys[ok ? ga.w[u][j] >> 16 : junk], (double) (ga.v[u][j] * xv[u][j]));                           \
-            }                                                                                                               \
-            if (++t >= nsteps) break;                                                                                       \
-        }
-        for (int t = 0;;) {
-            SPMV_BLK_DENSE_PHASE(g0, g1, g2)
-            SPMV_BLK_DENSE_PHASE(g1, g2, g0)
-            SPMV_BLK_DENSE_PHASE(g2, g0, g1)
-        }
-#undef SPMV_BLK_DENSE_PHASE
-    }
-
-    if (d.ns > 0) { // ------------------------------------------------------------------ sparse groups: x gathered through L2
-        const int gs = d.nd, ns = d.ns, nsteps = (ns + UN - 1) / UN;
-        BlkStep<T, UN> g0, g1, g2; // the set of step s carries the headers of step s
+    const int *__restrict__ hd = hdr + d.g0;
+    const int ns = d.ns, nsteps = (ns + UN - 1) / UN;
+    if (ns > 0) {
+        BlkStep<T, UN> g0, g1, g2;
         T x0[UN][EPL], x1[UN][EPL];
         auto gather = [&](int s, const BlkStep<T, UN> &g, T(&xv)[UN][EPL]) {
 #pragma unroll
             for (int u = 0; u < UN; ++u) {
-                int base = __builtin_amdgcn_readlane(g.ha, u);
-                base = s * UN + u < ns ? base : 0; // wave-uniform; a group past the part's end gathers x[16-bit offset]: in bounds (offset < min(n, 65536))
+                int base = __builtin_amdgcn_readlane(g.h, u);
+                base = s * UN + u < ns ? base : 0; // wave-uniform; a group past the block's end gathers x[16-bit offset]: in bounds (offset < min(n, 65536))
                 const T *__restrict__ xs = x + base;
 #pragma unroll
                 for (int j = 0; j < EPL; ++j) xv[u][j] = (DBG & 1) ? x[lane * EPL + j + u * kWave * EPL] : xs[g.w[u][j] & 0xffffu];
@@ -467,11 +345,11 @@ __global__ __launch_bounds__(kWave) void blk_kernel(const int *__restrict__ row0
                 }
             }
         };
-        blk_load_step<T, UN, false>(gs, gs, lane, bv, bm, ha, hb, g0);
-        blk_load_step<T, UN, false>(gs + UN, gs + UN, lane, bv, bm, ha, hb, g1);
+        blk_load_step<T, UN>(0, lane, bv, bm, hd, g0);
+        blk_load_step<T, UN>(UN, lane, bv, bm, hd, g1);
         gather(0, g0, x0);
 #define SPMV_BLK_PHASE(ga, gb, gc, xa, xbb)                                                                                \
-        blk_load_step<T, UN, false>(gs + (t + 2) * UN, gs + (t + 2) * UN, lane, bv, bm, ha, hb, gc);                       \
+        blk_load_step<T, UN>((t + 2) * UN, lane, bv, bm, hd, gc);                                                          \
         gather(t + 1, gb, xbb);                                                                                            \
         add(t, ga, xa);                                                                                                    \
         if (++t >= nsteps) break;
@@ -487,8 +365,8 @@ __global__ __launch_bounds__(kWave) void blk_kernel(const int *__restrict__ row0
         if constexpr (DBG & 2) ys[lane] = dbg_acc;
     }
     __syncthreads();
-    const long long r0 = row0[blockIdx.x];
-    const int nr = row0[blockIdx.x + 1] - (int) r0;
+    const long long r0 = row0[blk];
+    const int nr = row0[blk + 1] - (int) r0;
     for (int i = lane; i < nr; i += kWave) y[r0 + i] = (T) ys[i];
 }
 

@@ -41,6 +41,7 @@ static int build_csr5(spmv_dev *d, Csr5Plan &P, int m, long long nnz, const int 
                       double mean_row_len, const int *out_rows, bool natural = false);
 template <typename T> static int autotune_vector(spmv_dev *d);
 template <typename T> static int autotune_blocked(spmv_dev *d);
+template <typename T> static double time_schedule(spmv_dev *d, int iters);
 template <typename T> static int build_tile_windows(spmv_dev *d, int tiles, const int *split, int rows_per_tile = kVecTileRows, bool wide = false);
 constexpr size_t kVecWideXTileBytes = 96 * 1024; // budget of the wide form (slot indices; two workgroups per CU)
 
@@ -395,92 +396,67 @@ static int build_csr5(spmv_dev *d, Csr5Plan &P, int m, long long nnz, const int 
     }
 }
 
-// Row blocks x column slabs (kernels/blocked.hpp): count the cells of every block, lay the parts out, fill.
-// blocked_fill runs the three inspector passes; values_only re-permutes new values into the positions of the existing
-// layout (spmv_hip_update_values): the counts are taken again (3 ms) rather than kept (up to 128 MB).
+// Row blocks x column slabs (kernels/blocked.hpp): the inspector's three kernels.  values_only re-permutes new values into the
+// positions of the existing layout (spmv_hip_update_values): cursors are recomputed inside the fill kernel, nothing is kept.
 template <typename T>
 static int blocked_fill(spmv_dev *d, bool values_only)
 {
     BlkSet &S = d->blk;
     const int B = S.B, K = S.K;
-    int *cnt = nullptr, *groups = nullptr;
-    i32x2 *parts = nullptr, *part_off = nullptr;
-    auto cleanup = [&]() { if (cnt) (void) pool_free(cnt); if (groups) (void) pool_free(groups); if (parts) (void) pool_free(parts); if (part_off) (void) pool_free(part_off); };
-    if (pool_malloc((void **) &cnt, sizeof(int) * (size_t) B * K) != hipSuccess || pool_malloc((void **) &groups, sizeof(int) * (size_t) B) != hipSuccess ||
-        pool_malloc((void **) &parts, sizeof(i32x2) * (size_t) B * kBlkParts) != hipSuccess || pool_malloc((void **) &part_off, sizeof(i32x2) * (size_t) B * kBlkParts) != hipSuccess) {
-        (void) hipGetLastError();
-        cleanup();
-        return fail(SPMV_HIP_E_ALLOC, "pool_malloc(block cells)");
-    }
-    ensure_lds<blk_count_kernel>(d, sizeof(unsigned) * (size_t) K);
-    blk_count_kernel<<<B, kBlkCountThreads, sizeof(unsigned) * (size_t) K, d->stream>>>(S.row0, K, S.wshift, S.dense_min, S.ge, S.nparts, S.S, d->rowptr, d->colidx, cnt, parts);
-    hipError_t e = hipGetLastError();
+    int *groups = nullptr;
+    unsigned short *rowin = nullptr;
+    auto cleanup = [&]() { if (groups) (void) pool_free(groups); if (rowin) (void) pool_free(rowin); };
+    hipError_t e = hipSuccess;
     if (!values_only) {
+        if (pool_malloc((void **) &groups, sizeof(int) * (size_t) B) != hipSuccess || pool_malloc((void **) &rowin, sizeof(unsigned short) * ((size_t) d->nnz + 8)) != hipSuccess) {
+            (void) hipGetLastError();
+            cleanup();
+            return fail(SPMV_HIP_E_ALLOC, "pool_malloc(block inspector scratch)");
+        }
+        ensure_lds<blk_rows_kernel>(d, sizeof(int) * ((size_t) S.R + 1));
+        blk_rows_kernel<<<B, kBlkThreads, sizeof(int) * ((size_t) S.R + 1), d->stream>>>(S.row0, d->rowptr, rowin);
+        ensure_lds<blk_count_kernel>(d, sizeof(unsigned) * (size_t) K);
+        blk_count_kernel<<<B, kBlkThreads, sizeof(unsigned) * (size_t) K, d->stream>>>(S.row0, K, S.wshift, S.ge, d->rowptr, d->colidx, groups);
+        e = hipGetLastError();
         int rc = dev_alloc(d, (void **) &S.gstart, sizeof(long long) * ((size_t) B + 1), true);
-        if (!rc) rc = dev_alloc(d, (void **) &S.dgroups, sizeof(int) * (size_t) B, true);
         if (!rc) rc = dev_alloc(d, (void **) &S.dir, sizeof(BlkDir) * (size_t) B, true);
         if (rc) { cleanup(); return rc; }
-    }
-    int *dg_scratch = nullptr; // values_only: the block directory exists; the layout pass only has to reproduce the part offsets
-    if (values_only && pool_malloc((void **) &dg_scratch, sizeof(int) * (size_t) B) != hipSuccess) { (void) hipGetLastError(); cleanup(); return fail(SPMV_HIP_E_ALLOC, "pool_malloc(block layout)"); }
-    blk_layout_kernel<<<grid_for(B, kBlock, INT_MAX), kBlock, 0, d->stream>>>(B, S.nparts, S.ge, parts, part_off, groups, values_only ? dg_scratch : S.dgroups);
-    if (e == hipSuccess) e = hipGetLastError();
-    if (!values_only) {
         scan_i32_to_i64_kernel<<<1, kBlock, 0, d->stream>>>(B, groups, S.gstart);
         long long total = 0;
-        std::vector<int> dg((size_t) B);
         if (e == hipSuccess) e = hipGetLastError();
         if (e == hipSuccess) e = hipMemcpyAsync(&total, S.gstart + B, sizeof(long long), hipMemcpyDeviceToHost, d->stream);
-        if (e == hipSuccess) e = hipMemcpyAsync(dg.data(), S.dgroups, sizeof(int) * (size_t) B, hipMemcpyDeviceToHost, d->stream);
         if (e == hipSuccess) e = hipStreamSynchronize(d->stream);
         if (e != hipSuccess) { cleanup(); return fail(SPMV_HIP_E_RUNTIME, "block inspector: %s", hipGetErrorString(e)); }
         S.groups = total;
-        S.dense_groups = 0;
-        for (int v : dg) S.dense_groups += v;
         if ((total + kBlkPadGroups) >> (31 - S.ge) > 0) { cleanup(); return fail(SPMV_HIP_E_RANGE, "blocked layout: %lld groups exceed 32-bit positions", total); }
         const size_t ng = (size_t) total + kBlkPadGroups, slots = ng << S.ge; // the executor loads up to three steps past a block's end, unguarded: keep that in bounds
-        int rc = dev_alloc(d, &S.val, sizeof(T) * slots, true);
+        rc = dev_alloc(d, &S.val, sizeof(T) * slots, true);
         if (!rc) rc = dev_alloc(d, (void **) &S.meta, sizeof(unsigned) * slots, true);
-        if (!rc) rc = dev_alloc(d, (void **) &S.hdr_a, sizeof(int) * ng, true);
-        if (!rc) rc = dev_alloc(d, (void **) &S.hdr_b, sizeof(int) * ng, true);
+        if (!rc) rc = dev_alloc(d, (void **) &S.hdr, sizeof(int) * ng, true);
         if (rc) { cleanup(); return rc; }
-        (void) hipMemsetAsync(S.val, 0, sizeof(T) * slots, d->stream);      // padding entries: value 0, column field 0,
+        (void) hipMemsetAsync(S.val, 0, sizeof(T) * slots, d->stream);      // padding entries: value 0, column offset 0,
         fill_value_kernel<unsigned><<<grid_for((long long) slots, kBlock * 4, d->cus * 16), kBlock, 0, d->stream>>>((long long) slots, S.meta, (unsigned) S.R << 16); // row = the junk accumulator
-        (void) hipMemsetAsync(S.hdr_a, 0, sizeof(int) * ng, d->stream);
-        (void) hipMemsetAsync(S.hdr_b, 0xff, sizeof(int) * ng, d->stream);  // -1: the group has no second slab
+        (void) hipMemsetAsync(S.hdr, 0, sizeof(int) * ng, d->stream);
     }
-    const size_t lds = sizeof(unsigned) * (2 * (size_t) S.range_cells + 128);
+    const size_t lds = sizeof(unsigned) * (size_t) K;
     if (values_only) {
         ensure_lds<blk_fill_kernel<T, true>>(d, lds);
-        blk_fill_kernel<T, true><<<B * S.nparts, kWave, lds, d->stream>>>(S.row0, K, S.wshift, S.dense_min, S.ge, S.nparts, S.S, S.range_cells, d->rowptr, d->colidx, (const T *) d->val,
-                                                                        cnt, part_off, S.gstart, S.dgroups, (T *) S.val, S.meta, S.hdr_a, S.hdr_b, S.dir);
+        blk_fill_kernel<T, true><<<B, kBlkThreads, lds, d->stream>>>(S.row0, K, S.wshift, S.ge, d->rowptr, d->colidx, (const T *) d->val, nullptr, S.gstart, (T *) S.val, S.meta, S.hdr, S.dir);
     } else {
         ensure_lds<blk_fill_kernel<T, false>>(d, lds);
-        blk_fill_kernel<T, false><<<B * S.nparts, kWave, lds, d->stream>>>(S.row0, K, S.wshift, S.dense_min, S.ge, S.nparts, S.S, S.range_cells, d->rowptr, d->colidx, (const T *) d->val,
-                                                                         cnt, part_off, S.gstart, S.dgroups, (T *) S.val, S.meta, S.hdr_a, S.hdr_b, S.dir);
+        blk_fill_kernel<T, false><<<B, kBlkThreads, lds, d->stream>>>(S.row0, K, S.wshift, S.ge, d->rowptr, d->colidx, (const T *) d->val, rowin, S.gstart, (T *) S.val, S.meta, S.hdr, S.dir);
     }
     if (e == hipSuccess) e = hipGetLastError();
     if (e == hipSuccess) e = hipStreamSynchronize(d->stream);
     cleanup();
-    if (dg_scratch) (void) pool_free(dg_scratch);
     if (e != hipSuccess) return fail(SPMV_HIP_E_RUNTIME, "block fill: %s", hipGetErrorString(e));
     return SPMV_HIP_OK;
 }
 
-// LDS of one executor workgroup: the block's accumulators (+ junk slot), and the slab buffers when the set has dense groups
-template <typename T>
-static size_t blocked_lds_bytes(const BlkSet &S)
-{
-    return sizeof(double) * (size_t) ((S.R + 2) & ~1) + (S.dense_groups > 0 ? sizeof(T) * (size_t) kBlkDenseUn * (2u << kBlkSlabShift) : 0);
-}
+// LDS of one executor workgroup: the block's accumulators + the junk slot
+static size_t blocked_lds_bytes(const BlkSet &S) { return sizeof(double) * (size_t) ((S.R + 2) & ~1); }
 
-// most rows of a block such that TWO blocks fit a CU's 160 KiB of LDS (78 KiB each), with / without slab buffers
-template <typename T>
-static int blocked_row_cap(bool dense)
-{
-    const size_t budget = 78 * 1024 - (dense ? sizeof(T) * (size_t) kBlkDenseUn * (2u << kBlkSlabShift) : 0);
-    return (int) (budget / sizeof(double)) - 2;
-}
+constexpr int kBlkRowCap = 78 * 1024 / (int) sizeof(double) - 2; // most rows of a block such that TWO blocks fit a CU's 160 KiB of LDS (78 KiB each)
 
 // How many row blocks, and how many rows at most in one.  rule 0 (first choice): FULL ROUNDS of fat blocks -- two blocks are
 // resident per CU (2 x 78 KiB of its 160 KiB of LDS), so the block count is a multiple of 2 * CUs with at most rmax rows each:
@@ -517,8 +493,8 @@ static void blocked_block_rule(const spmv_dev *d, int rule, int rmax, int *btarg
 static bool blocked_differs(const spmv_dev *d)
 {
     int b0, r0, b1, r1;
-    blocked_block_rule(d, 0, 9982, &b0, &r0);
-    blocked_block_rule(d, 1, 9982, &b1, &r1);
+    blocked_block_rule(d, 0, kBlkRowCap, &b0, &r0);
+    blocked_block_rule(d, 1, kBlkRowCap, &b1, &r1);
     return b0 != b1;
 }
 
@@ -527,7 +503,6 @@ static int blocked_partition(spmv_dev *d, int btarget, int rcap)
 {
     BlkSet &S = d->blk;
     const size_t cap_blocks = (size_t) btarget + (size_t) (d->m / rcap) + 2;
-    if (S.row0) sched_free(d, S.row0);
     int rc = dev_alloc(d, (void **) &S.row0, sizeof(int) * (cap_blocks + 1), true);
     if (rc) return rc;
     int B = btarget, R = rcap;
@@ -560,9 +535,9 @@ static int build_blocked(spmv_dev *d, int rule)
 {
     BlkSet &S = d->blk;
     S = BlkSet();
-    // Slab width: 128 columns (the unit the dense part stages in LDS; narrow slabs also put entries that gather from the
-    // same cache line into neighbouring lanes, which the L1/TA path merges into one L2 request), wider only when a block
-    // would have more than 32768 cells (the count kernel's LDS histogram), or by option slab_kib.
+    // Slab width: 128 columns, wider only when a block would have more than 32768 cells (the inspector's cursors live in LDS),
+    // or by option slab_kib.  Entries that share an executor instruction are 64 consecutive ones of the (slab, CSR) order, so what a
+    // narrow slab buys is that the few entries a block has in the same cache line of x end up in the same instruction and merge.
     int wshift = kBlkSlabShift;
     if (d->plan.slab_kib > 0) {
         wshift = 0;
@@ -572,49 +547,87 @@ static int build_blocked(spmv_dev *d, int rule)
     if (wshift > kBlkSuperShift) wshift = kBlkSuperShift;
     S.wshift = wshift;
     S.K = (int) ((((long long) d->n - 1) >> wshift) + 1);
-    S.S = (int) ((((long long) d->n - 1) >> kBlkSuperShift) + 1);
-    S.nparts = S.S < kBlkParts ? S.S : kBlkParts;
     S.ge = sizeof(T) == 8 ? 7 : 8; // 64 lanes x 16 bytes of values
-    // dense cells: at least one group's worth of entries in 128 columns (option dense_cells = 0: none, > 1: that many)
-    S.dense_min = INT_MAX;
-    if (wshift == kBlkSlabShift && d->n >= 512 && d->plan.dense_cells != 0)
-        S.dense_min = d->plan.dense_cells > (1 << S.ge) ? d->plan.dense_cells : 1 << S.ge;
-    S.range_cells = std::min(S.K, ((S.S + S.nparts - 1) / S.nparts) << (kBlkSuperShift - wshift));
-    int rc = SPMV_HIP_OK;
-    for (int pass = 0; pass < 2; ++pass) {
-        // pass 0 assumes no dense groups (fattest blocks); if dense groups turn up and the blocks are too fat to leave room
-        // for the slab buffers, the rows are cut again under the smaller cap
-        int btarget = 1, rcap = 1024;
-        blocked_block_rule(d, rule, blocked_row_cap<T>(pass == 1), &btarget, &rcap);
-        rc = blocked_partition(d, btarget, rcap);
-        if (rc) return rc;
-        if (pass == 1) { // drop the first pass's streams
-            for (void *p : {(void *) S.gstart, (void *) S.dgroups, (void *) S.dir, S.val, (void *) S.meta, (void *) S.hdr_a, (void *) S.hdr_b}) if (p) sched_free(d, p);
-            S.gstart = nullptr; S.dgroups = nullptr; S.dir = nullptr; S.val = nullptr; S.meta = nullptr; S.hdr_a = S.hdr_b = nullptr;
-        }
-        rc = blocked_fill<T>(d, false);
-        if (rc) return rc;
-        if (S.dense_groups == 0 || blocked_lds_bytes<T>(S) <= 80 * 1024 || d->plan.block_rows > 0) break;
-    }
+    int btarget = 1, rcap = 1024;
+    blocked_block_rule(d, rule, kBlkRowCap, &btarget, &rcap);
+    int rc = blocked_partition(d, btarget, rcap);
+    if (!rc) rc = blocked_fill<T>(d, false);
+    if (rc) return rc;
     d->blk_on = true;
     return SPMV_HIP_OK;
 }
 
-// Does the schedule just built gather x from L1/L2 although x is far larger than an L2?  Then every gather
-// crosses the fabric (8 % of roofline): switch the executor (option "cache_block": 1 automatic, 2 always).
-static bool wants_blocked(const spmv_dev *d, int staged_groups)
+// Is the matrix large enough for the row-block x column-slab executor to pay?  From which x size on?  Uniformly random columns,
+// 16 nnz/row (tools/ab_threshold.py): the blocked executor wins as soon as x reaches one XCD's L2 -- fp64, x = 4 / 8 / 16 / 32 MB:
+// 49 / 94 / 180 / 352 us against 55-62 / 157-168 / 434-450 / 1030-1050 us on the tile kernels (all four of them); at 2 MB the tile
+// kernels lead (45 vs 50 us).  With very short rows the per-row work of a block (zeroing and writing its y) weighs more: the
+// 1e6-row power-law stand-in (2.6 nnz/row) at x = 8 / 16 / 32 MB (tools/ab_short_rows.py): tile 26.8 / 50.4 / 98.4 us against
+// blocked 28.0 / 46.9 / 77.4 (R-MAT columns), 21.9 / 41.3 / 76.1 against 25.0 / 36.2 / 58.2 (web-like), 38.2 / 90.9 / 201 against
+// 37.2 / 64.5 / 121 (uniform) -> 12 MiB there.
+static bool blocked_size_ok(const spmv_dev *d)
 {
-    if (d->plan.cache_block == 2) return d->nnz > 0;
-    if (d->plan.variant == 3) return false; // A/B: the tile executors with global gathers
-    // From which x size on?  Uniformly random columns, 16 nnz/row (tools/ab_threshold.py): the blocked executor wins as
-    // soon as x reaches one XCD's L2 -- fp64, x = 4 / 8 / 16 / 32 MB: 49 / 94 / 180 / 352 us against 55-62 / 157-168 /
-    // 434-450 / 1030-1050 us on the tile kernels (all four of them); at 2 MB the tile kernels lead (45 vs 50 us).  With
-    // very short rows the per-row work of a block (zeroing and writing its y) weighs more: the 1e6-row power-law
-    // stand-in (2.6 nnz/row) at x = 8 / 16 / 32 MB (tools/ab_short_rows.py, three-stage executor forms): tile 26.8 / 50.4 / 98.4 us
-    // against blocked 28.0 / 46.9 / 77.4 (R-MAT columns), 21.9 / 41.3 / 76.1 against 25.0 / 36.2 / 58.2 (web-like), 38.2 / 90.9 /
-    // 201 against 37.2 / 64.5 / 121 (uniform) -> 12 MiB there.
     const long long min_x = d->stats.mean_row_len >= 8.0 ? (4ll << 20) : (12ll << 20);
-    return d->plan.cache_block == 1 && staged_groups == 0 && d->nnz >= (1ll << 21) && (long long) d->n * (long long) d->vsize >= min_x;
+    return d->nnz >= (1ll << 21) && (long long) d->n * (long long) d->vsize >= min_x;
+}
+
+// The tile schedule just built stages `staged` of its `groups` tile groups' x windows in LDS; the others gather x through
+// L1/L2 -- across the fabric when x is far larger than an L2 (8 % of roofline).  Who multiplies?  0: the tile schedule,
+// 1: row blocks x column slabs, 2: build both and let create() time them (option "cache_block": 1 automatic, 2 always, 0 never).
+// Round 2's rule was staged == 0, which left a random-column matrix with ONE stageable group among 39 063 on the 6 ms kernels.
+static int blocked_mode(const spmv_dev *d, int staged, int groups)
+{
+    if (d->plan.cache_block == 2) return d->nnz > 0 ? 1 : 0;
+    if (d->plan.cache_block != 1 || d->plan.variant == 3) return 0; // variant 3: A/B, the tile executors with global gathers
+    if (!blocked_size_ok(d) || groups <= 0 || staged >= groups) return 0;
+    if ((long long) staged * 2 < groups) return 1;                   // most groups gather globally: no contest (the tile inspectors do not even stage the rest then)
+    if ((long long) (groups - staged) * 200 < groups) return 0;      // under 0.5 % of the groups: at most a few percent of the time
+    return d->plan.autotune ? 2 : ((long long) (groups - staged) * 10 >= groups ? 1 : 0); // without timing: from 10 % on
+}
+
+// Sample before building anything: 64 windows of 4096 consecutive non-zeros, evenly spaced.  A window "has no locality" when
+// its entries touch so many distinct 64-column segments of x that not even the largest LDS budget (128 KiB) could hold them,
+// and more than a third of its entries sit in a segment of their own.  If (nearly) every window says so, no tile schedule will
+// stage anything and its inspector products (windows, CSR5 transposes, SELL slabs) would be built only to be dropped.
+__global__ __launch_bounds__(kBlock) void locality_sample_kernel(long long nnz, int windows, int wlen, const int *__restrict__ colidx, int seg_limit, int *__restrict__ hopeless)
+{
+    constexpr int kSlots = 8192; // open-addressing set of segment ids, 2 x the window length
+    __shared__ int set[kSlots];
+    __shared__ int distinct;
+    for (int i = threadIdx.x; i < kSlots; i += kBlock) set[i] = -1;
+    if (threadIdx.x == 0) distinct = 0;
+    __syncthreads();
+    const long long start = windows > 1 ? (nnz - wlen) / (windows - 1) * blockIdx.x : 0;
+    int mine = 0;
+    for (int i = threadIdx.x; i < wlen; i += kBlock) {
+        const int seg = colidx[start + i] >> 6;
+        unsigned h = ((unsigned) seg * 2654435761u) >> 19; // 13 bits
+        for (;;) {
+            const int prev = atomicCAS(&set[h], -1, seg);
+            if (prev == -1) { ++mine; break; }
+            if (prev == seg) break;
+            h = (h + 1) & (kSlots - 1);
+        }
+    }
+    if (mine) atomicAdd(&distinct, mine);
+    __syncthreads();
+    if (threadIdx.x == 0 && distinct > seg_limit && distinct * 3 > wlen) atomicAdd(hopeless, 1);
+}
+
+static bool sample_says_no_locality(spmv_dev *d)
+{
+    constexpr int kWindows = 64, kLen = 4096;
+    if (d->nnz < (long long) kWindows * kLen * 4) return false;
+    int *cnt = nullptr, h = 0;
+    if (pool_malloc((void **) &cnt, sizeof(int)) != hipSuccess) { (void) hipGetLastError(); return false; }
+    hipError_t e = hipMemsetAsync(cnt, 0, sizeof(int), d->stream);
+    const int seg_limit = (int) (kCsr5XTileBytes / d->vsize / 64); // segments the largest x-window budget holds
+    locality_sample_kernel<<<kWindows, kBlock, 0, d->stream>>>(d->nnz, kWindows, kLen, d->colidx, seg_limit, cnt);
+    if (e == hipSuccess) e = hipGetLastError();
+    if (e == hipSuccess) e = hipMemcpyAsync(&h, cnt, sizeof(int), hipMemcpyDeviceToHost, d->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(d->stream);
+    (void) pool_free(cnt);
+    if (e != hipSuccess) { (void) hipGetLastError(); return false; }
+    return h * 16 >= kWindows * 15; // 15 of 16 windows
 }
 
 // ------------------------------------------------------------------------------------ traffic model
@@ -675,8 +688,8 @@ static int account_stream_bytes(spmv_dev *d)
     const long long s = (long long) d->vsize, m = d->m, n = d->n;
     Traffic t;
     int rc = SPMV_HIP_OK;
-    if (d->blk_on) { // value + (column | row) word per stored entry, the group headers (dense: two), the block directory, y once
-        t.bytes = (d->blk.groups << d->blk.ge) * (s + 4) + 4ll * (d->blk.groups + d->blk.dense_groups) + (long long) (sizeof(BlkDir) + 8) * d->blk.B + s * m;
+    if (d->blk_on) { // value + (column | row) word per stored entry, the group headers, the block directory, y once
+        t.bytes = (d->blk.groups << d->blk.ge) * (s + 4) + 4ll * d->blk.groups + (long long) (sizeof(BlkDir) + 8) * d->blk.B + s * m;
         t.gathers_global = true;
     } else {
         switch (d->plan.sched) {

@@ -110,44 +110,36 @@ static int autotune_vector(spmv_dev *d)
     return SPMV_HIP_OK;
 }
 
-// Row blocks x column slabs (kernels/blocked.hpp): one single-wave workgroup per row block.  Forms = groups per step of
-// the sparse loop: 4 / 8 / 12 (d->blk.form 0 / 1 / 2, chosen by autotune_blocked; option variant 29 / 35 / 37 forces one --
-// all three add the same products in the same order: tests compare their bits).
+// Row blocks x column slabs (kernels/blocked.hpp): one single-wave workgroup per row block.  Forms = groups per pipeline
+// step: 8 / 12 (d->blk.form 0 / 1, chosen by autotune_blocked; option variant 35 / 37 forces one -- both add the same products
+// in the same order: tests compare their bits).  4 groups per step lost everywhere (Orkut-style 0.82 vs 0.58-0.63 ms) and is gone.
 template <typename T>
 static void launch_blocked(spmv_dev *d, const T *x, T *y)
 {
     const BlkSet &S = d->blk;
-    const size_t lds = blocked_lds_bytes<T>(S);
-#define SPMV_BLK_LAUNCH(UN)                                                                                                       \
+    const size_t lds = blocked_lds_bytes(S);
+#define SPMV_BLK_LAUNCH(UN, DBG)                                                                                                  \
     do {                                                                                                                          \
-        ensure_lds<blk_kernel<T, UN>>(d, lds);                                                                                    \
-        blk_kernel<T, UN><<<S.B, kWave, lds, d->stream>>>(S.row0, S.R, S.dir, (const T *) S.val, S.meta, S.hdr_a, S.hdr_b, x, d->n, y); \
+        ensure_lds<blk_kernel<T, UN, DBG>>(d, lds);                                                                               \
+        blk_kernel<T, UN, DBG><<<S.B, kWave, lds, d->stream>>>(S.row0, S.R, S.dir, (const T *) S.val, S.meta, S.hdr, x, y);       \
     } while (0)
 #ifdef SPMV_BLK_DEBUG_FORMS // A/B builds of tools/ only (wrong results): variant 51 / 52 / 53 = no gathers / no LDS adds / neither, 8 groups per step
-#define SPMV_BLK_DBG_LAUNCH(DBG)                                                                                                  \
-    do {                                                                                                                          \
-        ensure_lds<blk_kernel<T, 8, DBG>>(d, lds);                                                                                \
-        blk_kernel<T, 8, DBG><<<S.B, kWave, lds, d->stream>>>(S.row0, S.R, S.dir, (const T *) S.val, S.meta, S.hdr_a, S.hdr_b, x, d->n, y); \
-    } while (0)
-    if (d->plan.variant == 51) { SPMV_BLK_DBG_LAUNCH(1); return; }
-    if (d->plan.variant == 52) { SPMV_BLK_DBG_LAUNCH(2); return; }
-    if (d->plan.variant == 53) { SPMV_BLK_DBG_LAUNCH(3); return; }
-#undef SPMV_BLK_DBG_LAUNCH
+    if (d->plan.variant == 51) { SPMV_BLK_LAUNCH(8, 1); return; }
+    if (d->plan.variant == 52) { SPMV_BLK_LAUNCH(8, 2); return; }
+    if (d->plan.variant == 53) { SPMV_BLK_LAUNCH(8, 3); return; }
 #endif
-    const int form = d->plan.variant == 29 ? 0 : (d->plan.variant == 35 ? 1 : (d->plan.variant == 37 ? 2 : S.form));
-    if (form == 0) SPMV_BLK_LAUNCH(4);
-    else if (form == 2) SPMV_BLK_LAUNCH(12);
-    else SPMV_BLK_LAUNCH(8);
+    const int form = d->plan.variant == 35 ? 0 : (d->plan.variant == 37 ? 1 : S.form);
+    if (form == 1) SPMV_BLK_LAUNCH(12, 0);
+    else SPMV_BLK_LAUNCH(8, 0);
 #undef SPMV_BLK_LAUNCH
 }
 
-// Time the three executor forms on the resident streams (x = 1: the gather pattern does not depend on the values) and keep
-// the fastest: the three-stage forms win where the gathers dominate (config 2-ii 2.00 -> 1.75 ms, Orkut-style 0.85 -> 0.73 /
-// 1.26 -> 1.05), the two-stage form where the stream does (web-like 4e6 x 24: 0.257 vs 0.27).
+// Time the executor forms on the resident streams (x = 1: the gather pattern does not depend on the values) and keep the faster.
 template <typename T>
 static int autotune_blocked(spmv_dev *d)
 {
-    d->blk.form = 1;
+    d->blk.form = 0;
+    d->blk.tune_ms[0] = d->blk.tune_ms[1] = d->blk.tune_ms[2] = 0;
     if (!d->blk_on || !d->plan.autotune || d->plan.variant != 0) return SPMV_HIP_OK;
     T *x = nullptr, *y = nullptr;
     if (pool_malloc((void **) &x, sizeof(T) * (size_t) d->n) != hipSuccess || pool_malloc((void **) &y, sizeof(T) * (size_t) d->m) != hipSuccess) {
@@ -159,10 +151,11 @@ static int autotune_blocked(spmv_dev *d)
     hipEvent_t e0, e1;
     (void) hipEventCreate(&e0);
     (void) hipEventCreate(&e1);
-    float tmin[3] = {1e30f, 1e30f, 1e30f};
-    for (int f = 0; f < 3; ++f) { d->blk.form = f; launch_blocked<T>(d, x, y); } // warm every form once
-    for (int round = 0; round < 5; ++round) // interleaved rounds: min per form (three rounds once picked the slow form on config 2-ii)
-        for (int f = 0; f < 3; ++f) {
+    constexpr int kForms = 2;
+    float tmin[kForms] = {1e30f, 1e30f};
+    for (int f = 0; f < kForms; ++f) { d->blk.form = f; launch_blocked<T>(d, x, y); } // warm every form once
+    for (int round = 0; round < 4; ++round) // interleaved rounds: min per form
+        for (int f = 0; f < kForms; ++f) {
             d->blk.form = f;
             (void) hipEventRecord(e0, d->stream);
             launch_blocked<T>(d, x, y);
@@ -172,14 +165,14 @@ static int autotune_blocked(spmv_dev *d)
             (void) hipEventElapsedTime(&ms, e0, e1);
             if (ms < tmin[f]) tmin[f] = ms;
         }
-    int best = 1;
-    for (int f = 0; f < 3; ++f) { d->blk.tune_ms[f] = tmin[f]; if (tmin[f] < tmin[best]) best = f; }
+    int best = 0;
+    for (int f = 0; f < kForms; ++f) { d->blk.tune_ms[f] = tmin[f]; if (tmin[f] < tmin[best]) best = f; }
     d->blk.form = best;
     (void) hipEventDestroy(e0);
     (void) hipEventDestroy(e1);
     (void) pool_free(x);
     (void) pool_free(y);
-    if (hipGetLastError() != hipSuccess) d->blk.form = 1;
+    if (hipGetLastError() != hipSuccess) d->blk.form = 0;
     return SPMV_HIP_OK;
 }
 
@@ -334,4 +327,37 @@ static int launch(spmv_dev *d, const T *x, T *y)
     }
     HIP_TRY(hipGetLastError());
     return SPMV_HIP_OK;
+}
+
+// min over `iters` launches of the schedule as built, on scratch vectors (x = 1), in ms; < 0 if it cannot be timed
+template <typename T>
+static double time_schedule(spmv_dev *d, int iters)
+{
+    T *x = nullptr, *y = nullptr;
+    if (pool_malloc((void **) &x, sizeof(T) * (size_t) (d->n > 0 ? d->n : 1)) != hipSuccess || pool_malloc((void **) &y, sizeof(T) * (size_t) (d->m > 0 ? d->m : 1)) != hipSuccess) {
+        (void) hipGetLastError();
+        if (x) (void) pool_free(x);
+        return -1.0;
+    }
+    fill_value_kernel<T><<<grid_for(d->n, kBlock, d->cus * 8), kBlock, 0, d->stream>>>(d->n, x, T(1));
+    hipEvent_t e0, e1;
+    (void) hipEventCreate(&e0);
+    (void) hipEventCreate(&e1);
+    float best = 1e30f;
+    int rc = launch<T>(d, x, y); // warm
+    for (int i = 0; i < iters && !rc; ++i) {
+        (void) hipEventRecord(e0, d->stream);
+        rc = launch<T>(d, x, y);
+        (void) hipEventRecord(e1, d->stream);
+        (void) hipEventSynchronize(e1);
+        float ms = 0;
+        (void) hipEventElapsedTime(&ms, e0, e1);
+        best = ms < best ? ms : best;
+    }
+    (void) hipEventDestroy(e0);
+    (void) hipEventDestroy(e1);
+    (void) pool_free(x);
+    (void) pool_free(y);
+    if (rc || hipGetLastError() != hipSuccess) return -1.0;
+    return (double) best;
 }

@@ -161,17 +161,16 @@ struct Csr5Plan {
 // One row-block x column-slab layout (kernels/blocked.hpp; built by build_blocked).
 struct BlkSet {
     int R = 0, K = 0, B = 0, wshift = kBlkSlabShift; // most rows of a block (= the junk accumulator's slot), slabs, blocks, log2(columns per slab)
-    int S = 1, nparts = 1, ge = 7, dense_min = INT_MAX, range_cells = 0; // super-slabs, column ranges of the fill, log2(entries per group), dense-cell threshold
-    int form = 1;                 // executor form: groups per step of the sparse loop 4 / 8 / 12 (launch_blocked; chosen by autotune_blocked)
+    int ge = 7;                   // log2(entries per group)
+    int form = 0;                 // executor form: 0 / 1 = 8 / 12 groups per step (launch_blocked; chosen by autotune_blocked)
     float tune_ms[3] = {0, 0, 0};
-    long long groups = 0, dense_groups = 0; // groups stored (without the padding behind the last block), of which dense
+    long long groups = 0;         // groups stored (without the padding behind the last block)
     int *row0 = nullptr;          // [B + 1] first row of every block (equal-work cut points, blk_partition_kernel)
     long long *gstart = nullptr;  // [B + 1] first group of every block
-    int *dgroups = nullptr;       // [B] dense groups of every block
     BlkDir *dir = nullptr;        // [B] what the executor reads
     void *val = nullptr;
-    unsigned *meta = nullptr;     // 16-bit column field | 16-bit row in the block
-    int *hdr_a = nullptr, *hdr_b = nullptr; // per group: dense: slabs A and B (B < 0: none); sparse: first column of the super-slab
+    unsigned *meta = nullptr;     // 16-bit column offset | 16-bit row in the block
+    int *hdr = nullptr;           // per group: first column of its super-slab
 };
 
 struct spmv_dev {
@@ -225,6 +224,7 @@ struct spmv_dev {
     void *x_stage = nullptr, *y_stage = nullptr, *scratch8 = nullptr;
     long long stream_bytes = 0, x_bytes = 0; // traffic model of one launch (account_stream_bytes)
     int x_groups_seen = 0;                   // tile groups analysed before the blocked executor took over
+    float route_ms[2] = {0, 0};              // measured tile schedule vs blocked executor (spmv_shim_build, mode 2)
     long long device_bytes = 0;
     double inspect_ms = 0;
     std::vector<std::pair<void *, size_t>> sched_allocs; // (pointer, bytes): freed when the schedule is rebuilt

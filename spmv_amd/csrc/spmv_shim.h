@@ -46,7 +46,6 @@ typedef struct spmv_plan {
     int sell_c, sell_sigma, sell_lds_x, sell_long_thr;
     int csr5_sigma;
     int slab_kib, block_rows; /* row-block x column-slab executor shape (0 = defaults) */
-    int dense_cells;    /* ... dense cells read x through LDS: 0 no, 1 yes, > 1 = entries a cell needs */
     int cache_block;    /* nnz-split family: 0 never, 1 automatic, 2 always use the row-block x column-slab executor */
     int rowblock_nnz;
     int variant;

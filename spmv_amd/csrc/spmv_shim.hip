@@ -161,11 +161,21 @@ extern "C" int spmv_shim_build(spmv_dev *d, const spmv_plan *plan)
     if (plan->sched < 0 || plan->sched >= SPMV_SCHED_COUNT) return fail(SPMV_HIP_E_ARG, "unknown schedule %d", plan->sched);
     free_schedule(d);
     d->plan = *plan;
+    d->route_ms[0] = d->route_ms[1] = 0;
     const auto t0 = std::chrono::steady_clock::now();
     int rc = SPMV_HIP_OK, staged = -1; // staged: tile groups with x windows in LDS (-1: schedule without windows)
     const bool f64 = d->vsize == sizeof(double);
     DeviceGuard guard(d->device);
     if (!guard.ok) return fail(SPMV_HIP_E_RUNTIME, "hipSetDevice(%d) failed", d->device);
+    int groups = 0;                    // ... out of this many
+    // Decided before anything is built: the blocked executor multiplies whatever the tile schedule would look like (option
+    // cache_block = 2), or a sample of the columns shows that no tile group could stage its x windows -- then the tile schedule's
+    // inspector is skipped altogether (round 2 built windows / CSR5 transposes / SELL slabs and dropped them: 40-80 ms for 3e8 nnz).
+    bool tiles = true;
+    if (plan->sched != SPMV_SCHED_CSR_SCALAR && d->nnz > 0 && plan->variant != 3 &&
+        (plan->cache_block == 2 || (plan->cache_block == 1 && blocked_size_ok(d) && !(plan->sched == SPMV_SCHED_SELL && !plan->sell_lds_x) && sample_says_no_locality(d))))
+        tiles = false;
+    if (tiles)
     switch (plan->sched) {
     case SPMV_SCHED_CSR_SCALAR: break;
     case SPMV_SCHED_CSR_VECTOR: {
@@ -177,7 +187,8 @@ extern "C" int spmv_shim_build(spmv_dev *d, const spmv_plan *plan)
         rc = f64 ? build_long_rows<double>(d, thr) : build_long_rows<float>(d, thr);
         if (!rc) rc = f64 ? build_vector_tiles<double>(d) : build_vector_tiles<float>(d);
         staged = d->vt_staged;
-        if (!rc && plan->autotune && !wants_blocked(d, staged)) rc = f64 ? autotune_vector<double>(d) : autotune_vector<float>(d);
+        groups = d->vt_tiles;
+        if (!rc && plan->autotune && blocked_mode(d, staged, groups) != 1) rc = f64 ? autotune_vector<double>(d) : autotune_vector<float>(d);
         break;
     }
     case SPMV_SCHED_NNZ_SPLIT:
@@ -185,6 +196,7 @@ extern "C" int spmv_shim_build(spmv_dev *d, const spmv_plan *plan)
         rc = f64 ? build_csr5<double>(d, d->ns, d->m, d->nnz, d->rowptr, d->colidx, (const double *) d->val, d->stats.empty_rows, d->stats.mean_row_len, nullptr, true)
                  : build_csr5<float>(d, d->ns, d->m, d->nnz, d->rowptr, d->colidx, (const float *) d->val, d->stats.empty_rows, d->stats.mean_row_len, nullptr, true);
         staged = d->ns.staged;
+        groups = d->ns.groups;
         break;
     case SPMV_SCHED_ROWBLOCK:
         if (plan->rowblock_nnz < 64) return fail(SPMV_HIP_E_ARG, "rowblock_nnz must be >= 64");
@@ -192,38 +204,57 @@ extern "C" int spmv_shim_build(spmv_dev *d, const spmv_plan *plan)
         rc = build_rowblock(d);
         if (!rc) rc = f64 ? build_rowblock_tiles<double>(d) : build_rowblock_tiles<float>(d);
         staged = d->vt_staged;
+        groups = d->vt_tiles;
         break;
     case SPMV_SCHED_SELL:
         rc = f64 ? build_sell<double>(d) : build_sell<float>(d);
         staged = d->plan.sell_lds_x ? d->sell_staged : -1; // sell_lds_x = 0: the caller asked for the plain slab kernel
+        groups = d->sell_nwin;
         break;
     case SPMV_SCHED_CSR5:
         rc = f64 ? build_csr5<double>(d, d->c5, d->m, d->nnz, d->rowptr, d->colidx, (const double *) d->val, d->stats.empty_rows, d->stats.mean_row_len, nullptr)
                  : build_csr5<float>(d, d->c5, d->m, d->nnz, d->rowptr, d->colidx, (const float *) d->val, d->stats.empty_rows, d->stats.mean_row_len, nullptr);
         staged = d->c5.staged;
+        groups = d->c5.groups;
         break;
     }
-    // Columns without locality (no tile group's x windows fit LDS) and x far larger than an L2: every gather of
-    // the tile executors crosses the fabric -> row blocks x column slabs (kernels/blocked.hpp) take over the
-    // multiply, whatever the method (CSR-scalar, the debug kernel, excepted).  The tile schedule's products are
-    // released once the blocked streams exist.
-    if (!rc && staged >= 0 && wants_blocked(d, staged)) {
+    // Columns without locality (tile groups whose x windows do not fit LDS) and x far larger than an L2: every gather of such a
+    // group crosses the fabric -> row blocks x column slabs (kernels/blocked.hpp) take over the multiply, whatever the method
+    // (CSR-scalar, the debug kernel, excepted).  When only PART of the groups stage, both executors exist for a moment and create()
+    // keeps the one that multiplies faster (the share of unstaged groups at which the blocked executor wins depends on what the
+    // staged part looks like: 2-15 %).  The loser's products are released.
+    const int mode = !tiles ? 1 : (!rc && staged >= 0 ? blocked_mode(d, staged, groups) : 0);
+    if (!rc && mode) {
         const size_t keep_from = d->sched_allocs.size();
-        d->x_groups_seen = plan->sched == SPMV_SCHED_NNZ_SPLIT ? d->ns.groups : (plan->sched == SPMV_SCHED_CSR5 ? d->c5.groups : (plan->sched == SPMV_SCHED_SELL ? d->sell_nwin : d->vt_tiles));
+        d->x_groups_seen = groups;
+        double tile_ms = -1.0;
+        if (mode == 2) tile_ms = f64 ? time_schedule<double>(d, 5) : time_schedule<float>(d, 5);
         rc = f64 ? build_blocked<double>(d, 0) : build_blocked<float>(d, 0);
-        if (!rc && d->blk_on) drop_tile_schedule(d, keep_from);
         if (!rc && d->blk_on) rc = f64 ? autotune_blocked<double>(d) : autotune_blocked<float>(d);
+        if (!rc && d->blk_on && mode == 2) {
+            const double blk_ms = d->blk.tune_ms[1] > 0 && d->blk.tune_ms[1] < d->blk.tune_ms[0] ? d->blk.tune_ms[1] : d->blk.tune_ms[0];
+            d->route_ms[0] = (float) tile_ms;
+            d->route_ms[1] = (float) blk_ms;
+            if (tile_ms > 0 && (blk_ms <= 0 || tile_ms <= blk_ms)) { // the tile schedule stays
+                const BlkSet b = d->blk;
+                quiesce(d);
+                for (void *p : {(void *) b.row0, (void *) b.gstart, (void *) b.dir, b.val, (void *) b.meta, (void *) b.hdr}) if (p) sched_free(d, p);
+                d->blk = BlkSet();
+                d->blk_on = false;
+            }
+        }
+        if (!rc && d->blk_on) drop_tile_schedule(d, keep_from);
         // Stream-bound under rule 0 (the streams alone move >= 3.6 TB/s; web-like 4e6 x 24 in fp32 sits at 4.2)?  Then thinner blocks may do better: build the
         // rule-1 set next to this one, time it, keep the faster (one more inspector pass, only for such matrices).
         if (!rc && d->blk_on && plan->autotune && plan->variant == 0 && plan->block_rows == 0 && d->nnz >= (1ll << 22) &&
             blocked_differs(d)) {
-            auto best_of = [](const BlkSet &b) { float t = b.tune_ms[0]; for (int f = 1; f < 3; ++f) t = b.tune_ms[f] < t ? b.tune_ms[f] : t; return t; };
+            auto best_of = [](const BlkSet &b) { return b.tune_ms[1] > 0 && b.tune_ms[1] < b.tune_ms[0] ? b.tune_ms[1] : b.tune_ms[0]; };
             const float best0 = best_of(d->blk);
             const double rate = best0 > 0 ? (double) d->nnz * ((double) d->vsize + 4.0) / ((double) best0 * 1e-3) : 0.0;
             if (rate >= 3.6e12) {
                 auto release = [&](const BlkSet &b) {
                     quiesce(d);
-                    for (void *p : {(void *) b.row0, (void *) b.gstart, (void *) b.dgroups, (void *) b.dir, b.val, (void *) b.meta, (void *) b.hdr_a, (void *) b.hdr_b}) if (p) sched_free(d, p);
+                    for (void *p : {(void *) b.row0, (void *) b.gstart, (void *) b.dir, b.val, (void *) b.meta, (void *) b.hdr}) if (p) sched_free(d, p);
                 };
                 const BlkSet first = d->blk;
                 d->blk_on = false;
@@ -480,7 +511,7 @@ extern "C" int spmv_shim_info(const spmv_dev *d, spmv_hip_info *o)
     const long long s = (long long) d->vsize;
     o->alg_bytes = 4ll * ((long long) d->m + 1) + d->nnz * (4 + s) + s * d->n + s * d->m;
     o->inspect_ms = d->inspect_ms;
-    o->tuned_choice = d->blk_on ? 100 + d->blk.form : d->vec_choice; // cache_blocked: 100 / 101 / 102 = 4 / 8 / 12 groups per step
+    o->tuned_choice = d->blk_on ? 100 + d->blk.form : d->vec_choice; // cache_blocked: 100 / 101 = 8 / 12 groups per step
     for (int k = 0; k < 3; ++k) o->tune_ms[k] = d->blk_on ? d->blk.tune_ms[k] : d->tune_ms[k];
     o->schedule_name = kSchedNames[d->plan.sched];
     o->kernel_name = kKernelNames[d->plan.sched];
@@ -491,6 +522,8 @@ extern "C" int spmv_shim_info(const spmv_dev *d, spmv_hip_info *o)
     o->cache_blocked = d->blk_on ? 1 : 0;
     o->stream_bytes = d->stream_bytes;
     o->x_bytes = d->x_bytes;
+    o->route_ms[0] = d->route_ms[0];
+    o->route_ms[1] = d->route_ms[1];
     if (d->blk_on) { o->stored_nnz = d->blk.groups << d->blk.ge; o->x_groups = d->x_groups_seen; o->x_groups_staged = 0; }
     if (!d->blk_on) switch (d->plan.sched) {
     case SPMV_SCHED_CSR_VECTOR:

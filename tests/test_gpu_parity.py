@@ -532,8 +532,8 @@ def test_blocked_executor_equal_work_cut_points_on_a_lopsided_matrix(method):
 
 @pytest.mark.parametrize("dtype", [np.float64, np.float32])
 def test_blocked_executor_forms_give_the_same_bits_and_create_picks_one_by_timing(dtype):
-    """The row-block executor runs 4, 8 or 12 groups per pipeline step (blocked.hpp: blk_kernel<T, UN>); create() times
-    the three forms and keeps the fastest (info.tuned_choice 100 / 101 / 102, info.tune_ms).  They issue the same
+    """The row-block executor runs 8 or 12 groups per pipeline step (blocked.hpp: blk_kernel<T, UN>); create() times
+    the two forms and keeps the faster (info.tuned_choice 100 / 101, info.tune_ms).  They issue the same
     additions in the same order, so on inexact data every form -- and hence whichever one a handle happened to pick --
     gives the same bits; power-law rows with hubs make blocks of very different lengths (partial last steps)."""
     import torch
@@ -548,14 +548,14 @@ def test_blocked_executor_forms_give_the_same_bits_and_create_picks_one_by_timin
     ys = {}
     try:
         api.set_option("cache_block", 2)
-        for variant in (0, 29, 35, 37):
+        for variant in (0, 35, 37):
             api.set_option("variant", variant)
             y = torch.full((m,), float("nan"), dtype=tdt, device=dev)
             with api.Handle(m, n, rp, ci, va, M.Method_Balanced2) as h:
                 info = h.info()
                 assert info["cache_blocked"] == 1 and info["kernel_name"] == "blk_kernel", info
                 if variant == 0:
-                    assert info["tuned_choice"] in (100, 101, 102) and min(info["tune_ms"]) > 0, info
+                    assert info["tuned_choice"] in (100, 101) and min(info["tune_ms"][:2]) > 0, info
                 h.spmv(x, y)
             torch.cuda.synchronize()
             assert not bool(torch.isnan(y).any())
@@ -569,14 +569,12 @@ def test_blocked_executor_forms_give_the_same_bits_and_create_picks_one_by_timin
 
 @pytest.mark.parametrize("dtype", [np.float64, np.float32])
 @pytest.mark.parametrize("block_rows", [0, 512])
-def test_blocked_executor_dense_cells_and_sparse_super_slabs(dtype, block_rows):
-    """The blocked layout has two parts per row block (blocked.hpp): DENSE (block, 128-column slab) cells with at least a
-    group's worth of entries, whose x is read through LDS (two slabs per group, the 16-bit column field names the slab and
-    the offset), and the SPARSE rest, stored super-slab (65536 columns) after super-slab with 16-bit offsets.  A matrix with
-    a few hot column ranges (dense cells of very different sizes, some straddling groups), a uniform background over four
-    super-slabs, the last column range ending in the middle of a slab, empty rows, and one hub row: exact data, so every
-    executor form must equal the definition bit for bit -- with the dense part on (default), off, and with a higher
-    threshold -- and spmv_hip_update_values must hit the same positions."""
+def test_blocked_executor_hot_cells_and_super_slabs(dtype, block_rows):
+    """The blocked layout stores a row block's entries slab after slab with 16-bit column offsets inside super-slabs of 65536
+    columns, every super-slab's run padded to whole groups (blocked.hpp).  A matrix with a few hot column ranges (cells of
+    thousands of entries, one straddling the super-slab boundary at 131072), a uniform background over four super-slabs, the
+    last column range ending in the middle of a slab, empty rows, and one hub row: exact data, so every executor form must
+    equal the definition bit for bit, and spmv_hip_update_values must hit the same positions."""
     import torch
     dev = torch.device("cuda:0")
     tdt = torch.float64 if dtype == np.float64 else torch.float32
@@ -600,14 +598,13 @@ def test_blocked_executor_dense_cells_and_sparse_super_slabs(dtype, block_rows):
     cs = torch.cat([torch.zeros(1, dtype=torch.float64, device=dev), torch.cumsum(prod, 0)])
     want = (cs[rp[1:]] - cs[rp[:-1]]).to(tdt)
     rp32 = rp.to(torch.int32)
-    keep = {k: api.get_option(k) for k in ("cache_block", "variant", "block_rows", "dense_cells")}
+    keep = {k: api.get_option(k) for k in ("cache_block", "variant", "block_rows")}
     try:
         api.set_option("cache_block", 2)
         api.set_option("block_rows", block_rows)
         stored = {}
-        for dense in (1, 0, 700):
-            api.set_option("dense_cells", dense)
-            for variant in (0, 29, 35, 37):
+        for dense in (1,):
+            for variant in (0, 35, 37):
                 api.set_option("variant", variant)
                 y = torch.full((m,), float("nan"), dtype=tdt, device=dev)
                 with api.Handle(m, n, rp32, ci, va, M.Method_Balanced2) as h:
@@ -622,7 +619,7 @@ def test_blocked_executor_dense_cells_and_sparse_super_slabs(dtype, block_rows):
                         h.spmv(x, y)
                         torch.cuda.synchronize()
                         assert torch.equal(y, 2 * want), (dense, "update_values")
-        assert stored[1] >= nnz and stored[0] >= nnz
+        assert stored[1] >= nnz
     finally:
         for k, v in keep.items():
             api.set_option(k, v)
