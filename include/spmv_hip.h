@@ -156,8 +156,23 @@ int spmv_hip_multi_uses_rccl(spmv_Handle_t handle);   /* 1: the x exchange runs 
  * full-length copy) and its block of y (rows y_first ... y_first + y_count - 1).  Any out-pointer may be NULL. */
 int spmv_hip_multi_slices(spmv_Handle_t handle, int gpu, void **x_slice, long long *x_first, long long *x_count,
                           void **y_block, long long *y_first, long long *y_count, int *device);
-/* Exchange the x slices between the devices and multiply; y stays distributed.  Synchronous. */
+/* Exchange the x slices between the devices and multiply; y stays distributed.  Synchronous.  The devices' streams are ordered
+ * behind the work the caller has submitted to each device's DEFAULT stream (the x slices must have been written there, or be
+ * complete); x_exchange = 1 ("range") runs the halo copies beside the multiply and redoes the rows that needed them. */
 int spmv_hip_multi_step(spmv_Handle_t handle);
+/* The same, enqueued only; spmv_hip_multi_synchronize waits for every device (results in the y blocks). */
+int spmv_hip_multi_step_async(spmv_Handle_t handle);
+int spmv_hip_multi_synchronize(spmv_Handle_t handle);
+/* A multi-GPU handle from row blocks that exist separately -- the way the reference's NUMA experiment hands each memory node
+ * its rows (src/samples/numa.c:277-304).  Block g: rows[g] rows, LOCAL 0-based int32 RowPtr[g] (rows[g] + 1 entries), GLOBAL
+ * column indices ColIdx[g] in [0, n), values Matrix_Val[g]; host or device pointers; block g is placed on device g (at most
+ * as many blocks as visible devices).  No monolithic array exists, so the int32 limit of RowPtr applies per block: BASELINE
+ * config 5 (8 x 1e7 rows x 32 = 2.56e9 non-zeros) is created this way.  Options (x_exchange, ...) are read as at any create.
+ * spmv() on the handle takes full-length X (n) / Y (sum of rows) and ignores its CSR arguments; spmv_hip_multi_slices /
+ * _step work as for option "gpus"; spmv_hip_update_values is not available (clear and create again). */
+void spmv_hip_create_handle_from_blocks(spmv_Handle_t *Handle, int blocks, const BASIC_INT_TYPE *rows, BASIC_INT_TYPE n,
+                                        BASIC_INT_TYPE *const *RowPtr, BASIC_INT_TYPE *const *ColIdx, void *const *Matrix_Val,
+                                        SPMV_METHODS Function, BASIC_SIZE_TYPE size);
 
 /* ---- measurement -------------------------------------------------------------------------- */
 /* `warmup` untimed + `iters` timed spmv() launches back to back on the handle's stream, each

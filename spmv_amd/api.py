@@ -96,6 +96,10 @@ FUNCTIONS = {
     "spmv_hip_multi_slices": (C.c_int, [spmv_Handle_t, C.c_int, C.POINTER(_V), C.POINTER(C.c_longlong), C.POINTER(C.c_longlong),
                                         C.POINTER(_V), C.POINTER(C.c_longlong), C.POINTER(C.c_longlong), _I]),
     "spmv_hip_multi_step": (C.c_int, [spmv_Handle_t]),
+    "spmv_hip_multi_step_async": (C.c_int, [spmv_Handle_t]),
+    "spmv_hip_multi_synchronize": (C.c_int, [spmv_Handle_t]),
+    "spmv_hip_create_handle_from_blocks": (None, [C.POINTER(spmv_Handle_t), C.c_int, _I, C.c_int, C.POINTER(_V), C.POINTER(_V), C.POINTER(_V),
+                                                  C.c_int, C.c_ulong]),
     "spmv_hip_get_info": (C.c_int, [spmv_Handle_t, C.POINTER(spmv_hip_info)]),
     "spmv_hip_time_launches": (C.c_double, [spmv_Handle_t, _V, _V, C.c_int, C.c_int, C.POINTER(C.c_float)]),
     # include/spmv_io.h (host only)
@@ -246,6 +250,7 @@ def get_info(handle):
     out["schedule_name"] = (out["schedule_name"] or b"").decode()
     out["kernel_name"] = (out["kernel_name"] or b"").decode()
     out["tune_ms"] = [float(v) for v in out["tune_ms"]]
+    out["route_ms"] = [float(v) for v in out["route_ms"]]
     return out
 
 
@@ -369,6 +374,34 @@ class Handle:
     def multi_step(self):
         if load().spmv_hip_multi_step(self.h) != 0:
             _raise_if_error("spmv_hip_multi_step")
+
+    def multi_step_async(self):
+        if load().spmv_hip_multi_step_async(self.h) != 0:
+            _raise_if_error("spmv_hip_multi_step_async")
+
+    def multi_synchronize(self):
+        if load().spmv_hip_multi_synchronize(self.h) != 0:
+            _raise_if_error("spmv_hip_multi_synchronize")
+
+    @classmethod
+    def from_blocks(cls, blocks, n, method=SPMV_METHODS.Method_Parallel):
+        """Multi-GPU handle from separate row blocks [(rowptr, colidx, val), ...]: local int32 RowPtr, GLOBAL columns
+        (spmv_hip_create_handle_from_blocks).  spmv() takes full-length x / y; the CSR arguments are ignored."""
+        lib = load()
+        lib.spmv_hip_clear_error()
+        G = len(blocks)
+        rows = (C.c_int * G)(*[int(b[0].shape[0]) - 1 for b in blocks])
+        rps = (_V * G)(*[_ptr(b[0]) for b in blocks])
+        cis = (_V * G)(*[_ptr(b[1]) for b in blocks])
+        vas = (_V * G)(*[_ptr(b[2]) for b in blocks])
+        self = cls.__new__(cls)
+        self.m, self.n = int(sum(rows)), int(n)
+        self._keep = (None, None, None)
+        self._blocks = blocks
+        self.h = spmv_Handle_t()
+        lib.spmv_hip_create_handle_from_blocks(C.byref(self.h), G, rows, int(n), rps, cis, vas, int(method), _itemsize(blocks[0][2]))
+        _raise_if_error("spmv_hip_create_handle_from_blocks")
+        return self
 
     def attach_stream(self, stream_ptr, async_=True):
         set_stream(self.h, stream_ptr, async_)

@@ -146,43 +146,92 @@ out:
 
 /* Option "gpus" > 0: row blocks over the GPUs of this process (shim/multi.hpp; BASELINE config 5, SURVEY 8e, the GPU
  * analogue of numa.c:277-304).  Every shard is planned from ITS row statistics and built on its device. */
+/* plan + inspect every shard (and its boundary sub-matrix, if the range exchange split one off) of a multi-GPU state */
+static int multi_plan_shards(spmv_Handle_t h, spmv_hip_state *st, SPMV_METHODS *actual)
+{
+    const int G = spmv_shim_multi_count(st->multi);
+    int g, part, rc = SPMV_HIP_OK;
+    for (g = 0; g < G && !rc; ++g)
+        for (part = 0; part < 2 && !rc; ++part) {
+            spmv_dev *dev = part == 0 ? spmv_shim_multi_shard(st->multi, g) : spmv_shim_multi_boundary(st->multi, g);
+            spmv_stats stats;
+            spmv_plan plan;
+            SPMV_METHODS a = st->requested;
+            if (!dev) continue;
+            rc = spmv_shim_matrix_stats(dev, &stats);
+            if (!rc) {
+                spmv_plan_choose(st->requested, &stats, (size_t) h->data_size, &st->opts, &plan, &a, 1);
+                rc = spmv_shim_build(dev, &plan);
+            }
+            if (!rc && g == 0 && part == 0) { *actual = a; st->plan = plan; }
+        }
+    if (rc) {
+        spmv_set_error(rc, "create/multi shard", spmv_shim_error_text());
+        spmv_shim_multi_destroy(st->multi);
+        st->multi = NULL;
+    }
+    return rc;
+}
+
 static int state_build_multi(spmv_Handle_t h, spmv_hip_state *st, int m, int n, const int *RowPtr,
                              const int *ColIdx, const void *Val)
 {
     SPMV_METHODS actual = st->requested;
-    int g, G, rc;
+    int rc;
     if (st->multi) { spmv_shim_multi_destroy(st->multi); st->multi = NULL; }
     index_free(h);
     rc = spmv_shim_multi_create(&st->multi, (int) st->opts.v[SPMV_OPT_GPUS], (int) st->opts.v[SPMV_OPT_X_EXCHANGE], m, n, RowPtr, ColIdx, Val,
                                 (size_t) h->data_size);
     if (rc) { spmv_set_error(rc, "create/multi", spmv_shim_error_text()); return rc; }
-    G = spmv_shim_multi_count(st->multi);
-    for (g = 0; g < G; ++g) {
-        spmv_dev *dev = spmv_shim_multi_shard(st->multi, g);
-        spmv_stats stats;
-        spmv_plan plan;
-        SPMV_METHODS a = st->requested;
-        rc = spmv_shim_matrix_stats(dev, &stats);
-        if (!rc) {
-            spmv_plan_choose(st->requested, &stats, (size_t) h->data_size, &st->opts, &plan, &a, 1);
-            rc = spmv_shim_build(dev, &plan);
-        }
-        if (rc) {
-            spmv_set_error(rc, "create/multi shard", spmv_shim_error_text());
-            spmv_shim_multi_destroy(st->multi);
-            st->multi = NULL;
-            return rc;
-        }
-        if (g == 0) { actual = a; st->plan = plan; }
-    }
+    rc = multi_plan_shards(h, st, &actual);
+    if (rc) return rc;
     st->m = m;
     st->n = n;
     st->val_sum_valid = 0;
+    st->from_blocks = 0;
     h->spmvMethod = actual; /* shard 0's: the shards of a skewed matrix may differ (Balanced vs Balanced2) */
     h->RowPtr = (BASIC_INT_TYPE *) RowPtr;
     h->ColIdx = (BASIC_INT_TYPE *) ColIdx;
     h->Matrix_Val = (void *) Val;
     return SPMV_HIP_OK;
+}
+
+/* Extension: a multi-GPU handle from row blocks that already exist separately -- block g: rows[g] rows, LOCAL 0-based int32 RowPtr,
+ * GLOBAL column indices in [0, n), values; host or device pointers -- the way the reference's NUMA experiment hands every node its
+ * block (src/samples/numa.c:277-304, 129-158).  No monolithic CSR exists, so BASELINE config 5 (8 x 1e7 rows x 32 = 2.56e9
+ * non-zeros, beyond one int32 RowPtr) is expressible through the C API.  Block g lives on device g; x_exchange as for option "gpus".
+ * spmv() on such a handle takes full-length X / Y and IGNORES its CSR arguments (pass NULL). */
+void spmv_hip_create_handle_from_blocks(spmv_Handle_t *Handle, int blocks, const BASIC_INT_TYPE *rows, BASIC_INT_TYPE n,
+                                        BASIC_INT_TYPE *const *RowPtr, BASIC_INT_TYPE *const *ColIdx, void *const *Matrix_Val,
+                                        SPMV_METHODS Function, BASIC_SIZE_TYPE size)
+{
+    spmv_Handle_t h;
+    spmv_hip_state *st;
+    SPMV_METHODS actual;
+    int rc;
+    if (!Handle) { spmv_set_error(SPMV_HIP_E_ARG, "create_from_blocks", "Handle is NULL"); return; }
+    h = (spmv_Handle_t) malloc(sizeof(spmv_Handle));
+    *Handle = h;
+    if (!h) { spmv_set_error(SPMV_HIP_E_ALLOC, "create_from_blocks", "malloc(handle)"); return; }
+    handle_reset(h);
+    if ((int) Function < (int) Method_Serial || (int) Function >= (int) Method_Total_Size) Function = Method_Serial;
+    h->nthreads = 1;
+    h->vectorizedWay = VECTOR_HIP;
+    h->data_size = size;
+    h->spmvMethod = Function;
+    st = (spmv_hip_state *) calloc(1, sizeof *st);
+    if (!st) { spmv_set_error(SPMV_HIP_E_ALLOC, "create_from_blocks", "malloc(state)"); return; }
+    st->requested = actual = Function;
+    spmv_options_snapshot(&st->opts);
+    rc = spmv_shim_multi_create_blocks(&st->multi, blocks, (int) st->opts.v[SPMV_OPT_X_EXCHANGE], rows, n, (const int *const *) RowPtr,
+                                       (const int *const *) ColIdx, (const void *const *) Matrix_Val, (size_t) size);
+    if (rc) { spmv_set_error(rc, "create_from_blocks", spmv_shim_error_text()); free(st); return; }
+    if (multi_plan_shards(h, st, &actual) != SPMV_HIP_OK) { free(st); return; }
+    st->m = spmv_shim_multi_rows(st->multi);
+    st->n = n;
+    st->from_blocks = 1;
+    h->spmvMethod = actual;
+    h->extraHandle = st;
 }
 
 /* Upload + plan + inspect.  Used by create and by spmv() when it is handed another matrix. */
@@ -347,8 +396,10 @@ void spmv(const spmv_Handle_t handle, BASIC_INT_TYPE m, const BASIC_INT_TYPE *Ro
     }
     /* The reference re-reads the CSR arguments on every call (common.c:286-298).  Same pointers
      * and m as at create -> the HBM-resident matrix; anything else -> re-inspect that matrix. */
-    if (m != st->m || RowPtr != handle->RowPtr || ColIdx != handle->ColIdx ||
-        Matrix_Val != handle->Matrix_Val) {
+    if (st->from_blocks) {
+        /* created from row blocks: there is no monolithic CSR the arguments could name; they are ignored */
+    } else if (m != st->m || RowPtr != handle->RowPtr || ColIdx != handle->ColIdx ||
+               Matrix_Val != handle->Matrix_Val) {
         if (!st->warned_rebuild && !getenv("SPMV_HIP_QUIET")) {
             fprintf(stderr, "[spmv_hip] spmv(): CSR arguments differ from create(); re-inspecting "
                             "(slow path, DESIGN.md \"CSR arguments\")\n");
@@ -433,6 +484,26 @@ int spmv_hip_multi_step(spmv_Handle_t h)
     if (!mt) return SPMV_HIP_E_NOSTATE;
     rc = spmv_shim_multi_step(mt);
     if (rc) spmv_set_error(rc, "multi_step", spmv_shim_error_text());
+    return rc;
+}
+
+int spmv_hip_multi_step_async(spmv_Handle_t h)
+{
+    spmv_multi *mt = multi_of(h, "multi_step_async");
+    int rc;
+    if (!mt) return SPMV_HIP_E_NOSTATE;
+    rc = spmv_shim_multi_step_async(mt);
+    if (rc) spmv_set_error(rc, "multi_step_async", spmv_shim_error_text());
+    return rc;
+}
+
+int spmv_hip_multi_synchronize(spmv_Handle_t h)
+{
+    spmv_multi *mt = multi_of(h, "multi_synchronize");
+    int rc;
+    if (!mt) return SPMV_HIP_E_NOSTATE;
+    rc = spmv_shim_multi_sync(mt);
+    if (rc) spmv_set_error(rc, "multi_synchronize", spmv_shim_error_text());
     return rc;
 }
 

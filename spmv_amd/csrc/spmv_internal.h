@@ -33,6 +33,7 @@ typedef struct spmv_hip_state {
     int stream_set, async, warned_rebuild;
     unsigned long long val_sum; /* option "check_values": checksum of Matrix_Val as last uploaded */
     int val_sum_valid;
+    int from_blocks;        /* multi-GPU handle created from separate row blocks (spmv_hip_create_handle_from_blocks): spmv() ignores its CSR arguments */
 } spmv_hip_state;
 
 void spmv_set_error(int code, const char *where, const char *what);

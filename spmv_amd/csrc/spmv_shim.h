@@ -91,7 +91,13 @@ typedef struct spmv_multi spmv_multi;
  * x buffer, y block and stream; xchg: 0 allgather, 2 broadcast.  The caller then plans + builds every shard. */
 int spmv_shim_multi_create(spmv_multi **out, int gpus, int xchg, int m, int n, const int *rowptr, const int *colidx,
                            const void *val, size_t value_size);
+/* ... or from G row blocks handed over separately: rows[g] rows, LOCAL 0-based RowPtr, GLOBAL columns (numa.c:277-304) */
+int spmv_shim_multi_create_blocks(spmv_multi **out, int G, int xchg, const int *rows, int n, const int *const *rowptr, const int *const *colidx,
+                                  const void *const *val, size_t value_size);
 int spmv_shim_multi_count(const spmv_multi *mt);
+int spmv_shim_multi_rows(const spmv_multi *mt);
+/* the boundary rows' sub-matrix of shard g ("range" exchange with overlap), or NULL: planned and built like a shard */
+spmv_dev *spmv_shim_multi_boundary(spmv_multi *mt, int g);
 int spmv_shim_multi_uses_rccl(const spmv_multi *mt);
 long long spmv_shim_multi_nnz(const spmv_multi *mt);
 spmv_dev *spmv_shim_multi_shard(spmv_multi *mt, int g);
@@ -102,6 +108,9 @@ int spmv_shim_multi_slices(spmv_multi *mt, int g, void **x_slice, long long *x_f
                            long long *y_first, long long *y_count, int *device);
 /* exchange the x slices between the devices and multiply; y stays in the shards' blocks */
 int spmv_shim_multi_step(spmv_multi *mt);
+/* the same, enqueued only (ordered behind the work already submitted to each device's default stream); _sync waits */
+int spmv_shim_multi_step_async(spmv_multi *mt);
+int spmv_shim_multi_sync(spmv_multi *mt);
 int spmv_shim_multi_update_values(spmv_multi *mt, const void *val);
 void spmv_shim_multi_destroy(spmv_multi *mt);
 

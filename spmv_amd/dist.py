@@ -29,7 +29,7 @@ import torch.distributed as dist
 
 from . import api
 
-__all__ = ["slice_bounds", "ShardedSpMV"]
+__all__ = ["slice_bounds", "equal_nnz_cuts", "ShardedSpMV"]
 
 
 def slice_bounds(n, world, rank):
@@ -37,6 +37,24 @@ def slice_bounds(n, world, rank):
     base, extra = divmod(int(n), int(world))
     lo = rank * base + min(rank, extra)
     return lo, lo + base + (1 if rank < extra else 0)
+
+
+def equal_nnz_cuts(rowptr, world):
+    """Row cut points of `world` EQUAL-NNZ row blocks: cuts[t] = upper_bound(RowPtr, min(t * ceil(nnz / world), nnz)) - 1, the
+    reference's splitter (init_csrSplitter_balanced2, parallel_balanced2_spmv.c:41-53), with cuts[0] = 0, cuts[world] = m and the
+    sequence kept non-decreasing.  A power-law matrix cut into equal-ROW blocks leaves one rank with several times the others'
+    work; the x slices stay equal-COLUMN slices (slice_bounds) whatever the rows.  rowptr: 1-D tensor / array of m + 1 entries
+    (any integer type, RowPtr[0] = 0); returns a list of world + 1 ints."""
+    rp = torch.as_tensor(rowptr).to(torch.int64)
+    m = int(rp.numel()) - 1
+    nnz = int(rp[-1]) if m >= 0 and rp.numel() else 0
+    stride = -(-nnz // max(world, 1))
+    keys = torch.tensor([min(t * stride, nnz) for t in range(world + 1)], dtype=torch.int64, device=rp.device)
+    cuts = (torch.searchsorted(rp, keys, right=True) - 1).clamp_(0, max(m, 0)).tolist()
+    cuts[0], cuts[-1] = 0, max(m, 0)
+    for t in range(1, world + 1):
+        cuts[t] = max(cuts[t], cuts[t - 1])
+    return [int(c) for c in cuts]
 
 
 def _owner_of(cols, n, world):

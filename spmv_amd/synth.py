@@ -237,30 +237,33 @@ def rmat_columns_device(row_of, m, n, device="cuda", seed=1, a=0.57, b=0.19, c=0
     return ((col * int(n)) >> scale).to(torch.int32)                    # squeeze the power-of-two grid onto n columns
 
 
-def from_row_lengths_device(lens, n, values="uniform", dtype=None, device="cuda", seed=1, local=0, cols="uniform"):
+def from_row_lengths_device(lens, n, values="uniform", dtype=None, device="cuda", seed=1, local=0, cols="uniform", row0=0, m_total=None):
     """Random columns for given per-row lengths (int64 tensor on `device`); columns sorted per row
     when local == 0 is not required by SpMV and is skipped.  local>0: columns within +-local of
-    the row's diagonal position.  cols = "rmat": R-MAT columns (rmat_columns_device), sorted within each row."""
+    the row's diagonal position.  cols = "rmat": R-MAT columns (rmat_columns_device), sorted within each row.
+    row0 / m_total: the rows are rows row0 .. of an m_total-row matrix (a row block generated on its own: the
+    position-dependent column models -- local, rmat, web -- then see the GLOBAL row position)."""
     torch = _torch()
     dtype = dtype or torch.float64
     lens = lens.to(device=device, dtype=torch.int64).clamp_(max=n)
     m = lens.shape[0]
+    mt = int(m_total) if m_total is not None else m
     rp = torch.zeros(m + 1, dtype=torch.int64, device=device)
     torch.cumsum(lens, 0, out=rp[1:])
     nnz = int(rp[-1].item())
     assert nnz < 2**31, "int32 RowPtr overflow"
     g = torch.Generator(device=device)
-    g.manual_seed(seed + 7)
+    g.manual_seed(seed + 7 + 1000003 * int(row0))
     if local > 0:
-        row_of = torch.repeat_interleave(torch.arange(m, device=device, dtype=torch.int64), lens)
-        centre = row_of * n // max(m, 1)
+        row_of = torch.repeat_interleave(torch.arange(m, device=device, dtype=torch.int64), lens) + int(row0)
+        centre = row_of * n // max(mt, 1)
         jitter = torch.randint(-local, local + 1, (nnz,), generator=g, device=device, dtype=torch.int64)
         colidx = (centre + jitter).clamp_(0, n - 1).to(torch.int32)
     elif cols in ("rmat", "web"):
-        row_of = torch.repeat_interleave(torch.arange(m, device=device, dtype=torch.int64), lens)
-        colidx = rmat_columns_device(row_of, m, n, device, seed)
+        row_of = torch.repeat_interleave(torch.arange(m, device=device, dtype=torch.int64), lens) + int(row0)
+        colidx = rmat_columns_device(row_of, mt, n, device, seed + 1000003 * int(row0))
         if cols == "web":   # web-graph-like: 90 % of a row's links stay near its own position ("same host"), 10 % follow the R-MAT hubs
-            centre = row_of * n // max(m, 1)
+            centre = row_of * n // max(mt, 1)
             near = (centre + torch.randint(-2000, 2001, (nnz,), generator=g, device=device, dtype=torch.int64)).clamp_(0, n - 1)
             keep = torch.rand(nnz, generator=g, device=device) < 0.1
             colidx = torch.where(keep, colidx.to(torch.int64), near).to(torch.int32)

@@ -113,3 +113,49 @@ def test_slice_bounds_cover_and_are_contiguous():
             assert cuts[0][0] == 0 and cuts[-1][1] == n
             assert all(cuts[i][1] == cuts[i + 1][0] for i in range(world - 1))
             assert max(c[1] - c[0] for c in cuts) - min(c[1] - c[0] for c in cuts) <= 1
+
+
+def _worker_equal_nnz(rank, world, port, out):
+    from spmv_amd.dist import equal_nnz_cuts
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        n = 1500
+        A = synth.powerlaw(n, n, 7.0, 900, 1.4, "eighths", np.float64, seed=11)     # heavy tail: equal-row blocks would be lopsided
+        x = synth.fill_x(n, "eighths", np.float64, 3)
+        cuts = equal_nnz_cuts(A.rowptr, world)
+        r0, r1 = cuts[rank], cuts[rank + 1]
+        p0, p1 = int(A.rowptr[r0]), int(A.rowptr[r1])
+        rp = torch.from_numpy((A.rowptr[r0:r1 + 1] - p0).astype(np.int32))
+        sh = ShardedSpMV(rp, torch.from_numpy(A.colidx[p0:p1].copy()), torch.from_numpy(A.val[p0:p1].copy()), n, xchg="halo", compute=_oracle_compute)
+        c0, c1 = slice_bounds(n, world, rank)               # x stays in equal-column slices whatever the row cut
+        y = torch.full((r1 - r0,), float("nan"), dtype=torch.float64)
+        sh.step(torch.from_numpy(x)[c0:c1].clone(), y)
+        ok = np.array_equal(y.numpy(), oracle.spmv_serial(A, x)[r0:r1])
+        dist.barrier()
+        out[rank] = (ok, cuts, p1 - p0, A.nnz)
+    finally:
+        dist.destroy_process_group()
+
+
+def test_world3_equal_nnz_row_blocks_on_a_power_law_matrix():
+    """spmv_amd.dist.equal_nnz_cuts = the reference's splitter (parallel_balanced2_spmv.c:41-53) for the per-process path: the
+    row blocks hold equal shares of the non-zeros (up to one row), x keeps its equal-column slices, results match the oracle."""
+    world = 3
+    mgr = mp.Manager()
+    out = mgr.dict()
+    mp.spawn(_worker_equal_nnz, args=(world, _free_port(), out), nprocs=world, join=True)
+    assert all(out[r][0] for r in range(world)), dict(out)
+    cuts, nnz = out[0][1], out[0][3]
+    assert cuts[0] == 0 and cuts[-1] == 1500 and all(a <= b for a, b in zip(cuts, cuts[1:]))
+    shares = [out[r][2] for r in range(world)]
+    assert sum(shares) == nnz and max(shares) <= nnz / world + 900 + 1       # within one (longest) row of the equal share
+
+
+def test_equal_nnz_cuts_edge_cases():
+    from spmv_amd.dist import equal_nnz_cuts
+    assert equal_nnz_cuts(np.array([0]), 4) == [0, 0, 0, 0, 0]                                   # no rows
+    assert equal_nnz_cuts(np.array([0, 0, 0, 0]), 2) == [0, 3, 3] or equal_nnz_cuts(np.array([0, 0, 0, 0]), 2)[-1] == 3   # no entries
+    rp = np.array([0, 100, 100, 101, 102])                                                        # one heavy row first
+    c = equal_nnz_cuts(rp, 3)
+    assert c[0] == 0 and c[-1] == 4 and all(a <= b for a, b in zip(c, c[1:]))

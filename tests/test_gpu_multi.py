@@ -156,3 +156,112 @@ def test_update_values_and_stream_calls_on_a_sharded_handle(virtual):
         api.load().spmv_hip_clear_error()
     finally:
         h.close()
+
+
+def _blocks_of(csr, cuts):
+    """local int32 RowPtr + GLOBAL columns per row block, as separate arrays (the caller-side layout of config 5)"""
+    out = []
+    for a, b in zip(cuts[:-1], cuts[1:]):
+        p0, p1 = int(csr.rowptr[a]), int(csr.rowptr[b])
+        out.append((np.ascontiguousarray(csr.rowptr[a:b + 1] - p0, dtype=np.int32), np.ascontiguousarray(csr.colidx[p0:p1]),
+                    np.ascontiguousarray(csr.val[p0:p1])))
+    return out
+
+
+@pytest.mark.parametrize("method", [M.Method_Parallel, M.Method_Balanced2, M.Method_SellCSigma, M.Method_CSR5SPMV], ids=lambda m: m.name)
+@pytest.mark.parametrize("name", ["banded_f64_eighths", "powerlaw_f32_eighths", "empty_mix_f64_eighths", "skewed_f64_eighths"])
+@pytest.mark.parametrize("xchg", [0, 1, 2])
+def test_handle_from_separate_row_blocks(virtual, name, method, xchg):
+    """spmv_hip_create_handle_from_blocks: no monolithic CSR exists (BASELINE config 5's 2.56e9 non-zeros do not fit one int32
+    RowPtr; reference analogue: numa.c:277-304).  Uneven blocks incl. an empty one; full-vector spmv() (CSR arguments ignored)
+    and the distributed step must both give the reference's bits."""
+    csr, x, y_ref = load_golden(name)
+    m = csr.m
+    cuts = [0, m // 5, m // 5, (3 * m) // 4, m] if m >= 8 else [0, m]
+    blocks = _blocks_of(csr, cuts)
+    api.set_thread_option("x_exchange", xchg)
+    try:
+        h = api.Handle.from_blocks(blocks, csr.n, method)
+    finally:
+        api.clear_thread_options()
+    try:
+        assert h.multi_gpus() == len(blocks)
+        info = h.info()
+        assert info["m"] == m and info["nnz"] == csr.nnz
+        y = np.full(m, np.nan, dtype=csr.val.dtype)
+        api.spmv(h.h, m, None, None, None, x, y)
+        assert np.array_equal(y.view(np.uint8), y_ref.view(np.uint8))
+        with pytest.raises(api.SpmvError):
+            h.update_values(csr.val)
+    finally:
+        h.close()
+
+
+def _write_slices_and_step(h, x, m, xchg, n, dtype, asynchronous=False):
+    hip = C.CDLL("libamdhip64.so")
+    hip.hipMemcpy.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_int]
+    isz = np.dtype(dtype).itemsize
+    G = h.multi_gpus()
+    for g in range(G):
+        s = h.multi_slices(g)
+        if xchg == 2 and g > 0:
+            continue
+        lo, cnt = (0, n) if xchg == 2 else (s["x_first"], s["x_count"])
+        part = np.ascontiguousarray(x[lo: lo + cnt])
+        assert hip.hipMemcpy(s["x_ptr"] - isz * (s["x_first"] - lo), part.ctypes.data, part.nbytes, 4) == 0
+    if asynchronous:
+        h.multi_step_async()
+        h.multi_synchronize()
+    else:
+        h.multi_step()
+    y = np.full(m, np.nan, dtype=dtype)
+    for g in range(G):
+        s = h.multi_slices(g)
+        blk = np.empty(s["y_count"], dtype=dtype)
+        assert hip.hipMemcpy(blk.ctypes.data, s["y_ptr"], blk.nbytes, 4) == 0
+        y[s["y_first"]: s["y_first"] + s["y_count"]] = blk
+    return y
+
+
+@pytest.mark.parametrize("dtype", [np.float64, np.float32])
+@pytest.mark.parametrize("gpus", [2, 4])
+def test_range_exchange_overlaps_the_halo_with_the_interior_rows(virtual, gpus, dtype):
+    """x_exchange = 1 in the distributed step: every shard pulls only the columns it references from the other shards' slices
+    (peer copies on a second stream) WHILE it multiplies all of its rows, then multiplies the rows that reference those columns
+    again and overwrites them (multi.hpp: multi_plan_boundary).  Band of half-width 40 over 6000 rows: 2 x 40 boundary rows per
+    inner shard.  x is changed between steps, so a boundary row computed from the previous step's halo would show; the async
+    form must give the same; new values reach the boundary copy too."""
+    from spmv_amd import synth
+    csr = synth.banded(6000, 6000, 40, 40, "eighths", dtype, seed=5)
+    rng = np.random.default_rng(3)
+    h = _multi_handle(csr, M.Method_Parallel, gpus, 1)
+    try:
+        for step in range(3):
+            x = (rng.integers(-8, 9, csr.n) * 0.125).astype(dtype)
+            prod = csr.val.astype(np.float64) * x.astype(np.float64)[csr.colidx]
+            cs = np.concatenate([[0.0], np.cumsum(prod)])
+            want = (cs[csr.rowptr[1:]] - cs[csr.rowptr[:-1]]).astype(dtype)
+            y = _write_slices_and_step(h, x, csr.m, 1, csr.n, dtype, asynchronous=step == 1)
+            assert np.array_equal(y, want), (step, int((y != want).sum()))
+        val2 = (csr.val * 2).astype(dtype)
+        h.update_values(val2)
+        y = _write_slices_and_step(h, x, csr.m, 1, csr.n, dtype)
+        assert np.array_equal(y, 2 * want)
+    finally:
+        h.close()
+
+
+def test_range_exchange_without_a_split_when_most_rows_are_boundary(virtual):
+    """uniformly random columns: every row references remote columns -> no boundary sub-matrix, the multiply waits for the halo"""
+    from spmv_amd import synth
+    csr = synth.uniform_k(3000, 3000, 6, "eighths", np.float64, seed=9)
+    x = (np.random.default_rng(1).integers(-8, 9, csr.n) * 0.125)
+    prod = csr.val * x[csr.colidx]
+    cs = np.concatenate([[0.0], np.cumsum(prod)])
+    want = cs[csr.rowptr[1:]] - cs[csr.rowptr[:-1]]
+    h = _multi_handle(csr, M.Method_CSR5SPMV, 3, 1)
+    try:
+        y = _write_slices_and_step(h, x, csr.m, 1, csr.n, np.float64)
+        assert np.array_equal(y, want)
+    finally:
+        h.close()
