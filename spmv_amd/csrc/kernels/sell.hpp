@@ -226,49 +226,59 @@ __device__ __forceinline__ void sell_chunk(const int *__restrict__ pc, const uns
 // One workgroup per GROUP of consecutive sigma windows (chunks_per_win chunks); the group's x windows are
 // staged in LDS when they fit.  A group is one sigma window unless staging is expensive next to the
 // group's own stream (build_sell widens it then).
+//
+// y.  A group covers rows_per_group CONSECUTIVE original rows (sorting happens inside a sigma window), so the row sums are
+// collected in LDS (ys, behind the x windows) and written by one coalesced sweep -- round 2 scattered them through `perm`, 64
+// different lines per store instruction (0.67 of the HBM roofline on config 4's slabs).  Rows of the group that are not in
+// the slabs -- the long rows, which the CSR5 sub-matrix launched BEHIND this kernel overwrites -- get the 0 the sweep finds.
+// Chunks.  Sorted by width inside a sigma window, so the 8 waves take them from a counter in LDS, widest first (longest
+// processing time first): a wave that drew a wide chunk simply draws fewer (round 2 dealt them by index, mirrored every other
+// pass: 38 vs 23 columns per window between the busiest and the idlest wave before the mirroring, ~10 % after).
 template <typename T>
-__global__ __launch_bounds__(kSellWinThreads) void sell_window_kernel(int chunks_per_win, long long nchunks,
+__global__ __launch_bounds__(kSellWinThreads) void sell_window_kernel(int chunks_per_win, long long nchunks, int m,
                                                                       const long long *__restrict__ chunk_ptr,
                                                                       const int *__restrict__ scol,
                                                                       const unsigned short *__restrict__ scol16,
                                                                       const T *__restrict__ sval,
                                                                       const int *__restrict__ perm,
                                                                       const TileWindows *__restrict__ wins,
-                                                                      const T *__restrict__ x, T *__restrict__ y)
+                                                                      const T *__restrict__ x, T *__restrict__ y, int ys_offset)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char sell_x_lds[];
+    __shared__ int next_chunk;
     T *xs = reinterpret_cast<T *>(sell_x_lds);
+    T *ys = reinterpret_cast<T *>(sell_x_lds + ys_offset);
     const int w = blockIdx.x;
     const TileWindows &tw = wins[w];
     const bool staged = tw.nwin > 0;
+    const int rows_per_group = chunks_per_win * kSellC;
+    const long long row0 = (long long) w * rows_per_group;
+    for (int i = threadIdx.x; i < rows_per_group; i += kSellWinThreads) ys[i] = T(0);
+    if (threadIdx.x == 0) next_chunk = 0;
     stage_windows<kSellWinThreads, T>(tw, x, xs);
-    if (staged) {
-        if (threadIdx.x == 0) xs[tw.total] = T(0); // the zero slot of padding entries
-        __syncthreads();
-    }
+    if (staged && threadIdx.x == 0) xs[tw.total] = T(0); // the zero slot of padding entries
+    __syncthreads();
     const int lane = threadIdx.x & (kWave - 1);
-    // Chunks are sorted by width inside a sigma window (widest first): handing them to the 8 waves round-robin gives wave 0 the
-    // widest chunk of every pass and wave 7 the narrowest, and the workgroup -- its x windows in LDS -- lasts as long as wave 0
-    // (config 4's slabs: 38 columns per sigma window for wave 0, 23 for wave 7).  Every second pass therefore runs the other way:
-    // wave v takes chunks v and 15 - v of each group of 16.
-    constexpr int kWaves = kSellWinThreads / kWave;
-    const int wave = threadIdx.x / kWave;
-    const bool mirror = (chunks_per_win % (2 * kWaves)) == 0;
-    for (int i = 0; i * kWaves < chunks_per_win; ++i) {
-        const int k = i * kWaves + ((mirror && (i & 1)) ? kWaves - 1 - wave : wave);
+    for (;;) {
+        int k = 0;
+        if (lane == 0) k = atomicAdd(&next_chunk, 1);
+        k = __builtin_amdgcn_readfirstlane(k);
         const long long c = (long long) w * chunks_per_win + k;
-        if (k >= chunks_per_win || c >= nchunks) continue; // a short last pass / last window group: other waves may still hold valid chunks
+        if (k >= chunks_per_win || c >= nchunks) break;
         const long long c0 = chunk_ptr[c];
         const int width = (int) (chunk_ptr[c + 1] - c0);
         const int *pc = scol + (size_t) c0 * kSellC + lane;
         const unsigned short *pc16 = scol16 + (size_t) c0 * kSellC + lane;
         const T *pv = sval + (size_t) c0 * kSellC + lane;
+        const int row = perm[c * kSellC + lane];
         T sum = 0;
         if (staged) sell_chunk<T, true>(pc, pc16, pv, width, xs, x, sum);
         else sell_chunk<T, false>(pc, pc16, pv, width, xs, x, sum);
-        const int row = perm[c * kSellC + lane];
-        if (row >= 0) y[row] = sum;
+        if (row >= 0) ys[row - row0] = sum;
     }
+    __syncthreads();
+    for (int i = threadIdx.x; i < rows_per_group; i += kSellWinThreads)
+        if (row0 + i < m) y[row0 + i] = ys[i];
 }
 
 } // namespace spmv

@@ -247,7 +247,9 @@ static int build_sell(spmv_dev *d)
         };
         int rc = inspect(1);
         if (rc) return rc;
-        while (d->sell_staged > 0 && d->sell_group < 8 &&
+        // LDS of a workgroup: the group's x windows (<= 96 KiB) + its row sums (sell_window_kernel collects them for one coalesced store)
+        auto lds_fits = [&](int g) { return kSellXTileBytes + sizeof(T) * (size_t) g * (size_t) sigma <= 150 * 1024; };
+        while (d->sell_staged > 0 && d->sell_group < 8 && lds_fits(d->sell_group * 2) &&
                (double) d->sell_maxspan * sizeof(T) > 0.15 * (double) slots * (sizeof(T) + 2) / (double) d->sell_nwin) {
             const int prev = d->sell_group;
             rc = inspect(prev * 2);
@@ -256,7 +258,6 @@ static int build_sell(spmv_dev *d)
         }
         if (d->sell_staged == d->sell_nwin) { sched_free(d, d->scol); d->scol = nullptr; } // no window reads global columns
         else if (d->sell_staged == 0) { sched_free(d, d->scol16); d->scol16 = nullptr; }
-        ensure_lds<sell_window_kernel<T>>(d, kSellXTileBytes);
     }
     HIP_TRY(hipStreamSynchronize(d->stream));
     return SPMV_HIP_OK;
@@ -307,7 +308,6 @@ static int build_csr5_sigma(spmv_dev *d, Csr5Plan &P, const int *rp, int m2, con
     // narrow windows lose 3-7 % with larger groups, so they keep 16).
     static_assert(kCsr5XTileBytes / sizeof(float) <= 65536, "LDS slots must fit 16 bits");
     const int base_gt = P.natural ? 2 * kCsr5GroupTiles : kCsr5GroupTiles;
-    const int forced_gt = d->plan.variant == 40 ? 32 : (d->plan.variant == 41 ? 64 : (d->plan.variant == 42 ? 8 : 0)); // A/B
     const long long total = P.natural ? P.nnz : (long long) p * TN;
     const int max_cols = (int) ((P.natural ? kNatXTileBytes : kCsr5XTileBytes) / sizeof(T)) - 1;
     ALLOC_TRY(d, &P.wins, sizeof(TileWindows) * (size_t) ((p + 7) / 8), true);
@@ -323,9 +323,9 @@ static int build_csr5_sigma(spmv_dev *d, Csr5Plan &P, const int *rp, int m2, con
         return build_range_windows(d, d->plan.variant == 3 ? 0 : P.groups, total, (long long) gt * TN, nullptr, 1, 1, max_cols, P.col, P.wins,
                                    &P.staged, &P.maxspan, P.col16, P.natural ? 0 : SIGMA);
     };
-    int rc = inspect(forced_gt ? forced_gt : base_gt);
+    int rc = inspect(base_gt);
     if (rc) return rc;
-    while (!forced_gt && P.staged > 0 && P.group_tiles < 64 &&
+    while (P.staged > 0 && P.group_tiles < 64 &&
            (double) P.maxspan * sizeof(T) > 0.15 * (double) P.group_tiles * TN * (sizeof(T) + 2)) {
         const int prev = P.group_tiles;
         rc = inspect(prev * 2);

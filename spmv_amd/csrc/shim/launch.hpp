@@ -10,7 +10,7 @@ constexpr int kVecNB = 4;
 // Kernel forms of the CSR-vector schedule.  Which one is fastest differs between MI355X boxes by a
 // few percent, so create() times the applicable ones once on the resident matrix
 // (autotune_vector) and keeps the winner in d->vec_choice; plan.variant overrides for A/B runs.
-enum { VEC_AUTO = 0, VEC_NO_LONG = 2, VEC_PIPE = 4, VEC_TILE_D2 = 5, VEC_TILE_D8 = 6, VEC_TILE_D4 = 10, VEC_TILE_D4_NOPRE = 11, VEC_TILE_D2_NOPRE = 12 };
+enum { VEC_AUTO = 0, VEC_PIPE = 4, VEC_TILE_D2 = 5, VEC_TILE_D8 = 6, VEC_TILE_D4 = 10, VEC_TILE_D4_NOPRE = 11, VEC_TILE_D2_NOPRE = 12 };
 
 template <typename T, int L, int DEPTH, bool PRE = true>
 static void launch_vector_tile(spmv_dev *d, const T *x, T *y, int long_thr)
@@ -25,7 +25,7 @@ template <typename T, int L>
 static void launch_vector(spmv_dev *d, const T *x, T *y)
 {
     const int v = d->plan.variant ? d->plan.variant : d->vec_choice;
-    const int long_thr = v == VEC_NO_LONG ? INT_MAX : d->long_thr;
+    const int long_thr = d->long_thr;
     const bool tile_default = d->vt_staged * 2 >= d->vt_tiles; // most x tiles fit LDS
     const bool tile_forced = v == VEC_TILE_D2 || v == VEC_TILE_D4 || v == VEC_TILE_D8 || v == VEC_TILE_D4_NOPRE || v == VEC_TILE_D2_NOPRE;
     if (d->vt_tiles > 0 && v != VEC_PIPE && (tile_default || tile_forced)) { // tile kernel (unstaged tiles gather from L1/L2)
@@ -292,7 +292,7 @@ static int launch(spmv_dev *d, const T *x, T *y)
         if (d->blk_on) { launch_blocked<T>(d, x, y); break; } // no x window could be staged (option "cache_block")
         if (d->vt_wide) launch_rows_any<T>(d, x, y, nullptr); // wide x windows: uniform 1024-row blocks, slot-index stream
         else launch_vector_any<T>(d, x, y);
-        if (d->plan.variant != 2) launch_long_rows<T>(d, x, y);
+        launch_long_rows<T>(d, x, y);
         break;
     case SPMV_SCHED_NNZ_SPLIT: {
         if (d->blk_on) { launch_blocked<T>(d, x, y); break; }
@@ -309,9 +309,14 @@ static int launch(spmv_dev *d, const T *x, T *y)
         if (d->blk_on) { launch_blocked<T>(d, x, y); break; }
         // staged path when at least half of the windows fit their x span in LDS; the LDS request is
         // sized by the largest staged span actually present (rounded to 16 KiB) to keep occupancy
-        if (d->sell_staged > 0)
-            sell_window_kernel<T><<<d->sell_nwin, kSellWinThreads, ((((size_t) d->sell_maxspan + 1) * sizeof(T)) + 1023) & ~(size_t) 1023, d->stream>>>(
-                d->sell_group * (d->plan.sell_sigma / kSellC), (long long) d->nchunks, d->chunk_ptr, d->scol, d->scol16, (const T *) d->sval, d->perm, d->sell_wins, x, y);
+        if (d->sell_staged > 0) {
+            const int cpw = d->sell_group * (d->plan.sell_sigma / kSellC);
+            const size_t xbytes = ((((size_t) d->sell_maxspan + 1) * sizeof(T)) + 1023) & ~(size_t) 1023; // x windows + the zero slot
+            const size_t lds = xbytes + sizeof(T) * (size_t) cpw * kSellC;                                  // + the group's row sums
+            ensure_lds<sell_window_kernel<T>>(d, lds);
+            sell_window_kernel<T><<<d->sell_nwin, kSellWinThreads, lds, d->stream>>>(cpw, (long long) d->nchunks, d->m, d->chunk_ptr, d->scol, d->scol16, (const T *) d->sval,
+                                                                                     d->perm, d->sell_wins, x, y, (int) xbytes);
+        }
         else
             sell_kernel<T><<<grid_for(d->nchunks, kBlock / kWave, INT_MAX), kBlock, 0, d->stream>>>(
                 d->nchunks, d->chunk_ptr, d->scol, (const T *) d->sval, d->perm, x, y);

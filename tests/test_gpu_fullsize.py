@@ -275,3 +275,56 @@ def test_nnz_just_below_int32_limit():
         assert torch.equal(y, want), sched
         del y
         torch.cuda.empty_cache()
+
+
+def _abs_segments(rp, ci, va, x):
+    """sum of |a x| per row: what the north_star tolerance scales with"""
+    nnz = ci.numel()
+    cs = torch.zeros(nnz + 1, dtype=torch.float64, device=va.device)
+    step = 1 << 26
+    carry = torch.zeros((), dtype=torch.float64, device=va.device)
+    for p0 in range(0, nnz, step):
+        p1 = min(nnz, p0 + step)
+        prod = (va[p0:p1].double() * x[ci[p0:p1].long()].double()).abs()
+        torch.cumsum(prod, 0, out=cs[p0 + 1:p1 + 1])
+        cs[p0 + 1:p1 + 1] += carry
+        carry = cs[p1].clone()
+    r = rp.long()
+    return cs[r[1:]] - cs[r[:-1]]
+
+
+def _check_rounding(m, n, rp, ci, va, methods, tol):
+    g = torch.Generator(device=DEV); g.manual_seed(99)
+    x = torch.rand(n, generator=g, device=DEV, dtype=va.dtype) * 2 - 1
+    want = _definition_segments(rp, ci, va, x)
+    scale = _abs_segments(rp, ci, va, x)
+    # the fp64 prefix sums themselves carry ~1e-16 x |prefix| of error: far below tol x scale for every non-empty row
+    for method in methods:
+        y, sched = _run(m, n, rp, ci, va, x, method)
+        assert not bool(torch.isnan(y).any()), (method, sched)
+        err = (y.double() - want).abs()
+        bad = err > tol * scale + 1e-9 * (scale == 0)
+        assert not bool(bad.any()), (method.name, sched, int(bad.sum()), float((err / scale.clamp(min=1e-300)).max()))
+
+
+@pytest.mark.parametrize("dtype,tol", [(torch.float64, 1e-6), (torch.float32, 1e-3)])
+@pytest.mark.parametrize("cols", ["rmat", "uniform"])
+def test_rounding_at_size_orkut_style_named_schedule(cols, dtype, tol):
+    """Config 3's large stand-in at full size on INEXACT data (uniform(-1, 1) values and x): the named schedule
+    (Method_Balanced2 -> row blocks x column slabs: products in the value type, double accumulators in LDS, a summation order
+    of its own) and CSR5 must stay within the north_star tolerance of the fp64 definition, scaled by the row's sum of |a x|.
+    The exact-arithmetic tests above prove the indexing at this size; this proves the rounding."""
+    m = 3_070_000
+    lens = synth.powerlaw_lengths_device(m, 76, 33000, 1.5, DEV, 1)
+    _, _, rp, ci, va = synth.from_row_lengths_device(lens, m, "uniform", dtype, DEV, 1, cols=cols)
+    _check_rounding(m, m, rp, ci, va, [M.Method_Balanced2, M.Method_CSR5SPMV], tol)
+
+
+@pytest.mark.parametrize("dtype,tol", [(torch.float32, 1e-3), (torch.float64, 1e-6)])
+def test_rounding_at_size_config4_named_schedule(dtype, tol):
+    """Config 4 at full size (1e7 skewed rows, 5.4e8 non-zeros) on inexact data: SELL-C-sigma (slabs + long-row CSR5 sub-matrix
+    + carry fix-up), CSR5 and nnz-split within the north_star tolerance of the fp64 definition."""
+    m = 10_000_000
+    lens = synth.skewed_lengths_device(m, DEV, 1)
+    _, _, rp, ci, va = synth.from_row_lengths_device(lens, m, "uniform", dtype, DEV, 1, local=4096)
+    _check_rounding(m, m, rp, ci, va, [M.Method_SellCSigma, M.Method_CSR5SPMV, M.Method_Balanced_Yid], tol)
