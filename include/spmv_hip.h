@@ -85,6 +85,8 @@ int spmv_hip_update_values(spmv_Handle_t handle, const void *Matrix_Val);
  *                      multiply to the row-block x column-slab executor when no x window of the matrix fits LDS,
  *                      nnz >= 2^21 and n * size >= 4 MiB (x as large as an XCD's L2; 12 MiB when rows average fewer than 8 entries): ~3x faster on columns
  *                      without locality.  One wavefront owns a row block, so results are bit-reproducible.)
+ *       "split" (0/1, default 1: a matrix whose entries are partly local, partly scattered may be multiplied as A_near + A_far when
+ *               create() measures that faster -- spmv_hip_info.split_ms, far_nnz)
  *       "slab_kib" (KiB of x per column slab, 0 = as narrow as the cell table allows)
  *       "block_rows" (rows per block, 0 = 64 KiB of y)
  *       "host_rows" (0/1, default 0: 1 = handles created with VECTOR_NONE and Method_Serial / Method_Parallel run
@@ -134,6 +136,10 @@ typedef struct spmv_hip_info {
     float route_ms[2];          /* only when part of the tile groups stage their x windows and part do not: create() builds the tile
                                  * schedule AND the row-block x column-slab executor, times both -- [0] tile schedule, [1] blocked
                                  * executor, ms -- and keeps the faster (0, 0: the choice needed no measurement) */
+    float split_ms[2];          /* when a sizeable part of the entries -- not all -- lies near its tile's centre column, create() also builds
+                                 * A = A_near + A_far (near: the tile schedule, every tile staged; far: the blocked executor, accumulating) and
+                                 * times it: [0] schedule as built, [1] the split pair, ms (0, 0: not tried) */
+    long long far_nnz;          /* entries the blocked executor multiplies in a split handle (0: the handle is not split) */
 } spmv_hip_info;
 int spmv_hip_get_info(spmv_Handle_t handle, spmv_hip_info *out);
 

@@ -42,6 +42,7 @@ static int build_csr5(spmv_dev *d, Csr5Plan &P, int m, long long nnz, const int 
 template <typename T> static int autotune_vector(spmv_dev *d);
 template <typename T> static int autotune_blocked(spmv_dev *d);
 template <typename T> static double time_schedule(spmv_dev *d, int iters);
+template <typename T> static int split_make(spmv_dev *d, spmv_dev **near_out, spmv_dev **far_out, bool values_only);
 template <typename T> static int build_tile_windows(spmv_dev *d, int tiles, const int *split, int rows_per_tile = kVecTileRows, bool wide = false);
 constexpr size_t kVecWideXTileBytes = 96 * 1024; // budget of the wide form (slot indices; two workgroups per CU)
 
@@ -450,6 +451,17 @@ static int blocked_fill(spmv_dev *d, bool values_only)
     if (e == hipSuccess) e = hipStreamSynchronize(d->stream);
     cleanup();
     if (e != hipSuccess) return fail(SPMV_HIP_E_RUNTIME, "block fill: %s", hipGetErrorString(e));
+    if (!values_only) { // launch order (blk_kernel): the blocks with entries in row order, then the empty ones
+        std::vector<BlkDir> hd((size_t) B);
+        std::vector<int> order;
+        order.reserve((size_t) B);
+        HIP_TRY(hipMemcpy(hd.data(), S.dir, sizeof(BlkDir) * (size_t) B, hipMemcpyDeviceToHost));
+        for (int b = 0; b < B; ++b) if (hd[(size_t) b].ns > 0) order.push_back(b);
+        for (int b = 0; b < B; ++b) if (hd[(size_t) b].ns <= 0) order.push_back(b);
+        int rc = dev_alloc(d, (void **) &S.order, sizeof(int) * (size_t) B, true);
+        if (rc) return rc;
+        HIP_TRY(hipMemcpy(S.order, order.data(), sizeof(int) * (size_t) B, hipMemcpyHostToDevice));
+    }
     return SPMV_HIP_OK;
 }
 
@@ -514,7 +526,10 @@ static int blocked_partition(spmv_dev *d, int btarget, int rcap)
     } else {
         int *out = nullptr, hout[2] = {0, 0}; // [0..1] results, [2 ..] the kernel's cut-point scratch
         HIP_TRY(pool_malloc((void **) &out, sizeof(int) * ((size_t) btarget + 3)));
-        const long long c = std::max<long long>(1, (long long) (d->stats.mean_row_len / 8.0)); // fixed cost of a row, in entries
+        // fixed cost of a row, in entries.  The far half of a split matrix (shim/split.hpp) has rows without any entry by construction --
+        // often long stretches of them (a banded matrix whose last tenth is random: 9e6 empty rows, which at cost 1 each took a fifth
+        // of the "work" and left the real entries to 120 of 1024 blocks): there a row costs nothing and the row cap alone ends blocks
+        const long long c = d->accumulate ? 0 : std::max<long long>(1, (long long) (d->stats.mean_row_len / 8.0));
         blk_partition_kernel<<<1, kBlock, 0, d->stream>>>(d->m, d->rowptr, btarget, rcap, c, out + 2, S.row0, out);
         hipError_t e = hipGetLastError();
         if (e == hipSuccess) e = hipMemcpyAsync(hout, out, sizeof hout, hipMemcpyDeviceToHost, d->stream);
@@ -553,6 +568,8 @@ static int build_blocked(spmv_dev *d, int rule)
     int rc = blocked_partition(d, btarget, rcap);
     if (!rc) rc = blocked_fill<T>(d, false);
     if (rc) return rc;
+    if (getenv("SPMV_HIP_BLK_DEBUG"))
+        fprintf(stderr, "[spmv_hip] blocked: m %d nnz %lld -> B %d (target %d) R %d K %d wshift %d groups %lld accumulate %d\n", d->m, d->nnz, S.B, btarget, S.R, S.K, S.wshift, S.groups, (int) d->accumulate);
     d->blk_on = true;
     return SPMV_HIP_OK;
 }

@@ -117,11 +117,12 @@ template <typename T>
 static void launch_blocked(spmv_dev *d, const T *x, T *y)
 {
     const BlkSet &S = d->blk;
-    const size_t lds = blocked_lds_bytes(S);
+    static const size_t lds_pad = getenv("SPMV_HIP_BLK_LDS_PAD") ? (size_t) atol(getenv("SPMV_HIP_BLK_LDS_PAD")) : 0; // experiment knob
+    const size_t lds = blocked_lds_bytes(S) + lds_pad;
 #define SPMV_BLK_LAUNCH(UN, DBG)                                                                                                  \
     do {                                                                                                                          \
         ensure_lds<blk_kernel<T, UN, DBG>>(d, lds);                                                                               \
-        blk_kernel<T, UN, DBG><<<S.B, kWave, lds, d->stream>>>(S.row0, S.R, S.dir, (const T *) S.val, S.meta, S.hdr, x, y);       \
+        blk_kernel<T, UN, DBG><<<S.B, kWave, lds, d->stream>>>(S.row0, S.R, S.dir, (const T *) S.val, S.meta, S.hdr, S.order, x, y, d->accumulate ? 1 : 0); \
     } while (0)
 #ifdef SPMV_BLK_DEBUG_FORMS // A/B builds of tools/ only (wrong results): variant 51 / 52 / 53 = no gathers / no LDS adds / neither, 8 groups per step
     if (d->plan.variant == 51) { SPMV_BLK_LAUNCH(8, 1); return; }
@@ -278,7 +279,13 @@ template <typename T>
 static int launch(spmv_dev *d, const T *x, T *y)
 {
     if (d->m == 0) return SPMV_HIP_OK;
-    if (d->nnz == 0) { // nothing to multiply: y = 0
+    if (d->sp_near && d->sp_far) { // A = A_near + A_far (shim/split.hpp): the tile schedule writes every row, the blocked executor adds its part
+        d->sp_near->stream = d->sp_far->stream = d->stream;
+        const int rc = launch<T>(d->sp_near, x, y);
+        return rc ? rc : launch<T>(d->sp_far, x, y);
+    }
+    if (d->nnz == 0) { // nothing to multiply: y = 0 (the far half of a split: y += 0)
+        if (d->accumulate) return SPMV_HIP_OK;
         fill_zero_kernel<T><<<grid_for(d->m, kBlock, d->cus * 8), kBlock, 0, d->stream>>>(d->m, y);
         HIP_TRY(hipGetLastError());
         return SPMV_HIP_OK;

@@ -168,6 +168,7 @@ struct BlkSet {
     int *row0 = nullptr;          // [B + 1] first row of every block (equal-work cut points, blk_partition_kernel)
     long long *gstart = nullptr;  // [B + 1] first group of every block
     BlkDir *dir = nullptr;        // [B] what the executor reads
+    int *order = nullptr;         // [B] launch order: blocks with entries first (row order), empty blocks last
     void *val = nullptr;
     unsigned *meta = nullptr;     // 16-bit column offset | 16-bit row in the block
     int *hdr = nullptr;           // per group: first column of its super-slab
@@ -225,6 +226,13 @@ struct spmv_dev {
     long long stream_bytes = 0, x_bytes = 0; // traffic model of one launch (account_stream_bytes)
     int x_groups_seen = 0;                   // tile groups analysed before the blocked executor took over
     float route_ms[2] = {0, 0};              // measured tile schedule vs blocked executor (spmv_shim_build, mode 2)
+    // A = A_near + A_far (shim/split.hpp): the two halves, planned and built like any matrix; the parent keeps the resident CSR
+    spmv_dev *sp_near = nullptr, *sp_far = nullptr;
+    int *sp_centre = nullptr;                // centre column of every 256-row tile
+    int sp_half = 0;                         // near = within +-sp_half of the tile's centre
+    float near_share = -1.f;                 // sampled share of near entries (-1: not sampled)
+    float split_ms[2] = {0, 0};              // measured: schedule as built vs the split pair
+    bool accumulate = false;                 // this matrix is the far half of a split: y += A x (blocked executor only)
     long long device_bytes = 0;
     double inspect_ms = 0;
     std::vector<std::pair<void *, size_t>> sched_allocs; // (pointer, bytes): freed when the schedule is rebuilt

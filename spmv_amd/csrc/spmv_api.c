@@ -234,6 +234,55 @@ void spmv_hip_create_handle_from_blocks(spmv_Handle_t *Handle, int blocks, const
     h->extraHandle = st;
 }
 
+/* A matrix with locality in PART of its entries (every tenth row random; web graphs: 90 % of a row near the diagonal, 10 % on hub
+ * columns) stages no x window -- one stray entry per tile is enough -- and the blocked executor pays for the local entries too.  When
+ * the shim's sample says a real part of the entries, but not all, lies near its tile's centre column, the matrix is split once into
+ * A_near + A_far (csrc/kernels/split.hpp), each half planned and inspected like any matrix -- near: the method's tile schedule, every
+ * tile staged by construction, never the blocked executor; far: always the blocked executor, accumulating into y -- and the pair is
+ * timed against the schedule as built; the faster stays (spmv_hip_info.split_ms, far_nnz). */
+static void try_split(spmv_Handle_t h, spmv_hip_state *st, SPMV_METHODS actual)
+{
+    spmv_dev *halves[2] = {NULL, NULL};
+    double t_built, t_split = -1.0;
+    int k, ok = 1;
+    if (st->opts.v[SPMV_OPT_SPLIT] != 1 || !spmv_shim_split_candidate(st->dev)) return;
+    t_built = spmv_shim_time_self(st->dev, 5);
+    if (t_built <= 0.0 || spmv_shim_split(st->dev, &halves[0], &halves[1]) != SPMV_HIP_OK) return;
+    for (k = 0; k < 2 && ok; ++k) {
+        spmv_stats stats;
+        spmv_plan plan;
+        spmv_options o = st->opts;
+        SPMV_METHODS a = actual;
+        o.v[SPMV_OPT_CACHE_BLOCK] = k == 0 ? 0 : 2;
+        /* the near half of a CSR-vector request: rows that lost entries to the far half are no longer regular (every tenth row empty:
+         * 57 % of CSR-vector's 8-row steps run masked, 0.89 vs 0.55 ms under CSR5) -- let the row statistics choose, as auto_method = 1 does */
+        if (k == 0 && actual == Method_Parallel && o.v[SPMV_OPT_AUTO_METHOD] < 1) o.v[SPMV_OPT_AUTO_METHOD] = 1;
+        ok = spmv_shim_matrix_stats(halves[k], &stats) == SPMV_HIP_OK;
+        if (ok) {
+            spmv_plan_choose(actual == Method_Serial ? Method_Parallel : actual, &stats, (size_t) h->data_size, &o, &plan, &a, k == 0 && actual == Method_Parallel);
+            ok = spmv_shim_build(halves[k], &plan) == SPMV_HIP_OK;
+        }
+    }
+    if (ok && getenv("SPMV_HIP_SPLIT_DEBUG")) {
+        spmv_hip_info a, b;
+        double tn = spmv_shim_time_self(halves[0], 5), tf = spmv_shim_time_self(halves[1], 5);
+        (void) spmv_shim_info(halves[0], &a);
+        (void) spmv_shim_info(halves[1], &b);
+        fprintf(stderr, "[spmv_hip] split: as built %.4f ms; near %lld nnz %s %.4f ms; far %lld nnz %s %.4f ms (inspect %.1f / %.1f ms)\n", t_built, a.nnz, a.kernel_name,
+                tn, b.nnz, b.kernel_name, tf, a.inspect_ms, b.inspect_ms);
+    }
+    if (ok && spmv_shim_attach_split(st->dev, halves[0], halves[1], 0) == SPMV_HIP_OK) {
+        t_split = spmv_shim_time_self(st->dev, 5);
+        if (t_split > 0.0 && t_split < 0.9 * t_built) (void) spmv_shim_attach_split(st->dev, halves[0], halves[1], 1); /* keep: drop the unsplit schedule */
+        else (void) spmv_shim_attach_split(st->dev, NULL, NULL, 0);                                                    /* destroys the halves */
+    } else {
+        if (halves[0]) spmv_shim_matrix_destroy(halves[0]);
+        if (halves[1]) spmv_shim_matrix_destroy(halves[1]);
+    }
+    spmv_shim_note_split_ms(st->dev, t_built, t_split);
+    spmv_hip_clear_error();
+}
+
 /* Upload + plan + inspect.  Used by create and by spmv() when it is handed another matrix. */
 static int state_build(spmv_Handle_t h, spmv_hip_state *st, int m, int n, const int *RowPtr,
                        const int *ColIdx, const void *Val)
@@ -302,6 +351,7 @@ static int state_build(spmv_Handle_t h, spmv_hip_state *st, int m, int n, const 
         st->plan = best_plan;
         actual = best_method;
     }
+    try_split(h, st, actual);
     if (st->stream_set) spmv_shim_set_stream(st->dev, st->stream);
     spmv_shim_set_async(st->dev, st->async);
     st->m = m;

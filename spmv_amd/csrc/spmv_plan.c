@@ -46,6 +46,8 @@ static opt_t g_opts[SPMV_N_OPTS] = {
                                                                        * 1 = automatic (every schedule but CSR-scalar), 2 = always, 0 = never */
     [SPMV_OPT_SLAB_KIB] = {"slab_kib", 0, 0, 1 << 16, 1, 0},          /* ... KiB of x per column slab (0 = as narrow as the cell table allows) */
     [SPMV_OPT_BLOCK_ROWS] = {"block_rows", 0, 0, 16384, 1, 0},        /* ... uniform blocks of that many rows (0 = equal-work blocks, two per CU) */
+    [SPMV_OPT_SPLIT] = {"split", 1, 0, 1, 0, 0},                      /* 1: a matrix with locality in PART of its entries may be multiplied as A_near (tile schedule) +
+                                                                       * A_far (blocked executor) when create() measures that faster (kernels/split.hpp); 0: never */
     [SPMV_OPT_VARIANT] = {"variant", 0, 0, 1 << 20, 0, 0},            /* kernel-form selector of the A/B harness and the variant tests, 0 = default */
     [SPMV_OPT_AUTO_METHOD] = {"auto_method", 0, 0, 2, 0, 0},          /* 1: create() picks the schedule from the matrix by rules (two stages, spmv_api.c);
                                                                        * 2: ... by building the candidate schedules and timing them */

@@ -85,6 +85,12 @@ int spmv_shim_update_values(spmv_dev *d, const void *val);
 /* Order-independent 64-bit checksum (sum of the 32-bit words) of nnz values at `val` (host or device). */
 int spmv_shim_checksum(spmv_dev *d, const void *val, unsigned long long *out);
 
+/* ---- A = A_near + A_far (shim/split.hpp): a matrix with locality in part of its entries ---- */
+int spmv_shim_split_candidate(spmv_dev *d);                                   /* 1: worth building and timing */
+int spmv_shim_split(spmv_dev *d, spmv_dev **near_out, spmv_dev **far_out);    /* the two halves, unplanned; far multiplies accumulating */
+int spmv_shim_attach_split(spmv_dev *d, spmv_dev *near_dev, spmv_dev *far_dev, int release_parent_schedule); /* NULLs: detach + destroy */
+void spmv_shim_note_split_ms(spmv_dev *d, double as_built_ms, double split_ms);
+
 /* ---- row blocks over several GPUs of this process (shim/multi.hpp; option "gpus") ---- */
 typedef struct spmv_multi spmv_multi;
 /* Split the matrix into min(gpus, visible devices) equal-nnz row blocks, one shard (spmv_dev) per device, each with its

@@ -30,11 +30,46 @@
 #include "kernels/csr5.hpp"
 #include "kernels/long_rows.hpp"
 #include "kernels/blocked.hpp"
+#include "kernels/split.hpp"
 #include "kernels/csr_vector_tile.hpp"
 
 using namespace spmv;
 
 #include "shim/state.hpp"
+
+// row statistics of the resident RowPtr (also validates it): d->nnz, d->stats
+static int matrix_row_stats(spmv_dev *d)
+{
+    const int m = d->m, n = d->n;
+    DevStats hs{0, INT_MAX, 0, 0, 0, 0};
+    DevStats *ds = nullptr;
+    if (pool_malloc((void **) &ds, sizeof(DevStats)) != hipSuccess) return fail(SPMV_HIP_E_ALLOC, "pool_malloc(stats)");
+    (void) hipMemcpy(ds, &hs, sizeof hs, hipMemcpyHostToDevice);
+    if (m > 0) {
+        stats_kernel<<<grid_for(m, kBlock, d->cus * 8), kBlock>>>(m, d->rowptr, ds);
+        if (hipGetLastError() != hipSuccess) { (void) pool_free(ds); return fail(SPMV_HIP_E_RUNTIME, "stats kernel launch failed"); }
+    }
+    hipError_t e = hipMemcpy(&hs, ds, sizeof hs, hipMemcpyDeviceToHost);
+    (void) pool_free(ds);
+    if (e != hipSuccess) return fail(SPMV_HIP_E_RUNTIME, "stats kernel: %s", hipGetErrorString(e));
+    if (m > 0 && (hs.bad || hs.first != 0 || hs.last < 0))
+        return fail(SPMV_HIP_E_ARG, "RowPtr must start at 0 and be non-decreasing (RowPtr[0]=%d)", hs.first);
+    d->nnz = m > 0 ? hs.last : 0;
+    if (d->nnz > (long long) INT_MAX - 4096)
+        return fail(SPMV_HIP_E_RANGE, "nnz = %lld is within 4096 of INT_MAX: 16 B tail reads would overflow int32 indices", d->nnz);
+    d->stats.m = m;
+    d->stats.n = n;
+    d->stats.nnz = d->nnz;
+    d->stats.max_row_len = m > 0 ? hs.max_len : 0;
+    d->stats.min_row_len = m > 0 ? hs.min_len : 0;
+    d->stats.empty_rows = hs.empty;
+    d->stats.mean_row_len = m > 0 ? (double) d->nnz / m : 0.0;
+    for (int b = 0; b < SPMV_LEN_BUCKETS; ++b) {
+        d->stats.hist_rows[b] = (long long) hs.hist_rows[b];
+        d->stats.hist_nnz[b] = (long long) hs.hist_nnz[b];
+    }
+    return SPMV_HIP_OK;
+}
 
 // ------------------------------------------------------------------------------------ create
 extern "C" int spmv_shim_matrix_create(spmv_dev **out, int m, int n, const int *rowptr, const int *colidx,
@@ -67,35 +102,8 @@ extern "C" int spmv_shim_matrix_create(spmv_dev **out, int m, int n, const int *
     } else {
         (void) hipMemset(d->rowptr, 0, sizeof(int));
     }
-    // row statistics (also validates RowPtr)
-    DevStats hs{0, INT_MAX, 0, 0, 0, 0};
-    DevStats *ds = nullptr;
-    if (pool_malloc((void **) &ds, sizeof(DevStats)) != hipSuccess) return bail(fail(SPMV_HIP_E_ALLOC, "pool_malloc(stats)"));
-    (void) hipMemcpy(ds, &hs, sizeof hs, hipMemcpyHostToDevice);
-    if (m > 0) {
-        stats_kernel<<<grid_for(m, kBlock, d->cus * 8), kBlock>>>(m, d->rowptr, ds);
-        if (hipGetLastError() != hipSuccess) { (void) pool_free(ds); return bail(fail(SPMV_HIP_E_RUNTIME, "stats kernel launch failed")); }
-    }
-    hipError_t e = hipMemcpy(&hs, ds, sizeof hs, hipMemcpyDeviceToHost);
-    (void) pool_free(ds);
-    if (e != hipSuccess) return bail(fail(SPMV_HIP_E_RUNTIME, "stats kernel: %s", hipGetErrorString(e)));
-    if (m > 0 && (hs.bad || hs.first != 0 || hs.last < 0))
-        return bail(fail(SPMV_HIP_E_ARG, "RowPtr must start at 0 and be non-decreasing (RowPtr[0]=%d)", hs.first));
-    d->nnz = m > 0 ? hs.last : 0;
-    if (d->nnz > (long long) INT_MAX - 4096)
-        return bail(fail(SPMV_HIP_E_RANGE, "nnz = %lld is within 4096 of INT_MAX: 16 B tail reads would overflow int32 indices", d->nnz));
+    if ((rc = matrix_row_stats(d))) return bail(rc);
     if (d->nnz > 0 && (!colidx || !val)) return bail(fail(SPMV_HIP_E_ARG, "ColIdx / Matrix_Val is NULL"));
-    d->stats.m = m;
-    d->stats.n = n;
-    d->stats.nnz = d->nnz;
-    d->stats.max_row_len = m > 0 ? hs.max_len : 0;
-    d->stats.min_row_len = m > 0 ? hs.min_len : 0;
-    d->stats.empty_rows = hs.empty;
-    d->stats.mean_row_len = m > 0 ? (double) d->nnz / m : 0.0;
-    for (int b = 0; b < SPMV_LEN_BUCKETS; ++b) {
-        d->stats.hist_rows[b] = (long long) hs.hist_rows[b];
-        d->stats.hist_nnz[b] = (long long) hs.hist_nnz[b];
-    }
 
     // padded by kStreamPad elements: the 16 B-per-lane kernels round a row's tail read up
     if ((rc = dev_alloc(d, (void **) &d->colidx, sizeof(int) * ((size_t) d->nnz + kStreamPad), false))) return bail(rc);
@@ -143,6 +151,9 @@ extern "C" void spmv_shim_matrix_destroy(spmv_dev *d)
 {
     if (!d) return;
     quiesce(d); // an asynchronous multiply may still read the arrays that go back to the pool below
+    if (d->sp_near) { spmv_shim_matrix_destroy(d->sp_near); d->sp_near = nullptr; }
+    if (d->sp_far) { spmv_shim_matrix_destroy(d->sp_far); d->sp_far = nullptr; }
+    if (d->sp_centre) { (void) pool_free(d->sp_centre); d->sp_centre = nullptr; }
     free_schedule(d);
     if (d->rowptr) (void) pool_free(d->rowptr);
     if (d->colidx) (void) pool_free(d->colidx);
@@ -159,9 +170,15 @@ extern "C" int spmv_shim_build(spmv_dev *d, const spmv_plan *plan)
 {
     if (!d || !plan) return fail(SPMV_HIP_E_ARG, "build: NULL");
     if (plan->sched < 0 || plan->sched >= SPMV_SCHED_COUNT) return fail(SPMV_HIP_E_ARG, "unknown schedule %d", plan->sched);
+    if (d->sp_near || d->sp_far) { // a rebuild starts from the unsplit matrix
+        if (d->sp_near) spmv_shim_matrix_destroy(d->sp_near);
+        if (d->sp_far) spmv_shim_matrix_destroy(d->sp_far);
+        d->sp_near = d->sp_far = nullptr;
+    }
     free_schedule(d);
     d->plan = *plan;
     d->route_ms[0] = d->route_ms[1] = 0;
+    d->split_ms[0] = d->split_ms[1] = 0;
     const auto t0 = std::chrono::steady_clock::now();
     int rc = SPMV_HIP_OK, staged = -1; // staged: tile groups with x windows in LDS (-1: schedule without windows)
     const bool f64 = d->vsize == sizeof(double);
@@ -238,7 +255,7 @@ extern "C" int spmv_shim_build(spmv_dev *d, const spmv_plan *plan)
             if (tile_ms > 0 && (blk_ms <= 0 || tile_ms <= blk_ms)) { // the tile schedule stays
                 const BlkSet b = d->blk;
                 quiesce(d);
-                for (void *p : {(void *) b.row0, (void *) b.gstart, (void *) b.dir, b.val, (void *) b.meta, (void *) b.hdr}) if (p) sched_free(d, p);
+                for (void *p : {(void *) b.row0, (void *) b.gstart, (void *) b.dir, (void *) b.order, b.val, (void *) b.meta, (void *) b.hdr}) if (p) sched_free(d, p);
                 d->blk = BlkSet();
                 d->blk_on = false;
             }
@@ -254,7 +271,7 @@ extern "C" int spmv_shim_build(spmv_dev *d, const spmv_plan *plan)
             if (rate >= 3.6e12) {
                 auto release = [&](const BlkSet &b) {
                     quiesce(d);
-                    for (void *p : {(void *) b.row0, (void *) b.gstart, (void *) b.dir, b.val, (void *) b.meta, (void *) b.hdr}) if (p) sched_free(d, p);
+                    for (void *p : {(void *) b.row0, (void *) b.gstart, (void *) b.dir, (void *) b.order, b.val, (void *) b.meta, (void *) b.hdr}) if (p) sched_free(d, p);
                 };
                 const BlkSet first = d->blk;
                 d->blk_on = false;
@@ -299,7 +316,7 @@ template <typename T>
 static int update_values(spmv_dev *d, const void *val)
 {
     if (d->nnz == 0) return SPMV_HIP_OK;
-    HIP_TRY(hipMemcpyAsync(d->val, val, sizeof(T) * (size_t) d->nnz, hipMemcpyDefault, d->stream));
+    if (val != d->val) HIP_TRY(hipMemcpyAsync(d->val, val, sizeof(T) * (size_t) d->nnz, hipMemcpyDefault, d->stream)); // the halves of a split handle refresh in place
     const T *v = (const T *) d->val;
     int rc = SPMV_HIP_OK;
     if (d->blk_on) { // the blocked streams are the only copy the executor reads
@@ -329,6 +346,13 @@ extern "C" int spmv_shim_update_values(spmv_dev *d, const void *val)
     if (!val && d->nnz > 0) return fail(SPMV_HIP_E_ARG, "update_values: NULL");
     DeviceGuard guard(d->device);
     if (!guard.ok) return fail(SPMV_HIP_E_RUNTIME, "hipSetDevice(%d) failed", d->device);
+    if (d->sp_near && d->sp_far) { // split handle: the resident values first, then both halves from them (same positions as at create)
+        HIP_TRY(hipMemcpyAsync(d->val, val, d->vsize * (size_t) d->nnz, hipMemcpyDefault, d->stream));
+        int rc = d->vsize == sizeof(double) ? split_make<double>(d, nullptr, nullptr, true) : split_make<float>(d, nullptr, nullptr, true);
+        if (!rc) rc = spmv_shim_update_values(d->sp_near, d->sp_near->val);
+        if (!rc) rc = spmv_shim_update_values(d->sp_far, d->sp_far->val);
+        return rc;
+    }
     return d->vsize == sizeof(double) ? update_values<double>(d, val) : update_values<float>(d, val);
 }
 
@@ -378,6 +402,7 @@ extern "C" int spmv_shim_checksum(spmv_dev *d, const void *val, unsigned long lo
 extern "C" int spmv_shim_is_device_ptr(const void *p) { return is_device_ptr(p) ? 1 : 0; }
 
 #include "shim/launch.hpp"
+#include "shim/split.hpp"
 
 extern "C" int spmv_shim_run(spmv_dev *d, const void *x, void *y)
 {
@@ -492,6 +517,25 @@ static const char *kKernelNames[] = {"csr_scalar_kernel", "csr_vector_pipe_kerne
 extern "C" int spmv_shim_info(const spmv_dev *d, spmv_hip_info *o)
 {
     if (!d || !o) return fail(SPMV_HIP_E_ARG, "info: NULL");
+    if (d->sp_near && d->sp_far) { // split handle: the near half names schedule and kernel; sizes and bytes are the whole matrix's
+        const int rc = spmv_shim_info(d->sp_near, o);
+        if (rc) return rc;
+        spmv_hip_info f;
+        (void) spmv_shim_info(d->sp_far, &f);
+        const long long s = (long long) d->vsize;
+        o->nnz = d->nnz;
+        o->stored_nnz += f.stored_nnz;
+        o->max_row_len = d->stats.max_row_len; o->min_row_len = d->stats.min_row_len; o->empty_rows = d->stats.empty_rows; o->mean_row_len = d->stats.mean_row_len;
+        o->device_bytes = d->device_bytes + d->sp_near->device_bytes + d->sp_far->device_bytes;
+        o->alg_bytes = 4ll * ((long long) d->m + 1) + d->nnz * (4 + s) + s * d->n + s * d->m;
+        o->stream_bytes += f.stream_bytes;
+        o->x_bytes += f.x_bytes;
+        o->inspect_ms = d->inspect_ms;
+        o->route_ms[0] = d->route_ms[0]; o->route_ms[1] = d->route_ms[1];
+        o->split_ms[0] = d->split_ms[0]; o->split_ms[1] = d->split_ms[1];
+        o->far_nnz = d->sp_far->nnz;
+        return SPMV_HIP_OK;
+    }
     memset(o, 0, sizeof *o);
     o->device = d->device;
     o->schedule = d->plan.sched;
@@ -524,6 +568,9 @@ extern "C" int spmv_shim_info(const spmv_dev *d, spmv_hip_info *o)
     o->x_bytes = d->x_bytes;
     o->route_ms[0] = d->route_ms[0];
     o->route_ms[1] = d->route_ms[1];
+    o->split_ms[0] = d->split_ms[0];
+    o->split_ms[1] = d->split_ms[1];
+    o->far_nnz = d->sp_far ? d->sp_far->nnz : 0;
     if (d->blk_on) { o->stored_nnz = d->blk.groups << d->blk.ge; o->x_groups = d->x_groups_seen; o->x_groups_staged = 0; }
     if (!d->blk_on) switch (d->plan.sched) {
     case SPMV_SCHED_CSR_VECTOR:

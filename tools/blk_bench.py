@@ -52,7 +52,8 @@ for cfg in a.cfgs:
                                    "ms_mean": round(float(mean), 4), "frac_alg": round(info["alg_bytes"] / t / 1e6 / 8000, 4),
                                    "frac_moved": round(info["stream_bytes"] / t / 1e6 / 8000, 4), "inspect_ms": round(info["inspect_ms"], 1),
                                    "stored_over_nnz": round(info["stored_nnz"] / max(info["nnz"], 1), 4), "tuned": info["tuned_choice"],
-                                   "tune_ms": [round(v, 4) for v in info["tune_ms"]], "rel_err": err}), flush=True)
+                                   "tune_ms": [round(v, 4) for v in info["tune_ms"]], "split_ms": [round(v, 4) for v in info["split_ms"]],
+                                   "far_share": round(info["far_nnz"] / max(info["nnz"], 1), 4), "rel_err": err}), flush=True)
         h.close()
         for k, v in keep.items():
             api.set_option(k, v)

@@ -19,6 +19,13 @@ def mixed(kind):
         return rp, cb, va
     _, _, _, cr, _ = synth.uniform_k_device(m, m, k, "uniform", torch.float64, dev, 1)
     rows = torch.arange(m, device=dev)
+    if kind == "emptyprefix1":      # the first 1 % of the rows empty, the rest random (what the far half of prefix1 looks like)
+        keep = (rows >= m // 100)
+        lens = keep.to(torch.int64) * k
+        rp2 = torch.zeros(m + 1, dtype=torch.int64, device=dev)
+        torch.cumsum(lens, 0, out=rp2[1:])
+        sel = keep.repeat_interleave(k)
+        return rp2.to(torch.int32), cr[sel].contiguous(), va[sel].contiguous()
     rnd = {"random": rows >= 0, "prefix1": rows >= m // 100, "tail10": rows >= m - m // 10, "every10": rows % 10 == 0}[kind]
     sel = rnd.repeat_interleave(k)
     ci = torch.where(sel, cr, cb)
@@ -35,7 +42,8 @@ for kind in sys.argv[2:] or ["banded", "random", "prefix1", "tail10", "every10"]
         mean, ms = api.time_launches(h.h, x, y, 5, 20)
         print("ROUTE " + json.dumps({"kind": kind, "method": api.SPMV_METHODS(method).name, "kernel": info["kernel_name"], "blocked": info["cache_blocked"],
                                      "ms_min": round(float(ms.min()), 4), "x_groups": info["x_groups"], "staged": info["x_groups_staged"],
-                                     "route_ms": [round(v, 4) for v in info["route_ms"]], "inspect_ms": round(info["inspect_ms"], 1)}), flush=True)
+                                     "route_ms": [round(v, 4) for v in info["route_ms"]], "split_ms": [round(v, 4) for v in info["split_ms"]],
+                                     "far_share": round(info["far_nnz"] / max(info["nnz"], 1), 4), "tuned": info["tuned_choice"], "tune_ms": [round(v, 4) for v in info["tune_ms"]], "stored": info["stored_nnz"], "inspect_ms": round(info["inspect_ms"], 1)}), flush=True)
         h.close()
     del rp, ci, va, x, y
     torch.cuda.empty_cache()
