@@ -9,7 +9,7 @@
 //
 // Here, for that case only (format of round 3; DESIGN.md 3.7 has the measurements):
 //   layout      rows are cut into blocks of at most R rows of EQUAL WORK (blk_partition_kernel), columns into slabs of
-//               2^wshift columns (128 unless that would make more than 32768 slabs).  The entries of a row block are
+//               2^wshift columns (128 unless that would make more than 12288 slabs).  The entries of a row block are
 //               stored sorted by slab -- the sweep over the slabs, in step over the blocks of an XCD, is what keeps x in L2 --
 //               in GROUPS of 64 lanes x 16 bytes of values (128 fp64 / 256 fp32 entries), as two streams: the value and a
 //               32-bit word (16-bit column offset | 16-bit row inside the block) -- 12 bytes per fp64 entry, the bytes of
@@ -27,7 +27,9 @@
 //               per round, wave w owning entries [256 w, 256 w + 256) of the round, and take TURNS (a barrier apiece) at
 //               advancing the cursors with LDS atomics: cursor updates therefore happen in CSR order, wave after wave,
 //               instruction after instruction (inside one instruction the LDS unit serialises the lanes that hit one
-//               cursor in a fixed order), so the stored order -- (slab, CSR order) -- is a function of the matrix alone.
+//               cursor in a fixed order), so an entry's rank inside its cell is its CSR rank and the stored order -- (slab, then
+//               blk_spread(CSR rank): the entries of a large cell dealt out so that one row's neighbours do not share an
+//               instruction) -- is a function of the matrix alone.
 //   executor    ONE WAVEFRONT per row block (a 64-thread workgroup, two blocks per CU).  y of the block lives in LDS
 //               as doubles (for fp32 values too -- see lds_add); the wave walks the block's groups three steps deep
 //               (stream loads of step t + 2, gathers of step t + 1, additions of step t) and adds every product into y's
@@ -50,7 +52,7 @@ namespace spmv {
 
 constexpr int kBlkSlabShift = 7;     // slabs of 128 columns unless that makes too many cells
 constexpr int kBlkSuperShift = 16;   // 16-bit column offsets inside super-slabs of 65536 columns
-constexpr int kBlkMaxCells = 32768;  // cells of one row block at most (the inspector's cursors: 128 KiB of LDS)
+constexpr int kBlkMaxCells = 12288;  // cells of one row block at most (the inspector keeps count, start and cursor of every cell in LDS: 144 KiB)
 constexpr int kBlkThreads = 1024;    // inspector workgroups: 16 waves per row block
 constexpr int kBlkTurn = 4;          // batches of 64 entries a wave places per turn
 constexpr int kBlkPadGroups = 128;   // zero groups behind the last block: three executor steps of the widest form, and header loads reach 64 groups ahead
@@ -185,8 +187,30 @@ __device__ __forceinline__ unsigned blk_stored_pos(unsigned pos, int ge, unsigne
     return (pos - gi) + (gi & (kWave - 1)) * epl + (gi >> 6);
 }
 
-// Inspector pass 2, the stable fill (see the header).  Dynamic LDS: K cursors.  VALUES_ONLY: re-permute new values into the
-// same positions (spmv_hip_update_values).
+// Where the q-th entry (CSR order) of a cell of c entries goes inside the cell.  Entries of ONE ROW that fall into the same cell
+// are neighbours in CSR order; left side by side they would sit in neighbouring lanes of one executor instruction and their LDS
+// adds would hit one accumulator -- the LDS unit serialises same-address atomics (a block of banded rows ran 2.5 x as long as a block
+// of random ones, and with two blocks per slot ten such blocks cost the whole launch a third round: 1.71 vs 1.39 ms).  So a cell is
+// dealt out in chunks of 64 s entries (s = min(32, c / 64)) transposed s x 64: positions 64 a .. 64 a + 63 of a chunk hold its
+// entries a, a + s, a + 2 s, ...: a run of up to s entries of one row meets one lane per instruction, and for banded rows the 64
+// lanes of an instruction hold the same entry of 64 consecutive rows -- consecutive columns, one coalesced gather.  Cells under
+// 128 entries (the sparse case) keep CSR order.  A pure function of (q, c): the stored order stays a function of the matrix alone.
+__device__ __forceinline__ unsigned blk_spread(unsigned q, unsigned c)
+{
+    unsigned s = c >> 6;
+    if (s < 2u) return q;
+    if (s > 32u) s = 32u;
+    const unsigned chunk = s << 6, base = q - q % chunk, rem = c - base; // entries from this chunk's start to the cell's end
+    if (rem < chunk) {        // the cell's last, partial chunk: a narrower transpose, its own last < 64 entries in place
+        s = rem >> 6;
+        if (s < 2u || q - base >= (s << 6)) return q;
+    }
+    const unsigned i = q - base;
+    return base + (i % s) * 64u + i / s;
+}
+
+// Inspector pass 2, the stable fill (see the header).  Dynamic LDS: 3 K words (count, start and cursor of every cell).  VALUES_ONLY:
+// re-permute new values into the same positions (spmv_hip_update_values).
 template <typename T, bool VALUES_ONLY>
 __global__ __launch_bounds__(kBlkThreads) void blk_fill_kernel(const int *__restrict__ row0, int K, int wshift, int ge, const int *__restrict__ rowptr,
                                                                const int *__restrict__ colidx, const T *__restrict__ val, const unsigned short *__restrict__ rowin,
@@ -194,13 +218,16 @@ __global__ __launch_bounds__(kBlkThreads) void blk_fill_kernel(const int *__rest
                                                                int *__restrict__ hdr, BlkDir *__restrict__ dir)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char blk_fill_lds[];
-    unsigned *cur = reinterpret_cast<unsigned *>(blk_fill_lds); // counts, then the next position of every cell (entries from the block region's start)
+    unsigned *cnt = reinterpret_cast<unsigned *>(blk_fill_lds); // entries of every cell
+    unsigned *cst = cnt + K;                                     // first position of the cell (entries from the block region's start)
+    unsigned *cur = cst + K;                                     // entries of the cell placed so far
     const int b = blockIdx.x;
     const int wave = threadIdx.x / kWave, lane = threadIdx.x % kWave;
     const int p0 = rowptr[row0[b]], p1 = rowptr[row0[b + 1]];
     const long long g0 = gstart[b];
-    blk_count_cells(cur, K, wshift, p0, p1, colidx);
-    if (wave == 0) { // counts -> cursors, super-slab after super-slab (every lane a contiguous run of the super-slab's cells); group headers
+    blk_count_cells(cnt, K, wshift, p0, p1, colidx);
+    for (int i = threadIdx.x; i < K; i += kBlkThreads) cur[i] = 0u;
+    if (wave == 0) { // counts -> cell starts, super-slab after super-slab (every lane a contiguous run of the super-slab's cells); group headers
         const int cs = kBlkSuperShift - wshift, S = (K + (1 << cs) - 1) >> cs, gsize = 1 << ge;
         int off = 0;
         for (int s = 0; s < S; ++s) {
@@ -208,13 +235,12 @@ __global__ __launch_bounds__(kBlkThreads) void blk_fill_kernel(const int *__rest
             const int per = (kb - ka + kWave - 1) / kWave;
             const int a = min(ka + lane * per, kb), e = min(a + per, kb);
             int c = 0;
-            for (int k = a; k < e; ++k) c += (int) cur[k];
+            for (int k = a; k < e; ++k) c += (int) cnt[k];
             int tot;
             int pos = off + wave_excl_scan(c, lane, &tot);
             for (int k = a; k < e; ++k) {
-                const int ck = (int) cur[k];
-                cur[k] = (unsigned) pos;
-                pos += ck;
+                cst[k] = (unsigned) pos;
+                pos += (int) cnt[k];
             }
             const int end = ((off + tot + gsize - 1) >> ge) << ge; // the super-slab's run, in whole groups
             if (!VALUES_ONLY)
@@ -232,7 +258,7 @@ __global__ __launch_bounds__(kBlkThreads) void blk_fill_kernel(const int *__rest
         T v[kBlkTurn];
         unsigned pos[kBlkTurn];
 #pragma unroll
-        for (int i = 0; i < kBlkTurn; ++i) { // padded ColIdx / Val: reads up to kStreamPad past nnz stay in bounds only for the last block -- guard by position
+        for (int i = 0; i < kBlkTurn; ++i) {
             const int p = q + (wave * kBlkTurn + i) * kWave + lane;
             const bool on = p < p1;
             c[i] = on ? ld_stream(colidx + p) : -1;
@@ -243,14 +269,15 @@ __global__ __launch_bounds__(kBlkThreads) void blk_fill_kernel(const int *__rest
             if (wave == turn) {
 #pragma unroll
                 for (int i = 0; i < kBlkTurn; ++i)
-                    if (c[i] >= 0) pos[i] = atomicAdd(&cur[c[i] >> wshift], 1u);
+                    if (c[i] >= 0) pos[i] = atomicAdd(&cur[c[i] >> wshift], 1u); // rank of the entry inside its cell, CSR order
             }
             __syncthreads();
         }
 #pragma unroll
         for (int i = 0; i < kBlkTurn; ++i)
             if (c[i] >= 0) {
-                const long long sp = e0 + blk_stored_pos(pos[i], ge, EPL);
+                const int k = c[i] >> wshift;
+                const long long sp = e0 + blk_stored_pos(cst[k] + blk_spread(pos[i], cnt[k]), ge, EPL);
                 bval[sp] = v[i];
                 if constexpr (!VALUES_ONLY) bmeta[sp] = ((unsigned) c[i] & ((1u << kBlkSuperShift) - 1u)) | ((unsigned) r[i] << 16);
             }

@@ -439,7 +439,7 @@ static int blocked_fill(spmv_dev *d, bool values_only)
         fill_value_kernel<unsigned><<<grid_for((long long) slots, kBlock * 4, d->cus * 16), kBlock, 0, d->stream>>>((long long) slots, S.meta, (unsigned) S.R << 16); // row = the junk accumulator
         (void) hipMemsetAsync(S.hdr, 0, sizeof(int) * ng, d->stream);
     }
-    const size_t lds = sizeof(unsigned) * (size_t) K;
+    const size_t lds = 3 * sizeof(unsigned) * (size_t) K;
     if (values_only) {
         ensure_lds<blk_fill_kernel<T, true>>(d, lds);
         blk_fill_kernel<T, true><<<B, kBlkThreads, lds, d->stream>>>(S.row0, K, S.wshift, S.ge, d->rowptr, d->colidx, (const T *) d->val, nullptr, S.gstart, (T *) S.val, S.meta, S.hdr, S.dir);
@@ -550,7 +550,7 @@ static int build_blocked(spmv_dev *d, int rule)
 {
     BlkSet &S = d->blk;
     S = BlkSet();
-    // Slab width: 128 columns, wider only when a block would have more than 32768 cells (the inspector's cursors live in LDS),
+    // Slab width: 128 columns, wider only when a block would have more than 12288 cells (the inspector's per-cell state lives in LDS),
     // or by option slab_kib.  Entries that share an executor instruction are 64 consecutive ones of the (slab, CSR) order, so what a
     // narrow slab buys is that the few entries a block has in the same cache line of x end up in the same instruction and merge.
     int wshift = kBlkSlabShift;
@@ -581,8 +581,12 @@ static int build_blocked(spmv_dev *d, int rule)
 // 1e6-row power-law stand-in (2.6 nnz/row) at x = 8 / 16 / 32 MB (tools/ab_short_rows.py): tile 26.8 / 50.4 / 98.4 us against
 // blocked 28.0 / 46.9 / 77.4 (R-MAT columns), 21.9 / 41.3 / 76.1 against 25.0 / 36.2 / 58.2 (web-like), 38.2 / 90.9 / 201 against
 // 37.2 / 64.5 / 121 (uniform) -> 12 MiB there.
+// the inspector keeps a row block's cells in LDS: at most kBlkMaxCells slabs of at most 65536 columns
+static bool blocked_possible(const spmv_dev *d) { return (long long) d->n <= (long long) kBlkMaxCells << kBlkSuperShift; }
+
 static bool blocked_size_ok(const spmv_dev *d)
 {
+    if (!blocked_possible(d)) return false;
     const long long min_x = d->stats.mean_row_len >= 8.0 ? (4ll << 20) : (12ll << 20);
     return d->nnz >= (1ll << 21) && (long long) d->n * (long long) d->vsize >= min_x;
 }
@@ -593,7 +597,7 @@ static bool blocked_size_ok(const spmv_dev *d)
 // Round 2's rule was staged == 0, which left a random-column matrix with ONE stageable group among 39 063 on the 6 ms kernels.
 static int blocked_mode(const spmv_dev *d, int staged, int groups)
 {
-    if (d->plan.cache_block == 2) return d->nnz > 0 ? 1 : 0;
+    if (d->plan.cache_block == 2) return d->nnz > 0 && blocked_possible(d) ? 1 : 0;
     if (d->plan.cache_block != 1 || d->plan.variant == 3) return 0; // variant 3: A/B, the tile executors with global gathers
     if (!blocked_size_ok(d) || groups <= 0 || staged >= groups) return 0;
     if ((long long) staged * 2 < groups) return 1;                   // most groups gather globally: no contest (the tile inspectors do not even stage the rest then)

@@ -190,7 +190,7 @@ extern "C" int spmv_shim_build(spmv_dev *d, const spmv_plan *plan)
     // inspector is skipped altogether (round 2 built windows / CSR5 transposes / SELL slabs and dropped them: 40-80 ms for 3e8 nnz).
     bool tiles = true;
     if (plan->sched != SPMV_SCHED_CSR_SCALAR && d->nnz > 0 && plan->variant != 3 &&
-        (plan->cache_block == 2 || (plan->cache_block == 1 && blocked_size_ok(d) && !(plan->sched == SPMV_SCHED_SELL && !plan->sell_lds_x) && sample_says_no_locality(d))))
+        ((plan->cache_block == 2 && blocked_possible(d)) || (plan->cache_block == 1 && blocked_size_ok(d) && !(plan->sched == SPMV_SCHED_SELL && !plan->sell_lds_x) && sample_says_no_locality(d))))
         tiles = false;
     if (tiles)
     switch (plan->sched) {
