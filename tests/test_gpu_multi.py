@@ -265,3 +265,25 @@ def test_range_exchange_without_a_split_when_most_rows_are_boundary(virtual):
         assert np.array_equal(y, want)
     finally:
         h.close()
+
+
+def test_empty_matrix_and_info_totals_on_a_sharded_handle(virtual):
+    """m = 0 with gpus >= 3 once threw through the C boundary; get_info mixed whole-matrix sizes with shard-0 byte counts."""
+    e = synth_empty = __import__("spmv_amd.synth", fromlist=["CSR"]).CSR(0, 5, np.zeros(1, dtype=np.int32), np.zeros(0, dtype=np.int32), np.zeros(0))
+    h = _multi_handle(e, M.Method_Parallel, 4)
+    try:
+        assert h.multi_gpus() == 1
+        h.spmv(np.ones(5), np.empty(0))
+    finally:
+        h.close()
+    csr, x, _ = load_golden("skewed_f64_eighths")
+    single = api.Handle(csr.m, csr.n, csr.rowptr, csr.colidx, csr.val, M.Method_CSR5SPMV)
+    one = single.info()
+    single.close()
+    h = _multi_handle(csr, M.Method_CSR5SPMV, 3)
+    try:
+        info = h.info()
+        assert info["nnz"] == csr.nnz and info["m"] == csr.m and info["alg_bytes"] == one["alg_bytes"]
+        assert info["stored_nnz"] >= csr.nnz and info["stream_bytes"] >= 0.9 * one["stream_bytes"]     # summed over the three shards, not shard 0's third
+    finally:
+        h.close()

@@ -786,3 +786,77 @@ def test_auto_method_measured_mode_builds_times_and_keeps_a_candidate():
     assert chosen in (M.Method_Parallel, M.Method_CSR5SPMV, M.Method_SellCSigma, M.Method_Balanced_Yid, M.Method_Balanced, M.Method_Balanced2)
     assert sched in ("csr-vector", "csr5", "sell-c-sigma", "nnz-split", "row-block")
     assert torch.equal(y, want)
+
+
+def test_check_values_on_a_reordered_handle_rebuilds_instead_of_refreshing():
+    """with options reorder = 1 and check_values = 1 the resident matrix is P A P^T, whose value order is not the
+    caller's; a checksum mismatch must not push the caller's CSR-order values into it.  spmv() re-uploads and re-inspects."""
+    rng = np.random.default_rng(5)
+    m = 6000
+    band = synth.banded(m, m, 5, 5, "eighths", np.float64, seed=2)
+    sc = rng.permutation(m)
+    inv = np.empty(m, dtype=np.int64); inv[sc] = np.arange(m)
+    lens = np.diff(band.rowptr)[sc]
+    rp = np.zeros(m + 1, dtype=np.int32); np.cumsum(lens, out=rp[1:])
+    ci = np.empty(band.nnz, dtype=np.int32); va = np.empty(band.nnz)
+    for r in range(m):
+        s0, s1 = band.rowptr[sc[r]], band.rowptr[sc[r] + 1]
+        ci[rp[r]:rp[r + 1]] = inv[band.colidx[s0:s1]]
+        va[rp[r]:rp[r + 1]] = band.val[s0:s1]
+    x = synth.fill_x(m, "eighths", np.float64, 5)
+    api.set_thread_option("reorder", 1)
+    api.set_thread_option("check_values", 1)
+    try:
+        h = api.Handle(m, m, rp, ci, va, M.Method_CSR5SPMV)
+    finally:
+        api.clear_thread_options()
+    try:
+        def mul():
+            index = h.index
+            assert index is not None
+            yy = np.full(m, np.nan)
+            h.spmv(x[index], yy)
+            y = np.empty(m); y[index] = yy
+            return y
+        assert np.array_equal(mul(), oracle.spmv_serial(synth.CSR(m, m, rp, ci, va), x))
+        va[:] = np.roll(va, 7) * 2.0                                   # in place, behind the same pointer: not a permutation-invariant change
+        assert np.array_equal(mul(), oracle.spmv_serial(synth.CSR(m, m, rp, ci, va), x))
+    finally:
+        h.close()
+
+
+def test_check_values_sees_swapped_values():
+    """The checksum is position-weighted: two values exchanged in place (same multiset, same plain sum) are noticed."""
+    csr, x, _ = load_golden("banded_f64_uniform")
+    va = csr.val.copy()
+    api.set_thread_option("check_values", 1)
+    try:
+        h = api.Handle(csr.m, csr.n, csr.rowptr, csr.colidx, va, M.Method_Parallel)
+    finally:
+        api.clear_thread_options()
+    try:
+        y0 = h.spmv(x, np.empty(csr.m))
+        i, j = 3, csr.nnz - 5
+        assert va[i] != va[j]
+        va[i], va[j] = va[j], va[i]
+        y1 = h.spmv(x, np.empty(csr.m))
+        want = run_host(synth.CSR(csr.m, csr.n, csr.rowptr, csr.colidx, va), x, M.Method_Parallel)[0]
+        assert np.array_equal(y1, want) and not np.array_equal(y0, y1)
+    finally:
+        h.close()
+
+
+def test_block_rows_option_is_capped_and_every_row_is_written():
+    """the option table once allowed block_rows = 32768, which left half of y unwritten.  The range now ends at 16384."""
+    with pytest.raises(ValueError):
+        api.set_option("block_rows", 32768)
+    csr, x, y_ref = load_golden("powerlaw_f64_eighths")
+    keep = {k: api.get_option(k) for k in ("cache_block", "block_rows")}
+    try:
+        api.set_option("cache_block", 2)
+        api.set_option("block_rows", 16384)
+        y, _ = run_host(csr, x, M.Method_Balanced2)
+        assert not np.isnan(y).any() and np.array_equal(y, y_ref)
+    finally:
+        for k, v in keep.items():
+            api.set_option(k, v)
