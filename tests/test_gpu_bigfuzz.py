@@ -50,6 +50,9 @@ CASES = [  # (rows, columns, row-length kind, column locality, dtype)
     (3_000_000, 3_000_000, "short", 0, torch.float64),        # no locality, x = 24 MB: cache-blocked Balanced family
     (4_500_000, 4_500_000, "gaps", 0, torch.float32),         # no locality + runs of empty rows (x = 18 MB)
     (1_200_000, 5_000_000, "gaps", 600, torch.float64),       # n != m
+    (4_000_000, 4_000_000, "equal", "web", torch.float64),    # 90 % of a row near the diagonal, 10 % on R-MAT hubs: A = A_near + A_far is built and timed
+    (2_500_000, 2_500_000, "skewed", "rmat", torch.float32),  # R-MAT columns, heavy-tailed rows: hub cells of thousands of entries (blk_spread), fp32 groups of 256
+    (3_000_000, 3_000_000, "equal", "every7", torch.float64), # banded rows, every seventh row random: no tile stages, the split goes by entries
 ]
 
 
@@ -59,7 +62,16 @@ def test_big_shapes_every_schedule_matches_the_definition(case):
     g = torch.Generator(device=DEV)
     g.manual_seed(100 + case)
     lens = _lengths(kind, m, g).to(torch.int64)
-    _, _, rp, ci, va = synth.from_row_lengths_device(lens, n, "eighths", dt, DEV, seed=200 + case, local=local)
+    if local == "every7":
+        _, _, rp, ci, va = synth.from_row_lengths_device(lens, n, "eighths", dt, DEV, seed=200 + case, local=20)
+        _, _, _, cr, _ = synth.from_row_lengths_device(lens, n, "eighths", dt, DEV, seed=300 + case, local=0)
+        row_of = torch.repeat_interleave(torch.arange(m, device=DEV), lens)
+        ci = torch.where(row_of % 7 == 0, cr, ci)
+        del cr, row_of
+    elif isinstance(local, str):
+        _, _, rp, ci, va = synth.from_row_lengths_device(lens, n, "eighths", dt, DEV, seed=200 + case, cols=local)
+    else:
+        _, _, rp, ci, va = synth.from_row_lengths_device(lens, n, "eighths", dt, DEV, seed=200 + case, local=local)
     x = (torch.randint(-8, 9, (n,), generator=g, device=DEV).to(dt) * 0.125)
     want = _definition(rp, ci, va, x)
     seen = set()
@@ -68,9 +80,18 @@ def test_big_shapes_every_schedule_matches_the_definition(case):
         with api.Handle(m, n, rp, ci, va, method) as h:
             h.spmv(x, y)
             info = h.info()
-        torch.cuda.synchronize()
-        seen.add(info["kernel_name"])
-        bad = torch.nonzero(y != want)
-        assert bad.numel() == 0, (case, method.name, info["kernel_name"], int(bad[0]), float(y[bad[0]]), float(want[bad[0]]))
+            torch.cuda.synchronize()
+            seen.add(info["kernel_name"])
+            if info["far_nnz"] > 0:
+                seen.add("split")
+            bad = torch.nonzero(y != want)
+            assert bad.numel() == 0, (case, method.name, info["kernel_name"], int(bad[0]), float(y[bad[0]]), float(want[bad[0]]))
+            if isinstance(local, str) and method in (M.Method_Parallel, M.Method_CSR5SPMV):   # values refreshed in place: blocked streams, both halves of a split
+                h.update_values(va * 2)
+                h.spmv(x, y)
+                torch.cuda.synchronize()
+                assert torch.equal(y, 2 * want), (case, method.name, "update_values")
+    if local == "every7":
+        assert "split" in seen or "blk_kernel" in seen, seen
     if local == 0:
         assert "blk_kernel" in seen, seen           # the Balanced family found no x window to stage
