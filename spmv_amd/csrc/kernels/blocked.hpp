@@ -297,24 +297,29 @@ struct BlkStep { // the stream of one step: UN groups, per lane 16 bytes of valu
     int h;       // ... and, in lane u < UN, the header (first column of the super-slab) of group u of the step
 };
 
-// stream and headers of the UN groups from group g on (relative to the block's region)
+// stream and headers of the UN groups from group g on (relative to the block's region).  Addresses are a wave-uniform base (scalar
+// registers: the step's first byte of each stream) + the lane's constant byte offset + an immediate per group: no vector arithmetic per
+// load (indexing the arrays with a 32-bit element index cost three VALU instructions per load, a quarter of the loop's vector work).
 template <typename T, int UN>
 __device__ __forceinline__ void blk_load_step(int g, int lane, const T *__restrict__ bv, const unsigned *__restrict__ bm, const int *__restrict__ hd, BlkStep<T, UN> &s)
 {
     constexpr int EPL = 16 / (int) sizeof(T);
-    s.h = hd[g + lane]; // one coalesced load for all groups of a step (the array is padded by kBlkPadGroups); a scalar load per group would have to be
-                        // waited for with lgkmcnt(0), i.e. together with every LDS operation in flight
+    const char *pv = reinterpret_cast<const char *>(bv) + (size_t) g * (kWave * 16);               // 1 KiB of values per group
+    const char *pm = reinterpret_cast<const char *>(bm) + (size_t) g * (kWave * EPL * 4);          // 512 B (fp64) / 1 KiB (fp32) of words per group
+    const unsigned lv = (unsigned) lane * 16u, lm = (unsigned) lane * (EPL * 4u);
+    s.h = *reinterpret_cast<const int *>(reinterpret_cast<const char *>(hd) + (size_t) g * 4 + (unsigned) lane * 4u);
+    // ^ one coalesced load for all groups of a step (the array is padded by kBlkPadGroups); a scalar load per group would have to be
+    //   waited for with lgkmcnt(0), i.e. together with every LDS operation in flight
 #pragma unroll
     for (int u = 0; u < UN; ++u) {
-        const int p = ((g + u) * kWave + lane) * EPL;
         if constexpr (EPL == 2) {
-            const f64x2 q = __builtin_nontemporal_load(reinterpret_cast<const f64x2 *>(bv + p));
-            const i32x2 cc = __builtin_nontemporal_load(reinterpret_cast<const i32x2 *>(bm + p));
+            const f64x2 q = __builtin_nontemporal_load(reinterpret_cast<const f64x2 *>(pv + lv + u * (kWave * 16)));
+            const i32x2 cc = __builtin_nontemporal_load(reinterpret_cast<const i32x2 *>(pm + lm + u * (kWave * 8)));
             s.v[u][0] = q.x; s.v[u][1] = q.y;
             s.w[u][0] = (unsigned) cc.x; s.w[u][1] = (unsigned) cc.y;
         } else {
-            const f32x4 q = __builtin_nontemporal_load(reinterpret_cast<const f32x4 *>(bv + p));
-            const i32x4 cc = __builtin_nontemporal_load(reinterpret_cast<const i32x4 *>(bm + p));
+            const f32x4 q = __builtin_nontemporal_load(reinterpret_cast<const f32x4 *>(pv + lv + u * (kWave * 16)));
+            const i32x4 cc = __builtin_nontemporal_load(reinterpret_cast<const i32x4 *>(pm + lm + u * (kWave * 16)));
             s.v[u][0] = q.x; s.v[u][1] = q.y; s.v[u][2] = q.z; s.v[u][3] = q.w;
             s.w[u][0] = (unsigned) cc.x; s.w[u][1] = (unsigned) cc.y; s.w[u][2] = (unsigned) cc.z; s.w[u][3] = (unsigned) cc.w;
         }
