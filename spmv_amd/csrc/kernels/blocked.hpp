@@ -55,6 +55,7 @@ constexpr int kBlkSuperShift = 16;   // 16-bit column offsets inside super-slabs
 constexpr int kBlkMaxCells = 12288;  // cells of one row block at most (the inspector keeps count, start and cursor of every cell in LDS: 144 KiB)
 constexpr int kBlkThreads = 1024;    // inspector workgroups: 16 waves per row block
 constexpr int kBlkTurn = 4;          // batches of 64 entries a wave places per turn
+constexpr int kBlkStepGroups = 24;   // a block's region is padded to a multiple of this: whole executor steps of either form (8 or 12 groups), nothing to mask
 constexpr int kBlkPadGroups = 128;   // zero groups behind the last block: three executor steps of the widest form, and header loads reach 64 groups ahead
 
 struct BlkDir {      // one row block's region: groups [g0, g0 + ns)
@@ -176,7 +177,7 @@ __global__ __launch_bounds__(kBlkThreads) void blk_count_kernel(const int *__res
     }
     if (lane == 0 && mine) atomicAdd(&total, mine);
     __syncthreads();
-    if (threadIdx.x == 0) groups[b] = total;
+    if (threadIdx.x == 0) groups[b] = (total + kBlkStepGroups - 1) / kBlkStepGroups * kBlkStepGroups; // whole steps (padding groups: junk row, value 0)
 }
 
 // position of entry i of a group's sorted order inside the group's 2^ge stored entries: lane (i mod 64) holds it as its
@@ -247,7 +248,7 @@ __global__ __launch_bounds__(kBlkThreads) void blk_fill_kernel(const int *__rest
                 for (int g = (off >> ge) + lane; g < (end >> ge); g += kWave) hdr[g0 + g] = s << kBlkSuperShift; // first column of the super-slab
             off = end;
         }
-        if (!VALUES_ONLY && lane == 0) dir[b] = BlkDir{g0, off >> ge, 0};
+        if (!VALUES_ONLY && lane == 0) dir[b] = BlkDir{g0, ((off >> ge) + kBlkStepGroups - 1) / kBlkStepGroups * kBlkStepGroups, 0};
     }
     __syncthreads();
     const long long e0 = g0 << ge; // first entry of the block's region
@@ -352,44 +353,42 @@ __global__ __launch_bounds__(kWave) void blk_kernel(const int *__restrict__ row0
     if (accumulate && d.ns == 0) return; // y += 0: nothing to do for a block without entries (the far half of a split matrix has many)
     for (int i = lane; i <= R; i += kWave) ys[i] = 0.0;
     __syncthreads();
-    const unsigned junk = (unsigned) R;
     const long long e0 = d.g0 * (long long) (kWave * EPL);
     const T *__restrict__ bv = bval + e0;           // the block's region: groups [0, ns)
     const unsigned *__restrict__ bm = bmeta + e0;
     const int *__restrict__ hd = hdr + d.g0;
-    const int ns = d.ns, nsteps = (ns + UN - 1) / UN;
+    static_assert(kBlkStepGroups % UN == 0, "a block's region is a whole number of steps");
+    const int ns = d.ns, nsteps = ns / UN; // whole steps: the region is padded (junk-row entries) to a multiple of kBlkStepGroups groups
     if (ns > 0) {
         BlkStep<T, UN> g0, g1, g2;
         T x0[UN][EPL], x1[UN][EPL];
-        auto gather = [&](int s, const BlkStep<T, UN> &g, T(&xv)[UN][EPL]) {
+        // Steps past the block's end are LOADED (streams and headers of the next block, or the padding behind the last one) and GATHERED
+        // (a consistent header / offset pair: a valid column) by the pipeline's look-ahead, never added.
+        auto gather = [&](const BlkStep<T, UN> &g, T(&xv)[UN][EPL]) {
 #pragma unroll
             for (int u = 0; u < UN; ++u) {
-                int base = __builtin_amdgcn_readlane(g.h, u);
-                base = s * UN + u < ns ? base : 0; // wave-uniform; a group past the block's end gathers x[16-bit offset]: in bounds (offset < min(n, 65536))
-                const T *__restrict__ xs = x + base;
+                const T *__restrict__ xs = x + __builtin_amdgcn_readlane(g.h, u);
 #pragma unroll
                 for (int j = 0; j < EPL; ++j) xv[u][j] = (DBG & 1) ? x[lane * EPL + j + u * kWave * EPL] : xs[g.w[u][j] & 0xffffu];
             }
         };
         double dbg_acc = 0.0;
-        auto add = [&](int s, const BlkStep<T, UN> &g, const T(&xv)[UN][EPL]) {
+        auto add = [&](const BlkStep<T, UN> &g, const T(&xv)[UN][EPL]) {
 #pragma unroll
-            for (int u = 0; u < UN; ++u) {
-                const bool ok = s * UN + u < ns;
+            for (int u = 0; u < UN; ++u)
 #pragma unroll
                 for (int j = 0; j < EPL; ++j) {
-                    if constexpr (DBG & 2) dbg_acc += (double) (g.v[u][j] * xv[u][j]) * (double) (ok ? g.w[u][j] >> 16 : junk);
-                    else lds_add(&ys[ok ? g.w[u][j] >> 16 : junk], (double) (g.v[u][j] * xv[u][j]));
+                    if constexpr (DBG & 2) dbg_acc += (double) (g.v[u][j] * xv[u][j]) * (double) (g.w[u][j] >> 16);
+                    else lds_add(&ys[g.w[u][j] >> 16], (double) (g.v[u][j] * xv[u][j]));
                 }
-            }
         };
         blk_load_step<T, UN>(0, lane, bv, bm, hd, g0);
         blk_load_step<T, UN>(UN, lane, bv, bm, hd, g1);
-        gather(0, g0, x0);
+        gather(g0, x0);
 #define SPMV_BLK_PHASE(ga, gb, gc, xa, xbb)                                                                                \
         blk_load_step<T, UN>((t + 2) * UN, lane, bv, bm, hd, gc);                                                          \
-        gather(t + 1, gb, xbb);                                                                                            \
-        add(t, ga, xa);                                                                                                    \
+        gather(gb, xbb);                                                                                                   \
+        add(ga, xa);                                                                                                       \
         if (++t >= nsteps) break;
         for (int t = 0;;) {
             SPMV_BLK_PHASE(g0, g1, g2, x0, x1)
