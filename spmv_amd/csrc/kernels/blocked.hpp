@@ -158,26 +158,34 @@ __device__ __forceinline__ void blk_count_cells(unsigned *cells, int K, int wshi
 // Inspector pass 1: groups[b] = groups of 2^ge entries row block b needs -- its cells counted in LDS (K counters), every
 // super-slab's run rounded up to whole groups.
 __global__ __launch_bounds__(kBlkThreads) void blk_count_kernel(const int *__restrict__ row0, int K, int wshift, int ge, const int *__restrict__ rowptr,
-                                                                const int *__restrict__ colidx, int *__restrict__ groups)
+                                                                const int *__restrict__ colidx, int *__restrict__ groups, int *__restrict__ occupied)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char blk_count_lds[];
     unsigned *cells = reinterpret_cast<unsigned *>(blk_count_lds);
-    __shared__ int total;
+    __shared__ int total, occ;
     const int b = blockIdx.x;
-    if (threadIdx.x == 0) total = 0;
+    if (threadIdx.x == 0) total = occ = 0;
     blk_count_cells(cells, K, wshift, rowptr[row0[b]], rowptr[row0[b + 1]], colidx);
     const int wave = threadIdx.x / kWave, lane = threadIdx.x % kWave;
     const int cs = kBlkSuperShift - wshift, S = (K + (1 << cs) - 1) >> cs; // cells per super-slab = 2^cs
-    int mine = 0;
+    int mine = 0, nz = 0;
     for (int s = wave; s < S; s += kBlkThreads / kWave) {
         const int ka = s << cs, kb = min((s + 1) << cs, K);
         int c = 0;
-        for (int k = ka + lane; k < kb; k += kWave) c += (int) cells[k];
+        for (int k = ka + lane; k < kb; k += kWave) {
+            c += (int) cells[k];
+            nz += cells[k] != 0u;
+        }
         mine += (wave_sum(c) + (1 << ge) - 1) >> ge;
     }
+    nz = wave_sum(nz);
     if (lane == 0 && mine) atomicAdd(&total, mine);
+    if (lane == 0 && nz) atomicAdd(&occ, nz);
     __syncthreads();
-    if (threadIdx.x == 0) groups[b] = (total + kBlkStepGroups - 1) / kBlkStepGroups * kBlkStepGroups; // whole steps (padding groups: junk row, value 0)
+    if (threadIdx.x == 0) {
+        groups[b] = (total + kBlkStepGroups - 1) / kBlkStepGroups * kBlkStepGroups; // whole steps (padding groups: junk row, value 0)
+        occupied[b] = occ;                                                          // cells with entries: how scattered the block's gathers are
+    }
 }
 
 // position of entry i of a group's sorted order inside the group's 2^ge stored entries: lane (i mod 64) holds it as its
@@ -344,10 +352,10 @@ __global__ __launch_bounds__(kWave) void blk_kernel(const int *__restrict__ row0
     double *ys = reinterpret_cast<double *>(blk_y_lds);
     constexpr int EPL = 16 / (int) sizeof(T);
     const int lane = threadIdx.x;
-    // Launch order: blocks WITH entries first, in row order, the empty ones last (blocked_fill).  The blocks resident on an XCD sweep
-    // the column slabs in step -- that is what keeps the slabs of x they gather from in L2 -- and a block that ends at once hands its
-    // slot to a successor that then runs out of step with everyone else for the rest of the launch: 1 % of empty (or quick) leading
-    // blocks cost 25 % (1e7 x 32 random columns behind a 1 % prefix of other rows: 1.80 vs 1.39 ms).
+    // Launch order (blocked_fill): the blocks whose entries are scattered over the most cells first, blocks of few cells (local rows: quick) behind
+    // them, empty ones last; row order inside a class.  The blocks resident on an XCD sweep the column slabs in step -- that is what keeps the
+    // slabs of x they gather from in L2 -- and a block that ends early hands its slot to a successor that then runs out of step with everyone
+    // else for the rest of the launch: 1 % of quick leading blocks cost 25 % (1e7 x 32 random columns behind a 1 % banded prefix: 1.71 vs 1.39 ms).
     const int blk = order[blockIdx.x];
     const BlkDir d = dir[blk];
     if (accumulate && d.ns == 0) return; // y += 0: nothing to do for a block without entries (the far half of a split matrix has many)

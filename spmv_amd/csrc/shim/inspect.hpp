@@ -404,12 +404,14 @@ static int blocked_fill(spmv_dev *d, bool values_only)
 {
     BlkSet &S = d->blk;
     const int B = S.B, K = S.K;
-    int *groups = nullptr;
+    int *groups = nullptr, *occupied = nullptr;
     unsigned short *rowin = nullptr;
-    auto cleanup = [&]() { if (groups) (void) pool_free(groups); if (rowin) (void) pool_free(rowin); };
+    std::vector<int> occ_h;
+    auto cleanup = [&]() { if (groups) (void) pool_free(groups); if (occupied) (void) pool_free(occupied); if (rowin) (void) pool_free(rowin); };
     hipError_t e = hipSuccess;
     if (!values_only) {
-        if (pool_malloc((void **) &groups, sizeof(int) * (size_t) B) != hipSuccess || pool_malloc((void **) &rowin, sizeof(unsigned short) * ((size_t) d->nnz + 8)) != hipSuccess) {
+        if (pool_malloc((void **) &groups, sizeof(int) * (size_t) B) != hipSuccess || pool_malloc((void **) &occupied, sizeof(int) * (size_t) B) != hipSuccess ||
+            pool_malloc((void **) &rowin, sizeof(unsigned short) * ((size_t) d->nnz + 8)) != hipSuccess) {
             (void) hipGetLastError();
             cleanup();
             return fail(SPMV_HIP_E_ALLOC, "pool_malloc(block inspector scratch)");
@@ -417,7 +419,7 @@ static int blocked_fill(spmv_dev *d, bool values_only)
         ensure_lds<blk_rows_kernel>(d, sizeof(int) * ((size_t) S.R + 1));
         blk_rows_kernel<<<B, kBlkThreads, sizeof(int) * ((size_t) S.R + 1), d->stream>>>(S.row0, d->rowptr, rowin);
         ensure_lds<blk_count_kernel>(d, sizeof(unsigned) * (size_t) K);
-        blk_count_kernel<<<B, kBlkThreads, sizeof(unsigned) * (size_t) K, d->stream>>>(S.row0, K, S.wshift, S.ge, d->rowptr, d->colidx, groups);
+        blk_count_kernel<<<B, kBlkThreads, sizeof(unsigned) * (size_t) K, d->stream>>>(S.row0, K, S.wshift, S.ge, d->rowptr, d->colidx, groups, occupied);
         e = hipGetLastError();
         int rc = dev_alloc(d, (void **) &S.gstart, sizeof(long long) * ((size_t) B + 1), true);
         if (!rc) rc = dev_alloc(d, (void **) &S.dir, sizeof(BlkDir) * (size_t) B, true);
@@ -425,7 +427,9 @@ static int blocked_fill(spmv_dev *d, bool values_only)
         scan_i32_to_i64_kernel<<<1, kBlock, 0, d->stream>>>(B, groups, S.gstart);
         long long total = 0;
         if (e == hipSuccess) e = hipGetLastError();
+        occ_h.resize((size_t) B);
         if (e == hipSuccess) e = hipMemcpyAsync(&total, S.gstart + B, sizeof(long long), hipMemcpyDeviceToHost, d->stream);
+        if (e == hipSuccess) e = hipMemcpyAsync(occ_h.data(), occupied, sizeof(int) * (size_t) B, hipMemcpyDeviceToHost, d->stream);
         if (e == hipSuccess) e = hipStreamSynchronize(d->stream);
         if (e != hipSuccess) { cleanup(); return fail(SPMV_HIP_E_RUNTIME, "block inspector: %s", hipGetErrorString(e)); }
         S.groups = total;
@@ -451,13 +455,19 @@ static int blocked_fill(spmv_dev *d, bool values_only)
     if (e == hipSuccess) e = hipStreamSynchronize(d->stream);
     cleanup();
     if (e != hipSuccess) return fail(SPMV_HIP_E_RUNTIME, "block fill: %s", hipGetErrorString(e));
-    if (!values_only) { // launch order (blk_kernel): the blocks with entries in row order, then the empty ones
+    if (!values_only) { // launch order (blk_kernel): by how scattered a block's entries are -- classes of occupied cells per entry, the most scattered first --, row order inside a class, empty blocks last
         std::vector<BlkDir> hd((size_t) B);
-        std::vector<int> order;
-        order.reserve((size_t) B);
         HIP_TRY(hipMemcpy(hd.data(), S.dir, sizeof(BlkDir) * (size_t) B, hipMemcpyDeviceToHost));
-        for (int b = 0; b < B; ++b) if (hd[(size_t) b].ns > 0) order.push_back(b);
-        for (int b = 0; b < B; ++b) if (hd[(size_t) b].ns <= 0) order.push_back(b);
+        auto klass = [&](int b) { // 0 = empty (last); else 1 + log2-ish class of occupied cells per group, capped: homogeneous matrices stay in row order
+            if (hd[(size_t) b].ns <= 0) return 0;
+            const double per_group = (double) occ_h[(size_t) b] / (double) hd[(size_t) b].ns; // <= 2^ge
+            int k = 1;
+            for (double t = 0.25; t <= per_group && k < 12; t *= 2.0) ++k;
+            return k;
+        };
+        std::vector<int> order((size_t) B);
+        for (int b = 0; b < B; ++b) order[(size_t) b] = b;
+        std::stable_sort(order.begin(), order.end(), [&](int a, int b) { return klass(a) > klass(b); });
         int rc = dev_alloc(d, (void **) &S.order, sizeof(int) * (size_t) B, true);
         if (rc) return rc;
         HIP_TRY(hipMemcpy(S.order, order.data(), sizeof(int) * (size_t) B, hipMemcpyHostToDevice));
