@@ -129,7 +129,30 @@ static int check_plan(void)
     hist_put(&st, 32, 10000000); st.mean_row_len = 32.0;
     (spmv_options_snapshot(&op), spmv_plan_choose(Method_SellCSigma, &st, 8, &op, &pl, &act, 1));
     if (pl.sell_long_thr != 0) rc = 19; /* equal rows: everything stays in the slabs */
+    /* very short heavy-tailed rows (webbase-1M-style: most rows 1..3 entries, a few thousands): the row-granular schedules hand the multiply
+     * to the nnz-split executor below the method; a forced lanes_per_row keeps CSR-vector; regular short rows (5-point stencil) stay */
+    memset(&st, 0, sizeof st); st.min_row_len = 1 << 30; st.n = 1000000;
+    hist_put(&st, 0, 200000); hist_put(&st, 1, 400000); hist_put(&st, 3, 300000); hist_put(&st, 7, 90000); hist_put(&st, 40, 9000); hist_put(&st, 600, 900); hist_put(&st, 4000, 100);
+    st.mean_row_len = (double) st.nnz / (double) st.m;
+    (spmv_options_snapshot(&op), spmv_plan_choose(Method_Parallel, &st, 8, &op, &pl, &act, 1));
+    printf("webbase-style: Parallel sched=%d act=%d mean=%.2f\n", pl.sched, act, st.mean_row_len);
+    if (pl.sched != SPMV_SCHED_NNZ_SPLIT || act != Method_Parallel) rc = 20;
+    (spmv_options_snapshot(&op), spmv_plan_choose(Method_SellCSigma, &st, 8, &op, &pl, &act, 1));
+    if (pl.sched != SPMV_SCHED_NNZ_SPLIT || act != Method_SellCSigma) rc = 21;
+    (spmv_options_snapshot(&op), spmv_plan_choose(Method_CSR5SPMV, &st, 8, &op, &pl, &act, 1));
+    if (pl.sched != SPMV_SCHED_CSR5) rc = 22;
+    spmv_hip_set_thread_option("lanes_per_row", 2);
+    (spmv_options_snapshot(&op), spmv_plan_choose(Method_Parallel, &st, 8, &op, &pl, &act, 1));
+    if (pl.sched != SPMV_SCHED_CSR_VECTOR) rc = 23;
+    spmv_hip_clear_thread_options();
+    memset(&st, 0, sizeof st); st.min_row_len = 1 << 30; st.n = 16000000;
+    hist_put(&st, 5, 16000000); st.mean_row_len = 5.0;
+    (spmv_options_snapshot(&op), spmv_plan_choose(Method_Parallel, &st, 8, &op, &pl, &act, 1));
+    printf("stencil5: sched=%d L=%d\n", pl.sched, pl.lanes_per_row);
+    if (pl.sched != SPMV_SCHED_CSR_VECTOR) rc = 24;
     /* a thread-local override wins over the process-wide value for creates on this thread, and only there */
+    memset(&st, 0, sizeof st); st.min_row_len = 1 << 30; st.n = 10000000;
+    hist_put(&st, 32, 10000000); st.mean_row_len = 32.0;
     if (spmv_hip_set_thread_option("lanes_per_row", 16) != 0) rc = 15;
     (spmv_options_snapshot(&op), spmv_plan_choose(Method_Parallel, &st, 8, &op, &pl, &act, 1));
     if (pl.lanes_per_row != 16 || spmv_hip_get_option("lanes_per_row") != 16 || spmv_options_get(&op, "lanes_per_row") != 16) rc = 16;
