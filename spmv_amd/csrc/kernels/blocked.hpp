@@ -343,7 +343,11 @@ __device__ __forceinline__ void blk_load_step(int g, int lane, const T *__restri
 // the step that issued it.  Three stream register sets and two x sets are used in rotation (the loop body is written out for
 // six consecutive steps), so no loaded register is ever copied.  Group headers travel with the stream sets as ONE vector load
 // per step (lane u = group u) and are broadcast with v_readlane when the gathers are issued, a step after they were loaded.
-template <typename T, int UN, int DBG = 0> // DBG (tools only, wrong results): 1 = coalesced x reads instead of gathers, 2 = no LDS adds, 3 = both
+#ifdef SPMV_BLK_DEBUG_FORMS
+__device__ unsigned long long blk_dbg_times[4 * 8192]; // per workgroup: start, end (s_memrealtime, 100 MHz), XCC id, block (tools: SPMV_BLK_DEBUG_FORMS builds only)
+#endif
+
+template <typename T, int UN, int DBG = 0> // DBG (tools only, wrong results): 1 = coalesced x reads instead of gathers, 2 = no LDS adds, 3 = both; right results: 4 / 5 / 6 = gathers as nontemporal / agent-scope / system-scope loads
 __global__ __launch_bounds__(kWave) void blk_kernel(const int *__restrict__ row0, int R, const BlkDir *__restrict__ dir, const T *__restrict__ bval,
                                                     const unsigned *__restrict__ bmeta, const int *__restrict__ hdr, const int *__restrict__ order,
                                                     const T *__restrict__ x, T *__restrict__ y, int accumulate /* y += (the far half of a split matrix, shim/split.hpp) instead of y = */)
@@ -357,6 +361,9 @@ __global__ __launch_bounds__(kWave) void blk_kernel(const int *__restrict__ row0
     // slabs of x they gather from in L2 -- and a block that ends early hands its slot to a successor that then runs out of step with everyone
     // else for the rest of the launch: 1 % of quick leading blocks cost 25 % (1e7 x 32 random columns behind a 1 % banded prefix: 1.71 vs 1.39 ms).
     const int blk = order[blockIdx.x];
+#ifdef SPMV_BLK_DEBUG_FORMS
+    const unsigned long long dbg_t0 = __builtin_amdgcn_s_memrealtime();
+#endif
     const BlkDir d = dir[blk];
     if (accumulate && d.ns == 0) return; // y += 0: nothing to do for a block without entries (the far half of a split matrix has many)
     for (int i = lane; i <= R; i += kWave) ys[i] = 0.0;
@@ -377,7 +384,20 @@ __global__ __launch_bounds__(kWave) void blk_kernel(const int *__restrict__ row0
             for (int u = 0; u < UN; ++u) {
                 const T *__restrict__ xs = x + __builtin_amdgcn_readlane(g.h, u);
 #pragma unroll
-                for (int j = 0; j < EPL; ++j) xv[u][j] = (DBG & 1) ? x[lane * EPL + j + u * kWave * EPL] : xs[g.w[u][j] & 0xffffu];
+                for (int j = 0; j < EPL; ++j) {
+                    if constexpr (DBG == 4) xv[u][j] = __builtin_nontemporal_load(xs + (g.w[u][j] & 0xffffu));
+                    else if constexpr (DBG == 5 || DBG == 6) {
+                        if constexpr (sizeof(T) == 8) {
+                            const unsigned long long b = __hip_atomic_load(reinterpret_cast<const unsigned long long *>(xs + (g.w[u][j] & 0xffffu)), __ATOMIC_RELAXED,
+                                                                           DBG == 5 ? __HIP_MEMORY_SCOPE_AGENT : __HIP_MEMORY_SCOPE_SYSTEM);
+                            xv[u][j] = __builtin_bit_cast(T, b);
+                        } else {
+                            const unsigned b = __hip_atomic_load(reinterpret_cast<const unsigned *>(xs + (g.w[u][j] & 0xffffu)), __ATOMIC_RELAXED,
+                                                                 DBG == 5 ? __HIP_MEMORY_SCOPE_AGENT : __HIP_MEMORY_SCOPE_SYSTEM);
+                            xv[u][j] = __builtin_bit_cast(T, b);
+                        }
+                    } else xv[u][j] = (DBG & 1) ? x[lane * EPL + j + u * kWave * EPL] : xs[g.w[u][j] & 0xffffu];
+                }
             }
         };
         double dbg_acc = 0.0;
@@ -414,6 +434,17 @@ __global__ __launch_bounds__(kWave) void blk_kernel(const int *__restrict__ row0
     const int nr = row0[blk + 1] - (int) r0;
     if (accumulate) for (int i = lane; i < nr; i += kWave) y[r0 + i] += (T) ys[i];
     else for (int i = lane; i < nr; i += kWave) y[r0 + i] = (T) ys[i];
+#ifdef SPMV_BLK_DEBUG_FORMS
+    if (lane == 0 && blockIdx.x < 8192) {
+        unsigned xcc, hw;
+        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hw));
+        blk_dbg_times[4 * blockIdx.x] = dbg_t0;
+        blk_dbg_times[4 * blockIdx.x + 1] = __builtin_amdgcn_s_memrealtime();
+        blk_dbg_times[4 * blockIdx.x + 2] = (xcc & 0xf) | ((unsigned long long) hw << 8);
+        blk_dbg_times[4 * blockIdx.x + 3] = (unsigned long long) blk | ((unsigned long long) d.ns << 32);
+    }
+#endif
 }
 
 } // namespace spmv

@@ -588,4 +588,12 @@ extern "C" int spmv_shim_info(const spmv_dev *d, spmv_hip_info *o)
     return SPMV_HIP_OK;
 }
 
+#ifdef SPMV_BLK_DEBUG_FORMS
+// tools only: per-workgroup timestamps of the last blk_kernel launch (4 x 8192 words)
+extern "C" int spmv_shim_debug_blk_times(unsigned long long *out)
+{
+    return hipMemcpyFromSymbol(out, HIP_SYMBOL(blk_dbg_times), sizeof(unsigned long long) * 4 * 8192) == hipSuccess ? 0 : 1;
+}
+#endif
+
 #include "shim/multi.hpp"

@@ -3,7 +3,7 @@
     python tools/route_bench.py [rows]      prints per shape and method: ms, executor, create()'s measured choice (route_ms)"""
 import json, os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-sys.path.insert(0, ROOT)
+sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tools"))
 import torch
 from spmv_amd import api, build, synth
 build.build(); api.load()
@@ -12,24 +12,11 @@ m = int(sys.argv[1]) if len(sys.argv) > 1 else 10_000_000
 k = 32
 
 
+import route_bench_lib
+
+
 def mixed(kind):
-    """rows are banded or random by `kind`: 'banded', 'random', 'prefix1' (first 1 % banded), 'tail10' (last 10 % random), 'every10' (every 10th row random)"""
-    _, _, rp, cb, va = synth.banded_device(m, m, k, "uniform", torch.float64, dev, 1)
-    if kind == "banded":
-        return rp, cb, va
-    _, _, _, cr, _ = synth.uniform_k_device(m, m, k, "uniform", torch.float64, dev, 1)
-    rows = torch.arange(m, device=dev)
-    if kind == "emptyprefix1":      # the first 1 % of the rows empty, the rest random (what the far half of prefix1 looks like)
-        keep = (rows >= m // 100)
-        lens = keep.to(torch.int64) * k
-        rp2 = torch.zeros(m + 1, dtype=torch.int64, device=dev)
-        torch.cumsum(lens, 0, out=rp2[1:])
-        sel = keep.repeat_interleave(k)
-        return rp2.to(torch.int32), cr[sel].contiguous(), va[sel].contiguous()
-    rnd = {"random": rows >= 0, "prefix1": rows >= m // 100, "tail10": rows >= m - m // 10, "every10": rows % 10 == 0}[kind]
-    sel = rnd.repeat_interleave(k)
-    ci = torch.where(sel, cr, cb)
-    return rp, ci, va
+    return route_bench_lib.mixed(kind, m, k, dev)
 
 
 for kind in sys.argv[2:] or ["banded", "random", "prefix1", "tail10", "every10"]:
