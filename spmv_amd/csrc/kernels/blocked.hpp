@@ -347,7 +347,7 @@ __device__ __forceinline__ void blk_load_step(int g, int lane, const T *__restri
 __device__ unsigned long long blk_dbg_times[4 * 8192]; // per workgroup: start, end (s_memrealtime, 100 MHz), XCC id, block (tools: SPMV_BLK_DEBUG_FORMS builds only)
 #endif
 
-template <typename T, int UN, int DBG = 0> // DBG (tools only, wrong results): 1 = coalesced x reads instead of gathers, 2 = no LDS adds, 3 = both; right results: 4 / 5 / 6 = gathers as nontemporal / agent-scope / system-scope loads
+template <typename T, int UN, int DBG = 0> // DBG (tools only, wrong results): 1 = coalesced x reads instead of gathers, 2 = no LDS adds, 3 = both
 __global__ __launch_bounds__(kWave) void blk_kernel(const int *__restrict__ row0, int R, const BlkDir *__restrict__ dir, const T *__restrict__ bval,
                                                     const unsigned *__restrict__ bmeta, const int *__restrict__ hdr, const int *__restrict__ order,
                                                     const T *__restrict__ x, T *__restrict__ y, int accumulate /* y += (the far half of a split matrix, shim/split.hpp) instead of y = */)
@@ -384,20 +384,7 @@ __global__ __launch_bounds__(kWave) void blk_kernel(const int *__restrict__ row0
             for (int u = 0; u < UN; ++u) {
                 const T *__restrict__ xs = x + __builtin_amdgcn_readlane(g.h, u);
 #pragma unroll
-                for (int j = 0; j < EPL; ++j) {
-                    if constexpr (DBG == 4) xv[u][j] = __builtin_nontemporal_load(xs + (g.w[u][j] & 0xffffu));
-                    else if constexpr (DBG == 5 || DBG == 6) {
-                        if constexpr (sizeof(T) == 8) {
-                            const unsigned long long b = __hip_atomic_load(reinterpret_cast<const unsigned long long *>(xs + (g.w[u][j] & 0xffffu)), __ATOMIC_RELAXED,
-                                                                           DBG == 5 ? __HIP_MEMORY_SCOPE_AGENT : __HIP_MEMORY_SCOPE_SYSTEM);
-                            xv[u][j] = __builtin_bit_cast(T, b);
-                        } else {
-                            const unsigned b = __hip_atomic_load(reinterpret_cast<const unsigned *>(xs + (g.w[u][j] & 0xffffu)), __ATOMIC_RELAXED,
-                                                                 DBG == 5 ? __HIP_MEMORY_SCOPE_AGENT : __HIP_MEMORY_SCOPE_SYSTEM);
-                            xv[u][j] = __builtin_bit_cast(T, b);
-                        }
-                    } else xv[u][j] = (DBG & 1) ? x[lane * EPL + j + u * kWave * EPL] : xs[g.w[u][j] & 0xffffu];
-                }
+                for (int j = 0; j < EPL; ++j) xv[u][j] = (DBG & 1) ? x[lane * EPL + j + u * kWave * EPL] : xs[g.w[u][j] & 0xffffu];
             }
         };
         double dbg_acc = 0.0;

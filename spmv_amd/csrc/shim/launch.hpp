@@ -128,9 +128,6 @@ static void launch_blocked(spmv_dev *d, const T *x, T *y)
     if (d->plan.variant == 51) { SPMV_BLK_LAUNCH(8, 1); return; }
     if (d->plan.variant == 52) { SPMV_BLK_LAUNCH(8, 2); return; }
     if (d->plan.variant == 53) { SPMV_BLK_LAUNCH(8, 3); return; }
-    if (d->plan.variant == 54) { SPMV_BLK_LAUNCH(8, 4); return; }
-    if (d->plan.variant == 55) { SPMV_BLK_LAUNCH(8, 5); return; }
-    if (d->plan.variant == 56) { SPMV_BLK_LAUNCH(8, 6); return; }
 #endif
     const int form = d->plan.variant == 35 ? 0 : (d->plan.variant == 37 ? 1 : S.form);
     if (form == 1) SPMV_BLK_LAUNCH(12, 0);
