@@ -166,7 +166,10 @@ int spmv_hip_multi_slices(spmv_Handle_t handle, int gpu, void **x_slice, long lo
  * behind the work the caller has submitted to each device's DEFAULT stream (the x slices must have been written there, or be
  * complete); x_exchange = 1 ("range") runs the halo copies beside the multiply and redoes the rows that needed them. */
 int spmv_hip_multi_step(spmv_Handle_t handle);
-/* The same, enqueued only; spmv_hip_multi_synchronize waits for every device (results in the y blocks). */
+/* The same, enqueued only; spmv_hip_multi_synchronize waits for every device (results in the y blocks).  Steps may be enqueued
+ * back to back (a step's halo copies wait for the previous step's multiplies); the caller writes the NEXT x slices on the default
+ * streams, which a step is ordered behind -- but nothing orders those writes behind a step still running: synchronize (or wait on
+ * an event of your own) before overwriting x slices a running step reads. */
 int spmv_hip_multi_step_async(spmv_Handle_t handle);
 int spmv_hip_multi_synchronize(spmv_Handle_t handle);
 /* A multi-GPU handle from row blocks that exist separately -- the way the reference's NUMA experiment hands each memory node

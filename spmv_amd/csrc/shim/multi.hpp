@@ -81,6 +81,7 @@ struct MultiShard {
     hipStream_t copy = nullptr;    // halo copies of the "range" exchange: run beside the interior multiply
     hipEvent_t ready = nullptr;    // "my slice of x (or, on device 0, all of x) is in place"
     hipEvent_t halo = nullptr;     // "the columns I pull from other devices' slices have arrived"
+    hipEvent_t done = nullptr;     // "my multiplies of the last step have read x": the next step's halo copies wait for it
     ncclComm_t_ comm = nullptr;
 };
 
@@ -107,6 +108,7 @@ static void multi_free(spmv_multi *mt)
         if (s.bnd_rows) (void) pool_free(s.bnd_rows);
         if (s.ready) (void) hipEventDestroy(s.ready);
         if (s.halo) (void) hipEventDestroy(s.halo);
+        if (s.done) (void) hipEventDestroy(s.done);
         if (s.stream) (void) hipStreamDestroy(s.stream);
         if (s.copy) (void) hipStreamDestroy(s.copy);
     }
@@ -207,7 +209,8 @@ static int multi_build(spmv_multi *mt, int ndev, const std::vector<std::vector<i
         s.device = g % ndev;
         if (hipSetDevice(s.device) != hipSuccess) { (void) hipGetLastError(); return bail(fail(SPMV_HIP_E_RUNTIME, "hipSetDevice(%d)", s.device)); }
         if (hipStreamCreateWithFlags(&s.stream, hipStreamNonBlocking) != hipSuccess || hipStreamCreateWithFlags(&s.copy, hipStreamNonBlocking) != hipSuccess ||
-            hipEventCreateWithFlags(&s.ready, hipEventDisableTiming) != hipSuccess || hipEventCreateWithFlags(&s.halo, hipEventDisableTiming) != hipSuccess) {
+            hipEventCreateWithFlags(&s.ready, hipEventDisableTiming) != hipSuccess || hipEventCreateWithFlags(&s.halo, hipEventDisableTiming) != hipSuccess ||
+            hipEventCreateWithFlags(&s.done, hipEventDisableTiming) != hipSuccess) {
             (void) hipGetLastError();
             return bail(fail(SPMV_HIP_E_RUNTIME, "multi: stream / event creation failed on device %d", s.device));
         }
@@ -415,6 +418,7 @@ static int multi_exchange(spmv_multi *mt)
             MultiShard &s = mt->sh[(size_t) g];
             const long long lo = s.dev->col_min, hi = (long long) s.dev->col_max + 1; // [lo, hi)
             (void) hipSetDevice(s.device);
+            HIP_TRY(hipStreamWaitEvent(s.copy, s.done, 0)); // two steps enqueued back to back: the last step's boundary rows still read the halo
             for (int h = 0; h < G && hi > lo; ++h) {
                 if (h == g) continue;
                 const MultiShard &o = mt->sh[(size_t) h];
@@ -467,13 +471,16 @@ static int multi_multiply(spmv_multi *mt, int g, bool halo_pending)
     (void) hipSetDevice(s.device);
     if (halo_pending && !s.bnd) HIP_TRY(hipStreamWaitEvent(s.stream, s.halo, 0)); // no split: the halo first
     int rc = spmv_shim_run(s.dev, s.x, s.y);
-    if (rc || !halo_pending || !s.bnd) return rc;
-    HIP_TRY(hipStreamWaitEvent(s.stream, s.halo, 0));
-    rc = spmv_shim_run(s.bnd, s.x, s.y_bnd);
     if (rc) return rc;
-    if (mt->vsize == sizeof(double)) scatter_rows_kernel<double><<<grid_for(s.nbnd, kBlock, INT_MAX), kBlock, 0, s.stream>>>(s.nbnd, s.bnd_rows, (const double *) s.y_bnd, (double *) s.y);
-    else scatter_rows_kernel<float><<<grid_for(s.nbnd, kBlock, INT_MAX), kBlock, 0, s.stream>>>(s.nbnd, s.bnd_rows, (const float *) s.y_bnd, (float *) s.y);
-    HIP_TRY(hipGetLastError());
+    if (halo_pending && s.bnd) {
+        HIP_TRY(hipStreamWaitEvent(s.stream, s.halo, 0));
+        rc = spmv_shim_run(s.bnd, s.x, s.y_bnd);
+        if (rc) return rc;
+        if (mt->vsize == sizeof(double)) scatter_rows_kernel<double><<<grid_for(s.nbnd, kBlock, INT_MAX), kBlock, 0, s.stream>>>(s.nbnd, s.bnd_rows, (const double *) s.y_bnd, (double *) s.y);
+        else scatter_rows_kernel<float><<<grid_for(s.nbnd, kBlock, INT_MAX), kBlock, 0, s.stream>>>(s.nbnd, s.bnd_rows, (const float *) s.y_bnd, (float *) s.y);
+        HIP_TRY(hipGetLastError());
+    }
+    if (halo_pending) HIP_TRY(hipEventRecord(s.done, s.stream));
     return SPMV_HIP_OK;
 }
 

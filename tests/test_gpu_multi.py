@@ -251,6 +251,42 @@ def test_range_exchange_overlaps_the_halo_with_the_interior_rows(virtual, gpus, 
         h.close()
 
 
+def test_async_steps_enqueued_back_to_back(virtual):
+    """three spmv_hip_multi_step_async calls without a synchronize in between (the same x: the caller may not overwrite slices a
+    running step reads), one synchronize: the halo copies of a step are ordered behind the previous step's multiplies"""
+    from spmv_amd import synth
+    csr = synth.banded(5000, 5000, 24, 24, "eighths", np.float64, seed=2)
+    x = (np.random.default_rng(4).integers(-8, 9, csr.n) * 0.125)
+    prod = csr.val * x[csr.colidx]
+    cs = np.concatenate([[0.0], np.cumsum(prod)])
+    want = cs[csr.rowptr[1:]] - cs[csr.rowptr[:-1]]
+    hip = C.CDLL("libamdhip64.so")
+    hip.hipMemcpy.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_int]
+    for xchg in (0, 1, 2):
+        h = _multi_handle(csr, M.Method_Balanced2, 3, xchg)
+        try:
+            G = h.multi_gpus()
+            for g in range(G):
+                s = h.multi_slices(g)
+                if xchg == 2 and g > 0:
+                    continue
+                lo, cnt = (0, csr.n) if xchg == 2 else (s["x_first"], s["x_count"])
+                part = np.ascontiguousarray(x[lo: lo + cnt])
+                assert hip.hipMemcpy(s["x_ptr"] - 8 * (s["x_first"] - lo), part.ctypes.data, part.nbytes, 4) == 0
+            for _ in range(3):
+                h.multi_step_async()
+            h.multi_synchronize()
+            y = np.full(csr.m, np.nan)
+            for g in range(G):
+                s = h.multi_slices(g)
+                blk = np.empty(s["y_count"])
+                assert hip.hipMemcpy(blk.ctypes.data, s["y_ptr"], blk.nbytes, 4) == 0
+                y[s["y_first"]: s["y_first"] + s["y_count"]] = blk
+            assert np.array_equal(y, want), xchg
+        finally:
+            h.close()
+
+
 def test_range_exchange_without_a_split_when_most_rows_are_boundary(virtual):
     """uniformly random columns: every row references remote columns -> no boundary sub-matrix, the multiply waits for the halo"""
     from spmv_amd import synth
