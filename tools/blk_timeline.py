@@ -10,13 +10,18 @@ from spmv_amd import api
 api.LIB_PATH = os.environ.get("SPMV_LIB", api.LIB_PATH)
 lib = api.load()
 import route_bench_lib as rb
+import run_config as rc
 dev = "cuda:0"
 m = int(os.environ.get("ROWS", "10000000"))
 api.set_option("split", 0)
 for kind in sys.argv[1:] or ["random", "prefix1"]:
-    rp, ci, va = rb.mixed(kind, m, 32, dev)
-    x = torch.rand(m, dtype=torch.float64, device=dev); y = torch.empty(m, dtype=torch.float64, device=dev)
-    h = api.Handle(m, m, rp, ci, va, 1)
+    if kind in ("2r", "3o", "3o-uniform", "3w", "4"):      # a BASELINE config (tools/run_config.py)
+        m, _, rp, ci, va = rc.make(kind, dev)
+    else:
+        m = int(os.environ.get("ROWS", "10000000"))
+        rp, ci, va = rb.mixed(kind, m, 32, dev)
+    x = torch.rand(m, dtype=va.dtype, device=dev); y = torch.empty(m, dtype=va.dtype, device=dev)
+    h = api.Handle(m, m, rp, ci, va, 4)
     for _ in range(3):
         h.spmv(x, y)
     torch.cuda.synchronize()
@@ -27,7 +32,10 @@ for kind in sys.argv[1:] or ["random", "prefix1"]:
     t0 = a[:, 0].min()
     start, dur = (a[:, 0] - t0) / 100.0, (a[:, 1] - a[:, 0]) / 100.0      # microseconds
     blk, ns = a[:, 3] & 0xffffffff, a[:, 3] >> 32
-    print(f"== {kind}: {len(a)} workgroups, makespan {((a[:, 1] - t0).max()) / 100.0:.0f} us, info {h.info()['tuned_choice']}")
+    end = start + dur
+    slots = 2 * 256
+    print(f"== {kind}: {len(a)} workgroups, makespan {end.max():.0f} us, sum of durations / {slots} slots {dur.sum() / slots:.0f} us, "
+          f"dur min/median/max {dur.min():.0f}/{np.median(dur):.0f}/{dur.max():.0f}, info {h.info()['tuned_choice']} {h.info()['kernel_name']}")
     for lo in range(0, len(a), max(1, len(a) // 8)):
         s = slice(lo, lo + max(1, len(a) // 8))
         print(f"   wg {lo:5d}..: start {start[s].min():7.0f}-{start[s].max():7.0f} us  dur mean {dur[s].mean():7.0f} min {dur[s].min():7.0f} max {dur[s].max():7.0f}  groups {ns[s].mean():.0f}")
