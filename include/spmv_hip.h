@@ -128,7 +128,7 @@ typedef struct spmv_hip_info {
     int x_groups_staged;        /* ... of which have their x windows staged in LDS (0: every gather goes to L1/L2) */
     int cache_blocked;          /* 1: the row-block x column-slab executor runs (option "cache_block") */
     long long stream_bytes;     /* HBM bytes ONE spmv() has to move given the schedule's storage format: the value and
-                                 * column streams as stored (2 B/nnz LDS slots where x windows are staged, padding
+                                 * column streams as stored (2 B/nnz LDS slots where x windows are staged -- none for run_nnz --, padding
                                  * included), row pointers / descriptors / window tables, the x elements staged (or n
                                  * once where x is gathered through L2), y written once, carries.  This -- not alg_bytes --
                                  * is what divides by the launch time to give the HBM rate actually sustained. */
@@ -140,6 +140,8 @@ typedef struct spmv_hip_info {
                                  * A = A_near + A_far (near: the tile schedule, every tile staged; far: the blocked executor, accumulating) and
                                  * times it: [0] schedule as built, [1] the split pair, ms (0, 0: not tried) */
     long long far_nnz;          /* entries the blocked executor multiplies in a split handle (0: the handle is not split) */
+    long long run_nnz;          /* CSR-vector / row-block tile kernels: entries in RUN tiles -- staged tiles whose rows each reference one run of
+                                 * consecutive columns (banded matrices); their column stream is not read at all (a 16-bit slot per ROW instead) */
 } spmv_hip_info;
 int spmv_hip_get_info(spmv_Handle_t handle, spmv_hip_info *out);
 

@@ -17,6 +17,10 @@
 //     12 B/nnz for fp64.  The executor stages the windows once per tile (coalesced) and every
 //     gather is xs[slot], with no index arithmetic at all.  Tiles whose columns do not fit read
 //     the original ColIdx and gather from L1/L2;
+//   - RUN tiles: a staged tile whose rows each reference ONE run of consecutive columns (banded matrices, 1-D stencils, dense row
+//     blocks: col[p] = col[p0] + p - p0) needs no column stream at all: the LDS slot of a row's first column (16 bits per ROW,
+//     row_slot) + the entry's position in the row IS the slot.  fp64: 8 B/nnz + 2 B/row instead of 10 B/nnz -- BASELINE config 2's
+//     banded matrix streams 2.8 instead of 3.4 GB per multiply.  Same products, same order of additions: the same bits;
 //   - matrix stream: 16 B lane loads, DEPTH steps in flight per wave;
 //   - the 64 row sums of a wave are collected through LDS and written by ONE coalesced store.
 // Rows longer than long_thr are left to the long-row path (a CSR5 plan over their sub-matrix, long_rows.hpp) and
@@ -48,7 +52,8 @@ __global__ __launch_bounds__(kBlock) void csr_tile_windows_kernel(int m, int n, 
                                                                   const int *__restrict__ colidx,
                                                                   TileWindows *__restrict__ wins,
                                                                   unsigned short *__restrict__ col_local,
-                                                                  int *__restrict__ staged /* [0] tiles staged, [1] max total */)
+                                                                  unsigned short *__restrict__ row_slot /* NULL: no run tiles */,
+                                                                  int *__restrict__ staged /* [0] tiles staged, [1] max total, [2] run tiles, [3] their entries, [4] their rows */)
 {
     long long r0, r1;
     tile_rows(blockIdx.x, m, rows_per_tile, split, r0, r1);
@@ -62,6 +67,42 @@ __global__ __launch_bounds__(kBlock) void csr_tile_windows_kernel(int m, int n, 
     };
     auto store = [&](long long pos, int slot, int) { col_local[pos] = (unsigned short) (slot * slot_bytes); };
     build_windows(n, max_cols, loop, store, wins[blockIdx.x], staged, true);
+    if (!row_slot) return;
+    // RUN tile?  every (non-long) row one run of consecutive columns: then row_slot[r] = slot of the row's first column, in the column
+    // stream's unit, and the executor never reads col_local for this tile
+    __syncthreads(); // wins[blockIdx.x] as written by thread 0
+    const TileWindows &tw = wins[blockIdx.x];
+    const int nwin = tw.nwin;
+    int ok = nwin > 0, entries = 0;
+    if (nwin > 0)
+        for (long long r = r0 + sub; r < r1; r += kBlock / 16) {
+            const int p0 = rowptr[r], p1 = rowptr[r + 1];
+            if (p1 - p0 > long_thr || p1 == p0) continue;
+            const int c0 = colidx[p0];
+            for (int p = p0 + l; p < p1; p += 16) ok &= colidx[p] == c0 + (p - p0);
+            if (l == 0) entries += p1 - p0;
+        }
+    ok = __syncthreads_and(ok);
+    if (!ok) return;
+    for (long long r = r0 + sub * 16 + l; r < r1; r += kBlock) { // one thread per row now
+        const int p0 = rowptr[r], p1 = rowptr[r + 1];
+        int slot = 0;
+        if (p1 > p0 && p1 - p0 <= long_thr) {
+            const int c0 = colidx[p0];
+            int w = 0;
+            for (int k = 1; k < nwin; ++k) w = c0 >= tw.start[k] ? k : w;
+            slot = (tw.base[w] + (c0 - tw.start[w])) * slot_bytes; // the whole run lies in window w: windows are maximal runs of touched 64-column segments
+        }
+        row_slot[r] = (unsigned short) slot;
+    }
+#pragma unroll
+    for (int o = kWave / 2; o > 0; o >>= 1) entries += __shfl_xor(entries, o, kWave);
+    if ((threadIdx.x & (kWave - 1)) == 0 && entries) atomicAdd(staged + 3, entries);
+    if (threadIdx.x == 0) {
+        wins[blockIdx.x].runs = 1;
+        atomicAdd(staged + 2, 1);
+        atomicAdd(staged + 4, (int) (r1 - r0));
+    }
 }
 
 // Which four entries of a 4L-entry chunk a lane takes.  Every load instruction should cover one
@@ -109,12 +150,18 @@ struct Lane4 {
 // One step of one lane group: lane l of the L lanes of row [p0, p1) multiplies its four entries
 // (c, v: already loaded by Lane4 from the chunk starting at the 16 B-aligned position p0 & ~3) and, for
 // rows longer than that chunk, walks on in chunks of 4L.  Returns the lane's partial sum (not yet reduced over the group).
-template <typename T, int L, bool STAGED, int SHIFT = 0>
+// MODE 0: unstaged (global columns), 1: staged (16-bit slots from the column stream), 2: staged RUN tile (slots = rs + position in the row;
+// cc0 unused)
+template <typename T, int L, int MODE, int SHIFT = 0>
 __device__ __forceinline__ T csr_vector_step(int p0, int p1, int l, const int (&cc0)[4], const T (&vv0)[4],
                                              const int *__restrict__ colidx, const unsigned short *__restrict__ col_local,
                                              const T *__restrict__ val, const T *__restrict__ x,
-                                             const unsigned char *__restrict__ xb, unsigned zoff)
+                                             const unsigned char *__restrict__ xb, unsigned zoff, unsigned rs = 0)
 {
+    constexpr bool STAGED = MODE != 0;
+    constexpr unsigned INC = SHIFT ? 1u : (unsigned) sizeof(T); // slot unit of the stream: indices (wide form) or bytes
+    // slot of entry e (e - p0 < row length) of a RUN tile's row
+    auto run_slot = [&](int e) { return rs + (unsigned) (e - p0) * INC; };
     // SHIFT = 0: the stream holds LDS byte offsets; SHIFT = log2(sizeof(T)): slot indices (windows above 64 KiB)
     auto xat = [&](unsigned off) { return *reinterpret_cast<const T *>(xb + ((size_t) off << SHIFT)); };
     using LM = Lane4<T, L>;
@@ -125,8 +172,8 @@ __device__ __forceinline__ T csr_vector_step(int p0, int p1, int l, const int (&
         const bool full = (e0 >= p0) & (e3 < p1), none = e0 >= p1;
         if (__all(full | none)) {
             if (full) {
-                const T x0 = xat(lds_slot<0>(cc0)), x1 = xat(lds_slot<1>(cc0)), x2 = xat(lds_slot<2>(cc0)),
-                        x3 = xat(lds_slot<3>(cc0));
+                const T x0 = xat(MODE == 2 ? run_slot(e0) : lds_slot<0>(cc0)), x1 = xat(MODE == 2 ? run_slot(e1) : lds_slot<1>(cc0)),
+                        x2 = xat(MODE == 2 ? run_slot(e2) : lds_slot<2>(cc0)), x3 = xat(MODE == 2 ? run_slot(e3) : lds_slot<3>(cc0));
                 sum = fmadd(vv0[0], x0, sum);
                 sum = fmadd(vv0[1], x1, sum);
                 sum = fmadd(vv0[2], x2, sum);
@@ -136,8 +183,8 @@ __device__ __forceinline__ T csr_vector_step(int p0, int p1, int l, const int (&
             const unsigned len = (unsigned) (p1 - p0); // entry e is in the row iff e - p0 < len (unsigned)
             const bool k0 = (unsigned) (e0 - p0) < len, k1 = (unsigned) (e1 - p0) < len, k2 = (unsigned) (e2 - p0) < len,
                        k3 = (unsigned) (e3 - p0) < len;
-            const T x0 = xat(k0 ? lds_slot<0>(cc0) : zoff), x1 = xat(k1 ? lds_slot<1>(cc0) : zoff),
-                    x2 = xat(k2 ? lds_slot<2>(cc0) : zoff), x3 = xat(k3 ? lds_slot<3>(cc0) : zoff);
+            const T x0 = xat(k0 ? (MODE == 2 ? run_slot(e0) : lds_slot<0>(cc0)) : zoff), x1 = xat(k1 ? (MODE == 2 ? run_slot(e1) : lds_slot<1>(cc0)) : zoff),
+                    x2 = xat(k2 ? (MODE == 2 ? run_slot(e2) : lds_slot<2>(cc0)) : zoff), x3 = xat(k3 ? (MODE == 2 ? run_slot(e3) : lds_slot<3>(cc0)) : zoff);
             sum = fmadd(k0 ? vv0[0] : T(0), x0, sum);
             sum = fmadd(k1 ? vv0[1] : T(0), x1, sum);
             sum = fmadd(k2 ? vv0[2] : T(0), x2, sum);
@@ -156,12 +203,16 @@ __device__ __forceinline__ T csr_vector_step(int p0, int p1, int l, const int (&
     if (__any(base + 4 * L < p1)) { // some row of this step is longer than its first 4L-entry chunk
         for (int bb = base + 4 * L; __any(bb < p1); bb += 4 * L) {
             if (bb < p1) {
-                int cc[4];
+                int cc[4] = {0, 0, 0, 0};
                 T v2[4];
-                if (STAGED) LM::load_col16(col_local, bb, l, cc);
-                else LM::load_col32(colidx, bb, l, cc);
+                if (MODE == 1) LM::load_col16(col_local, bb, l, cc);
+                else if (MODE == 0) LM::load_col32(colidx, bb, l, cc);
                 LM::load_val(val, bb, l, v2);
-                if (STAGED) {
+                if (MODE == 2) {
+#pragma unroll
+                    for (int k = 0; k < 4; ++k)
+                        if (bb + LM::pos(l, k) < p1) sum = fmadd(v2[k], xat(run_slot(bb + LM::pos(l, k))), sum);
+                } else if (STAGED) {
                     if (bb + LM::pos(l, 0) < p1) sum = fmadd(v2[0], xat(lds_slot<0>(cc)), sum);
                     if (bb + LM::pos(l, 1) < p1) sum = fmadd(v2[1], xat(lds_slot<1>(cc)), sum);
                     if (bb + LM::pos(l, 2) < p1) sum = fmadd(v2[2], xat(lds_slot<2>(cc)), sum);
@@ -182,9 +233,10 @@ __device__ __forceinline__ T csr_vector_step(int p0, int p1, int l, const int (&
 // zoff is the byte offset of a slot that holds 0 (masked entries read it: 0 * 0, never x's NaN/Inf).
 // A step whose lanes all hold four entries of their row, or none (regular matrices: every step),
 // takes the unmasked path.  The order of the fused multiply-adds is the same on both paths.
-template <typename T, int L, bool STAGED, int DEPTH, bool PRE = true, int SHIFT = 0>
+template <typename T, int L, int MODE, int DEPTH, bool PRE = true, int SHIFT = 0>
 __device__ __forceinline__ void csr_vector_tile_wave(long long row_end, int long_thr, long long rw0, int lane,
-                                                     const int *__restrict__ rp_lds, T *__restrict__ y_lds,
+                                                     const int *__restrict__ rp_lds, const unsigned short *__restrict__ rs_lds /* MODE 2: slot of each row's first column */,
+                                                     T *__restrict__ y_lds,
                                                      const int *__restrict__ colidx, const unsigned short *__restrict__ col_local,
                                                      const T *__restrict__ val,
                                                      const T *__restrict__ x, const T *__restrict__ xs, unsigned zoff,
@@ -197,6 +249,9 @@ __device__ __forceinline__ void csr_vector_tile_wave(long long row_end, int long
     int c[D][4];
     T v[D][4];
     int pp0[D], pp1[D];
+    unsigned rs[D];
+#pragma unroll
+    for (int k = 0; k < D; ++k) rs[k] = 0;
 #pragma unroll
     for (int k = 0; k < 4; ++k) { c[0][k] = c0[k]; v[0][k] = v0[k]; } // PRE: step 0 was issued before the barrier
     auto issue = [&](int s) { // RowPtr pair of step s from LDS, then its stream loads
@@ -204,10 +259,11 @@ __device__ __forceinline__ void csr_vector_tile_wave(long long row_end, int long
         pp0[slot] = rp_lds[s * RW + sub];
         pp1[slot] = rp_lds[s * RW + sub + 1];
         if (pp1[slot] - pp0[slot] > long_thr) pp1[slot] = pp0[slot];
+        if (MODE == 2) rs[slot] = rs_lds[s * RW + sub];
         if (s > 0 || !PRE) {
             const int an = pp0[slot] & ~3;
-            if (STAGED) Lane4<T, L>::load_col16(col_local, an, l, c[slot]);
-            else Lane4<T, L>::load_col32(colidx, an, l, c[slot]);
+            if (MODE == 1) Lane4<T, L>::load_col16(col_local, an, l, c[slot]);
+            else if (MODE == 0) Lane4<T, L>::load_col32(colidx, an, l, c[slot]);
             Lane4<T, L>::load_val(val, an, l, v[slot]);
         }
     };
@@ -217,7 +273,7 @@ __device__ __forceinline__ void csr_vector_tile_wave(long long row_end, int long
     for (int s = 0; s < L; ++s) {
         const int cur = s % D;
         const int p0 = pp0[cur], p1 = pp1[cur];
-        T sum = csr_vector_step<T, L, STAGED, SHIFT>(p0, p1, l, c[cur], v[cur], colidx, col_local, val, x, xb, zoff);
+        T sum = csr_vector_step<T, L, MODE, SHIFT>(p0, p1, l, c[cur], v[cur], colidx, col_local, val, x, xb, zoff, rs[cur]);
         sum = group_sum_dpp<L>(sum);
         if (l == 0) y_lds[s * RW + sub] = sum;
         if (s + D < L) issue(s + D); // refill the slot just consumed
@@ -234,11 +290,13 @@ __global__ __launch_bounds__(kVecTileThreads) void csr_vector_tile_kernel(int m,
                                                                           const unsigned short *__restrict__ col_local,
                                                                           const T *__restrict__ val,
                                                                           const TileWindows *__restrict__ wins,
+                                                                          const unsigned short *__restrict__ row_slot,
                                                                           const T *__restrict__ x, T *__restrict__ y)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char vec_x_lds[]; // the tile's staged x
     T *xs = reinterpret_cast<T *>(vec_x_lds);
     __shared__ int rp_lds[kVecTileThreads / kWave][kWave + 2];
+    __shared__ unsigned short rs_lds[kVecTileThreads / kWave][kWave];
     __shared__ T y_lds[kVecTileThreads / kWave][kWave];
     const int lane = threadIdx.x & (kWave - 1), wave = threadIdx.x / kWave;
     const long long rw0 = (long long) blockIdx.x * kVecTileRows + wave * kWave;
@@ -249,7 +307,7 @@ __global__ __launch_bounds__(kVecTileThreads) void csr_vector_tile_kernel(int m,
     const int rp = rowptr[r];
     const int rpe = rowptr[re]; // wave-uniform
     const TileWindows &tw = wins[blockIdx.x];
-    const bool staged = tw.nwin > 0;
+    const bool staged = tw.nwin > 0, runs = tw.runs != 0; // runs implies staged
     // step 0 of the matrix stream is issued straight from registers (RowPtr handed over by
     // shuffles), BEFORE the x staging and the barrier, so neither sits in front of the first loads
     int c0[4] = {0, 0, 0, 0};
@@ -258,19 +316,22 @@ __global__ __launch_bounds__(kVecTileThreads) void csr_vector_tile_kernel(int m,
         const int sub = lane / L, l = lane % L;
         const int q0 = __shfl(rp, sub, kWave);
         const int a = q0 & ~3;
-        if (staged) Lane4<T, L>::load_col16(col_local, a, l, c0);
+        if (runs) {}
+        else if (staged) Lane4<T, L>::load_col16(col_local, a, l, c0);
         else Lane4<T, L>::load_col32(colidx, a, l, c0);
         Lane4<T, L>::load_val(val, a, l, v0);
     }
     rp_lds[wave][lane] = rp;
     if (lane == 0) rp_lds[wave][kWave] = rpe;
+    if (runs) rs_lds[wave][lane] = row_slot[r]; // r <= m: the array has m + 1 entries
     stage_windows<kVecTileThreads, T>(tw, x, xs);
     if (threadIdx.x == 0) xs[tw.total] = T(0); // the zero slot of masked entries
     __syncthreads();
     if (rw0 >= m) return;
     const unsigned zoff = (unsigned) tw.total * (unsigned) sizeof(T);
-    if (staged) csr_vector_tile_wave<T, L, true, DEPTH, PRE>((long long) m, long_thr, rw0, lane, rp_lds[wave], y_lds[wave], colidx, col_local, val, x, xs, zoff, y, c0, v0);
-    else csr_vector_tile_wave<T, L, false, DEPTH, PRE>((long long) m, long_thr, rw0, lane, rp_lds[wave], y_lds[wave], colidx, col_local, val, x, xs, zoff, y, c0, v0);
+    if (runs) csr_vector_tile_wave<T, L, 2, DEPTH, PRE>((long long) m, long_thr, rw0, lane, rp_lds[wave], rs_lds[wave], y_lds[wave], colidx, col_local, val, x, xs, zoff, y, c0, v0);
+    else if (staged) csr_vector_tile_wave<T, L, 1, DEPTH, PRE>((long long) m, long_thr, rw0, lane, rp_lds[wave], rs_lds[wave], y_lds[wave], colidx, col_local, val, x, xs, zoff, y, c0, v0);
+    else csr_vector_tile_wave<T, L, 0, DEPTH, PRE>((long long) m, long_thr, rw0, lane, rp_lds[wave], rs_lds[wave], y_lds[wave], colidx, col_local, val, x, xs, zoff, y, c0, v0);
 }
 
 // Balanced form (Method_Balanced): the same wave program over EQUAL-NNZ row blocks.  Block b owns
@@ -285,6 +346,7 @@ __global__ __launch_bounds__(kVecTileThreads) void csr_vector_rows_kernel(int lo
                                                                           const unsigned short *__restrict__ col_local,
                                                                           const T *__restrict__ val,
                                                                           const TileWindows *__restrict__ wins,
+                                                                          const unsigned short *__restrict__ row_slot,
                                                                           const T *__restrict__ x, T *__restrict__ y)
 {
     // WIDE: x windows above 64 KiB (fp64 rows whose columns scatter over thousands of columns): the column
@@ -294,12 +356,13 @@ __global__ __launch_bounds__(kVecTileThreads) void csr_vector_rows_kernel(int lo
     extern __shared__ __attribute__((aligned(16))) unsigned char vec_x_lds[];
     T *xs = reinterpret_cast<T *>(vec_x_lds);
     __shared__ int rp_lds[kVecTileThreads / kWave][kWave + 2];
+    __shared__ unsigned short rs_lds[kVecTileThreads / kWave][kWave];
     __shared__ T y_lds[kVecTileThreads / kWave][kWave];
     const int lane = threadIdx.x & (kWave - 1), wave = threadIdx.x / kWave;
     long long r_begin, r_end;
     tile_rows(blockIdx.x, m, rows_per_block, split, r_begin, r_end);
     const TileWindows &tw = wins[blockIdx.x];
-    const bool staged = tw.nwin > 0;
+    const bool staged = tw.nwin > 0, runs = tw.runs != 0;
     stage_windows<kVecTileThreads, T>(tw, x, xs);
     if (threadIdx.x == 0) xs[tw.total] = T(0); // the zero slot of masked entries
     __syncthreads();
@@ -312,9 +375,11 @@ __global__ __launch_bounds__(kVecTileThreads) void csr_vector_rows_kernel(int lo
         if (re > r_end) re = r_end;
         rp_lds[wave][lane] = rowptr[r];
         if (lane == 0) rp_lds[wave][kWave] = rowptr[re];
+        if (runs) rs_lds[wave][lane] = row_slot[r];
         wave_lds_sync();
-        if (staged) csr_vector_tile_wave<T, L, true, DEPTH, false, SHIFT>(r_end, long_thr, rw0, lane, rp_lds[wave], y_lds[wave], colidx, col_local, val, x, xs, zoff, y, c0, v0);
-        else csr_vector_tile_wave<T, L, false, DEPTH, false, SHIFT>(r_end, long_thr, rw0, lane, rp_lds[wave], y_lds[wave], colidx, col_local, val, x, xs, zoff, y, c0, v0);
+        if (runs) csr_vector_tile_wave<T, L, 2, DEPTH, false, SHIFT>(r_end, long_thr, rw0, lane, rp_lds[wave], rs_lds[wave], y_lds[wave], colidx, col_local, val, x, xs, zoff, y, c0, v0);
+        else if (staged) csr_vector_tile_wave<T, L, 1, DEPTH, false, SHIFT>(r_end, long_thr, rw0, lane, rp_lds[wave], rs_lds[wave], y_lds[wave], colidx, col_local, val, x, xs, zoff, y, c0, v0);
+        else csr_vector_tile_wave<T, L, 0, DEPTH, false, SHIFT>(r_end, long_thr, rw0, lane, rp_lds[wave], rs_lds[wave], y_lds[wave], colidx, col_local, val, x, xs, zoff, y, c0, v0);
         wave_lds_sync(); // y_lds / rp_lds are reused by the next slab
     }
 }

@@ -30,6 +30,7 @@ struct TileWindows {
     int start[kWinMax];  // first column of each window (ascending)
     int len[kWinMax];
     int base[kWinMax];   // LDS slot of the window's first column
+    int runs;            // CSR-vector tiles only: 1 = every row's columns are ONE run of consecutive columns (csr_vector_tile.hpp: no column stream)
 };
 
 // sum of TileWindows::total over `count` tiles: the x elements one launch stages (traffic model, spmv_hip_info.stream_bytes)
@@ -165,6 +166,7 @@ __device__ __forceinline__ void build_windows(int n, int max_cols, Loop loop, St
     if (threadIdx.x == 0) {
         out.nwin = nwin;
         out.total = nwin ? s_total : 0;
+        out.runs = 0;
         for (int k = 0; k < kWinMax; ++k) {
             out.start[k] = k < nwin ? s_start[k] : 0;
             out.len[k] = k < nwin ? s_end[k] - s_start[k] : 0;

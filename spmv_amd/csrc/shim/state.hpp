@@ -198,6 +198,8 @@ struct spmv_dev {
     int vt_rows = 256;
     float tune_ms[3] = {0, 0, 0}; // tile D4, tile D2, pipe (autotune_vector)
     unsigned short *vt_col = nullptr; // tile-local column stream: 16-bit LDS slots (staged tiles only)
+    unsigned short *vt_rowslot = nullptr; // RUN tiles (every row one run of consecutive columns): slot of each row's first column; no column stream read
+    int vt_run_tiles = 0, vt_run_nnz = 0, vt_run_rows = 0;
     TileWindows *vt_wins = nullptr; // x windows of every tile
     // long rows (csr-vector, sell)
     int nlong = 0, long_thr = INT_MAX;
@@ -273,6 +275,7 @@ static void reset_tile_fields(spmv_dev *d)
     d->nblocks = d->nchunks = d->nlong = 0;
     d->long_thr = INT_MAX;
     d->vt_col = nullptr; d->vt_wins = nullptr; d->vt_tiles = d->vt_staged = d->vt_maxspan = 0; d->vt_wide = false; d->vt_rows = 256;
+    d->vt_rowslot = nullptr; d->vt_run_tiles = d->vt_run_nnz = d->vt_run_rows = 0;
     d->c5 = Csr5Plan();
     d->c5_long = Csr5Plan();
     d->ns = Csr5Plan();

@@ -617,6 +617,7 @@ int spmv_hip_get_info(spmv_Handle_t h, spmv_hip_info *out)
             out->empty_rows += o.empty_rows;
             out->x_groups += o.x_groups;
             out->x_groups_staged += o.x_groups_staged;
+            out->run_nnz += o.run_nnz;
             if (o.inspect_ms > out->inspect_ms) out->inspect_ms = o.inspect_ms;
             if (o.max_row_len > out->max_row_len) out->max_row_len = o.max_row_len;
             if (o.min_row_len < out->min_row_len) out->min_row_len = o.min_row_len;

@@ -753,9 +753,18 @@ def test_stream_bytes_model_of_the_storage_format():
     with api.Handle(m, n, rp, ci, va, M.Method_Parallel) as h:
         i = h.info()
     assert i["kernel_name"] == "csr_vector_tile_kernel" and i["x_groups_staged"] == i["x_groups"]
-    fixed = 4 * (m + 1) + nnz * (8 + 2) + 8 * m                      # RowPtr, values + 16-bit slots, y
+    # every row one run of 32 consecutive columns except the wrapped rows at both ends: all tiles but the first and the last are RUN tiles
+    assert nnz - 2 * 256 * 32 <= i["run_nnz"] <= nnz, i
+    fixed = 4 * (m + 1) + nnz * 8 + (nnz - i["run_nnz"]) * 2 + i["run_nnz"] // 32 * 2 + 8 * m   # RowPtr, values, 16-bit slots per entry / per row of a RUN tile, y
     assert fixed < i["stream_bytes"] < fixed + 8 * 2 * n + 300 * i["x_groups"]   # + window tables + staged x (tiles overlap by the band)
     assert 8 * n <= i["x_bytes"] < 8 * 2 * n and i["stream_bytes"] < i["alg_bytes"]
+    # a second diagonal 1000 columns away: two runs per row -> no RUN tile, the 16-bit column stream is read again
+    ci2 = ci.clone().view(m, 32)
+    ci2[:, 16:] = (ci2[:, 16:] + 1000) % n
+    ci2 = torch.sort(ci2, dim=1).values.reshape(-1).contiguous()
+    with api.Handle(m, n, rp, ci2, va, M.Method_Parallel) as h:
+        i2 = h.info()
+    assert i2["kernel_name"] == "csr_vector_tile_kernel" and i2["run_nnz"] == 0 and i2["stream_bytes"] > i["stream_bytes"] + nnz
     with api.Handle(m, n, rp, ci, va, M.Method_Serial) as h:
         i = h.info()
     assert i["stream_bytes"] == i["alg_bytes"]
@@ -860,3 +869,87 @@ def test_block_rows_option_is_capped_and_every_row_is_written():
     finally:
         for k, v in keep.items():
             api.set_option(k, v)
+
+
+def _run_rows_matrix(m, n, lens, start, dtype, dev, seed):
+    """CSR whose row i holds the run of lens[i] consecutive columns start[i] .. (exact 'eighths' values)"""
+    import torch
+    rp = torch.zeros(m + 1, dtype=torch.int64, device=dev)
+    torch.cumsum(lens, 0, out=rp[1:])
+    nnz = int(rp[-1])
+    row_of = torch.repeat_interleave(torch.arange(m, device=dev), lens)
+    ci = (start[row_of] + torch.arange(nnz, device=dev) - rp[:-1][row_of]).to(torch.int32)
+    assert int(ci.min()) >= 0 and int(ci.max()) < n
+    g = torch.Generator(device=dev); g.manual_seed(seed)
+    va = (torch.randint(-8, 9, (nnz,), generator=g, device=dev) * 0.125).to(dtype)
+    return rp.to(torch.int32), ci, va, row_of
+
+
+def _segment_sums(prod, rp):
+    import torch
+    cs = torch.cat([torch.zeros(1, dtype=torch.float64, device=prod.device), torch.cumsum(prod.double(), 0)])
+    return cs[rp[1:].long()] - cs[rp[:-1].long()]
+
+
+@pytest.mark.parametrize("method", [M.Method_Parallel, M.Method_Balanced], ids=lambda m: m.name)
+@pytest.mark.parametrize("dtype", ["f64", "f32"])
+@pytest.mark.parametrize("shape", ["ragged", "two_bands", "chunks", "wide", "broken_rows"])
+def test_run_tiles_need_no_column_stream(shape, dtype, method):
+    """RUN tiles of the CSR-vector tile kernels (csr_vector_tile.hpp): rows that are one run of consecutive columns get their LDS
+    slots from a 16-bit slot per ROW.  Exact data, so the sums must equal the definition bit for bit.
+      ragged       run lengths 0..40 (empty rows, single entries, rows past one 4L-entry chunk), runs start within +-600 of the diagonal
+      two_bands    even rows run near the diagonal, odd rows 200 000 columns away: two x windows per tile, every row still one run
+      chunks       64..200 entries per row: several chunks per row, under the long-row threshold
+      wide         8-entry runs starting within +-5000 columns of the diagonal: the fp64 tile's x span exceeds 48 KiB -> wide form (slot indices)
+      broken_rows  the ragged matrix with one entry of every 3000th row moved: those tiles fall back to the column stream, the others stay RUN"""
+    import torch
+    dev = torch.device("cuda:0")
+    tdt = torch.float64 if dtype == "f64" else torch.float32
+    m = n = 300_000
+    g = torch.Generator(device=dev); g.manual_seed(11)
+    rows = torch.arange(m, device=dev)
+    if shape in ("ragged", "broken_rows"):
+        lens = torch.randint(0, 41, (m,), generator=g, device=dev)
+        start = (rows + torch.randint(-600, 601, (m,), generator=g, device=dev)).clamp_(0, n - 41)
+    elif shape == "two_bands":
+        lens = torch.full((m,), 12, device=dev)
+        start = torch.where(rows % 2 == 0, rows, (rows + 200_000) % n).clamp_(0, n - 12)
+    elif shape == "chunks":
+        lens = torch.randint(64, 201, (m,), generator=g, device=dev)
+        start = (rows - 100).clamp_(0, n - 201)
+    else:
+        lens = torch.full((m,), 8, device=dev)
+        start = (rows + torch.randint(-5000, 5001, (m,), generator=g, device=dev)).clamp_(0, n - 8)
+    rp, ci, va, row_of = _run_rows_matrix(m, n, lens, start, tdt, dev, 5)
+    nnz = int(rp[-1])
+    broken = 0
+    if shape == "broken_rows":
+        pick = torch.nonzero((rows % 3000 == 7) & (lens >= 2)).flatten()
+        pos = rp[pick].long() + 1
+        ci[pos] = (ci[pos] + 3).clamp_(max=n - 1)         # second entry of the row: no longer c0 + 1 (a duplicate of a later column is legal CSR)
+        broken = int(pick.numel())
+    x = (torch.randint(-8, 9, (n,), generator=g, device=dev) * 0.125).to(tdt)
+    want = _segment_sums(va.double() * x.double()[ci.long()], rp).to(tdt)
+    y = torch.full((m,), float("nan"), dtype=tdt, device=dev)
+    if shape == "chunks":   # left alone the planner hands every row above 64 entries to the long-row path (CSR5 sub-matrix): force 4 lanes per row,
+        api.set_thread_option("lanes_per_row", 4)   # i.e. 16-entry chunks, up to 13 per row, long-row threshold 256
+    try:
+        h = api.Handle(m, n, rp, ci, va, method)
+    finally:
+        api.clear_thread_options()
+    with h:
+        h.spmv(x, y)
+        info = h.info()
+        torch.cuda.synchronize()
+        assert torch.equal(y, want), (info["kernel_name"], int((y != want).sum()))
+        assert info["kernel_name"] in ("csr_vector_tile_kernel", "csr_vector_rows_kernel") and info["cache_blocked"] == 0, info
+        if shape == "broken_rows":
+            if method == M.Method_Parallel:   # 256-row tiles: exactly the tiles holding a moved entry read their column stream
+                assert nnz - broken * 256 * 40 <= info["run_nnz"] < nnz, (info["run_nnz"], nnz, broken)
+        else:
+            assert info["run_nnz"] == nnz, (info["run_nnz"], nnz, info["x_groups"], info["x_groups_staged"])
+        va2 = (va * 2).contiguous()                       # values only: the row slots stay
+        h.update_values(va2)
+        h.spmv(x, y)
+        torch.cuda.synchronize()
+        assert torch.equal(y, 2 * want)
