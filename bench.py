@@ -506,7 +506,9 @@ def run_rank(args):
                 "note": "achieved = bytes the kernel moves (storage-format model spmv_hip_info.stream_bytes, checked against the "
                         "rocprofv3 counters in profiles/) / mean launch time from HIP events on the launch stream; achieved_alg "
                         "divides SURVEY 8d's algorithmic bytes (4 B ColIdx per nnz, which this kernel replaces by a 2 B LDS-slot "
-                        "stream) by the same time and is an effective rate, not an HBM rate",
+                        "stream -- or, in tiles whose rows are runs of consecutive columns (run_nnz entries), by a 2 B slot per ROW) by "
+                        "the same time and is an effective rate, not an HBM rate",
+                "run_nnz": int(info.get("run_nnz", 0)),
             },
         }
         if world > 1:
