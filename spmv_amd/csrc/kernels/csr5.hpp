@@ -209,7 +209,36 @@ __global__ __launch_bounds__(kBlock) void csr5_desc_kernel(int m2, int nnz, int 
     }
 }
 
-// Tile-transposed copies: dst[t*T + i*64 + x] = src[t*T + x*SIGMA + i]; padding col = -1, val = 0.
+// Where entry i of lane x sits inside the tile's transposed VALUE copy: 16 bytes per lane and load instruction (E = 4 floats / 2 doubles:
+// entries i = gE .. gE + E - 1 of a lane side by side), 1 KiB per wave-instruction instead of the 256 / 512 B of one value per lane
+// (config 4, fp32: CSR5 0.571 -> 0.52 ms with the two-deep loop below).  The column copies: tcol [i * 64 + x], tcol16 packed alike (pack16).
+template <typename T, int SIGMA>
+__device__ __forceinline__ int csr5_val_pos(int i, int lane)
+{
+    constexpr int E = 16 / (int) sizeof(T);
+    static_assert(SIGMA % E == 0, "sigma is a multiple of the values per 16-byte load");
+    return (i / E) * (E * kWave) + lane * E + (i % E);
+}
+
+// v[i] = the lane's SIGMA values of tile t (SIGMA / E loads of 16 bytes)
+template <typename T, int SIGMA>
+__device__ __forceinline__ void csr5_load_vals(const T *__restrict__ tval, int t, int lane, T (&v)[SIGMA])
+{
+    constexpr int E = 16 / (int) sizeof(T), TN = kWave * SIGMA;
+    const T *src = tval + (long long) t * TN + lane * E;
+#pragma unroll
+    for (int g = 0; g < SIGMA / E; ++g) {
+        if constexpr (E == 4) {
+            const f32x4 q = __builtin_nontemporal_load(reinterpret_cast<const f32x4 *>(src + g * (E * kWave)));
+            v[4 * g] = q.x; v[4 * g + 1] = q.y; v[4 * g + 2] = q.z; v[4 * g + 3] = q.w;
+        } else {
+            const f64x2 q = __builtin_nontemporal_load(reinterpret_cast<const f64x2 *>(src + g * (E * kWave)));
+            v[2 * g] = q.x; v[2 * g + 1] = q.y;
+        }
+    }
+}
+
+// Tile-transposed copies: tcol[t*T + i*64 + x] = colidx[t*T + x*SIGMA + i], tval[t*T + csr5_val_pos(i, x)] = val[...]; padding col = -1, val = 0.
 template <typename T, int SIGMA>
 __global__ __launch_bounds__(kBlock) void csr5_transpose_kernel(int nnz, int p, const int *__restrict__ colidx,
                                                                 const T *__restrict__ val,
@@ -225,7 +254,7 @@ __global__ __launch_bounds__(kBlock) void csr5_transpose_kernel(int nnz, int p, 
         const long long src = base + (long long) lane * SIGMA + i;
         const bool in = src < nnz;
         if (tcol) tcol[base + i * kWave + lane] = in ? colidx[src] : -1; // NULL: values only (spmv_hip_update_values)
-        tval[base + i * kWave + lane] = in ? val[src] : T(0);
+        tval[base + csr5_val_pos<T, SIGMA>(i, lane)] = in ? val[src] : T(0);
     }
 }
 
@@ -351,8 +380,7 @@ __device__ __forceinline__ void csr5_tile(int t, int lane, const int *__restrict
 #pragma unroll
         for (int i = 0; i < SIGMA; ++i) c[i] = ld_stream(tcol + base + i * kWave);
     }
-#pragma unroll
-    for (int i = 0; i < SIGMA; ++i) v[i] = ld_stream(tval + base + i * kWave);
+    csr5_load_vals<T, SIGMA>(tval, t, lane, v);
     if constexpr (MAPPED) csr5_stage_row_map<SIGMA>(lane, r0, r1, row_map, rm);
     csr5_tile_compute<T, SIGMA, MAPPED, STAGED>(t, lane, c, v, d, r0, rm, x, xs, y, carry);
 }
@@ -417,6 +445,118 @@ __global__ __launch_bounds__(kBlock) void csr5_group_kernel(int group_tiles, int
         if (t >= p) break;
         if (staged) csr5_tile<T, SIGMA, MAPPED, true>(t, lane, tile_ptr, desc, tcol, tcol16, tval, row_map, rm, x, xs, y, carry);
         else csr5_tile<T, SIGMA, MAPPED, false>(t, lane, tile_ptr, desc, tcol, tcol16, tval, row_map, rm, x, xs, y, carry);
+    }
+}
+
+// The same group kernel, two tiles deep (plans whose groups are all staged).  A wave of
+// csr5_group_kernel takes its tiles strictly one after the other: descriptor + row range + streams -> wait -> [row map -> wait] ->
+// compute -> next tile, and the x windows (up to 128 KiB) leave a CU 1-4 workgroups to hide those round trips behind.  Here a
+// wave reads the row ranges of ALL its tiles first (one vector load, lane j = tile j, handed out by v_readlane), issues tile j + 1's
+// streams -- and the first 64 entries of its row map, no longer behind the row range -- before it computes tile j, and keeps the two
+// tiles in two register sets (the loop is unrolled, so the sets are never copied).  The column slots stay packed (two per
+// register) until they are used.  Config 4 (fp32): long rows of the SELL / CSR-vector schedules (MAPPED) and CSR5 itself.
+template <typename T, int SIGMA>
+struct Csr5TileRegs {
+    int w[SIGMA / 4][2]; // 16-bit slots, packed
+    T v[SIGMA];
+    unsigned d;
+    int first;           // MAPPED: row_map[r0 + min(lane, span)]
+};
+
+template <typename T, int SIGMA, bool MAPPED>
+__device__ __forceinline__ void csr5_tile_issue(int t, int lane, int r0, int r1, const unsigned *__restrict__ desc, const unsigned short *__restrict__ tcol16,
+                                                const T *__restrict__ tval, const int *__restrict__ row_map, Csr5TileRegs<T, SIGMA> &R)
+{
+    constexpr int TN = kWave * SIGMA;
+    R.d = desc[(long long) t * kWave + lane];
+#pragma unroll
+    for (int q = 0; q < SIGMA / 4; ++q) {
+        const i32x2 u = __builtin_nontemporal_load(reinterpret_cast<const i32x2 *>(tcol16 + (long long) t * TN + q * (4 * kWave) + lane * 4));
+        R.w[q][0] = u.x; R.w[q][1] = u.y;
+    }
+    csr5_load_vals<T, SIGMA>(tval, t, lane, R.v);
+    R.first = 0;
+    if constexpr (MAPPED) {
+        const int span = r1 - r0;
+        R.first = row_map[r0 + (lane < span ? lane : span)];
+    }
+}
+
+template <typename T, int SIGMA, bool MAPPED>
+__device__ __forceinline__ void csr5_tile_finish(int t, int lane, int r0, int r1, const Csr5TileRegs<T, SIGMA> &R, const int *__restrict__ row_map, int *__restrict__ rm,
+                                                 const T *__restrict__ x, const T *__restrict__ xs, T *__restrict__ y, T *__restrict__ carry)
+{
+    int c[SIGMA];
+#pragma unroll
+    for (int q = 0; q < SIGMA / 4; ++q) {
+        c[4 * q + 0] = (int) ((unsigned) R.w[q][0] & 0xffffu);
+        c[4 * q + 1] = (int) ((unsigned) R.w[q][0] >> 16);
+        c[4 * q + 2] = (int) ((unsigned) R.w[q][1] & 0xffffu);
+        c[4 * q + 3] = (int) ((unsigned) R.w[q][1] >> 16);
+    }
+    if constexpr (MAPPED) {
+        const int span = r1 - r0; // wave-uniform
+        if (span >= kWave) {      // many row starts in this tile: the rest of its row map (csr5_stage_row_map)
+            int tmp[SIGMA];
+#pragma unroll
+            for (int j = 1; j <= SIGMA; ++j) {
+                const int k = j * kWave + lane;
+                tmp[j - 1] = row_map[r0 + (k < span ? k : span)];
+            }
+#pragma unroll
+            for (int j = 1; j <= SIGMA; ++j) rm[j * kWave + lane] = tmp[j - 1];
+        }
+        rm[lane] = R.first;
+        wave_lds_sync();
+    }
+    csr5_tile_compute<T, SIGMA, MAPPED, true>(t, lane, c, R.v, R.d, r0, rm, x, xs, y, carry);
+}
+
+constexpr int kCsr5PipeMaxGroupTiles = kWave * (kBlock / kWave); // lane j of a wave holds the row range of the wave's j-th tile
+
+template <typename T, int SIGMA, bool MAPPED>
+__global__ __launch_bounds__(kBlock) void csr5_group_pipe_kernel(int group_tiles, int p, const int *__restrict__ tile_ptr,
+                                                                 const unsigned *__restrict__ desc, const unsigned short *__restrict__ tcol16,
+                                                                 const T *__restrict__ tval, const int *__restrict__ row_map,
+                                                                 const TileWindows *__restrict__ wins,
+                                                                 const T *__restrict__ x, T *__restrict__ y,
+                                                                 T *__restrict__ carry, int n_empty, const int *__restrict__ empty_list, int rm_off, int rm_stride)
+{
+    if (MAPPED) zero_empty_rows(n_empty, empty_list, y);
+    extern __shared__ __attribute__((aligned(16))) unsigned char csr5_x_lds[]; // x windows, then (MAPPED) the waves' row maps at byte rm_off
+    T *xs = reinterpret_cast<T *>(csr5_x_lds);
+    const TileWindows &tw = wins[blockIdx.x]; // every group of the plan is staged (launch_csr5_form)
+    constexpr int NW = kBlock / kWave;
+    const int lane = threadIdx.x & (kWave - 1);
+    const int wave = __builtin_amdgcn_readfirstlane((int) (threadIdx.x / kWave));
+    const int t0 = blockIdx.x * group_tiles;
+    // the wave's tiles: t0 + wave + j * NW, j < nt
+    int last = group_tiles < p - t0 ? group_tiles : p - t0; // tiles of this group that exist
+    const int nt = last > wave ? (last - wave + NW - 1) / NW : 0;
+    int lp0 = 0, lp1 = 0; // lane j: row range of the wave's j-th tile (one vector load for all of them, in flight during the x staging)
+    if (lane < nt) {
+        lp0 = tile_ptr[t0 + wave + lane * NW];
+        lp1 = tile_ptr[t0 + wave + lane * NW + 1];
+    }
+    Csr5TileRegs<T, SIGMA> R0, R1;
+    // tile 0's streams are issued before the x staging and the barrier (its row map follows the row range: after the barrier)
+    auto issue = [&](int j, Csr5TileRegs<T, SIGMA> &R) {
+        csr5_tile_issue<T, SIGMA, MAPPED>(t0 + wave + j * NW, lane, __builtin_amdgcn_readlane(lp0, j), __builtin_amdgcn_readlane(lp1, j), desc, tcol16, tval, row_map, R);
+    };
+    int *rm = wave_row_map(csr5_x_lds, rm_off, rm_stride);
+    auto finish = [&](int j, const Csr5TileRegs<T, SIGMA> &R) {
+        csr5_tile_finish<T, SIGMA, MAPPED>(t0 + wave + j * NW, lane, __builtin_amdgcn_readlane(lp0, j), __builtin_amdgcn_readlane(lp1, j), R, row_map, rm, x, xs, y, carry);
+    };
+    if (nt > 0) issue(0, R0);
+    stage_windows<kBlock, T>(tw, x, xs);
+    if (threadIdx.x == 0) xs[tw.total] = T(0); // the zero slot of padding entries
+    __syncthreads();
+    for (int j = 0; j < nt; j += 2) {
+        if (j + 1 < nt) issue(j + 1, R1);
+        finish(j, R0);
+        if (j + 1 >= nt) break;
+        if (j + 2 < nt) issue(j + 2, R0);
+        finish(j + 1, R1);
     }
 }
 

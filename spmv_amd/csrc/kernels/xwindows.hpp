@@ -16,6 +16,7 @@
 // 0.78 -> 0.60 ms.
 #pragma once
 #include <climits>
+#include <type_traits>
 #include "common.hpp"
 
 namespace spmv {
@@ -45,19 +46,46 @@ __global__ __launch_bounds__(kBlock) void wins_total_kernel(int count, const Til
     if ((threadIdx.x & (kWave - 1)) == 0 && c) { atomicAdd(sum, t); atomicAdd(staged_tiles, c); }
 }
 
-// Stage the tile's windows: xs[base_w + i] = x[start_w + i].  NT = threads of the workgroup.
+// Stage the tile's windows: xs[base_w + i] = x[start_w + i].  NT = threads of the workgroup.  16-byte loads, four in flight per
+// thread, from the first 16-byte boundary of the window on (x is the caller's pointer: any element alignment): a wide window --
+// 10 000 columns of a CSR5 / SELL group whose rows scatter +-4096 around the diagonal -- is three round trips to L2 instead of eleven,
+// and the workgroup does nothing else while it stages.
 template <int NT, typename T>
 __device__ __forceinline__ void stage_windows(const TileWindows &tw, const T *__restrict__ x, T *__restrict__ xs)
 {
+    constexpr int E = 16 / (int) sizeof(T);
+    using V = typename std::conditional<E == 4, f32x4, f64x2>::type;
     const int nwin = tw.nwin;
     for (int w = 0; w < nwin; ++w) {
         const int st = tw.start[w], ln = tw.len[w], bs = tw.base[w];
-        int i = threadIdx.x;
-        for (; i + 3 * NT < ln; i += 4 * NT) { // four loads in flight per thread (wide windows: thousands of columns)
-            const T a = x[st + i], b = x[st + i + NT], c = x[st + i + 2 * NT], d = x[st + i + 3 * NT];
-            xs[bs + i] = a; xs[bs + i + NT] = b; xs[bs + i + 2 * NT] = c; xs[bs + i + 3 * NT] = d;
+        const T *src = x + st;
+        if (ln <= 16 * NT) { // narrow windows (banded matrices: a few hundred to a few thousand columns): element loads, four in flight per thread --
+            int i = threadIdx.x; // the set-up of the 16-byte path costs such a group more than it saves (nnz-split on config 2: +1.3 %)
+            for (; i + 3 * NT < ln; i += 4 * NT) {
+                const T a = src[i], b = src[i + NT], c = src[i + 2 * NT], d = src[i + 3 * NT];
+                xs[bs + i] = a; xs[bs + i + NT] = b; xs[bs + i + 2 * NT] = c; xs[bs + i + 3 * NT] = d;
+            }
+            for (; i < ln; i += NT) xs[bs + i] = src[i];
+            continue;
         }
-        for (; i < ln; i += NT) xs[bs + i] = x[st + i];
+        int head = (int) (((16u - (unsigned) (reinterpret_cast<size_t>(src) & 15u)) & 15u) / (unsigned) sizeof(T)); // elements in front of the boundary
+        if (head > ln) head = ln;
+        if ((int) threadIdx.x < head) xs[bs + threadIdx.x] = src[threadIdx.x];
+        const int nv = (ln - head) / E;
+        const V *vs = reinterpret_cast<const V *>(src + head);
+        T *dst = xs + bs + head;
+        auto put = [&](int i, const V &q) {
+            if constexpr (E == 4) { dst[4 * i] = q.x; dst[4 * i + 1] = q.y; dst[4 * i + 2] = q.z; dst[4 * i + 3] = q.w; }
+            else { dst[2 * i] = q.x; dst[2 * i + 1] = q.y; }
+        };
+        int i = threadIdx.x;
+        for (; i + 3 * NT < nv; i += 4 * NT) {
+            const V a = vs[i], b = vs[i + NT], c = vs[i + 2 * NT], d = vs[i + 3 * NT];
+            put(i, a); put(i + NT, b); put(i + 2 * NT, c); put(i + 3 * NT, d);
+        }
+        for (; i < nv; i += NT) put(i, vs[i]);
+        const int done = head + nv * E; // fewer than E elements left
+        if ((int) threadIdx.x < ln - done) xs[bs + done + threadIdx.x] = src[done + threadIdx.x];
     }
 }
 

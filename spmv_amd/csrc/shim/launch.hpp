@@ -204,6 +204,15 @@ static void launch_csr5_form(spmv_dev *d, const Csr5Plan &P, const T *x, T *y)
             }
             return;
         }
+        // two tiles deep when EVERY group is staged (the pipelined kernel has no global-column path); plan.variant 61 / 62: never / also for fp64 (A/B)
+        const bool pipe_ok = P.staged == P.groups && P.group_tiles <= kCsr5PipeMaxGroupTiles;
+        const bool pipe = pipe_ok && d->plan.variant != 61 && (sizeof(T) == 4 || d->plan.variant == 62);
+        if (pipe) {
+            ensure_lds<csr5_group_pipe_kernel<T, SIGMA, MAPPED>>(d, lds + rmb);
+            csr5_group_pipe_kernel<T, SIGMA, MAPPED><<<P.groups, kBlock, lds + rmb, d->stream>>>(P.group_tiles, P.tiles, P.tile_ptr, P.desc, P.col16, (const T *) P.val, P.row_map, P.wins,
+                                                                                                x, y, (T *) P.carry, P.n_empty, P.empty_list, (int) lds, rm_stride);
+            return;
+        }
         ensure_lds<csr5_group_kernel<T, SIGMA, MAPPED>>(d, lds + rmb);
         csr5_group_kernel<T, SIGMA, MAPPED><<<P.groups, kBlock, lds + rmb, d->stream>>>(P.group_tiles, P.tiles, P.tile_ptr, P.desc, P.col, P.col16, (const T *) P.val, P.row_map, P.wins,
                                                                                        x, y, (T *) P.carry, P.n_empty, P.empty_list, (int) lds, rm_stride);

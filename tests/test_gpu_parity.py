@@ -242,8 +242,8 @@ def test_auto_method_picks_schedule_from_row_statistics():
     ("csr5_sigma", [4, 8, 16], M.Method_Balanced_Yid),           # nnz-split = natural-layout tiles of 64 x sigma
     ("variant", [3], M.Method_Balanced_Yid),                     # no x windows (global gathers)
     ("variant", [4, 5, 6, 10, 11, 12], M.Method_Parallel),       # CSR-vector kernel forms
-    ("variant", [3], M.Method_SellCSigma),
-    ("variant", [3], M.Method_CSR5SPMV),
+    ("variant", [3, 61, 62], M.Method_SellCSigma),               # 61 / 62: the staged CSR5 group kernel one tile / two tiles deep (long rows)
+    ("variant", [3, 61, 62], M.Method_CSR5SPMV),
 ])
 @pytest.mark.parametrize("name", ["skewed_f64_eighths", "empty_mix_f32_eighths", "banded_wide_f64_eighths"])
 def test_tuning_options_do_not_change_results(key, values, method, name):
@@ -953,3 +953,33 @@ def test_run_tiles_need_no_column_stream(shape, dtype, method):
         h.spmv(x, y)
         torch.cuda.synchronize()
         assert torch.equal(y, 2 * want)
+
+
+@pytest.mark.parametrize("method", [M.Method_CSR5SPMV, M.Method_SellCSigma, M.Method_Balanced_Yid, M.Method_Parallel], ids=lambda m: m.name)
+@pytest.mark.parametrize("dtype", ["f64", "f32"])
+def test_wide_x_windows_are_staged_from_any_element_alignment(dtype, method):
+    """stage_windows reads wide x windows with 16-byte loads from the first 16-byte boundary on: x (and y) handed over one, two and
+    three elements past an aligned address must give the bits of the aligned call.  Rows scattered +-3000 columns around the diagonal:
+    windows of 6000+ columns, staged by every tile schedule."""
+    import torch
+    dev = torch.device("cuda:0")
+    tdt = torch.float64 if dtype == "f64" else torch.float32
+    m = n = 200_000
+    lens = torch.full((m,), 20, dtype=torch.int64, device=dev)
+    _, _, rp, ci, va = synth.from_row_lengths_device(lens, n, "eighths", tdt, dev, seed=8, local=3000)
+    g = torch.Generator(device=dev); g.manual_seed(12)
+    xbig = (torch.randint(-8, 9, (n + 8,), generator=g, device=dev) * 0.125).to(tdt)
+    ybig = torch.empty(m + 8, dtype=tdt, device=dev)
+    want = _segment_sums(va.double() * xbig[:n].double()[ci.long()], rp).to(tdt)
+    with api.Handle(m, n, rp, ci, va, method) as h:
+        info = h.info()
+        assert info["cache_blocked"] == 0 and info["x_groups_staged"] > 0, info
+        for off in (0, 1, 2, 3):
+            x = xbig[off: off + n]
+            x.copy_(xbig[:n].clone())                    # the same values at the shifted address
+            y = ybig[off: off + m]
+            y.fill_(float("nan"))
+            h.spmv(x, y)
+            torch.cuda.synchronize()
+            assert torch.equal(y, want), (off, info["kernel_name"], int((y != want).sum()))
+            xbig[:n].copy_(x.clone())

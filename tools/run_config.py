@@ -58,7 +58,10 @@ def main():
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--opt", action="append", default=[], help="library option key=value")
     a = ap.parse_args()
-    build.build()
+    if os.environ.get("SPMV_LIB"):   # same-box A/B against another build of the library (e.g. the previous commit's)
+        api.LIB_PATH = os.environ["SPMV_LIB"]
+    else:
+        build.build()
     api.load()
     dev = "cuda:0"
     for kv in a.opt:
