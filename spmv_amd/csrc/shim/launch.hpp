@@ -177,6 +177,15 @@ static int autotune_blocked(spmv_dev *d)
     return SPMV_HIP_OK;
 }
 
+// The staged CSR5 group kernel two tiles deep (csr5_group_pipe_kernel)?  When EVERY group is staged (the pipelined kernel has no
+// global-column path) and the values are fp32: in fp64 the second register set costs a wave per SIMD and measured no gain (config 2
+// under CSR5: 0.511 vs 0.515 ms).  plan.variant 61 / 62: never / also for fp64 (A/B).
+static bool csr5_two_deep(const spmv_dev *d, const Csr5Plan &P)
+{
+    if (P.natural || P.staged <= 0 || P.staged != P.groups || P.group_tiles > kCsr5PipeMaxGroupTiles || d->plan.variant == 61) return false;
+    return d->vsize == sizeof(float) || d->plan.variant == 62;
+}
+
 template <typename T, int SIGMA, bool MAPPED>
 static void launch_csr5_form(spmv_dev *d, const Csr5Plan &P, const T *x, T *y)
 {
@@ -204,10 +213,7 @@ static void launch_csr5_form(spmv_dev *d, const Csr5Plan &P, const T *x, T *y)
             }
             return;
         }
-        // two tiles deep when EVERY group is staged (the pipelined kernel has no global-column path); plan.variant 61 / 62: never / also for fp64 (A/B)
-        const bool pipe_ok = P.staged == P.groups && P.group_tiles <= kCsr5PipeMaxGroupTiles;
-        const bool pipe = pipe_ok && d->plan.variant != 61 && (sizeof(T) == 4 || d->plan.variant == 62);
-        if (pipe) {
+        if (csr5_two_deep(d, P)) {
             ensure_lds<csr5_group_pipe_kernel<T, SIGMA, MAPPED>>(d, lds + rmb);
             csr5_group_pipe_kernel<T, SIGMA, MAPPED><<<P.groups, kBlock, lds + rmb, d->stream>>>(P.group_tiles, P.tiles, P.tile_ptr, P.desc, P.col16, (const T *) P.val, P.row_map, P.wins,
                                                                                                 x, y, (T *) P.carry, P.n_empty, P.empty_list, (int) lds, rm_stride);

@@ -587,7 +587,7 @@ extern "C" int spmv_shim_info(const spmv_dev *d, spmv_hip_info *o)
     if (d->blk_on) o->kernel_name = "blk_kernel";
     else if (d->plan.sched == SPMV_SCHED_NNZ_SPLIT)
         o->kernel_name = d->ns.staged > 0 ? "nat_group_kernel" : "nat_kernel";
-    if (d->plan.sched == SPMV_SCHED_CSR5 && d->c5.staged > 0) o->kernel_name = "csr5_group_kernel";
+    if (d->plan.sched == SPMV_SCHED_CSR5 && d->c5.staged > 0) o->kernel_name = csr5_two_deep(d, d->c5) ? "csr5_group_pipe_kernel" : "csr5_group_kernel";
     if (d->plan.sched == SPMV_SCHED_SELL && d->sell_staged > 0) o->kernel_name = "sell_window_kernel";
     return SPMV_HIP_OK;
 }

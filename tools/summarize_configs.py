@@ -70,7 +70,7 @@ def stats_table(base, out_csv):
 
 STATS_ITERS, STATS_WARMUP = 20, 3   # tools/profile_configs.sh: run_config.py --iters 20 (warm-up 3) in the stats pass
 MULTIPLY = ("csr_vector_tile_kernel", "csr_vector_pipe_kernel", "csr_vector_rows_kernel", "csr_scalar_kernel", "nat_group_kernel", "nat_kernel",
-            "csr5_group_kernel", "csr5_kernel", "csr5_fixup_kernel", "sell_window_kernel", "sell_kernel", "blk_kernel", "fill_zero_kernel")
+            "csr5_group_kernel", "csr5_group_pipe_kernel", "csr5_kernel", "csr5_fixup_kernel", "sell_window_kernel", "sell_kernel", "blk_kernel", "fill_zero_kernel")
 summary = {"tag": tag, "units": "FETCH_SIZE / WRITE_SIZE in KiB (rocprofv3) -> bytes = KiB x 1024; hbm_bytes = 2 x FETCH + WRITE (gfx950 wide-read "
            "under-count, MI355X_MICROARCH.md 'HBM'); fractions are of 8.0 TB/s", "configs": {}}
 entries = []
