@@ -344,6 +344,18 @@ static int build_csr5_sigma(spmv_dev *d, Csr5Plan &P, const int *rp, int m2, con
             break;
         }
     }
+    if (getenv("SPMV_HIP_CSR5_DEBUG") && P.groups > 0) { // developer print: the distribution of the groups' staged window sizes
+        std::vector<TileWindows> hw((size_t) P.groups);
+        if (hipMemcpy(hw.data(), P.wins, sizeof(TileWindows) * (size_t) P.groups, hipMemcpyDeviceToHost) == hipSuccess) {
+            std::vector<int> tot;
+            for (const auto &w : hw) if (w.nwin > 0) tot.push_back(w.total);
+            std::sort(tot.begin(), tot.end());
+            auto q = [&](double f) { return tot.empty() ? 0 : tot[(size_t) (f * (double) (tot.size() - 1))]; };
+            fprintf(stderr, "[spmv_hip] csr5 plan: rows %d nnz %lld tiles %d group_tiles %d groups %d staged %d maxspan %d; window elements p50 %d p90 %d p99 %d p99.9 %d max %d\n",
+                    m2, P.nnz, p, P.group_tiles, P.groups, P.staged, P.maxspan, q(0.5), q(0.9), q(0.99), q(0.999), q(1.0));
+        }
+        (void) hipGetLastError();
+    }
     if (P.staged == 0) { sched_free(d, P.col16); P.col16 = nullptr; }
     else if (!P.natural && P.staged == P.groups) { sched_free(d, P.col); P.col = nullptr; } // no group reads global columns
     return SPMV_HIP_OK;
