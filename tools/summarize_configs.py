@@ -49,7 +49,7 @@ def counters(base):
 def short(name):
     n = name.split("(")[0]
     n = n.replace("void ", "").replace("spmv::", "").split("<")[0]
-    return "blk_kernel" if n == "blk_kernel3" else n   # the executor's three-stage form: one family in spmv_hip_info.kernel_name
+    return n
 
 
 def stats_table(base, out_csv):
