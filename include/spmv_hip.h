@@ -129,8 +129,8 @@ typedef struct spmv_hip_info {
     int cache_blocked;          /* 1: the row-block x column-slab executor runs (option "cache_block") */
     long long stream_bytes;     /* HBM bytes ONE spmv() has to move given the schedule's storage format: the value and
                                  * column streams as stored (2 B/nnz LDS slots where x windows are staged -- none for run_nnz --, padding
-                                 * included), row pointers / descriptors / window tables, the x elements staged (or n
-                                 * once where x is gathered through L2), y written once, carries.  This -- not alg_bytes --
+                                 * included), row pointers / descriptors / window tables, the x elements staged (at most
+                                 * 8 n: one pass per XCD; or n once where x is gathered through L2), y written once, carries.  This -- not alg_bytes --
                                  * is what divides by the launch time to give the HBM rate actually sustained. */
     long long x_bytes;          /* the part of stream_bytes charged for reading x */
     float route_ms[2];          /* only when part of the tile groups stage their x windows and part do not: create() builds the tile

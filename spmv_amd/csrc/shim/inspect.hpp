@@ -778,7 +778,11 @@ static int account_stream_bytes(spmv_dev *d)
         }
     }
     if (rc) return rc;
-    d->x_bytes = s * (t.x_elems + (t.gathers_global ? n : 0));
+    // x: the windows staged, but no more than one pass over x per XCD -- windows of neighbouring tiles that overlap almost entirely (rows scattered
+    // +-4096 columns around the diagonal: 256-row tiles stage 8 448 columns each) are re-read from that XCD's L2, not from memory (without the cap
+    // the model had CSR-vector on 1e7 x 16 such rows move 10 TB/s)
+    const long long x_cap = 8ll * n;
+    d->x_bytes = s * ((t.x_elems < x_cap ? t.x_elems : x_cap) + (t.gathers_global ? n : 0));
     d->stream_bytes = t.bytes + d->x_bytes;
     return SPMV_HIP_OK;
 }
