@@ -983,3 +983,48 @@ def test_wide_x_windows_are_staged_from_any_element_alignment(dtype, method):
             torch.cuda.synchronize()
             assert torch.equal(y, want), (off, info["kernel_name"], int((y != want).sum()))
             xbig[:n].copy_(x.clone())
+
+
+@pytest.mark.parametrize("shape", ["short_rows_many_empty", "long_rows", "mixed"])
+def test_two_deep_csr5_group_kernel(shape):
+    """fp32 CSR5 plans whose groups are all staged run csr5_group_pipe_kernel (two tiles in flight per wave, csr5.hpp).  Wide x windows
+    (rows scattered +-3000 columns) make the inspector grow the groups to 32 / 64 tiles, i.e. 8 / 16 tiles per wave:
+      short_rows_many_empty  0..6 entries per row, 1 in 7 rows empty: the row-mapped form with >= 64 row starts per tile (the rest of
+                             the row map is fetched when the tile is computed)
+      long_rows              2000..3000 entries per row: tiles inside one row, carries through the fix-up
+      mixed                  both, interleaved
+    fp64 plans keep the one-deep kernel.  Exact data: bit-equal to the definition; `variant` 61 (one deep) must give the same bits."""
+    import torch
+    dev = torch.device("cuda:0")
+    g = torch.Generator(device=dev); g.manual_seed(21)
+    if shape == "short_rows_many_empty":
+        m = 600_000
+        lens = torch.randint(0, 7, (m,), generator=g, device=dev)
+    elif shape == "long_rows":
+        m = 2_000
+        lens = torch.randint(2000, 3001, (m,), generator=g, device=dev)
+    else:
+        m = 200_000
+        lens = torch.randint(0, 9, (m,), generator=g, device=dev)
+        lens[::500] = 2500
+    n = max(m, 100_000)
+    _, _, rp, ci, va = synth.from_row_lengths_device(lens, n, "eighths", torch.float32, dev, seed=3, local=3000)
+    x = (torch.randint(-8, 9, (n,), generator=g, device=dev) * 0.125).to(torch.float32)
+    want = _segment_sums(va.double() * x.double()[ci.long()], rp).to(torch.float32)
+    ys = {}
+    keep = api.get_option("variant")
+    try:
+        for variant in (0, 61):
+            api.set_option("variant", variant)
+            with api.Handle(m, n, rp, ci, va, M.Method_CSR5SPMV) as h:
+                info = h.info()
+                y = torch.full((m,), float("nan"), dtype=torch.float32, device=dev)
+                h.spmv(x, y)
+                torch.cuda.synchronize()
+                assert info["kernel_name"] == ("csr5_group_pipe_kernel" if variant == 0 else "csr5_group_kernel"), info
+                assert torch.equal(y, want), (shape, variant, int((y != want).sum()))
+                ys[variant] = y
+    finally:
+        api.set_option("variant", keep)
+    with api.Handle(m, n, rp, ci, va.double(), M.Method_CSR5SPMV) as h:
+        assert h.info()["kernel_name"] == "csr5_group_kernel"
