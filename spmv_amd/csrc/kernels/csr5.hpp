@@ -390,8 +390,13 @@ __device__ __forceinline__ void csr5_tile(int t, int lane, const int *__restrict
 template <typename T>
 __device__ __forceinline__ void zero_empty_rows(int n_empty, const int *__restrict__ empty_list, T *__restrict__ y)
 {
-    for (long long i = (long long) blockIdx.x * blockDim.x + threadIdx.x; i < n_empty; i += (long long) gridDim.x * blockDim.x)
-        y[empty_list[i]] = T(0);
+    const long long stride = (long long) gridDim.x * blockDim.x;
+    long long i = (long long) blockIdx.x * blockDim.x + threadIdx.x;
+    for (; i + 3 * stride < n_empty; i += 4 * stride) { // four list entries in flight: the loop sits in front of the workgroup's first tile
+        const int a = empty_list[i], b = empty_list[i + stride], c = empty_list[i + 2 * stride], d = empty_list[i + 3 * stride];
+        y[a] = T(0); y[b] = T(0); y[c] = T(0); y[d] = T(0);
+    }
+    for (; i < n_empty; i += stride) y[empty_list[i]] = T(0);
 }
 
 template <typename T, int SIGMA, bool MAPPED>
