@@ -44,6 +44,7 @@ template <typename T> static int autotune_blocked(spmv_dev *d);
 template <typename T> static double time_schedule(spmv_dev *d, int iters);
 template <typename T> static int split_make(spmv_dev *d, spmv_dev **near_out, spmv_dev **far_out, bool values_only);
 template <typename T> static int build_tile_windows(spmv_dev *d, int tiles, const int *split, int rows_per_tile = kVecTileRows, bool wide = false);
+static int wins_sum(spmv_dev *d, const TileWindows *wins, int count, long long *elems, long long *tiles);
 constexpr size_t kVecWideXTileBytes = 96 * 1024; // budget of the wide form (slot indices; two workgroups per CU)
 
 static int build_rowblock(spmv_dev *d)
@@ -182,7 +183,25 @@ static int build_vector_tiles(spmv_dev *d)
     d->vt_tiles = (int) (((long long) d->m + rows - 1) / rows);
     if (d->vt_tiles == 0 || d->nnz == 0) return SPMV_HIP_OK;
     int rc = build_tile_windows<T>(d, d->vt_tiles, nullptr, rows);
-    if (rc || d->vt_staged * 2 >= d->vt_tiles || d->plan.variant != 0) return rc;
+    if (rc || d->plan.variant != 0) return rc;
+    if (d->vt_staged * 2 >= d->vt_tiles) {
+        // The narrow tiles stage -- but at what price?  Rows scattered +-4096 columns around the diagonal make every 256-row tile stage 8 448
+        // columns for 256 rows' worth of entries: with 16 entries per row the windows are 1.4 x the bytes the tile streams (fp32), read from L2,
+        // and the workgroup waits for them.  When the windows cost more than half of the stream, the same test is made for 1024-row blocks (wide
+        // form: a quarter of the window traffic per entry) and they are kept if every block stages.  SPMV_HIP_NO_WIDE_BY_COST=1: off (A/B).
+        long long welems = 0, wtiles = 0;
+        const long long stream = (d->nnz - d->lsub_nnz) * ((long long) sizeof(T) + 2);
+        if (getenv("SPMV_HIP_NO_WIDE_BY_COST") || wins_sum(d, d->vt_wins, d->vt_tiles, &welems, &wtiles) != SPMV_HIP_OK || stream <= 0 ||
+            (double) welems * sizeof(T) <= 0.5 * (double) stream)
+            return SPMV_HIP_OK;
+        const int narrow_tiles = d->vt_tiles, w_rows = 4 * kVecTileRows;
+        const int w_tiles = (int) (((long long) d->m + w_rows - 1) / w_rows);
+        rc = build_tile_windows<T>(d, w_tiles, nullptr, w_rows, true);
+        if (rc) return rc;
+        long long welems_w = 0;
+        if (d->vt_staged == d->vt_tiles && wins_sum(d, d->vt_wins, d->vt_tiles, &welems_w, &wtiles) == SPMV_HIP_OK && welems_w * 2 <= welems) return SPMV_HIP_OK;
+        return build_tile_windows<T>(d, narrow_tiles, nullptr, rows); // no: back to the narrow tiles
+    }
     // fewer than half of the 256-row tiles fit the 48 KiB budget.  Before settling for global gathers (pipe
     // form), try the WIDE form: 1024-row blocks walked by the rows kernel, 96 KiB budget, slot indices in the
     // stream (windows above 64 KiB: fp64 rows scattered over +-4096 columns, config 4 in fp64: 2.04 -> 1.52 ms)
