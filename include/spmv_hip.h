@@ -122,7 +122,7 @@ typedef struct spmv_hip_info {
     const char *kernel_name;    /* symbol of the dominant kernel (as rocprofv3 shows it) */
     int tuned_choice;           /* csr-vector autotune: 0 none, 10/11 tile 4-deep, 5/12 tile 2-deep, 4 pipe; cache_blocked: 100 / 101 =
                                    8 / 12 groups per pipeline step */
-    float tune_ms[3];           /* measured ms of {tile/4-deep, tile/2-deep, pipe} at create (0 if not tuned); cache_blocked: of the
+    float tune_ms[3];           /* measured ms of {tile/4-deep, tile/2-deep, pipe} at create (0 if not tuned; pipe: 0 when 99 % of the tiles stage their x windows -- not timed); cache_blocked: of the
                                    row-block executor's {8, 12} groups-per-step forms ([2] unused) */
     int x_groups;               /* tiles / tile groups / sigma windows the inspector analysed for x windows */
     int x_groups_staged;        /* ... of which have their x windows staged in LDS (0: every gather goes to L1/L2) */
