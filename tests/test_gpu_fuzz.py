@@ -62,6 +62,17 @@ def _case(seed):
     local = int(rng.choice([0, 0, 8, 200])) if n > 400 else 0
     dtype = np.float64 if rng.integers(0, 2) else np.float32
     csr = synth.from_row_lengths(lens, n, "eighths", dtype, seed=seed, local=local)
+    if rng.integers(0, 3) == 0 and csr.nnz > 0:        # rows as RUNS of consecutive columns (the tile kernels then read no column stream, csr_vector_tile.hpp) ...
+        rp = csr.rowptr.astype(np.int64)
+        ln = rp[1:] - rp[:-1]
+        near = (np.arange(m) * n // max(m, 1) + rng.integers(-40, 41, m)) if rng.integers(0, 2) else rng.integers(0, n, m)
+        start = np.clip(near, 0, np.maximum(n - ln, 0))
+        row_of = np.repeat(np.arange(m), ln)
+        ci = start[row_of] + (np.arange(csr.nnz) - rp[row_of])
+        if rng.integers(0, 2):                          # ... with a few rows broken: their tiles fall back to the column stream
+            idx = rng.integers(0, csr.nnz, max(1, csr.nnz // 400))
+            ci[idx] = rng.integers(0, n, idx.shape[0])
+        csr.colidx[:] = ci.astype(csr.colidx.dtype)
     x = (rng.integers(-8, 9, n) * 0.125).astype(dtype)
     return csr, x, rng
 
@@ -77,7 +88,7 @@ OPTIONS = {"csr5_sigma": [0, 4, 8, 16], "sell_sigma": [64, 1024], "rowblock_nnz"
            "cache_block": [1, 2], "variant": [0, 0, 0, 3, 35, 30, 37], "block_rows": [0, 0, 256, 4096]}
 
 
-# SPMV_FUZZ_FIRST / SPMV_FUZZ_SEEDS widen the sweep (seeds 48..847 were run once on the final kernels of round 2)
+# SPMV_FUZZ_FIRST / SPMV_FUZZ_SEEDS widen the sweep (seeds 48..847 were run once on the final kernels of round 2, seeds 0..399 with the run-structured cases on those of round 3)
 _FIRST, _COUNT = int(os.environ.get("SPMV_FUZZ_FIRST", "0")), int(os.environ.get("SPMV_FUZZ_SEEDS", "48"))
 
 
