@@ -234,6 +234,77 @@ __device__ __forceinline__ void sell_chunk(const int *__restrict__ pc, const uns
 // Chunks.  Sorted by width inside a sigma window, so the 8 waves take them from a counter in LDS, widest first (longest
 // processing time first): a wave that drew a wide chunk simply draws fewer (round 2 dealt them by index, mirrored every other
 // pass: 38 vs 23 columns per window between the busiest and the idlest wave before the mirroring, ~10 % after).
+// RUN groups (as csr_vector_tile.hpp's RUN tiles, for the row-granular SELL slabs): when every row of a staged window group references ONE
+// run of consecutive columns -- slot[j] = slot[0] + j for j < len -- the 16-bit slot slab is not read at all: a word per row slot
+// (sell_run: first slot | row length << 16) replaces it, entries past the row's length read the zero slot as before (0 * 0).
+template <typename T>
+__device__ __forceinline__ void sell_chunk_run(unsigned run, const T *__restrict__ pv, int width, const T *__restrict__ xs, unsigned zslot, T &sum)
+{
+    constexpr int U = 8;
+    const unsigned s0 = run & 0xffffu, len = run >> 16;
+    int j = 0;
+    for (; j + U <= width; j += U) {
+        T vv[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) vv[u] = ld_stream(pv + (size_t) (j + u) * kSellC);
+#pragma unroll
+        for (int u = 0; u < U; ++u) sum = fmadd(vv[u], xs[(unsigned) (j + u) < len ? s0 + (unsigned) (j + u) : zslot], sum);
+    }
+    const int r = __builtin_amdgcn_readfirstlane(width - j);
+    if (r > 0) {
+        T vv[U - 1];
+#pragma unroll
+        for (int u = 0; u < U - 1; ++u)
+            if (u < r) vv[u] = ld_stream(pv + (size_t) (j + u) * kSellC);
+#pragma unroll
+        for (int u = 0; u < U - 1; ++u)
+            if (u < r) sum = fmadd(vv[u], xs[(unsigned) (j + u) < len ? s0 + (unsigned) (j + u) : zslot], sum);
+    }
+}
+
+// Inspector: is window group w a RUN group?  One workgroup per group, a wave per chunk (lane = row slot) walks the row's slots in the
+// slab.  counters[0] += groups, [1] += entries (real ones), [2] += stored slab entries, [3] += row slots of the RUN groups.
+__global__ __launch_bounds__(kBlock) void sell_runs_kernel(int chunks_per_win, long long nchunks, const long long *__restrict__ chunk_ptr,
+                                                           const unsigned short *__restrict__ scol16, const int *__restrict__ perm,
+                                                           const int *__restrict__ rowptr, TileWindows *__restrict__ wins,
+                                                           unsigned *__restrict__ sell_run, unsigned long long *__restrict__ counters)
+{
+    const int w = blockIdx.x, lane = threadIdx.x & (kWave - 1), wave = threadIdx.x / kWave;
+    const TileWindows &tw = wins[w];
+    int ok = tw.nwin > 0;
+    unsigned long long entries = 0, stored = 0, slots = 0;
+    if (ok)
+        for (int k = wave; k < chunks_per_win; k += kBlock / kWave) {
+            const long long c = (long long) w * chunks_per_win + k;
+            if (c >= nchunks) break;
+            const long long c0 = chunk_ptr[c];
+            const int width = (int) (chunk_ptr[c + 1] - c0);
+            const int row = perm[c * kSellC + lane];
+            const int len = row >= 0 ? rowptr[row + 1] - rowptr[row] : 0; // rows kept out of the slabs (long rows) have perm = -1
+            const unsigned short *pc = scol16 + (size_t) c0 * kSellC + lane;
+            const unsigned s0 = len > 0 ? pc[0] : (unsigned) tw.total;
+            for (int j = 1; j < len && j < width; ++j) ok &= pc[(size_t) j * kSellC] == s0 + (unsigned) j;
+            ok &= len <= width && len < 65536;
+            entries += (unsigned long long) len;
+            if (lane == 0) { stored += (unsigned long long) width * kSellC; slots += kSellC; }
+        }
+    ok = __syncthreads_and(ok);
+    if (!ok) return;
+    for (int k = wave; k < chunks_per_win; k += kBlock / kWave) {
+        const long long c = (long long) w * chunks_per_win + k;
+        if (c >= nchunks) break;
+        const long long c0 = chunk_ptr[c];
+        const int row = perm[c * kSellC + lane];
+        const int len = row >= 0 ? rowptr[row + 1] - rowptr[row] : 0;
+        const unsigned s0 = len > 0 ? scol16[(size_t) c0 * kSellC + lane] : (unsigned) tw.total;
+        sell_run[c * kSellC + lane] = s0 | ((unsigned) len << 16);
+    }
+#pragma unroll
+    for (int o = kWave / 2; o > 0; o >>= 1) { entries += __shfl_xor(entries, o, kWave); stored += __shfl_xor(stored, o, kWave); slots += __shfl_xor(slots, o, kWave); }
+    if (lane == 0) { atomicAdd(counters + 1, entries); atomicAdd(counters + 2, stored); atomicAdd(counters + 3, slots); }
+    if (threadIdx.x == 0) { wins[w].runs = 1; atomicAdd(counters, 1ull); }
+}
+
 template <typename T>
 __global__ __launch_bounds__(kSellWinThreads) void sell_window_kernel(int chunks_per_win, long long nchunks, int m,
                                                                       const long long *__restrict__ chunk_ptr,
@@ -242,6 +313,7 @@ __global__ __launch_bounds__(kSellWinThreads) void sell_window_kernel(int chunks
                                                                       const T *__restrict__ sval,
                                                                       const int *__restrict__ perm,
                                                                       const TileWindows *__restrict__ wins,
+                                                                      const unsigned *__restrict__ sell_run,
                                                                       const T *__restrict__ x, T *__restrict__ y, int ys_offset)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char sell_x_lds[];
@@ -250,7 +322,7 @@ __global__ __launch_bounds__(kSellWinThreads) void sell_window_kernel(int chunks
     T *ys = reinterpret_cast<T *>(sell_x_lds + ys_offset);
     const int w = blockIdx.x;
     const TileWindows &tw = wins[w];
-    const bool staged = tw.nwin > 0;
+    const bool staged = tw.nwin > 0, runs = tw.runs != 0; // runs implies staged
     const int rows_per_group = chunks_per_win * kSellC;
     const long long row0 = (long long) w * rows_per_group;
     for (int i = threadIdx.x; i < rows_per_group; i += kSellWinThreads) ys[i] = T(0);
@@ -272,7 +344,8 @@ __global__ __launch_bounds__(kSellWinThreads) void sell_window_kernel(int chunks
         const T *pv = sval + (size_t) c0 * kSellC + lane;
         const int row = perm[c * kSellC + lane];
         T sum = 0;
-        if (staged) sell_chunk<T, true>(pc, pc16, pv, width, xs, x, sum);
+        if (runs) sell_chunk_run<T>(sell_run[c * kSellC + lane], pv, width, xs, (unsigned) tw.total, sum);
+        else if (staged) sell_chunk<T, true>(pc, pc16, pv, width, xs, x, sum);
         else sell_chunk<T, false>(pc, pc16, pv, width, xs, x, sum);
         if (row >= 0) ys[row - row0] = sum;
     }

@@ -285,6 +285,24 @@ static int build_sell(spmv_dev *d)
         }
         if (d->sell_staged == d->sell_nwin) { sched_free(d, d->scol); d->scol = nullptr; } // no window reads global columns
         else if (d->sell_staged == 0) { sched_free(d, d->scol16); d->scol16 = nullptr; }
+        if (d->sell_staged > 0 && !getenv("SPMV_HIP_NO_RUN_TILES")) { // RUN groups: rows that are runs of consecutive columns need no slot slab (sell.hpp)
+            unsigned long long *cnt = nullptr, h[4] = {0, 0, 0, 0};
+            ALLOC_TRY(d, &d->sell_run, sizeof(unsigned) * (size_t) d->nchunks * kSellC, true);
+            HIP_TRY(pool_malloc((void **) &cnt, sizeof h));
+            hipError_t e = hipMemsetAsync(cnt, 0, sizeof h, d->stream);
+            sell_runs_kernel<<<d->sell_nwin, kBlock, 0, d->stream>>>(d->sell_group * (sigma / kSellC), (long long) d->nchunks, d->chunk_ptr, d->scol16, d->perm, d->rowptr,
+                                                                    d->sell_wins, d->sell_run, cnt);
+            if (e == hipSuccess) e = hipGetLastError();
+            if (e == hipSuccess) e = hipMemcpyAsync(h, cnt, sizeof h, hipMemcpyDeviceToHost, d->stream);
+            if (e == hipSuccess) e = hipStreamSynchronize(d->stream);
+            (void) pool_free(cnt);
+            if (e != hipSuccess) return fail(SPMV_HIP_E_RUNTIME, "SELL run inspector: %s", hipGetErrorString(e));
+            d->sell_run_groups = (int) h[0];
+            d->sell_run_nnz = (long long) h[1];
+            d->sell_run_stored = (long long) h[2];
+            d->sell_run_slots = (long long) h[3];
+            if (getenv("SPMV_HIP_SELL_DEBUG")) fprintf(stderr, "[spmv_hip] sell: groups %d staged %d RUN %d (entries %lld, stored %lld, row slots %lld)\n", d->sell_nwin, d->sell_staged, d->sell_run_groups, d->sell_run_nnz, d->sell_run_stored, d->sell_run_slots);
+        }
     }
     HIP_TRY(hipStreamSynchronize(d->stream));
     return SPMV_HIP_OK;
@@ -784,6 +802,7 @@ static int account_stream_bytes(spmv_dev *d)
             if (d->sell_staged > 0) { rc = wins_sum(d, d->sell_wins, d->sell_nwin, &welems, &wtiles); if (rc) return rc; }
             const double fs = d->sell_nwin > 0 ? (double) wtiles / (double) d->sell_nwin : 0.0;
             t.bytes = stream_part(d->sell_cols * kSellC, s, fs) + 8ll * (d->nchunks + 1) + 4ll * d->nchunks * kSellC + s * (m - d->nlong);
+            t.bytes += 4ll * d->sell_run_slots - 2ll * d->sell_run_stored; // RUN groups: a word per row slot instead of a 16-bit slot per stored entry
             if (d->sell_staged > 0) t.bytes += (long long) sizeof(TileWindows) * d->sell_nwin;
             t.x_elems = welems;
             if (wtiles < d->sell_nwin) t.gathers_global = true;

@@ -770,7 +770,11 @@ def test_stream_bytes_model_of_the_storage_format():
     assert i["stream_bytes"] == i["alg_bytes"]
     with api.Handle(m, n, rp, ci, va, M.Method_SellCSigma) as h:
         i = h.info()
-    assert i["stream_bytes"] >= i["stored_nnz"] * 10 + 8 * m
+    # banded: nearly every sigma window is a RUN group (a word per row slot instead of 16 bits per stored entry); padding still counts
+    assert i["run_nnz"] >= 0.99 * nnz and i["stored_nnz"] * 8 + 12 * m <= i["stream_bytes"] < i["stored_nnz"] * 10 + 8 * m, i
+    with api.Handle(m, n, rp, ci2, va, M.Method_SellCSigma) as h:       # two runs per row: the 16-bit slot slabs are read
+        i = h.info()
+    assert i["run_nnz"] == 0 and i["stream_bytes"] >= i["stored_nnz"] * 10 + 8 * m
 
 
 def test_auto_method_measured_mode_builds_times_and_keeps_a_candidate():
@@ -891,12 +895,13 @@ def _segment_sums(prod, rp):
     return cs[rp[1:].long()] - cs[rp[:-1].long()]
 
 
-@pytest.mark.parametrize("method", [M.Method_Parallel, M.Method_Balanced], ids=lambda m: m.name)
+@pytest.mark.parametrize("method", [M.Method_Parallel, M.Method_Balanced, M.Method_SellCSigma], ids=lambda m: m.name)
 @pytest.mark.parametrize("dtype", ["f64", "f32"])
 @pytest.mark.parametrize("shape", ["ragged", "two_bands", "chunks", "wide", "broken_rows"])
 def test_run_tiles_need_no_column_stream(shape, dtype, method):
-    """RUN tiles of the CSR-vector tile kernels (csr_vector_tile.hpp): rows that are one run of consecutive columns get their LDS
-    slots from a 16-bit slot per ROW.  Exact data, so the sums must equal the definition bit for bit.
+    """RUN tiles of the row-granular schedules -- the CSR-vector tile kernels (csr_vector_tile.hpp) and the SELL slabs (sell.hpp: RUN window
+    groups) --: rows that are one run of consecutive columns get their LDS slots from 16 bits (SELL: a word) per ROW.  Exact data, so the sums
+    must equal the definition bit for bit.
       ragged       run lengths 0..40 (empty rows, single entries, rows past one 4L-entry chunk), runs start within +-600 of the diagonal
       two_bands    even rows run near the diagonal, odd rows 200 000 columns away: two x windows per tile, every row still one run
       chunks       64..200 entries per row: several chunks per row, under the long-row threshold
@@ -942,10 +947,14 @@ def test_run_tiles_need_no_column_stream(shape, dtype, method):
         info = h.info()
         torch.cuda.synchronize()
         assert torch.equal(y, want), (info["kernel_name"], int((y != want).sum()))
-        assert info["kernel_name"] in ("csr_vector_tile_kernel", "csr_vector_rows_kernel") and info["cache_blocked"] == 0, info
+        assert info["kernel_name"] in ("csr_vector_tile_kernel", "csr_vector_rows_kernel", "sell_window_kernel") and info["cache_blocked"] == 0, info
         if shape == "broken_rows":
             if method == M.Method_Parallel:   # 256-row tiles: exactly the tiles holding a moved entry read their column stream
                 assert nnz - broken * 256 * 40 <= info["run_nnz"] < nnz, (info["run_nnz"], nnz, broken)
+            elif method == M.Method_SellCSigma:   # the unit is the window group (1024 rows and up): most groups hold no moved entry
+                assert 0 < info["run_nnz"] < nnz, (info["run_nnz"], nnz, broken)
+        elif method == M.Method_SellCSigma:           # the slabs hold the rows under the planner's long-row threshold only (the others: CSR5 sub-matrix);
+            assert 0 < info["run_nnz"] <= info["stored_nnz"] and info["run_nnz"] >= 0.7 * info["stored_nnz"], info   # stored = slab entries incl. padding
         else:
             assert info["run_nnz"] == nnz, (info["run_nnz"], nnz, info["x_groups"], info["x_groups_staged"])
         va2 = (va * 2).contiguous()                       # values only: the row slots stay
