@@ -247,7 +247,8 @@ static int choose_sell_long_threshold(const spmv_stats *st, int sigma)
             const double rows = (double) st->hist_rows[b], nnz = (double) st->hist_nnz[b];
             if (rows <= 0.0) continue;
             if (b < cand) {
-                const double upper = b < NB - 1 ? (double) (4 << b) : (double) st->max_row_len;
+                double upper = b < NB - 1 ? (double) (4 << b) : (double) st->max_row_len;
+                if (upper > (double) st->max_row_len) upper = (double) st->max_row_len; /* the top class in use ends at the longest row, not at its bucket bound */
                 const double lower = b == 0 ? 0.0 : (double) (4 << (b - 1));
                 const double per_window = rows * (double) sigma / (double) st->m;
                 double span = (upper - lower) * (per_window >= 64.0 ? 64.0 / per_window : 1.0);
