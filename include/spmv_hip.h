@@ -140,9 +140,9 @@ typedef struct spmv_hip_info {
                                  * A = A_near + A_far (near: the tile schedule, every tile staged; far: the blocked executor, accumulating) and
                                  * times it: [0] schedule as built, [1] the split pair, ms (0, 0: not tried) */
     long long far_nnz;          /* entries the blocked executor multiplies in a split handle (0: the handle is not split) */
-    long long run_nnz;          /* CSR-vector / row-block tile kernels and SELL slabs: entries in RUN tiles / window groups -- staged ones whose rows each
-                                 * reference one run of consecutive columns (banded matrices); their column stream is not read at all (16 bits, SELL: a
-                                 * word, per ROW instead) */
+    long long run_nnz;          /* CSR-vector / row-block tile kernels, SELL slabs, CSR5 tile groups: entries in RUN tiles / groups -- staged ones whose rows
+                                 * each reference one run of consecutive columns (banded matrices; CSR5: of at least sigma entries); their column stream is
+                                 * not read at all (16 bits, SELL: a word, per ROW; CSR5: a word per lane and tile instead) */
 } spmv_hip_info;
 int spmv_hip_get_info(spmv_Handle_t handle, spmv_hip_info *out);
 

@@ -258,6 +258,72 @@ __global__ __launch_bounds__(kBlock) void csr5_transpose_kernel(int nnz, int p, 
     }
 }
 
+// RUN groups (as csr_vector_tile.hpp's RUN tiles, for the ENTRY-granular tiles of CSR5; the natural-layout nnz-split kernel measured no gain -- it is
+// bound by its LDS hand-over, not by the 2 B/nnz it would save -- and keeps its slot stream): when every lane of every tile of a staged
+// group holds runs of consecutive slots with AT MOST ONE row start past its first entry -- rows of at least SIGMA entries that are runs of
+// consecutive columns: banded matrices --, a word per lane and tile (lane_run: slot of the lane's first entry | slot at that row start << 16)
+// replaces the SIGMA 16-bit slots: 4 instead of 2 * SIGMA bytes per lane.  The row start's position is in the descriptor's flag bits.
+template <int SIGMA>
+__device__ __forceinline__ void csr5_run_slots(unsigned run, unsigned d, int (&c)[SIGMA])
+{
+    const unsigned s_first = run & 0xffffu, s_after = run >> 16;
+    const unsigned fl = (d & kCsr5FlagMask) >> 1;             // row starts at entries 1 .. SIGMA - 1
+    const int pos = fl ? __ffs((int) fl) : SIGMA;             // the entry the (one) row start sits at
+#pragma unroll
+    for (int i = 0; i < SIGMA; ++i) c[i] = (int) (i < pos ? s_first + (unsigned) i : s_after + (unsigned) (i - pos));
+}
+
+// slot of entry i of lane x of tile t in the 16-bit stream: transposed + packed (CSR5, pack16 = SIGMA) or the matrix's own order (nnz-split)
+template <int SIGMA>
+__device__ __forceinline__ long long csr5_slot_pos(int t, int lane, int i, bool natural)
+{
+    constexpr long long TN = (long long) kWave * SIGMA;
+    return natural ? t * TN + (long long) lane * SIGMA + i : t * TN + (i / 4) * (4 * kWave) + lane * 4 + (i % 4);
+}
+
+// Inspector: which staged groups are RUN groups?  One workgroup per group, a wave per tile.  counters[0] += groups, [1] += their tiles.
+template <int SIGMA>
+__global__ __launch_bounds__(kBlock) void csr5_runs_kernel(int group_tiles, int p, long long nnz, int natural, const unsigned *__restrict__ desc,
+                                                           const unsigned short *__restrict__ col16, TileWindows *__restrict__ wins,
+                                                           unsigned *__restrict__ lane_run, unsigned long long *__restrict__ counters)
+{
+    constexpr long long TN = (long long) kWave * SIGMA;
+    const int g = blockIdx.x, lane = threadIdx.x & (kWave - 1), wave = threadIdx.x / kWave;
+    const int t0 = g * group_tiles;
+    int ok = wins[g].nwin > 0;
+    int tiles = 0;
+    if (ok)
+        for (int k = wave; k < group_tiles; k += kBlock / kWave) {
+            const int t = t0 + k;
+            if (t >= p) break;
+            if ((long long) (t + 1) * TN > nnz) { ok = 0; break; } // the matrix's last, partly filled tile: padding slots
+            const unsigned fl = (desc[(long long) t * kWave + lane] & kCsr5FlagMask) >> 1;
+            ok &= __popc(fl) <= 1;
+            const int pos = fl ? __ffs((int) fl) : SIGMA;
+            unsigned prev = col16[csr5_slot_pos<SIGMA>(t, lane, 0, natural != 0)];
+#pragma unroll
+            for (int i = 1; i < SIGMA; ++i) {
+                const unsigned cur = col16[csr5_slot_pos<SIGMA>(t, lane, i, natural != 0)];
+                if (i != pos) ok &= cur == prev + 1u;
+                prev = cur;
+            }
+            if (lane == 0) ++tiles;
+        }
+    ok = __syncthreads_and(ok);
+    if (!ok) return;
+    for (int k = wave; k < group_tiles; k += kBlock / kWave) {
+        const int t = t0 + k;
+        if (t >= p) break;
+        const unsigned fl = (desc[(long long) t * kWave + lane] & kCsr5FlagMask) >> 1;
+        const int pos = fl ? __ffs((int) fl) : SIGMA;
+        const unsigned s_first = col16[csr5_slot_pos<SIGMA>(t, lane, 0, natural != 0)];
+        const unsigned s_after = pos < SIGMA ? col16[csr5_slot_pos<SIGMA>(t, lane, pos, natural != 0)] : 0u;
+        lane_run[(long long) t * kWave + lane] = s_first | (s_after << 16);
+    }
+    if (lane == 0 && tiles) atomicAdd(counters + 1, (unsigned long long) tiles);
+    if (threadIdx.x == 0) { wins[g].runs = 1; atomicAdd(counters, 1ull); }
+}
+
 // ---------------------------------------------------------------------------- executor
 // The arithmetic of one tile once the lane holds its SIGMA entries (c: LDS slots when STAGED, else
 // global columns with -1 = padding; v: values): gathers, per-lane segmented sums cut at the row-start
@@ -352,13 +418,13 @@ __device__ __forceinline__ void csr5_tile_compute(int t, int lane, const int (&c
 // One tile by one wavefront.  STAGED: the x windows of the workgroup's tiles are in LDS (xs) and the
 // column stream is tcol16: 16-bit LDS slots, four per lane and 8-byte load (range_windows_kernel,
 // pack16 = SIGMA); padding entries point at the zero slot behind the windows, so no entry needs a test.
-template <typename T, int SIGMA, bool MAPPED, bool STAGED>
+template <typename T, int SIGMA, bool MAPPED, bool STAGED, bool RUNS = false>
 __device__ __forceinline__ void csr5_tile(int t, int lane, const int *__restrict__ tile_ptr,
                                           const unsigned *__restrict__ desc, const int *__restrict__ tcol,
                                           const unsigned short *__restrict__ tcol16,
                                           const T *__restrict__ tval, const int *__restrict__ row_map, int *__restrict__ rm,
                                           const T *__restrict__ x, const T *__restrict__ xs,
-                                          T *__restrict__ y, T *__restrict__ carry)
+                                          T *__restrict__ y, T *__restrict__ carry, const unsigned *__restrict__ lane_run = nullptr)
 {
     constexpr int TN = kWave * SIGMA;
     const long long base = (long long) t * TN + lane;
@@ -366,7 +432,9 @@ __device__ __forceinline__ void csr5_tile(int t, int lane, const int *__restrict
     const int r0 = tile_ptr[t], r1 = MAPPED ? tile_ptr[t + 1] : 0;
     int c[SIGMA];
     T v[SIGMA];
-    if (STAGED) {
+    if constexpr (STAGED && RUNS) { // RUN group: a word per lane instead of SIGMA slots
+        csr5_run_slots<SIGMA>(lane_run[(long long) t * kWave + lane], d, c);
+    } else if (STAGED) {
 #pragma unroll
         for (int q = 0; q < SIGMA / 4; ++q) {
             int w[4];
@@ -428,7 +496,7 @@ __global__ __launch_bounds__(kBlock) void csr5_group_kernel(int group_tiles, int
                                                             const int *__restrict__ tcol, const unsigned short *__restrict__ tcol16,
                                                             const T *__restrict__ tval,
                                                             const int *__restrict__ row_map,
-                                                            const TileWindows *__restrict__ wins,
+                                                            const TileWindows *__restrict__ wins, const unsigned *__restrict__ lane_run,
                                                             const T *__restrict__ x, T *__restrict__ y,
                                                             T *__restrict__ carry, int n_empty, const int *__restrict__ empty_list, int rm_off, int rm_stride)
 {
@@ -436,7 +504,7 @@ __global__ __launch_bounds__(kBlock) void csr5_group_kernel(int group_tiles, int
     extern __shared__ __attribute__((aligned(16))) unsigned char csr5_x_lds[]; // x windows, then (MAPPED) the waves' row maps at byte rm_off
     T *xs = reinterpret_cast<T *>(csr5_x_lds);
     const TileWindows &tw = wins[blockIdx.x];
-    const bool staged = tw.nwin > 0;
+    const bool staged = tw.nwin > 0, runs = tw.runs != 0;
     stage_windows<kBlock, T>(tw, x, xs);
     if (staged) {
         if (threadIdx.x == 0) xs[tw.total] = T(0); // the zero slot of padding entries
@@ -448,7 +516,8 @@ __global__ __launch_bounds__(kBlock) void csr5_group_kernel(int group_tiles, int
     for (int k = threadIdx.x / kWave; k < group_tiles; k += kBlock / kWave) {
         const int t = t0 + k;
         if (t >= p) break;
-        if (staged) csr5_tile<T, SIGMA, MAPPED, true>(t, lane, tile_ptr, desc, tcol, tcol16, tval, row_map, rm, x, xs, y, carry);
+        if (runs) csr5_tile<T, SIGMA, MAPPED, true, true>(t, lane, tile_ptr, desc, tcol, tcol16, tval, row_map, rm, x, xs, y, carry, lane_run);
+        else if (staged) csr5_tile<T, SIGMA, MAPPED, true>(t, lane, tile_ptr, desc, tcol, tcol16, tval, row_map, rm, x, xs, y, carry);
         else csr5_tile<T, SIGMA, MAPPED, false>(t, lane, tile_ptr, desc, tcol, tcol16, tval, row_map, rm, x, xs, y, carry);
     }
 }
@@ -462,22 +531,27 @@ __global__ __launch_bounds__(kBlock) void csr5_group_kernel(int group_tiles, int
 // register) until they are used.  Config 4 (fp32): long rows of the SELL / CSR-vector schedules (MAPPED) and CSR5 itself.
 template <typename T, int SIGMA>
 struct Csr5TileRegs {
-    int w[SIGMA / 4][2]; // 16-bit slots, packed
+    int w[SIGMA / 4][2]; // 16-bit slots, packed (RUN group: w[0][0] = the lane's run word)
     T v[SIGMA];
     unsigned d;
     int first;           // MAPPED: row_map[r0 + min(lane, span)]
 };
 
-template <typename T, int SIGMA, bool MAPPED>
+template <typename T, int SIGMA, bool MAPPED, bool RUNS>
 __device__ __forceinline__ void csr5_tile_issue(int t, int lane, int r0, int r1, const unsigned *__restrict__ desc, const unsigned short *__restrict__ tcol16,
-                                                const T *__restrict__ tval, const int *__restrict__ row_map, Csr5TileRegs<T, SIGMA> &R)
+                                                const T *__restrict__ tval, const int *__restrict__ row_map, Csr5TileRegs<T, SIGMA> &R,
+                                                const unsigned *__restrict__ lane_run)
 {
     constexpr int TN = kWave * SIGMA;
     R.d = desc[(long long) t * kWave + lane];
+    if constexpr (RUNS) {
+        R.w[0][0] = (int) lane_run[(long long) t * kWave + lane];
+    } else {
 #pragma unroll
-    for (int q = 0; q < SIGMA / 4; ++q) {
-        const i32x2 u = __builtin_nontemporal_load(reinterpret_cast<const i32x2 *>(tcol16 + (long long) t * TN + q * (4 * kWave) + lane * 4));
-        R.w[q][0] = u.x; R.w[q][1] = u.y;
+        for (int q = 0; q < SIGMA / 4; ++q) {
+            const i32x2 u = __builtin_nontemporal_load(reinterpret_cast<const i32x2 *>(tcol16 + (long long) t * TN + q * (4 * kWave) + lane * 4));
+            R.w[q][0] = u.x; R.w[q][1] = u.y;
+        }
     }
     csr5_load_vals<T, SIGMA>(tval, t, lane, R.v);
     R.first = 0;
@@ -487,17 +561,21 @@ __device__ __forceinline__ void csr5_tile_issue(int t, int lane, int r0, int r1,
     }
 }
 
-template <typename T, int SIGMA, bool MAPPED>
+template <typename T, int SIGMA, bool MAPPED, bool RUNS>
 __device__ __forceinline__ void csr5_tile_finish(int t, int lane, int r0, int r1, const Csr5TileRegs<T, SIGMA> &R, const int *__restrict__ row_map, int *__restrict__ rm,
                                                  const T *__restrict__ x, const T *__restrict__ xs, T *__restrict__ y, T *__restrict__ carry)
 {
     int c[SIGMA];
+    if constexpr (RUNS) {
+        csr5_run_slots<SIGMA>((unsigned) R.w[0][0], R.d, c);
+    } else {
 #pragma unroll
-    for (int q = 0; q < SIGMA / 4; ++q) {
-        c[4 * q + 0] = (int) ((unsigned) R.w[q][0] & 0xffffu);
-        c[4 * q + 1] = (int) ((unsigned) R.w[q][0] >> 16);
-        c[4 * q + 2] = (int) ((unsigned) R.w[q][1] & 0xffffu);
-        c[4 * q + 3] = (int) ((unsigned) R.w[q][1] >> 16);
+        for (int q = 0; q < SIGMA / 4; ++q) {
+            c[4 * q + 0] = (int) ((unsigned) R.w[q][0] & 0xffffu);
+            c[4 * q + 1] = (int) ((unsigned) R.w[q][0] >> 16);
+            c[4 * q + 2] = (int) ((unsigned) R.w[q][1] & 0xffffu);
+            c[4 * q + 3] = (int) ((unsigned) R.w[q][1] >> 16);
+        }
     }
     if constexpr (MAPPED) {
         const int span = r1 - r0; // wave-uniform
@@ -519,18 +597,16 @@ __device__ __forceinline__ void csr5_tile_finish(int t, int lane, int r0, int r1
 
 constexpr int kCsr5PipeMaxGroupTiles = kWave * (kBlock / kWave); // lane j of a wave holds the row range of the wave's j-th tile
 
-template <typename T, int SIGMA, bool MAPPED>
-__global__ __launch_bounds__(kBlock) void csr5_group_pipe_kernel(int group_tiles, int p, const int *__restrict__ tile_ptr,
-                                                                 const unsigned *__restrict__ desc, const unsigned short *__restrict__ tcol16,
-                                                                 const T *__restrict__ tval, const int *__restrict__ row_map,
-                                                                 const TileWindows *__restrict__ wins,
-                                                                 const T *__restrict__ x, T *__restrict__ y,
-                                                                 T *__restrict__ carry, int n_empty, const int *__restrict__ empty_list, int rm_off, int rm_stride)
+// body of the two-deep group kernel; RUNS: the group is a RUN group (the whole workgroup takes the same instantiation)
+template <typename T, int SIGMA, bool MAPPED, bool RUNS>
+__device__ __forceinline__ void csr5_group_pipe_body(int group_tiles, int p, const int *__restrict__ tile_ptr,
+                                                     const unsigned *__restrict__ desc, const unsigned short *__restrict__ tcol16,
+                                                     const T *__restrict__ tval, const int *__restrict__ row_map,
+                                                     const TileWindows &tw, const unsigned *__restrict__ lane_run,
+                                                     const T *__restrict__ x, T *__restrict__ y, T *__restrict__ carry,
+                                                     unsigned char *__restrict__ lds, int rm_off, int rm_stride)
 {
-    if (MAPPED) zero_empty_rows(n_empty, empty_list, y);
-    extern __shared__ __attribute__((aligned(16))) unsigned char csr5_x_lds[]; // x windows, then (MAPPED) the waves' row maps at byte rm_off
-    T *xs = reinterpret_cast<T *>(csr5_x_lds);
-    const TileWindows &tw = wins[blockIdx.x]; // every group of the plan is staged (launch_csr5_form)
+    T *xs = reinterpret_cast<T *>(lds);
     constexpr int NW = kBlock / kWave;
     const int lane = threadIdx.x & (kWave - 1);
     const int wave = __builtin_amdgcn_readfirstlane((int) (threadIdx.x / kWave));
@@ -546,11 +622,11 @@ __global__ __launch_bounds__(kBlock) void csr5_group_pipe_kernel(int group_tiles
     Csr5TileRegs<T, SIGMA> R0, R1;
     // tile 0's streams are issued before the x staging and the barrier (its row map follows the row range: after the barrier)
     auto issue = [&](int j, Csr5TileRegs<T, SIGMA> &R) {
-        csr5_tile_issue<T, SIGMA, MAPPED>(t0 + wave + j * NW, lane, __builtin_amdgcn_readlane(lp0, j), __builtin_amdgcn_readlane(lp1, j), desc, tcol16, tval, row_map, R);
+        csr5_tile_issue<T, SIGMA, MAPPED, RUNS>(t0 + wave + j * NW, lane, __builtin_amdgcn_readlane(lp0, j), __builtin_amdgcn_readlane(lp1, j), desc, tcol16, tval, row_map, R, lane_run);
     };
-    int *rm = wave_row_map(csr5_x_lds, rm_off, rm_stride);
+    int *rm = wave_row_map(lds, rm_off, rm_stride);
     auto finish = [&](int j, const Csr5TileRegs<T, SIGMA> &R) {
-        csr5_tile_finish<T, SIGMA, MAPPED>(t0 + wave + j * NW, lane, __builtin_amdgcn_readlane(lp0, j), __builtin_amdgcn_readlane(lp1, j), R, row_map, rm, x, xs, y, carry);
+        csr5_tile_finish<T, SIGMA, MAPPED, RUNS>(t0 + wave + j * NW, lane, __builtin_amdgcn_readlane(lp0, j), __builtin_amdgcn_readlane(lp1, j), R, row_map, rm, x, xs, y, carry);
     };
     if (nt > 0) issue(0, R0);
     stage_windows<kBlock, T>(tw, x, xs);
@@ -563,6 +639,21 @@ __global__ __launch_bounds__(kBlock) void csr5_group_pipe_kernel(int group_tiles
         if (j + 2 < nt) issue(j + 2, R0);
         finish(j + 1, R1);
     }
+}
+
+template <typename T, int SIGMA, bool MAPPED>
+__global__ __launch_bounds__(kBlock) void csr5_group_pipe_kernel(int group_tiles, int p, const int *__restrict__ tile_ptr,
+                                                                 const unsigned *__restrict__ desc, const unsigned short *__restrict__ tcol16,
+                                                                 const T *__restrict__ tval, const int *__restrict__ row_map,
+                                                                 const TileWindows *__restrict__ wins, const unsigned *__restrict__ lane_run,
+                                                                 const T *__restrict__ x, T *__restrict__ y,
+                                                                 T *__restrict__ carry, int n_empty, const int *__restrict__ empty_list, int rm_off, int rm_stride)
+{
+    if (MAPPED) zero_empty_rows(n_empty, empty_list, y);
+    extern __shared__ __attribute__((aligned(16))) unsigned char csr5_x_lds[]; // x windows, then (MAPPED) the waves' row maps at byte rm_off
+    const TileWindows &tw = wins[blockIdx.x]; // every group of the plan is staged (launch_csr5_form)
+    if (tw.runs) csr5_group_pipe_body<T, SIGMA, MAPPED, true>(group_tiles, p, tile_ptr, desc, tcol16, tval, row_map, tw, lane_run, x, y, carry, csr5_x_lds, rm_off, rm_stride);
+    else csr5_group_pipe_body<T, SIGMA, MAPPED, false>(group_tiles, p, tile_ptr, desc, tcol16, tval, row_map, tw, lane_run, x, y, carry, csr5_x_lds, rm_off, rm_stride);
 }
 
 // ---- natural-layout tiles (the nnz-split schedule: Method_Balanced2 / Method_Balanced_Yid) ------------

@@ -393,6 +393,22 @@ static int build_csr5_sigma(spmv_dev *d, Csr5Plan &P, const int *rp, int m2, con
         }
         (void) hipGetLastError();
     }
+    P.run_groups = 0;
+    P.run_tiles = 0;
+    if (P.staged > 0 && !P.natural && d->plan.variant != 63 && !getenv("SPMV_HIP_NO_RUN_TILES")) { // RUN groups: a word per lane and tile instead of SIGMA slots (csr5.hpp; not for the natural layout: no gain); variant 63: off (tests)
+        unsigned long long *cnt = nullptr, h[2] = {0, 0};
+        ALLOC_TRY(d, &P.lane_run, sizeof(unsigned) * (size_t) p * kWave, true);
+        HIP_TRY(pool_malloc((void **) &cnt, sizeof h));
+        hipError_t e = hipMemsetAsync(cnt, 0, sizeof h, d->stream);
+        csr5_runs_kernel<SIGMA><<<P.groups, kBlock, 0, d->stream>>>(P.group_tiles, p, P.nnz, P.natural ? 1 : 0, P.desc, P.col16, P.wins, P.lane_run, cnt);
+        if (e == hipSuccess) e = hipGetLastError();
+        if (e == hipSuccess) e = hipMemcpyAsync(h, cnt, sizeof h, hipMemcpyDeviceToHost, d->stream);
+        if (e == hipSuccess) e = hipStreamSynchronize(d->stream);
+        (void) pool_free(cnt);
+        if (e != hipSuccess) return fail(SPMV_HIP_E_RUNTIME, "CSR5 run inspector: %s", hipGetErrorString(e));
+        P.run_groups = (int) h[0];
+        P.run_tiles = (long long) h[1];
+    }
     if (P.staged == 0) { sched_free(d, P.col16); P.col16 = nullptr; }
     else if (!P.natural && P.staged == P.groups) { sched_free(d, P.col); P.col = nullptr; } // no group reads global columns
     return SPMV_HIP_OK;
@@ -763,6 +779,7 @@ static int csr5_traffic(spmv_dev *d, const Csr5Plan &P, Traffic &t)
     t.bytes += 4 * (p + 1) + 4 * kWave * p + s * p;            // tile_ptr, descriptors, carries written
     if (P.fixup && p > 1) t.bytes += (s + 8) * p;               // fix-up launch: carries, tile_ptr, run_len
     if (P.staged > 0) t.bytes += (long long) sizeof(TileWindows) * P.groups;
+    t.bytes += P.run_tiles * (4ll * kWave - 2ll * TN); // RUN groups: a word per lane and tile instead of 16 bits per entry
     if (P.row_map) t.bytes += 4ll * P.m2;
     t.bytes += s * P.m2 + (s + 4) * (long long) P.n_empty;      // y of the plan's rows; zero fill of the empty rows
     t.x_elems += welems;

@@ -218,12 +218,12 @@ static void launch_csr5_form(spmv_dev *d, const Csr5Plan &P, const T *x, T *y)
         }
         if (csr5_two_deep(d, P)) {
             ensure_lds<csr5_group_pipe_kernel<T, SIGMA, MAPPED>>(d, lds + rmb);
-            csr5_group_pipe_kernel<T, SIGMA, MAPPED><<<P.groups, kBlock, lds + rmb, d->stream>>>(P.group_tiles, P.tiles, P.tile_ptr, P.desc, P.col16, (const T *) P.val, P.row_map, P.wins,
+            csr5_group_pipe_kernel<T, SIGMA, MAPPED><<<P.groups, kBlock, lds + rmb, d->stream>>>(P.group_tiles, P.tiles, P.tile_ptr, P.desc, P.col16, (const T *) P.val, P.row_map, P.wins, P.lane_run,
                                                                                                 x, y, (T *) P.carry, P.n_empty, P.empty_list, (int) lds, rm_stride);
             return;
         }
         ensure_lds<csr5_group_kernel<T, SIGMA, MAPPED>>(d, lds + rmb);
-        csr5_group_kernel<T, SIGMA, MAPPED><<<P.groups, kBlock, lds + rmb, d->stream>>>(P.group_tiles, P.tiles, P.tile_ptr, P.desc, P.col, P.col16, (const T *) P.val, P.row_map, P.wins,
+        csr5_group_kernel<T, SIGMA, MAPPED><<<P.groups, kBlock, lds + rmb, d->stream>>>(P.group_tiles, P.tiles, P.tile_ptr, P.desc, P.col, P.col16, (const T *) P.val, P.row_map, P.wins, P.lane_run,
                                                                                        x, y, (T *) P.carry, P.n_empty, P.empty_list, (int) lds, rm_stride);
         return;
     }

@@ -153,6 +153,9 @@ struct Csr5Plan {
     TileWindows *wins = nullptr;
     int *tile_ptr = nullptr, *run_len = nullptr, *col = nullptr; // col: transposed global columns (freed when every group is staged)
     unsigned short *col16 = nullptr; // 16-bit LDS slots of the staged groups
+    unsigned *lane_run = nullptr;    // RUN groups (csr5.hpp): per lane and tile, first slot | slot at the lane's one row start << 16 -- read instead of col16
+    int run_groups = 0;
+    long long run_tiles = 0;
     const int *row_map = nullptr; // CSR5 row -> y row (NULL: identity)
     unsigned *desc = nullptr;
     void *val = nullptr, *carry = nullptr;

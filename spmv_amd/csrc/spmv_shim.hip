@@ -575,6 +575,7 @@ extern "C" int spmv_shim_info(const spmv_dev *d, spmv_hip_info *o)
         const bool tiles_run = !d->blk_on && ((d->plan.sched == SPMV_SCHED_CSR_VECTOR && d->vt_tiles > 0 && (d->vt_wide || d->vt_staged * 2 >= d->vt_tiles) && d->vec_choice != VEC_PIPE) || d->plan.sched == SPMV_SCHED_ROWBLOCK);
         o->run_nnz = tiles_run ? d->vt_run_nnz : 0;
         if (!d->blk_on && d->plan.sched == SPMV_SCHED_SELL && d->sell_staged > 0) o->run_nnz = d->sell_run_nnz;
+        if (!d->blk_on && d->plan.sched == SPMV_SCHED_CSR5) o->run_nnz = d->c5.run_tiles * kWave * d->c5.sigma;
     }
     if (d->blk_on) { o->stored_nnz = d->blk.groups << d->blk.ge; o->x_groups = d->x_groups_seen; o->x_groups_staged = 0; }
     if (!d->blk_on) switch (d->plan.sched) {

@@ -243,7 +243,7 @@ def test_auto_method_picks_schedule_from_row_statistics():
     ("variant", [3], M.Method_Balanced_Yid),                     # no x windows (global gathers)
     ("variant", [4, 5, 6, 10, 11, 12], M.Method_Parallel),       # CSR-vector kernel forms
     ("variant", [3, 61, 62], M.Method_SellCSigma),               # 61 / 62: the staged CSR5 group kernel one tile / two tiles deep (long rows)
-    ("variant", [3, 61, 62], M.Method_CSR5SPMV),
+    ("variant", [3, 61, 62, 63], M.Method_CSR5SPMV),             # 63: no RUN groups (the 16-bit slot stream is read everywhere)
 ])
 @pytest.mark.parametrize("name", ["skewed_f64_eighths", "empty_mix_f32_eighths", "banded_wide_f64_eighths"])
 def test_tuning_options_do_not_change_results(key, values, method, name):
@@ -895,7 +895,7 @@ def _segment_sums(prod, rp):
     return cs[rp[1:].long()] - cs[rp[:-1].long()]
 
 
-@pytest.mark.parametrize("method", [M.Method_Parallel, M.Method_Balanced, M.Method_SellCSigma], ids=lambda m: m.name)
+@pytest.mark.parametrize("method", [M.Method_Parallel, M.Method_Balanced, M.Method_SellCSigma, M.Method_CSR5SPMV, M.Method_Balanced_Yid], ids=lambda m: m.name)
 @pytest.mark.parametrize("dtype", ["f64", "f32"])
 @pytest.mark.parametrize("shape", ["ragged", "two_bands", "chunks", "wide", "broken_rows"])
 def test_run_tiles_need_no_column_stream(shape, dtype, method):
@@ -947,8 +947,18 @@ def test_run_tiles_need_no_column_stream(shape, dtype, method):
         info = h.info()
         torch.cuda.synchronize()
         assert torch.equal(y, want), (info["kernel_name"], int((y != want).sum()))
-        assert info["kernel_name"] in ("csr_vector_tile_kernel", "csr_vector_rows_kernel", "sell_window_kernel") and info["cache_blocked"] == 0, info
-        if shape == "broken_rows":
+        entry_granular = method in (M.Method_CSR5SPMV, M.Method_Balanced_Yid)
+        assert info["kernel_name"] in ("csr_vector_tile_kernel", "csr_vector_rows_kernel", "sell_window_kernel", "csr5_group_kernel", "csr5_group_pipe_kernel",
+                                       "nat_group_kernel") and info["cache_blocked"] == 0, info
+        if entry_granular:
+            # CSR5 tiles (csr5.hpp RUN groups: a word per lane and tile) need runs with at most one row start per lane of SIGMA entries: the
+            # 64..200-entry rows qualify (all but the matrix's last, partly filled tile); shorter rows keep the 16-bit slot stream, and so does
+            # the natural-layout nnz-split kernel (no gain measured there)
+            if shape == "chunks" and method == M.Method_CSR5SPMV:
+                assert 0.95 * nnz <= info["run_nnz"] <= nnz, (info["run_nnz"], nnz)
+            if method == M.Method_Balanced_Yid:
+                assert info["run_nnz"] == 0
+        elif shape == "broken_rows":
             if method == M.Method_Parallel:   # 256-row tiles: exactly the tiles holding a moved entry read their column stream
                 assert nnz - broken * 256 * 40 <= info["run_nnz"] < nnz, (info["run_nnz"], nnz, broken)
             elif method == M.Method_SellCSigma:   # the unit is the window group (1024 rows and up): most groups hold no moved entry
