@@ -53,6 +53,8 @@ CASES = [  # (rows, columns, row-length kind, column locality, dtype)
     (4_000_000, 4_000_000, "equal", "web", torch.float64),    # 90 % of a row near the diagonal, 10 % on R-MAT hubs: A = A_near + A_far is built and timed
     (2_500_000, 2_500_000, "skewed", "rmat", torch.float32),  # R-MAT columns, heavy-tailed rows: hub cells of thousands of entries (blk_spread), fp32 groups of 256
     (3_000_000, 3_000_000, "equal", "every7", torch.float64), # banded rows, every seventh row random: no tile stages, the split goes by entries
+    (2_000_000, 2_000_000, "gaps", "runs", torch.float64),    # rows = runs of consecutive columns near the diagonal, 1 row in 20 000 broken: RUN tiles / window groups beside ordinary ones
+    (1_000_000, 1_000_000, "skewed", "runs", torch.float32),  # the same with 60..6000-entry rows among short ones: CSR5 RUN groups (one row start per lane) beside ordinary ones, long-row sub-matrices of runs
 ]
 
 
@@ -68,6 +70,16 @@ def test_big_shapes_every_schedule_matches_the_definition(case):
         row_of = torch.repeat_interleave(torch.arange(m, device=DEV), lens)
         ci = torch.where(row_of % 7 == 0, cr, ci)
         del cr, row_of
+    elif local == "runs":
+        _, _, rp, ci, va = synth.from_row_lengths_device(lens, n, "eighths", dt, DEV, seed=200 + case, local=20)
+        rows = torch.arange(m, device=DEV)
+        start = (rows * n // m + torch.randint(-300, 301, (m,), generator=g, device=DEV)).clamp_(min=0)
+        start = torch.minimum(start, (n - lens).clamp_(min=0))
+        row_of = torch.repeat_interleave(rows, lens)
+        ci = (start[row_of] + torch.arange(ci.numel(), device=DEV) - rp.long()[:-1][row_of]).to(torch.int32)
+        pick = torch.nonzero((rows % 20000 == 11) & (lens >= 2)).flatten()
+        ci[rp.long()[pick] + 1] = ci[rp.long()[pick]]                       # second entry = first: a duplicate column, no longer a run
+        del rows, start, row_of, pick
     elif isinstance(local, str):
         _, _, rp, ci, va = synth.from_row_lengths_device(lens, n, "eighths", dt, DEV, seed=200 + case, cols=local)
     else:
@@ -75,6 +87,7 @@ def test_big_shapes_every_schedule_matches_the_definition(case):
     x = (torch.randint(-8, 9, (n,), generator=g, device=DEV).to(dt) * 0.125)
     want = _definition(rp, ci, va, x)
     seen = set()
+    runs_seen = 0
     for method in METHODS:
         y = torch.full((m,), float("nan"), dtype=dt, device=DEV)
         with api.Handle(m, n, rp, ci, va, method) as h:
@@ -82,6 +95,7 @@ def test_big_shapes_every_schedule_matches_the_definition(case):
             info = h.info()
             torch.cuda.synchronize()
             seen.add(info["kernel_name"])
+            runs_seen += info["run_nnz"] > 0
             if info["far_nnz"] > 0:
                 seen.add("split")
             bad = torch.nonzero(y != want)
@@ -91,6 +105,8 @@ def test_big_shapes_every_schedule_matches_the_definition(case):
                 h.spmv(x, y)
                 torch.cuda.synchronize()
                 assert torch.equal(y, 2 * want), (case, method.name, "update_values")
+    if local == "runs":
+        assert runs_seen, "no schedule found a RUN tile / group"
     if local == "every7":
         assert "split" in seen or "blk_kernel" in seen, seen
     if local == 0:
