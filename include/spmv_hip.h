@@ -88,7 +88,13 @@ int spmv_hip_update_values(spmv_Handle_t handle, const void *Matrix_Val);
  *       "split" (0/1, default 1: a matrix whose entries are partly local, partly scattered may be multiplied as A_near + A_far when
  *               create() measures that faster -- spmv_hip_info.split_ms, far_nnz)
  *       "slab_kib" (KiB of x per column slab, 0 = as narrow as the cell table allows)
- *       "block_rows" (rows per block, 0 = 64 KiB of y)
+ *       "block_rows" (uniform row blocks of that many rows, at most 16384; 0 = equal-work blocks sized by the executor form: up to 9982 rows with a wave per
+                     block, up to 20350 in the wide forms)
+       "blk_waves" (0 automatic / 1 / 2 / 4 / 8: wavefronts sharing ONE row block's LDS accumulators; 0: create() builds the one-wave form and, on large
+                    matrices, the wide form that fits option "deterministic", times them and keeps the faster)
+       "blk_groups" (groups of 128 fp64 / 256 fp32 entries per pipeline step, 0 = timed at create)   "blk_subsort" (0/1, default 1)
+       "deterministic" (0/1, default 1: every executor adds a row's products in an order fixed by the matrix, so results are bit-identical run to
+                        run; 0 lets the wide blocked form add in arrival order -- 10-16 % faster on matrices without column locality, equal to rounding)
  *       "host_rows" (0/1, default 0: 1 = handles created with VECTOR_NONE and Method_Serial / Method_Parallel run
  *                    a plain-C row loop on the HOST over the caller's arrays (BASELINE config 1: the reference's
  *                    plumbing case); never selected automatically -- without it a missing GPU is an error)
@@ -143,6 +149,10 @@ typedef struct spmv_hip_info {
     long long run_nnz;          /* CSR-vector / row-block tile kernels, SELL slabs, CSR5 tile groups: entries in RUN tiles / groups -- staged ones whose rows
                                  * each reference one run of consecutive columns (banded matrices; CSR5: of at least sigma entries); their column stream is
                                  * not read at all (16 bits, SELL: a word, per ROW; CSR5: a word per lane and tile instead) */
+    int blk_waves;              /* cache_blocked: wavefronts that share one row block's accumulators (1: a wave per block, two blocks per CU; 2 / 4 / 8: the
+                                 * wide form, one block of up to ~20 k rows per CU); 0 when another executor runs */
+    int reproducible;           /* 1: the executor adds every row's products in an order fixed by the matrix -- identical bits run to run and handle to
+                                 * handle; 0 only for the wide blocked form under option "deterministic" = 0 */
 } spmv_hip_info;
 int spmv_hip_get_info(spmv_Handle_t handle, spmv_hip_info *out);
 

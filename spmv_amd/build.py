@@ -30,7 +30,9 @@ C_SOURCES = ["spmv_api.c", "spmv_plan.c", "host_rows.c", os.path.join("io", "mtx
 TOOL_SOURCES = {"test_spmv": os.path.join("tools", "test_spmv_csv.c")}   # -> spmv_amd/bin/<name>
 BINDIR = os.path.join(PKG, "bin")
 ROCM = os.environ.get("ROCM_PATH", "/opt/rocm")
-HIP_SOURCES = ["spmv_shim.hip"]
+# (source, extra defines, object name): compiled side by side.  The CSR-vector family's executors (seven lanes-per-row values x five
+# forms x two value types) are most of the device code: spmv_vector.hip is compiled four times, a quarter of the instantiations each
+HIP_SOURCES = [("spmv_shim.hip", [], "spmv_shim.hip.o")] + [("spmv_vector.hip", [f"SPMV_VEC_PART={k}"], f"spmv_vector{k}.hip.o") for k in range(4)]
 HIP_FLAGS = ["-O3", "-std=c++17", "-fPIC", f"--offload-arch={ARCH}", "-Wall", "-Wno-unused-function",
              "-ffp-contract=fast"]
 C_FLAGS = ["-O2", "-std=c11", "-fPIC", "-fopenmp", "-Wall", "-Wextra", "-D_POSIX_C_SOURCE=200809L"]
@@ -56,6 +58,20 @@ def _run(cmd):
         sys.stderr.write(r.stderr)
 
 
+def _run_all(cmds):
+    """Independent compiles, side by side."""
+    procs = [(c, subprocess.Popen(c, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True)) for c in cmds]
+    errs = []
+    for c, p in procs:
+        out, err = p.communicate()
+        if p.returncode != 0:
+            errs.append("build failed: " + " ".join(c) + "\n" + out + err)
+        elif err.strip():
+            sys.stderr.write(err)
+    if errs:
+        raise RuntimeError("\n".join(errs))
+
+
 def build_debug(defines, name="libspmv_hip_dbg.so", verbose=False):
     """A/B build for tools/ (never loaded by the package): the same sources with extra -D defines -> spmv_amd/lib/<name>."""
     os.makedirs(LIBDIR, exist_ok=True)
@@ -65,10 +81,12 @@ def build_debug(defines, name="libspmv_hip_dbg.so", verbose=False):
         obj = os.path.join(OBJDIR, "dbg_" + src.replace(os.sep, "_") + ".o")
         _run([CC, *C_FLAGS, f"-I{INC}", f"-I{CSRC}", "-c", os.path.join(CSRC, src), "-o", obj])
         objs.append(obj)
-    for src in HIP_SOURCES:
-        obj = os.path.join(OBJDIR, "dbg_" + src + ".o")
-        _run([HIPCC, *HIP_FLAGS, *[f"-D{d}" for d in defines], f"-I{INC}", f"-I{CSRC}", "-c", os.path.join(CSRC, src), "-o", obj])
+    cmds = []
+    for src, defs, oname in HIP_SOURCES:
+        obj = os.path.join(OBJDIR, "dbg_" + oname)
+        cmds.append([HIPCC, *HIP_FLAGS, *[f"-D{d}" for d in list(defines) + defs], f"-I{INC}", f"-I{CSRC}", "-c", os.path.join(CSRC, src), "-o", obj])
         objs.append(obj)
+    _run_all(cmds)
     gomp = subprocess.run([CC, "-print-file-name=libgomp.so"], capture_output=True, text=True).stdout.strip()
     out = os.path.join(LIBDIR, name)
     _run([HIPCC, "-shared", "-fPIC", f"--offload-arch={ARCH}", "-o", out, *objs, gomp, "-lpthread", "-lm"])
@@ -92,13 +110,15 @@ def build(force=False, verbose=False):
             print(" ".join(cmd))
         _run(cmd)
         objs.append(obj)
-    for src in HIP_SOURCES:
-        obj = os.path.join(OBJDIR, src + ".o")
-        cmd = [HIPCC, *HIP_FLAGS, f"-I{INC}", f"-I{CSRC}", "-c", os.path.join(CSRC, src), "-o", obj]
+    cmds = []
+    for src, defs, oname in HIP_SOURCES:
+        obj = os.path.join(OBJDIR, oname)
+        cmd = [HIPCC, *HIP_FLAGS, *[f"-D{d}" for d in defs], f"-I{INC}", f"-I{CSRC}", "-c", os.path.join(CSRC, src), "-o", obj]
         if verbose:
             print(" ".join(cmd))
-        _run(cmd)
+        cmds.append(cmd)
         objs.append(obj)
+    _run_all(cmds)
     # host_rows.c is compiled with -fopenmp by gcc: link GNU libgomp by path (hipcc's own -fopenmp would pull LLVM's runtime)
     gomp = subprocess.run([CC, "-print-file-name=libgomp.so"], capture_output=True, text=True).stdout.strip()
     cmd = [HIPCC, "-shared", "-fPIC", f"--offload-arch={ARCH}", "-o", LIB, *objs, gomp, "-lpthread", "-lm"]

@@ -56,7 +56,7 @@ constexpr int kBlkMaxCells = 12288;  // cells of one row block at most (the insp
 constexpr int kBlkThreads = 1024;    // inspector workgroups: 16 waves per row block
 constexpr int kBlkTurn = 4;          // batches of 64 entries a wave places per turn
 constexpr int kBlkStepGroups = 24;   // a block's region is padded to a multiple of this: whole executor steps of either form (8 or 12 groups), nothing to mask
-constexpr int kBlkPadGroups = 128;   // zero groups behind the last block: three executor steps of the widest form, and header loads reach 64 groups ahead
+constexpr int kBlkPadGroups = 384;   // zero groups behind the last block: the look-ahead of the widest form (wide: 3 x 8 waves x 12 groups), and header loads reach 64 groups ahead
 
 struct BlkDir {      // one row block's region: groups [g0, g0 + ns)
     long long g0;
@@ -69,7 +69,7 @@ struct BlkDir {      // one row block's region: groups [g0, g0 + ns)
 // row, so that stretches of empty rows still end a block), each block takes 1 / (blocks left) of the work left, never more than
 // rcap rows (its accumulators live in LDS).  One workgroup: B binary searches over RowPtr.  out[0] = blocks made (>= btarget when
 // the row cap cut some short), out[1] = most rows in a block.
-__global__ __launch_bounds__(kBlock) void blk_partition_kernel(int m, const int *__restrict__ rowptr, int btarget, int rcap, long long c,
+static __global__ __launch_bounds__(kBlock) void blk_partition_kernel(int m, const int *__restrict__ rowptr, int btarget, int rcap, long long c,
                                                                int *__restrict__ cut /* [btarget + 1] scratch */, int *__restrict__ row0, int *__restrict__ out)
 {
     // cut points of equal work, found independently: cut[b] = first row whose work reaches b / btarget of the total
@@ -128,7 +128,7 @@ __device__ __forceinline__ int wave_excl_scan(int v, int lane, int *total)
 
 // rowin[p] = row of entry p inside its row block, for every entry of block blockIdx.x: the block's row pointers in LDS
 // ((R + 1) ints), one binary search per entry.
-__global__ __launch_bounds__(kBlkThreads) void blk_rows_kernel(const int *__restrict__ row0, const int *__restrict__ rowptr, unsigned short *__restrict__ rowin)
+static __global__ __launch_bounds__(kBlkThreads) void blk_rows_kernel(const int *__restrict__ row0, const int *__restrict__ rowptr, unsigned short *__restrict__ rowin)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char blk_rows_lds[];
     int *rp = reinterpret_cast<int *>(blk_rows_lds);
@@ -157,7 +157,7 @@ __device__ __forceinline__ void blk_count_cells(unsigned *cells, int K, int wshi
 
 // Inspector pass 1: groups[b] = groups of 2^ge entries row block b needs -- its cells counted in LDS (K counters), every
 // super-slab's run rounded up to whole groups.
-__global__ __launch_bounds__(kBlkThreads) void blk_count_kernel(const int *__restrict__ row0, int K, int wshift, int ge, const int *__restrict__ rowptr,
+static __global__ __launch_bounds__(kBlkThreads) void blk_count_kernel(const int *__restrict__ row0, int K, int wshift, int ge, const int *__restrict__ rowptr,
                                                                 const int *__restrict__ colidx, int *__restrict__ groups, int *__restrict__ occupied)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char blk_count_lds[];
@@ -224,7 +224,7 @@ template <typename T, bool VALUES_ONLY>
 __global__ __launch_bounds__(kBlkThreads) void blk_fill_kernel(const int *__restrict__ row0, int K, int wshift, int ge, const int *__restrict__ rowptr,
                                                                const int *__restrict__ colidx, const T *__restrict__ val, const unsigned short *__restrict__ rowin,
                                                                const long long *__restrict__ gstart, T *__restrict__ bval, unsigned *__restrict__ bmeta,
-                                                               int *__restrict__ hdr, BlkDir *__restrict__ dir)
+                                                               int *__restrict__ hdr, BlkDir *__restrict__ dir, int subsort, unsigned short *__restrict__ kscr)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char blk_fill_lds[];
     unsigned *cnt = reinterpret_cast<unsigned *>(blk_fill_lds); // entries of every cell
@@ -289,6 +289,54 @@ __global__ __launch_bounds__(kBlkThreads) void blk_fill_kernel(const int *__rest
                 const long long sp = e0 + blk_stored_pos(cst[k] + blk_spread(pos[i], cnt[k]), ge, EPL);
                 bval[sp] = v[i];
                 if constexpr (!VALUES_ONLY) bmeta[sp] = ((unsigned) c[i] & ((1u << kBlkSuperShift) - 1u)) | ((unsigned) r[i] << 16);
+                else if (subsort) kscr[sp] = (unsigned short) ((unsigned) c[i] & ((1u << kBlkSuperShift) - 1u));
+            }
+    }
+    if (!subsort) return;
+    // Sparse cells -- fewer than 128 entries, the ones blk_spread leaves in CSR order -- are sorted by COLUMN (ties: CSR order).  One
+    // executor gather instruction covers 64 consecutive entries of the stored order; with a cell in CSR order an instruction that ends
+    // inside the cell takes a RANDOM subset of its entries, spread over all of the slab's cache lines, and the neighbour instruction
+    // fetches the same lines again.  Sorted, an instruction's entries cover a contiguous column range and everything the block has in
+    // those lines: (1 - exp(-l)) / l lines per entry for l entries per line and block instead of the average over the cut position
+    // (20 k-row blocks, 32 random columns per row of 1e7: 0.63 instead of 0.74).  A wave per cell; rank = entries with a smaller
+    // (column, CSR rank) key, counted with v_readlane over the cell's <= 128 keys; every load of the cell precedes its first store.
+    __syncthreads(); // the block's entries are in place (written by all waves)
+    for (int k = wave; k < K; k += kBlkThreads / kWave) {
+        const unsigned cc = (unsigned) __builtin_amdgcn_readfirstlane((int) cnt[k]); // wave-uniform: k is
+        if (cc < 2u || cc >= 128u) continue;
+        const unsigned base = (unsigned) __builtin_amdgcn_readfirstlane((int) cst[k]);
+        unsigned key[2], mw[2] = {0u, 0u};
+        long long sp[2];
+        T vv[2];
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const unsigned i = (unsigned) lane + 64u * j;
+            const bool on = i < cc;
+            sp[j] = e0 + blk_stored_pos(base + (on ? i : 0u), ge, EPL);
+            vv[j] = bval[sp[j]];
+            if constexpr (VALUES_ONLY) key[j] = kscr[sp[j]];
+            else { mw[j] = bmeta[sp[j]]; key[j] = mw[j] & 0xffffu; }
+            key[j] = on ? (key[j] << 7) | i : 0xffffffffu;
+        }
+        unsigned rank[2] = {0u, 0u};
+        const int c0 = cc < 64u ? (int) cc : 64, c1 = (int) cc - 64;
+        for (int q = 0; q < c0; ++q) {
+            const unsigned kq = (unsigned) __builtin_amdgcn_readlane((int) key[0], q);
+            rank[0] += kq < key[0];
+            rank[1] += kq < key[1];
+        }
+        for (int q = 0; q < c1; ++q) {
+            const unsigned kq = (unsigned) __builtin_amdgcn_readlane((int) key[1], q);
+            rank[0] += kq < key[0];
+            rank[1] += kq < key[1];
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); // every load of the cell before its first store
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+            if ((unsigned) lane + 64u * j < cc) {
+                const long long np = e0 + blk_stored_pos(base + rank[j], ge, EPL);
+                bval[np] = vv[j];
+                if constexpr (!VALUES_ONLY) bmeta[np] = mw[j];
             }
     }
 }
@@ -432,6 +480,101 @@ __global__ __launch_bounds__(kWave) void blk_kernel(const int *__restrict__ row0
         blk_dbg_times[4 * blockIdx.x + 3] = (unsigned long long) blk | ((unsigned long long) d.ns << 32);
     }
 #endif
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// The WIDE form (round 4): ONE row block per CU -- up to ~20 k rows, 159 KiB of double accumulators -- walked by W wavefronts of one
+// workgroup that SHARE the accumulators.  Why: what bounds the executor on columns without locality is the number of L2 lines
+// its gathers request (one 128-byte line per gathered double that does not merge with a neighbour in its
+// instruction); the lanes of one gather instruction hold 64 consecutive entries of the block's column-sorted order, so the
+// lines per entry are (1 - exp(-l)) / l with l = entries per line and block = rows x nnz-per-row x 16 / n -- 0.79 at 10 k rows
+// (two blocks per CU), 0.63 at 20 k.  More rows per accumulator set is the only lever, and one wavefront cannot keep a CU's
+// memory pipeline full alone (a block alone on its CU: 546 us against 690 us for two side by side, tools/blk_timeline.py).
+//   work split   wave w takes the block's steps w, w + W, w + 2 W, ... (a step = UN groups): all waves sweep the column slabs
+//                together, the XCD's blocks stay in step as before.
+//   ORD = 0      every wave adds its products as they arrive (ds_add_f64 on shared accumulators): the order in which two
+//                waves' additions reach one row is decided by the hardware -- results are correct to rounding but NOT
+//                reproducible bit for bit (option "deterministic" = 0).
+//   ORD = 1      the waves take TURNS at adding: in every phase (one step per wave) wave 0 adds, waits for its LDS
+//                operations, barrier, wave 1 adds, ... -- additions reach every row in (phase, wave, instruction, lane)
+//                order, a function of the stored stream alone: bit-reproducible like the one-wave form.  Loads and gathers
+//                are not ordered (they stay in flight across the barriers: s_barrier without the vmcnt drain of
+//                __syncthreads); the LDS unit executes one wave's adds at a time either way.
+template <typename T, int UN, int W, bool ORD>
+__global__ __launch_bounds__(kWave * W) void blk_wide_kernel(const int *__restrict__ row0, int R, const BlkDir *__restrict__ dir, const T *__restrict__ bval,
+                                                             const unsigned *__restrict__ bmeta, const int *__restrict__ hdr, const int *__restrict__ order,
+                                                             const T *__restrict__ x, T *__restrict__ y, int accumulate)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char blk_y_lds[];
+    double *ys = reinterpret_cast<double *>(blk_y_lds);
+    constexpr int EPL = 16 / (int) sizeof(T);
+    constexpr int NT = kWave * W;
+    const int tid = threadIdx.x, lane = tid & (kWave - 1);
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int blk = order[blockIdx.x];
+    const BlkDir d = dir[blk];
+    if (accumulate && d.ns == 0) return;
+    for (int i = tid; i <= R; i += NT) ys[i] = 0.0;
+    __syncthreads();
+    const long long e0 = d.g0 * (long long) (kWave * EPL);
+    const T *__restrict__ bv = bval + e0;
+    const unsigned *__restrict__ bm = bmeta + e0;
+    const int *__restrict__ hd = hdr + d.g0;
+    static_assert(kBlkStepGroups % UN == 0, "a block's region is a whole number of steps");
+    const int nsteps = d.ns / UN;
+    const int mine = nsteps > wave ? (nsteps - wave + W - 1) / W : 0; // steps wave, wave + W, ...
+    const int phases = (nsteps + W - 1) / W;
+    if (ORD ? phases > 0 : mine > 0) {
+        BlkStep<T, UN> g0, g1, g2;
+        T x0[UN][EPL], x1[UN][EPL];
+        auto gather = [&](const BlkStep<T, UN> &g, T(&xv)[UN][EPL]) {
+#pragma unroll
+            for (int u = 0; u < UN; ++u) {
+                const T *__restrict__ xs = x + __builtin_amdgcn_readlane(g.h, u);
+#pragma unroll
+                for (int j = 0; j < EPL; ++j) xv[u][j] = xs[g.w[u][j] & 0xffffu];
+            }
+        };
+        auto add = [&](const BlkStep<T, UN> &g, const T(&xv)[UN][EPL]) {
+#pragma unroll
+            for (int u = 0; u < UN; ++u)
+#pragma unroll
+                for (int j = 0; j < EPL; ++j) lds_add(&ys[g.w[u][j] >> 16], (double) (g.v[u][j] * xv[u][j]));
+        };
+        // step t of this wave = groups [(t W + wave) UN, ... + UN) of the region; steps past the block's end are loaded and gathered
+        // (the next block's region or the padding behind the last one: valid columns), never added
+        const int gw = wave * UN, gs = W * UN;
+        blk_load_step<T, UN>(gw, lane, bv, bm, hd, g0);
+        blk_load_step<T, UN>(gw + gs, lane, bv, bm, hd, g1);
+        gather(g0, x0);
+        const int last = ORD ? phases : mine;
+#define SPMV_BLK_WPHASE(ga, gb, gc, xa, xbb)                                                                               \
+        blk_load_step<T, UN>(gw + (t + 2) * gs, lane, bv, bm, hd, gc);                                                     \
+        gather(gb, xbb);                                                                                                   \
+        if constexpr (ORD) {                                                                                               \
+            for (int w = 0; w < W; ++w) {                                                                                  \
+                if (w == wave && t < mine) add(ga, xa);                                                                    \
+                asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");                                            \
+            }                                                                                                              \
+        } else {                                                                                                           \
+            add(ga, xa);                                                                                                   \
+        }                                                                                                                  \
+        if (++t >= last) break;
+        for (int t = 0;;) {
+            SPMV_BLK_WPHASE(g0, g1, g2, x0, x1)
+            SPMV_BLK_WPHASE(g1, g2, g0, x1, x0)
+            SPMV_BLK_WPHASE(g2, g0, g1, x0, x1)
+            SPMV_BLK_WPHASE(g0, g1, g2, x1, x0)
+            SPMV_BLK_WPHASE(g1, g2, g0, x0, x1)
+            SPMV_BLK_WPHASE(g2, g0, g1, x1, x0)
+        }
+#undef SPMV_BLK_WPHASE
+    }
+    __syncthreads();
+    const long long r0 = row0[blk];
+    const int nr = row0[blk + 1] - (int) r0;
+    if (accumulate) for (int i = tid; i < nr; i += NT) y[r0 + i] += (T) ys[i];
+    else for (int i = tid; i < nr; i += NT) y[r0 + i] = (T) ys[i];
 }
 
 } // namespace spmv

@@ -44,7 +44,7 @@ constexpr int kCsr5YoffShift = 16;
 
 // ---------------------------------------------------------------------------- inspector kernels
 // flags[r] = row r is non-empty
-__global__ __launch_bounds__(kBlock) void csr5_nonempty_kernel(int m, const int *__restrict__ rowptr, int *__restrict__ flags)
+static __global__ __launch_bounds__(kBlock) void csr5_nonempty_kernel(int m, const int *__restrict__ rowptr, int *__restrict__ flags)
 {
     const long long stride = (long long) gridDim.x * kBlock;
     for (long long r = (long long) blockIdx.x * kBlock + threadIdx.x; r < m; r += stride)
@@ -53,7 +53,7 @@ __global__ __launch_bounds__(kBlock) void csr5_nonempty_kernel(int m, const int 
 
 // Three-pass exclusive scan of int32 (block sums, scan of the sums by one workgroup, apply).
 constexpr int kScanTile = kBlock * 4;
-__global__ __launch_bounds__(kBlock) void scan_block_sums_kernel(long long n, const int *__restrict__ in, int *__restrict__ sums)
+static __global__ __launch_bounds__(kBlock) void scan_block_sums_kernel(long long n, const int *__restrict__ in, int *__restrict__ sums)
 {
     __shared__ int wsum[kBlock / kWave];
     const long long base = (long long) blockIdx.x * kScanTile;
@@ -69,7 +69,7 @@ __global__ __launch_bounds__(kBlock) void scan_block_sums_kernel(long long n, co
     __syncthreads();
     if (threadIdx.x == 0) sums[blockIdx.x] = wsum[0] + wsum[1] + wsum[2] + wsum[3];
 }
-__global__ __launch_bounds__(kBlock) void scan_sums_inplace_kernel(int nb, int *__restrict__ sums, int *__restrict__ total)
+static __global__ __launch_bounds__(kBlock) void scan_sums_inplace_kernel(int nb, int *__restrict__ sums, int *__restrict__ total)
 {
     __shared__ int wave_tot[kBlock / kWave];
     __shared__ int carry_s;
@@ -99,7 +99,7 @@ __global__ __launch_bounds__(kBlock) void scan_sums_inplace_kernel(int nb, int *
 // Compaction: for every non-empty row r (flag 1) at compacted position k: rp2[k] = rowptr[r],
 // row_map[k] = r.  One thread handles 4 strided-by-block elements in order, so positions are
 // block_offset + (prefix inside the block), computed with a workgroup scan per 256-element slab.
-__global__ __launch_bounds__(kBlock) void csr5_compact_kernel(long long m, const int *__restrict__ flags,
+static __global__ __launch_bounds__(kBlock) void csr5_compact_kernel(long long m, const int *__restrict__ flags,
                                                               const int *__restrict__ block_off,
                                                               const int *__restrict__ rowptr,
                                                               int *__restrict__ rp2, int *__restrict__ row_map,
@@ -137,7 +137,7 @@ __global__ __launch_bounds__(kBlock) void csr5_compact_kernel(long long m, const
 }
 
 // tile_ptr[t] = last row r (of the m2-row space) with rp[r] <= min(t*T, nnz), t = 0..p
-__global__ __launch_bounds__(kBlock) void csr5_tile_ptr_kernel(int m2, int nnz, int p, int tile_nnz,
+static __global__ __launch_bounds__(kBlock) void csr5_tile_ptr_kernel(int m2, int nnz, int p, int tile_nnz,
                                                                const int *__restrict__ rp, int *__restrict__ tile_ptr)
 {
     const int t = blockIdx.x * kBlock + threadIdx.x;
@@ -150,7 +150,7 @@ __global__ __launch_bounds__(kBlock) void csr5_tile_ptr_kernel(int m2, int nnz, 
 }
 
 // out[0] = max over the tiles of tile_ptr[t + 1] - tile_ptr[t] (out zeroed by the caller): sizes the waves' row-map buffers.
-__global__ __launch_bounds__(kBlock) void csr5_tile_rows_max_kernel(int p, const int *__restrict__ tile_ptr, int *__restrict__ out)
+static __global__ __launch_bounds__(kBlock) void csr5_tile_rows_max_kernel(int p, const int *__restrict__ tile_ptr, int *__restrict__ out)
 {
     const int t = blockIdx.x * kBlock + threadIdx.x;
     int v = t < p ? tile_ptr[t + 1] - tile_ptr[t] : 0;

@@ -46,7 +46,7 @@ __device__ __forceinline__ void tile_rows(int b, int m, int rows_per_tile, const
 
 // Inspector: windows of one row tile + the tile-local 16-bit column stream (written for staged tiles
 // only; unstaged tiles and long rows are computed from the original ColIdx).
-__global__ __launch_bounds__(kBlock) void csr_tile_windows_kernel(int m, int n, int rows_per_tile, int long_thr, int max_cols, int slot_bytes,
+static __global__ __launch_bounds__(kBlock) void csr_tile_windows_kernel(int m, int n, int rows_per_tile, int long_thr, int max_cols, int slot_bytes,
                                                                   const int *__restrict__ split,
                                                                   const int *__restrict__ rowptr,
                                                                   const int *__restrict__ colidx,

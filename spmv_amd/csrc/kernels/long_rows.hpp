@@ -17,21 +17,21 @@
 
 namespace spmv {
 
-__global__ __launch_bounds__(kBlock) void long_rows_flag_kernel(int m, int thr, const int *__restrict__ rowptr, int *__restrict__ flags)
+static __global__ __launch_bounds__(kBlock) void long_rows_flag_kernel(int m, int thr, const int *__restrict__ rowptr, int *__restrict__ flags)
 {
     const long long stride = (long long) gridDim.x * kBlock;
     for (long long r = (long long) blockIdx.x * kBlock + threadIdx.x; r < m; r += stride)
         flags[r] = rowptr[r + 1] - rowptr[r] > thr;
 }
 
-__global__ __launch_bounds__(kBlock) void long_rows_len_kernel(int nlong, const int *__restrict__ long_rows,
+static __global__ __launch_bounds__(kBlock) void long_rows_len_kernel(int nlong, const int *__restrict__ long_rows,
                                                                const int *__restrict__ rowptr, int *__restrict__ lens)
 {
     const int i = blockIdx.x * kBlock + threadIdx.x;
     if (i < nlong) lens[i] = rowptr[long_rows[i] + 1] - rowptr[long_rows[i]];
 }
 
-__global__ __launch_bounds__(kBlock) void narrow_i64_kernel(int n, const long long *__restrict__ in, int *__restrict__ out)
+static __global__ __launch_bounds__(kBlock) void narrow_i64_kernel(int n, const long long *__restrict__ in, int *__restrict__ out)
 {
     const int i = blockIdx.x * kBlock + threadIdx.x;
     if (i < n) out[i] = (int) in[i];

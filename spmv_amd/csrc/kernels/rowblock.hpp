@@ -15,7 +15,7 @@
 namespace spmv {
 
 // split[b], b = 0..nblocks
-__global__ __launch_bounds__(kBlock) void rowblock_split_kernel(int m, int nnz, int nblocks, int stride,
+static __global__ __launch_bounds__(kBlock) void rowblock_split_kernel(int m, int nnz, int nblocks, int stride,
                                                                 const int *__restrict__ rowptr,
                                                                 int *__restrict__ split)
 {

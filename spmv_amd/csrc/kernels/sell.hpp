@@ -30,7 +30,7 @@ namespace spmv {
 constexpr int kSellC = kWave;
 
 // One workgroup per sigma window: bitonic sort of (length, slot) keys in LDS.
-__global__ __launch_bounds__(kBlock) void sell_sort_kernel(int m, int sigma, int long_thr,
+static __global__ __launch_bounds__(kBlock) void sell_sort_kernel(int m, int sigma, int long_thr,
                                                            const int *__restrict__ rowptr,
                                                            int *__restrict__ perm,
                                                            int *__restrict__ chunk_width)
@@ -75,7 +75,7 @@ __global__ __launch_bounds__(kBlock) void sell_sort_kernel(int m, int sigma, int
 
 // Exclusive prefix sum int32 -> int64 over n values (+ the total at out[n]); one workgroup walks
 // the array in 256-element steps.  n is the chunk count (1.6e5 for 1e7 rows): inspector only.
-__global__ __launch_bounds__(kBlock) void scan_i32_to_i64_kernel(int n, const int *__restrict__ in,
+static __global__ __launch_bounds__(kBlock) void scan_i32_to_i64_kernel(int n, const int *__restrict__ in,
                                                                  long long *__restrict__ out)
 {
     __shared__ long long wave_tot[kBlock / kWave];
@@ -264,7 +264,7 @@ __device__ __forceinline__ void sell_chunk_run(unsigned run, const T *__restrict
 
 // Inspector: is window group w a RUN group?  One workgroup per group, a wave per chunk (lane = row slot) walks the row's slots in the
 // slab.  counters[0] += groups, [1] += entries (real ones), [2] += stored slab entries, [3] += row slots of the RUN groups.
-__global__ __launch_bounds__(kBlock) void sell_runs_kernel(int chunks_per_win, long long nchunks, const long long *__restrict__ chunk_ptr,
+static __global__ __launch_bounds__(kBlock) void sell_runs_kernel(int chunks_per_win, long long nchunks, const long long *__restrict__ chunk_ptr,
                                                            const unsigned short *__restrict__ scol16, const int *__restrict__ perm,
                                                            const int *__restrict__ rowptr, TileWindows *__restrict__ wins,
                                                            unsigned *__restrict__ sell_run, unsigned long long *__restrict__ counters)

@@ -29,7 +29,7 @@ __device__ __forceinline__ int median5(int a, int b, int c, int d, int e)
 }
 
 // centre[t] = median column of five entries spread over tile t's entries (-1: the tile has none)
-__global__ __launch_bounds__(kBlock) void split_center_kernel(int m, const int *__restrict__ rowptr, const int *__restrict__ colidx, int tiles, int *__restrict__ centre)
+static __global__ __launch_bounds__(kBlock) void split_center_kernel(int m, const int *__restrict__ rowptr, const int *__restrict__ colidx, int tiles, int *__restrict__ centre)
 {
     const int t = blockIdx.x * kBlock + threadIdx.x;
     if (t >= tiles) return;
@@ -42,7 +42,7 @@ __global__ __launch_bounds__(kBlock) void split_center_kernel(int m, const int *
 __device__ __forceinline__ bool split_is_near(int c, int centre, int half) { return centre >= 0 && c >= centre - half && c < centre + half; }
 
 // near[r] = entries of row r inside its tile's window; 16 lanes sweep a row
-__global__ __launch_bounds__(kBlock) void split_count_kernel(int m, const int *__restrict__ rowptr, const int *__restrict__ colidx, const int *__restrict__ centre, int half,
+static __global__ __launch_bounds__(kBlock) void split_count_kernel(int m, const int *__restrict__ rowptr, const int *__restrict__ colidx, const int *__restrict__ centre, int half,
                                                              int *__restrict__ near)
 {
     const int sub = threadIdx.x / 16, l = threadIdx.x % 16;
@@ -59,7 +59,7 @@ __global__ __launch_bounds__(kBlock) void split_count_kernel(int m, const int *_
 
 // out[i] = block_off[i / kScanTile] + exclusive prefix of in[] inside the 1024-element tile (third pass of the scan in csr5.hpp);
 // out[n] = total is written by the caller.  Also far_rp[i] = rowptr[i] - out[i] when far_rp != NULL (the other half's row pointer).
-__global__ __launch_bounds__(kBlock) void scan_apply_kernel(long long n, const int *__restrict__ in, const int *__restrict__ block_off, int *__restrict__ out,
+static __global__ __launch_bounds__(kBlock) void scan_apply_kernel(long long n, const int *__restrict__ in, const int *__restrict__ block_off, int *__restrict__ out,
                                                             const int *__restrict__ rowptr, int *__restrict__ far_rp)
 {
     __shared__ int wave_tot[kBlock / kWave];
@@ -133,7 +133,7 @@ __global__ __launch_bounds__(kBlock) void split_scatter_kernel(int m, const int 
 
 // Sampled estimate of the near share (before anything is built): 64 windows of 4096 consecutive entries, the window's centre =
 // median of five of its entries, near = within +-half of it.  out[0] += near entries, out[1] += entries looked at.
-__global__ __launch_bounds__(kBlock) void split_sample_kernel(long long nnz, int windows, int wlen, const int *__restrict__ colidx, int half, unsigned long long *__restrict__ out)
+static __global__ __launch_bounds__(kBlock) void split_sample_kernel(long long nnz, int windows, int wlen, const int *__restrict__ colidx, int half, unsigned long long *__restrict__ out)
 {
     const long long start = windows > 1 ? (nnz - wlen) / (windows - 1) * blockIdx.x : 0;
     int c = 0;

@@ -35,7 +35,7 @@ struct TileWindows {
 };
 
 // sum of TileWindows::total over `count` tiles: the x elements one launch stages (traffic model, spmv_hip_info.stream_bytes)
-__global__ __launch_bounds__(kBlock) void wins_total_kernel(int count, const TileWindows *__restrict__ wins, unsigned long long *__restrict__ sum,
+static __global__ __launch_bounds__(kBlock) void wins_total_kernel(int count, const TileWindows *__restrict__ wins, unsigned long long *__restrict__ sum,
                                                             unsigned long long *__restrict__ staged_tiles)
 {
     unsigned long long t = 0, c = 0;
@@ -223,7 +223,7 @@ __device__ __forceinline__ void build_windows(int n, int max_cols, Loop loop, St
 // 16-bit stream cols16, padding entries to the zero slot; pack16 = 0: same positions, pack16 =
 // sigma (CSR5): position t*64*sigma + i*64 + lane -> t*64*sigma + (i/4)*256 + lane*4 + i%4, so a
 // lane fetches four slots with one 8-byte load.
-__global__ __launch_bounds__(kBlock) void range_windows_kernel(long long total, long long group_len,
+static __global__ __launch_bounds__(kBlock) void range_windows_kernel(long long total, long long group_len,
                                                                const long long *__restrict__ bounds, int bstride, int scale,
                                                                long long nbounds /* bounds has nbounds + 1 entries */,
                                                                int n, int max_cols, int *__restrict__ cols,

@@ -516,16 +516,24 @@ static int blocked_fill(spmv_dev *d, bool values_only)
         (void) hipMemsetAsync(S.hdr, 0, sizeof(int) * ng, d->stream);
     }
     const size_t lds = 3 * sizeof(unsigned) * (size_t) K;
+    unsigned short *kscr = nullptr; // values-only refresh of a column-sorted layout: the cells' sort keys, which the stored words no longer hold in CSR order
     if (values_only) {
+        if (S.subsort && pool_malloc((void **) &kscr, sizeof(unsigned short) * (((size_t) S.groups + kBlkPadGroups) << S.ge)) != hipSuccess) {
+            (void) hipGetLastError();
+            return fail(SPMV_HIP_E_ALLOC, "pool_malloc(block refresh scratch)");
+        }
         ensure_lds<blk_fill_kernel<T, true>>(d, lds);
-        blk_fill_kernel<T, true><<<B, kBlkThreads, lds, d->stream>>>(S.row0, K, S.wshift, S.ge, d->rowptr, d->colidx, (const T *) d->val, nullptr, S.gstart, (T *) S.val, S.meta, S.hdr, S.dir);
+        blk_fill_kernel<T, true><<<B, kBlkThreads, lds, d->stream>>>(S.row0, K, S.wshift, S.ge, d->rowptr, d->colidx, (const T *) d->val, nullptr, S.gstart, (T *) S.val, S.meta, S.hdr, S.dir,
+                                                                     S.subsort ? 1 : 0, kscr);
     } else {
         ensure_lds<blk_fill_kernel<T, false>>(d, lds);
-        blk_fill_kernel<T, false><<<B, kBlkThreads, lds, d->stream>>>(S.row0, K, S.wshift, S.ge, d->rowptr, d->colidx, (const T *) d->val, rowin, S.gstart, (T *) S.val, S.meta, S.hdr, S.dir);
+        blk_fill_kernel<T, false><<<B, kBlkThreads, lds, d->stream>>>(S.row0, K, S.wshift, S.ge, d->rowptr, d->colidx, (const T *) d->val, rowin, S.gstart, (T *) S.val, S.meta, S.hdr, S.dir,
+                                                                      S.subsort ? 1 : 0, nullptr);
     }
     if (e == hipSuccess) e = hipGetLastError();
     if (e == hipSuccess) e = hipStreamSynchronize(d->stream);
     cleanup();
+    if (kscr) (void) pool_free(kscr);
     if (e != hipSuccess) return fail(SPMV_HIP_E_RUNTIME, "block fill: %s", hipGetErrorString(e));
     if (!values_only) { // launch order (blk_kernel): by how scattered a block's entries are -- classes of occupied cells per entry, the most scattered first --, row order inside a class, empty blocks last
         std::vector<BlkDir> hd((size_t) B);
@@ -551,6 +559,7 @@ static int blocked_fill(spmv_dev *d, bool values_only)
 static size_t blocked_lds_bytes(const BlkSet &S) { return sizeof(double) * (size_t) ((S.R + 2) & ~1); }
 
 constexpr int kBlkRowCap = 78 * 1024 / (int) sizeof(double) - 2; // most rows of a block such that TWO blocks fit a CU's 160 KiB of LDS (78 KiB each)
+constexpr int kBlkRowCapWide = 159 * 1024 / (int) sizeof(double) - 2; // wide form: ONE block per CU (159 KiB of accumulators)
 
 // How many row blocks, and how many rows at most in one.  rule 0 (first choice): FULL ROUNDS of fat blocks -- two blocks are
 // resident per CU (2 x 78 KiB of its 160 KiB of LDS), so the block count is a multiple of 2 * CUs with at most rmax rows each:
@@ -568,7 +577,7 @@ static void blocked_block_rule(const spmv_dev *d, int rule, int rmax, int *btarg
         return;
     }
     if (rule == 0) {
-        const long long slots = 2ll * (d->cus > 0 ? d->cus : 256);
+        const long long slots = (rmax > kBlkRowCap ? 1ll : 2ll) * (d->cus > 0 ? d->cus : 256); // wide form: one block per CU
         const long long rounds = ((long long) d->m + slots * rmax - 1) / (slots * rmax);
         long long B = slots * (rounds > 0 ? rounds : 1);
         if ((long long) d->m / B < 1024) B = ((long long) d->m + 1023) / 1024; // small matrices: blocks of about 1024 rows
@@ -628,7 +637,7 @@ static int blocked_partition(spmv_dev *d, int btarget, int rcap)
 }
 
 template <typename T>
-static int build_blocked(spmv_dev *d, int rule)
+static int build_blocked(spmv_dev *d, int rule, int waves, bool ordered)
 {
     BlkSet &S = d->blk;
     S = BlkSet();
@@ -646,12 +655,16 @@ static int build_blocked(spmv_dev *d, int rule)
     S.K = (int) ((((long long) d->n - 1) >> wshift) + 1);
     S.ge = sizeof(T) == 8 ? 7 : 8; // 64 lanes x 16 bytes of values
     int btarget = 1, rcap = 1024;
-    blocked_block_rule(d, rule, kBlkRowCap, &btarget, &rcap);
+    S.waves = waves;
+    if (S.waves != 1 && S.waves != 2 && S.waves != 4 && S.waves != 8) return fail(SPMV_HIP_E_ARG, "blk_waves must be 0, 1, 2, 4 or 8, got %d", waves);
+    S.ordered = ordered;
+    S.subsort = d->plan.blk_subsort != 0;
+    blocked_block_rule(d, S.waves > 1 ? 0 : rule, S.waves > 1 ? kBlkRowCapWide : kBlkRowCap, &btarget, &rcap);
     int rc = blocked_partition(d, btarget, rcap);
     if (!rc) rc = blocked_fill<T>(d, false);
     if (rc) return rc;
     if (getenv("SPMV_HIP_BLK_DEBUG"))
-        fprintf(stderr, "[spmv_hip] blocked: m %d nnz %lld -> B %d (target %d) R %d K %d wshift %d groups %lld accumulate %d\n", d->m, d->nnz, S.B, btarget, S.R, S.K, S.wshift, S.groups, (int) d->accumulate);
+        fprintf(stderr, "[spmv_hip] blocked: m %d nnz %lld -> B %d (target %d) R %d K %d wshift %d groups %lld accumulate %d waves %d ordered %d subsort %d\n", d->m, d->nnz, S.B, btarget, S.R, S.K, S.wshift, S.groups, (int) d->accumulate, S.waves, (int) S.ordered, (int) S.subsort);
     d->blk_on = true;
     return SPMV_HIP_OK;
 }
@@ -691,7 +704,7 @@ static int blocked_mode(const spmv_dev *d, int staged, int groups)
 // its entries touch so many distinct 64-column segments of x that not even the largest LDS budget (128 KiB) could hold them,
 // and more than a third of its entries sit in a segment of their own.  If (nearly) every window says so, no tile schedule will
 // stage anything and its inspector products (windows, CSR5 transposes, SELL slabs) would be built only to be dropped.
-__global__ __launch_bounds__(kBlock) void locality_sample_kernel(long long nnz, int windows, int wlen, const int *__restrict__ colidx, int seg_limit, int *__restrict__ hopeless)
+static __global__ __launch_bounds__(kBlock) void locality_sample_kernel(long long nnz, int windows, int wlen, const int *__restrict__ colidx, int seg_limit, int *__restrict__ hopeless)
 {
     constexpr int kSlots = 8192; // open-addressing set of segment ids, 2 x the window length
     __shared__ int set[kSlots];

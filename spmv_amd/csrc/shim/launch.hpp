@@ -4,57 +4,15 @@
 #pragma once
 
 // ------------------------------------------------------------------------------------ executors
-// One workgroup per kVecNB * (256/L) consecutive rows, dispatched in row order: measured on the
-// config-2 shape a plain in-order grid beats a persistent grid-stride loop by ~10 %.
-constexpr int kVecNB = 4;
-// Kernel forms of the CSR-vector schedule.  Which one is fastest differs between MI355X boxes by a
-// few percent, so create() times the applicable ones once on the resident matrix
-// (autotune_vector) and keeps the winner in d->vec_choice; plan.variant overrides for A/B runs.
-enum { VEC_AUTO = 0, VEC_PIPE = 4, VEC_TILE_D2 = 5, VEC_TILE_D8 = 6, VEC_TILE_D4 = 10, VEC_TILE_D4_NOPRE = 11, VEC_TILE_D2_NOPRE = 12 };
-
-template <typename T, int L, int DEPTH, bool PRE = true>
-static void launch_vector_tile(spmv_dev *d, const T *x, T *y, int long_thr)
-{
-    const size_t lds = ((((size_t) d->vt_maxspan + 1) * sizeof(T)) + 1023) & ~(size_t) 1023; // + the zero slot
-    ensure_lds<csr_vector_tile_kernel<T, L, DEPTH, PRE>>(d, lds);
-    csr_vector_tile_kernel<T, L, DEPTH, PRE><<<d->vt_tiles, kVecTileThreads, lds, d->stream>>>(d->m, long_thr, d->rowptr, d->colidx, d->vt_col, (const T *) d->val,
-                                                                                           d->vt_wins, d->vt_rowslot, x, y);
-}
-
-template <typename T, int L>
-static void launch_vector(spmv_dev *d, const T *x, T *y)
-{
-    const int v = d->plan.variant ? d->plan.variant : d->vec_choice;
-    const int long_thr = d->long_thr;
-    const bool tile_default = d->vt_staged * 2 >= d->vt_tiles; // most x tiles fit LDS
-    const bool tile_forced = v == VEC_TILE_D2 || v == VEC_TILE_D4 || v == VEC_TILE_D8 || v == VEC_TILE_D4_NOPRE || v == VEC_TILE_D2_NOPRE;
-    if (d->vt_tiles > 0 && v != VEC_PIPE && (tile_default || tile_forced)) { // tile kernel (unstaged tiles gather from L1/L2)
-        if (v == VEC_TILE_D2) launch_vector_tile<T, L, 2>(d, x, y, long_thr);
-        else if (v == VEC_TILE_D8) launch_vector_tile<T, L, 8>(d, x, y, long_thr);
-        else if (v == VEC_TILE_D4) launch_vector_tile<T, L, 4>(d, x, y, long_thr);
-        else if (v == VEC_TILE_D4_NOPRE) launch_vector_tile<T, L, 4, false>(d, x, y, long_thr);
-        else if (v == VEC_TILE_D2_NOPRE) launch_vector_tile<T, L, 2, false>(d, x, y, long_thr);
-        else launch_vector_tile<T, L, (sizeof(T) == 8 ? 4 : 2)>(d, x, y, long_thr); // measured default
-        return;
-    }
-    constexpr int rows = kBlock / L * kVecNB;
-    const int grid = grid_for(d->m, rows, INT_MAX);
-    csr_vector_pipe_kernel<T, L, kVecNB><<<grid, kBlock, 0, d->stream>>>(d->m, long_thr, d->rowptr, d->colidx, (const T *) d->val, x, y);
-}
-
-template <typename T>
-static void launch_vector_any(spmv_dev *d, const T *x, T *y)
-{
-    switch (d->plan.lanes_per_row) {
-    case 1: launch_vector<T, 1>(d, x, y); break;
-    case 2: launch_vector<T, 2>(d, x, y); break;
-    case 4: launch_vector<T, 4>(d, x, y); break;
-    case 8: launch_vector<T, 8>(d, x, y); break;
-    case 16: launch_vector<T, 16>(d, x, y); break;
-    case 32: launch_vector<T, 32>(d, x, y); break;
-    default: launch_vector<T, 64>(d, x, y); break;
-    }
-}
+// The CSR-vector family's launchers (tile / pipe / rows kernels for every lanes-per-row value: the bulk of the library's device
+// code) live in their own translation unit, spmv_vector.hip (shim/launch_vector.hpp), compiled beside this one.
+#include "vector_forms.hpp"
+template <typename T> void launch_vector_any(spmv_dev *d, const T *x, T *y);
+template <typename T> void launch_rows_any(spmv_dev *d, const T *x, T *y, const int *split);
+extern template void launch_vector_any<double>(spmv_dev *, const double *, double *);
+extern template void launch_vector_any<float>(spmv_dev *, const float *, float *);
+extern template void launch_rows_any<double>(spmv_dev *, const double *, double *, const int *);
+extern template void launch_rows_any<float>(spmv_dev *, const float *, float *, const int *);
 
 // Time the applicable CSR-vector forms on the resident matrix (x = 1) and keep the fastest.
 template <typename T>
@@ -113,29 +71,55 @@ static int autotune_vector(spmv_dev *d)
     return SPMV_HIP_OK;
 }
 
-// Row blocks x column slabs (kernels/blocked.hpp): one single-wave workgroup per row block.  Forms = groups per pipeline
-// step: 8 / 12 (d->blk.form 0 / 1, chosen by autotune_blocked; option variant 35 / 37 forces one -- both add the same products
-// in the same order: tests compare their bits).  4 groups per step lost everywhere (Orkut-style 0.82 vs 0.58-0.63 ms) and is gone.
+// Row blocks x column slabs (kernels/blocked.hpp).  One-wave form: a single-wave workgroup per row block, two per CU; wide form
+// (S.waves = 4 / 8): one workgroup of that many waves per block, one block per CU, the waves taking turns at adding (S.ordered) or
+// not.  Forms = groups per pipeline step (S.form 0 / 1, chosen by autotune_blocked; option blk_groups forces one): 8 / 12 with one
+// or four waves, 6 / 8 with eight (256 registers per wave).  All forms of one layout add the same products; the one-wave forms and
+// the ordered wide forms each in a fixed order (tests compare their bits).
+static void blocked_forms(const BlkSet &S, int un[2])
+{
+    un[0] = S.waves == 8 ? 6 : 8;
+    un[1] = S.waves == 8 ? 8 : 12;
+}
+
 template <typename T>
 static void launch_blocked(spmv_dev *d, const T *x, T *y)
 {
     const BlkSet &S = d->blk;
-    static const size_t lds_pad = getenv("SPMV_HIP_BLK_LDS_PAD") ? (size_t) atol(getenv("SPMV_HIP_BLK_LDS_PAD")) : 0; // experiment knob
-    const size_t lds = blocked_lds_bytes(S) + lds_pad;
+    const size_t lds = blocked_lds_bytes(S);
 #define SPMV_BLK_LAUNCH(UN, DBG)                                                                                                  \
     do {                                                                                                                          \
         ensure_lds<blk_kernel<T, UN, DBG>>(d, lds);                                                                               \
         blk_kernel<T, UN, DBG><<<S.B, kWave, lds, d->stream>>>(S.row0, S.R, S.dir, (const T *) S.val, S.meta, S.hdr, S.order, x, y, d->accumulate ? 1 : 0); \
     } while (0)
+#define SPMV_BLK_WLAUNCH(UN, W, ORD)                                                                                              \
+    do {                                                                                                                          \
+        ensure_lds<blk_wide_kernel<T, UN, W, ORD>>(d, lds);                                                                       \
+        blk_wide_kernel<T, UN, W, ORD><<<S.B, kWave * W, lds, d->stream>>>(S.row0, S.R, S.dir, (const T *) S.val, S.meta, S.hdr, S.order, x, y, d->accumulate ? 1 : 0); \
+    } while (0)
+#define SPMV_BLK_WFORM(UN, W) do { if (S.ordered) SPMV_BLK_WLAUNCH(UN, W, true); else SPMV_BLK_WLAUNCH(UN, W, false); } while (0)
 #ifdef SPMV_BLK_DEBUG_FORMS // A/B builds of tools/ only (wrong results): variant 51 / 52 / 53 = no gathers / no LDS adds / neither, 8 groups per step
     if (d->plan.variant == 51) { SPMV_BLK_LAUNCH(8, 1); return; }
     if (d->plan.variant == 52) { SPMV_BLK_LAUNCH(8, 2); return; }
     if (d->plan.variant == 53) { SPMV_BLK_LAUNCH(8, 3); return; }
 #endif
+    int un[2];
+    blocked_forms(S, un);
     const int form = d->plan.variant == 35 ? 0 : (d->plan.variant == 37 ? 1 : S.form);
-    if (form == 1) SPMV_BLK_LAUNCH(12, 0);
-    else SPMV_BLK_LAUNCH(8, 0);
+    const int g = d->plan.blk_groups > 0 ? d->plan.blk_groups : un[form];
+    if (S.waves == 2) {
+        if (g == 12) SPMV_BLK_WFORM(12, 2); else SPMV_BLK_WFORM(8, 2);
+    } else if (S.waves == 4) {
+        if (g == 12) SPMV_BLK_WFORM(12, 4); else if (g == 6) SPMV_BLK_WFORM(6, 4); else if (g == 4) SPMV_BLK_WFORM(4, 4); else SPMV_BLK_WFORM(8, 4);
+    } else if (S.waves == 8) {
+        if (g == 8) SPMV_BLK_WFORM(8, 8); else if (g == 4) SPMV_BLK_WFORM(4, 8); else SPMV_BLK_WFORM(6, 8);
+    } else {
+        if (g == 12) SPMV_BLK_LAUNCH(12, 0);
+        else SPMV_BLK_LAUNCH(8, 0);
+    }
+#undef SPMV_BLK_WFORM
 #undef SPMV_BLK_LAUNCH
+#undef SPMV_BLK_WLAUNCH
 }
 
 // Time the executor forms on the resident streams (x = 1: the gather pattern does not depend on the values) and keep the faster.
@@ -144,7 +128,7 @@ static int autotune_blocked(spmv_dev *d)
 {
     d->blk.form = 0;
     d->blk.tune_ms[0] = d->blk.tune_ms[1] = d->blk.tune_ms[2] = 0;
-    if (!d->blk_on || !d->plan.autotune || d->plan.variant != 0) return SPMV_HIP_OK;
+    if (!d->blk_on || !d->plan.autotune || d->plan.variant != 0 || d->plan.blk_groups != 0) return SPMV_HIP_OK;
     T *x = nullptr, *y = nullptr;
     if (pool_malloc((void **) &x, sizeof(T) * (size_t) d->n) != hipSuccess || pool_malloc((void **) &y, sizeof(T) * (size_t) d->m) != hipSuccess) {
         (void) hipGetLastError();
@@ -260,37 +244,6 @@ static int launch_csr5(spmv_dev *d, const Csr5Plan &P, const T *x, T *y)
         else csr5_fixup_kernel<T, false><<<g, kBlock, 0, d->stream>>>(P.tiles, P.tile_ptr, P.run_len, nullptr, (const T *) P.carry, y);
     }
     return SPMV_HIP_OK;
-}
-
-// The rows kernel: Balanced's equal-nnz row blocks (split), or CSR-vector's wide form (uniform blocks).
-template <typename T, int L>
-static void launch_rows(spmv_dev *d, const T *x, T *y, const int *split)
-{
-    constexpr int DEPTH = sizeof(T) == 8 ? 4 : 2;
-    const size_t lds = ((((size_t) d->vt_maxspan + 1) * sizeof(T)) + 1023) & ~(size_t) 1023; // + the zero slot
-    if (d->vt_wide) {
-        ensure_lds<csr_vector_rows_kernel<T, L, DEPTH, true>>(d, lds);
-        csr_vector_rows_kernel<T, L, DEPTH, true><<<d->vt_tiles, kVecTileThreads, lds, d->stream>>>(
-            d->long_thr, split, d->vt_rows, d->m, d->rowptr, d->colidx, d->vt_col, (const T *) d->val, d->vt_wins, d->vt_rowslot, x, y);
-        return;
-    }
-    ensure_lds<csr_vector_rows_kernel<T, L, DEPTH, false>>(d, lds);
-    csr_vector_rows_kernel<T, L, DEPTH><<<d->vt_tiles, kVecTileThreads, lds, d->stream>>>(
-        d->long_thr, split, d->vt_rows, d->m, d->rowptr, d->colidx, d->vt_col, (const T *) d->val, d->vt_wins, d->vt_rowslot, x, y);
-}
-
-template <typename T>
-static void launch_rows_any(spmv_dev *d, const T *x, T *y, const int *split)
-{
-    switch (d->plan.lanes_per_row) {
-    case 1: launch_rows<T, 1>(d, x, y, split); break;
-    case 2: launch_rows<T, 2>(d, x, y, split); break;
-    case 4: launch_rows<T, 4>(d, x, y, split); break;
-    case 8: launch_rows<T, 8>(d, x, y, split); break;
-    case 16: launch_rows<T, 16>(d, x, y, split); break;
-    case 32: launch_rows<T, 32>(d, x, y, split); break;
-    default: launch_rows<T, 64>(d, x, y, split); break;
-    }
 }
 
 template <typename T>

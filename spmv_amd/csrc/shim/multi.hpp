@@ -124,7 +124,7 @@ extern "C" void spmv_shim_multi_destroy(spmv_multi *mt)
 }
 
 // flags[r] = 1 if row r references a column outside [lo, hi); 16 lanes sweep a row
-__global__ __launch_bounds__(kBlock) void rows_outside_kernel(int m, const int *__restrict__ rowptr, const int *__restrict__ colidx, int lo, int hi, int *__restrict__ flags)
+static __global__ __launch_bounds__(kBlock) void rows_outside_kernel(int m, const int *__restrict__ rowptr, const int *__restrict__ colidx, int lo, int hi, int *__restrict__ flags)
 {
     const int sub = threadIdx.x / 16, l = threadIdx.x % 16;
     const long long stride = (long long) gridDim.x * (kBlock / 16);

@@ -16,7 +16,9 @@ static int fail(int code, const char *fmt, ...)
     return code;
 }
 
+#ifndef SPMV_TU_SECONDARY
 extern "C" const char *spmv_shim_error_text(void) { return t_err; }
+#endif
 
 #define HIP_TRY(expr)                                                                              \
     do {                                                                                           \
@@ -116,11 +118,13 @@ static hipError_t pool_free(void *p)
     return hipFree(p);
 }
 
+#ifndef SPMV_TU_SECONDARY
 extern "C" void spmv_shim_trim_pool(void)
 {
     std::lock_guard<std::mutex> g(g_pool_lock);
     pool_trim_locked();
 }
+#endif
 
 // Makes `device` current for the life of the guard and restores the caller's device afterwards.
 struct DeviceGuard {
@@ -165,7 +169,10 @@ struct Csr5Plan {
 struct BlkSet {
     int R = 0, K = 0, B = 0, wshift = kBlkSlabShift; // most rows of a block (= the junk accumulator's slot), slabs, blocks, log2(columns per slab)
     int ge = 7;                   // log2(entries per group)
-    int form = 0;                 // executor form: 0 / 1 = 8 / 12 groups per step (launch_blocked; chosen by autotune_blocked)
+    int form = 0;                 // executor form: 0 / 1 = the fewer / more groups per step of the width's two forms (launch_blocked; chosen by autotune_blocked)
+    int waves = 1;                // wavefronts sharing one block's accumulators: 1 = a wave per block, two blocks per CU; 4 / 8 = the wide form, one block per CU
+    bool ordered = true;          // wide form: the waves take turns at adding (bit-reproducible); false: arrival order (option deterministic = 0)
+    bool subsort = true;          // sparse cells stored sorted by column
     float tune_ms[3] = {0, 0, 0};
     long long groups = 0;         // groups stored (without the padding behind the last block)
     int *row0 = nullptr;          // [B + 1] first row of every block (equal-work cut points, blk_partition_kernel)
@@ -331,15 +338,17 @@ static bool is_device_ptr(const void *p)
     return a.type == hipMemoryTypeDevice || a.type == hipMemoryTypeManaged;
 }
 
+#ifndef SPMV_TU_SECONDARY
 extern "C" int spmv_shim_device_count(void)
 {
     int n = 0;
     if (hipGetDeviceCount(&n) != hipSuccess) { (void) hipGetLastError(); return 0; }
     return n;
 }
+#endif
 
 // ------------------------------------------------------------------------------------ stats
-__global__ __launch_bounds__(kBlock) void stats_kernel(int m, const int *__restrict__ rowptr, DevStats *s)
+static __global__ __launch_bounds__(kBlock) void stats_kernel(int m, const int *__restrict__ rowptr, DevStats *s)
 {
     __shared__ unsigned h_rows[SPMV_LEN_BUCKETS];
     __shared__ unsigned long long h_nnz[SPMV_LEN_BUCKETS];
@@ -379,7 +388,7 @@ __global__ __launch_bounds__(kBlock) void stats_kernel(int m, const int *__restr
     if (blockIdx.x == 0 && threadIdx.x == 0) { s->first = rowptr[0]; s->last = rowptr[m]; }
 }
 
-__global__ __launch_bounds__(kBlock) void count_longer_kernel(int m, int thr, const int *__restrict__ rowptr, int *count)
+static __global__ __launch_bounds__(kBlock) void count_longer_kernel(int m, int thr, const int *__restrict__ rowptr, int *count)
 {
     int c = 0;
     const long long stride = (long long) gridDim.x * kBlock;
@@ -391,7 +400,7 @@ __global__ __launch_bounds__(kBlock) void count_longer_kernel(int m, int thr, co
 }
 
 // min / max of ColIdx (create-time validation: an index outside [0, n) would make a gather fault)
-__global__ __launch_bounds__(kBlock) void colidx_range_kernel(long long nnz, const int *__restrict__ colidx, int *__restrict__ mnmx)
+static __global__ __launch_bounds__(kBlock) void colidx_range_kernel(long long nnz, const int *__restrict__ colidx, int *__restrict__ mnmx)
 {
     int mn = INT_MAX, mx = INT_MIN;
     const long long stride = (long long) gridDim.x * kBlock;

@@ -58,6 +58,12 @@ static opt_t g_opts[SPMV_N_OPTS] = {
     [SPMV_OPT_CHECK_VALUES] = {"check_values", 0, 0, 1, 0, 0},        /* 1: spmv() checksums Matrix_Val on every call and refreshes the resident
                                                                        * copy when it changed behind an unchanged pointer (common.c:286-298 semantics) */
     [SPMV_OPT_GPUS] = {"gpus", 0, 0, 64, 0, 0},                       /* > 0: row blocks over min(gpus, visible devices) GPUs in this one process (multi.hpp) */
+    [SPMV_OPT_BLK_WAVES] = {"blk_waves", 0, 0, 8, 1, 0},              /* row-block x column-slab executor: wavefronts that share ONE row block's accumulators: 1 = a wave per block, two blocks
+                                                                       * per CU (rounds 2-3); 4 / 8 = one block of up to ~20 k rows per CU (kernels/blocked.hpp "wide form"); 0 = automatic */
+    [SPMV_OPT_BLK_GROUPS] = {"blk_groups", 0, 0, 12, 0, 0},           /* ... groups per pipeline step, 0 = create() times the forms of the chosen width and keeps the faster */
+    [SPMV_OPT_BLK_SUBSORT] = {"blk_subsort", 1, 0, 1, 0, 0},          /* ... sparse (block, slab) cells stored sorted by column (1) or in CSR order (0: round 3's order, A/B) */
+    [SPMV_OPT_DETERMINISTIC] = {"deterministic", 1, 0, 1, 0, 0},      /* 1: results are bit-reproducible run to run and handle to handle (every executor); 0: the wide blocked form may let its
+                                                                       * waves add into the shared accumulators in arrival order (faster, correct to rounding, not reproducible) */
     [SPMV_OPT_X_EXCHANGE] = {"x_exchange", 0, 0, 2, 0, 0},            /* multi-GPU: 0 = allgather of the x slices, 1 = range (each device gets x[min col .. max col] of its block), 2 = broadcast from device 0 */
 };
 
@@ -288,6 +294,10 @@ void spmv_plan_choose(SPMV_METHODS requested, const spmv_stats *st, size_t value
     plan->cache_block = (int) opt->v[SPMV_OPT_CACHE_BLOCK];
     plan->slab_kib = (int) opt->v[SPMV_OPT_SLAB_KIB];
     plan->block_rows = (int) opt->v[SPMV_OPT_BLOCK_ROWS];
+    plan->blk_waves = (int) opt->v[SPMV_OPT_BLK_WAVES];
+    plan->blk_groups = (int) opt->v[SPMV_OPT_BLK_GROUPS];
+    plan->blk_subsort = (int) opt->v[SPMV_OPT_BLK_SUBSORT];
+    plan->deterministic = (int) opt->v[SPMV_OPT_DETERMINISTIC];
     plan->csr5_sigma = (int) opt->v[SPMV_OPT_CSR5_SIGMA];
     /* one workgroup's equal-nnz share (Method_Balanced): the non-zeros of 256 mean-length rows, so that a
      * block is about one 256-row slab of the CSR-vector wave program (8192 for config 2; a share that is

@@ -46,6 +46,8 @@ typedef struct spmv_plan {
     int sell_c, sell_sigma, sell_lds_x, sell_long_thr;
     int csr5_sigma;
     int slab_kib, block_rows; /* row-block x column-slab executor shape (0 = defaults) */
+    int blk_waves, blk_groups, blk_subsort; /* ... waves sharing a block's accumulators (0 auto / 1 / 4 / 8), groups per step (0 = timed), sparse cells sorted by column */
+    int deterministic;  /* 1: bit-reproducible results required (default) */
     int cache_block;    /* nnz-split family: 0 never, 1 automatic, 2 always use the row-block x column-slab executor */
     int rowblock_nnz;
     int variant;

@@ -192,102 +192,131 @@ extern "C" int spmv_shim_build(spmv_dev *d, const spmv_plan *plan)
     if (plan->sched != SPMV_SCHED_CSR_SCALAR && d->nnz > 0 && plan->variant != 3 &&
         ((plan->cache_block == 2 && blocked_possible(d)) || (plan->cache_block == 1 && blocked_size_ok(d) && !(plan->sched == SPMV_SCHED_SELL && !plan->sell_lds_x) && sample_says_no_locality(d))))
         tiles = false;
-    if (tiles)
-    switch (plan->sched) {
-    case SPMV_SCHED_CSR_SCALAR: break;
-    case SPMV_SCHED_CSR_VECTOR: {
-        const int L = plan->lanes_per_row;
-        if (L < 1 || L > 64 || (L & (L - 1))) return fail(SPMV_HIP_E_ARG, "lanes_per_row must be a power of two in [1, 64], got %d", L);
-        // a lane group takes 4L elements per step; rows longer than the planner's threshold (default: ~64
-        // steps) are handed to the long-row path
-        const int thr = plan->long_thr > 0 ? plan->long_thr : (L * 64 > 256 ? L * 64 : 256);
-        rc = f64 ? build_long_rows<double>(d, thr) : build_long_rows<float>(d, thr);
-        if (!rc) rc = f64 ? build_vector_tiles<double>(d) : build_vector_tiles<float>(d);
-        staged = d->vt_staged;
-        groups = d->vt_tiles;
-        if (!rc && plan->autotune && blocked_mode(d, staged, groups) != 1) rc = f64 ? autotune_vector<double>(d) : autotune_vector<float>(d);
-        break;
-    }
-    case SPMV_SCHED_NNZ_SPLIT:
-        // equal-nnz tiles over the matrix's own arrays: CSR5 descriptors + carry fix-up, natural layout
-        rc = f64 ? build_csr5<double>(d, d->ns, d->m, d->nnz, d->rowptr, d->colidx, (const double *) d->val, d->stats.empty_rows, d->stats.mean_row_len, nullptr, true)
-                 : build_csr5<float>(d, d->ns, d->m, d->nnz, d->rowptr, d->colidx, (const float *) d->val, d->stats.empty_rows, d->stats.mean_row_len, nullptr, true);
-        staged = d->ns.staged;
-        groups = d->ns.groups;
-        break;
-    case SPMV_SCHED_ROWBLOCK:
-        if (plan->rowblock_nnz < 64) return fail(SPMV_HIP_E_ARG, "rowblock_nnz must be >= 64");
-        if (d->stats.max_row_len > plan->rowblock_nnz) return fail(SPMV_HIP_E_ARG, "row-block schedule needs max_row_len <= rowblock_nnz");
-        rc = build_rowblock(d);
-        if (!rc) rc = f64 ? build_rowblock_tiles<double>(d) : build_rowblock_tiles<float>(d);
-        staged = d->vt_staged;
-        groups = d->vt_tiles;
-        break;
-    case SPMV_SCHED_SELL:
-        rc = f64 ? build_sell<double>(d) : build_sell<float>(d);
-        staged = d->plan.sell_lds_x ? d->sell_staged : -1; // sell_lds_x = 0: the caller asked for the plain slab kernel
-        groups = d->sell_nwin;
-        break;
-    case SPMV_SCHED_CSR5:
-        rc = f64 ? build_csr5<double>(d, d->c5, d->m, d->nnz, d->rowptr, d->colidx, (const double *) d->val, d->stats.empty_rows, d->stats.mean_row_len, nullptr)
-                 : build_csr5<float>(d, d->c5, d->m, d->nnz, d->rowptr, d->colidx, (const float *) d->val, d->stats.empty_rows, d->stats.mean_row_len, nullptr);
-        staged = d->c5.staged;
-        groups = d->c5.groups;
-        break;
-    }
+    auto build_tiles = [&]() -> int { // the inspector of the method's own tile schedule
+        int rc = SPMV_HIP_OK;
+        switch (plan->sched) {
+        case SPMV_SCHED_CSR_SCALAR: break;
+        case SPMV_SCHED_CSR_VECTOR: {
+            const int L = plan->lanes_per_row;
+            if (L < 1 || L > 64 || (L & (L - 1))) return fail(SPMV_HIP_E_ARG, "lanes_per_row must be a power of two in [1, 64], got %d", L);
+            // a lane group takes 4L elements per step; rows longer than the planner's threshold (default: ~64
+            // steps) are handed to the long-row path
+            const int thr = plan->long_thr > 0 ? plan->long_thr : (L * 64 > 256 ? L * 64 : 256);
+            rc = f64 ? build_long_rows<double>(d, thr) : build_long_rows<float>(d, thr);
+            if (!rc) rc = f64 ? build_vector_tiles<double>(d) : build_vector_tiles<float>(d);
+            staged = d->vt_staged;
+            groups = d->vt_tiles;
+            if (!rc && plan->autotune && blocked_mode(d, staged, groups) != 1) rc = f64 ? autotune_vector<double>(d) : autotune_vector<float>(d);
+            break;
+        }
+        case SPMV_SCHED_NNZ_SPLIT:
+            // equal-nnz tiles over the matrix's own arrays: CSR5 descriptors + carry fix-up, natural layout
+            rc = f64 ? build_csr5<double>(d, d->ns, d->m, d->nnz, d->rowptr, d->colidx, (const double *) d->val, d->stats.empty_rows, d->stats.mean_row_len, nullptr, true)
+                     : build_csr5<float>(d, d->ns, d->m, d->nnz, d->rowptr, d->colidx, (const float *) d->val, d->stats.empty_rows, d->stats.mean_row_len, nullptr, true);
+            staged = d->ns.staged;
+            groups = d->ns.groups;
+            break;
+        case SPMV_SCHED_ROWBLOCK:
+            if (plan->rowblock_nnz < 64) return fail(SPMV_HIP_E_ARG, "rowblock_nnz must be >= 64");
+            if (d->stats.max_row_len > plan->rowblock_nnz) return fail(SPMV_HIP_E_ARG, "row-block schedule needs max_row_len <= rowblock_nnz");
+            rc = build_rowblock(d);
+            if (!rc) rc = f64 ? build_rowblock_tiles<double>(d) : build_rowblock_tiles<float>(d);
+            staged = d->vt_staged;
+            groups = d->vt_tiles;
+            break;
+        case SPMV_SCHED_SELL:
+            rc = f64 ? build_sell<double>(d) : build_sell<float>(d);
+            staged = d->plan.sell_lds_x ? d->sell_staged : -1; // sell_lds_x = 0: the caller asked for the plain slab kernel
+            groups = d->sell_nwin;
+            break;
+        case SPMV_SCHED_CSR5:
+            rc = f64 ? build_csr5<double>(d, d->c5, d->m, d->nnz, d->rowptr, d->colidx, (const double *) d->val, d->stats.empty_rows, d->stats.mean_row_len, nullptr)
+                     : build_csr5<float>(d, d->c5, d->m, d->nnz, d->rowptr, d->colidx, (const float *) d->val, d->stats.empty_rows, d->stats.mean_row_len, nullptr);
+            staged = d->c5.staged;
+            groups = d->c5.groups;
+            break;
+        }
+        return rc;
+    };
+    if (tiles) rc = build_tiles();
     // Columns without locality (tile groups whose x windows do not fit LDS) and x far larger than an L2: every gather of such a
     // group crosses the fabric -> row blocks x column slabs (kernels/blocked.hpp) take over the multiply, whatever the method
     // (CSR-scalar, the debug kernel, excepted).  When only PART of the groups stage, both executors exist for a moment and create()
     // keeps the one that multiplies faster (the share of unstaged groups at which the blocked executor wins depends on what the
     // staged part looks like: 2-15 %).  The loser's products are released.
+    auto blk_best = [](const BlkSet &b) { return b.tune_ms[1] > 0 && b.tune_ms[1] < b.tune_ms[0] ? b.tune_ms[1] : b.tune_ms[0]; };
+    auto blk_release = [&](const BlkSet &b) {
+        quiesce(d);
+        for (void *p : {(void *) b.row0, (void *) b.gstart, (void *) b.dir, (void *) b.order, b.val, (void *) b.meta, (void *) b.hdr}) if (p) sched_free(d, p);
+    };
+    auto blk_build = [&](int rule, int waves, bool ordered) { return f64 ? build_blocked<double>(d, rule, waves, ordered) : build_blocked<float>(d, rule, waves, ordered); };
+    auto blk_tune = [&]() { return f64 ? autotune_blocked<double>(d) : autotune_blocked<float>(d); };
+    // another layout next to the one that stands: built, timed, kept when it multiplies at least 3 % faster -- otherwise (or when it cannot be
+    // built: memory) released again
+    auto blk_try = [&](int rule, int waves, bool ordered) {
+        const BlkSet first = d->blk;
+        const float best0 = blk_best(first);
+        d->blk_on = false;
+        d->blk = BlkSet();
+        const int rc2 = blk_build(rule, waves, ordered);
+        if (!rc2 && d->blk_on) {
+            (void) blk_tune();
+            const float best1 = blk_best(d->blk);
+            if (best1 > 0 && best1 < 0.97f * best0) blk_release(first);
+            else { blk_release(d->blk); d->blk = first; }
+        } else {
+            blk_release(d->blk);
+            d->blk = first;
+            (void) hipGetLastError();
+        }
+        d->blk_on = true;
+    };
     const int mode = !tiles ? 1 : (!rc && staged >= 0 ? blocked_mode(d, staged, groups) : 0);
     if (!rc && mode) {
         const size_t keep_from = d->sched_allocs.size();
         d->x_groups_seen = groups;
         double tile_ms = -1.0;
         if (mode == 2) tile_ms = f64 ? time_schedule<double>(d, 5) : time_schedule<float>(d, 5);
-        rc = f64 ? build_blocked<double>(d, 0) : build_blocked<float>(d, 0);
-        if (!rc && d->blk_on) rc = f64 ? autotune_blocked<double>(d) : autotune_blocked<float>(d);
+        // forced width (option blk_waves) or the one-wave form first; the wide forms are tried against it below
+        const int forced = plan->blk_waves;
+        int rcb = blk_build(0, forced > 0 ? forced : 1, plan->deterministic != 0);
+        if (!rcb && d->blk_on) rcb = blk_tune();
+        if (rcb) {
+            // The blocked executor could not be built (device memory, or padded positions beyond 32 bits).  It is an alternative, not a
+            // requirement: what it allocated goes back, the error is cleared and the tile schedule multiplies -- the one already built
+            // and timed (mode 2), or, when the sample had skipped its inspector, the one built now.
+            blk_release(d->blk);
+            d->blk = BlkSet();
+            d->blk_on = false;
+            (void) hipGetLastError();
+            if (plan->cache_block == 2 || rcb == SPMV_HIP_E_ARG) rc = rcb; // asked for explicitly (or a bad option): report
+            else if (!tiles) { rc = build_tiles(); tiles = true; }
+            if (mode == 2) d->route_ms[0] = (float) tile_ms;
+        }
         if (!rc && d->blk_on && mode == 2) {
-            const double blk_ms = d->blk.tune_ms[1] > 0 && d->blk.tune_ms[1] < d->blk.tune_ms[0] ? d->blk.tune_ms[1] : d->blk.tune_ms[0];
+            const double blk_ms = blk_best(d->blk);
             d->route_ms[0] = (float) tile_ms;
             d->route_ms[1] = (float) blk_ms;
             if (tile_ms > 0 && (blk_ms <= 0 || tile_ms <= blk_ms)) { // the tile schedule stays
-                const BlkSet b = d->blk;
-                quiesce(d);
-                for (void *p : {(void *) b.row0, (void *) b.gstart, (void *) b.dir, (void *) b.order, b.val, (void *) b.meta, (void *) b.hdr}) if (p) sched_free(d, p);
+                blk_release(d->blk);
                 d->blk = BlkSet();
                 d->blk_on = false;
             }
         }
         if (!rc && d->blk_on) drop_tile_schedule(d, keep_from);
+        const bool may_try = !rc && d->blk_on && plan->autotune && plan->variant == 0 && plan->block_rows == 0 && forced == 0 && d->nnz >= (1ll << 22);
+        const double rate = may_try && blk_best(d->blk) > 0 ? (double) d->nnz * ((double) d->vsize + 4.0) / ((double) blk_best(d->blk) * 1e-3) : 0.0; // the streams' bytes per second
         // Stream-bound under rule 0 (the streams alone move >= 3.6 TB/s; web-like 4e6 x 24 in fp32 sits at 4.2)?  Then thinner blocks may do better: build the
         // rule-1 set next to this one, time it, keep the faster (one more inspector pass, only for such matrices).
-        if (!rc && d->blk_on && plan->autotune && plan->variant == 0 && plan->block_rows == 0 && d->nnz >= (1ll << 22) &&
-            blocked_differs(d)) {
-            auto best_of = [](const BlkSet &b) { return b.tune_ms[1] > 0 && b.tune_ms[1] < b.tune_ms[0] ? b.tune_ms[1] : b.tune_ms[0]; };
-            const float best0 = best_of(d->blk);
-            const double rate = best0 > 0 ? (double) d->nnz * ((double) d->vsize + 4.0) / ((double) best0 * 1e-3) : 0.0;
-            if (rate >= 3.6e12) {
-                auto release = [&](const BlkSet &b) {
-                    quiesce(d);
-                    for (void *p : {(void *) b.row0, (void *) b.gstart, (void *) b.dir, (void *) b.order, b.val, (void *) b.meta, (void *) b.hdr}) if (p) sched_free(d, p);
-                };
-                const BlkSet first = d->blk;
-                d->blk_on = false;
-                const int rc2 = f64 ? build_blocked<double>(d, 1) : build_blocked<float>(d, 1);
-                if (!rc2 && d->blk_on) {
-                    (void) (f64 ? autotune_blocked<double>(d) : autotune_blocked<float>(d));
-                    const float best1 = best_of(d->blk);
-                    if (best1 > 0 && best1 < 0.97f * best0) release(first);
-                    else { release(d->blk); d->blk = first; }
-                } else { // the second set could not be built (memory): keep the first
-                    release(d->blk);
-                    d->blk = first;
-                    (void) hipGetLastError();
-                }
-                d->blk_on = true;
-            }
+        if (may_try && blocked_differs(d) && rate >= 3.6e12) blk_try(1, 1, true);
+        // The wide forms: ONE block of up to ~20 k rows per CU, its accumulators shared by the waves of a workgroup -- fewer cache lines of x per
+        // entry (kernels/blocked.hpp).  Reproducible results required (default): two waves taking turns at adding, tried where the one-wave
+        // form is gather-bound (config 2-ii: 1.40 -> 1.19 ms; stream-bound shapes lose 3-5 % to the turns and are not tried).  Option
+        // deterministic = 0: four waves adding as their products arrive (config 2-ii 1.22, Orkut-style R-MAT 0.55 -> 0.49, uniform
+        // 0.66 -> 0.54, web-like 4e6 x 24 0.243 -> 0.216).
+        if (may_try && (long long) d->m >= 2048ll * d->cus) {
+            if (plan->deterministic == 0) blk_try(0, 4, false);
+            else if (rate < 4.2e12) blk_try(0, 2, true);
         }
     }
     if (!rc) rc = account_stream_bytes(d);
@@ -364,7 +393,7 @@ __host__ __device__ static inline unsigned long long checksum_term(unsigned w, l
     return ((unsigned long long) w + 0x9E3779B97F4A7C15ull) * (2ull * (unsigned long long) i + 1ull);
 }
 
-__global__ __launch_bounds__(kBlock) void checksum_kernel(long long words, const unsigned *__restrict__ w, unsigned long long *__restrict__ out)
+static __global__ __launch_bounds__(kBlock) void checksum_kernel(long long words, const unsigned *__restrict__ w, unsigned long long *__restrict__ out)
 {
     unsigned long long s = 0;
     const long long stride = (long long) gridDim.x * kBlock;
@@ -534,6 +563,8 @@ extern "C" int spmv_shim_info(const spmv_dev *d, spmv_hip_info *o)
         o->route_ms[0] = d->route_ms[0]; o->route_ms[1] = d->route_ms[1];
         o->split_ms[0] = d->split_ms[0]; o->split_ms[1] = d->split_ms[1];
         o->far_nnz = d->sp_far->nnz;
+        o->blk_waves = f.blk_waves;
+        o->reproducible = o->reproducible && f.reproducible;
         return SPMV_HIP_OK;
     }
     memset(o, 0, sizeof *o);
@@ -586,7 +617,9 @@ extern "C" int spmv_shim_info(const spmv_dev *d, spmv_hip_info *o)
     case SPMV_SCHED_CSR5: o->x_groups = d->c5.groups; o->x_groups_staged = d->c5.staged; break;
     default: o->x_groups = o->x_groups_staged = 0; break;
     }
-    if (d->blk_on) o->kernel_name = "blk_kernel";
+    o->blk_waves = d->blk_on ? d->blk.waves : 0;
+    o->reproducible = d->blk_on && d->blk.waves > 1 && !d->blk.ordered ? 0 : 1;
+    if (d->blk_on) o->kernel_name = d->blk.waves > 1 ? "blk_wide_kernel" : "blk_kernel";
     else if (d->plan.sched == SPMV_SCHED_NNZ_SPLIT)
         o->kernel_name = d->ns.staged > 0 ? "nat_group_kernel" : "nat_kernel";
     if (d->plan.sched == SPMV_SCHED_CSR5 && d->c5.staged > 0) o->kernel_name = csr5_two_deep(d, d->c5) ? "csr5_group_pipe_kernel" : "csr5_group_kernel";

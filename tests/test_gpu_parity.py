@@ -109,7 +109,7 @@ def test_golden_row_block_column_slab_executor(name, method):
         api.set_option("cache_block", 2)
         try:
             with api.Handle(csr.m, csr.n, csr.rowptr, csr.colidx, csr.val, method) as h:
-                assert h.info()["kernel_name"] == "blk_kernel"
+                assert h.info()["kernel_name"] in ("blk_kernel", "blk_wide_kernel")
         finally:
             api.set_option("cache_block", 1)
     check(y, csr, x, y_ref, exact=name.endswith("eighths"))
@@ -480,7 +480,7 @@ def test_matrix_without_column_locality_runs_the_blocked_executor_deterministica
         y = torch.full((m,), float("nan"), dtype=tdt, device=dev)
         with api.Handle(m, n, rp, ci, va, method) as h:
             info = h.info()
-            assert info["cache_blocked"] == 1 and info["kernel_name"] == "blk_kernel", info
+            assert info["cache_blocked"] == 1 and info["kernel_name"] in ("blk_kernel", "blk_wide_kernel"), info
             h.spmv(x, y)
             y2 = torch.empty_like(y)
             h.spmv(x, y2)
@@ -544,16 +544,17 @@ def test_blocked_executor_forms_give_the_same_bits_and_create_picks_one_by_timin
     _, _, rp, ci, va = synth.from_row_lengths_device(lens, n, "uniform", tdt, dev, 3, cols="rmat")
     g = torch.Generator(device=dev); g.manual_seed(9)
     x = torch.rand(n, generator=g, device=dev, dtype=tdt) * 2 - 1
-    keep = {k: api.get_option(k) for k in ("cache_block", "variant")}
+    keep = {k: api.get_option(k) for k in ("cache_block", "variant", "blk_waves")}
     ys = {}
     try:
         api.set_option("cache_block", 2)
+        api.set_option("blk_waves", 1)      # the one-wave layout (create() may otherwise keep a wide one: another stored order)
         for variant in (0, 35, 37):
             api.set_option("variant", variant)
             y = torch.full((m,), float("nan"), dtype=tdt, device=dev)
             with api.Handle(m, n, rp, ci, va, M.Method_Balanced2) as h:
                 info = h.info()
-                assert info["cache_blocked"] == 1 and info["kernel_name"] == "blk_kernel", info
+                assert info["cache_blocked"] == 1 and info["kernel_name"] in ("blk_kernel", "blk_wide_kernel"), info
                 if variant == 0:
                     assert info["tuned_choice"] in (100, 101) and min(info["tune_ms"][:2]) > 0, info
                 h.spmv(x, y)
@@ -609,7 +610,7 @@ def test_blocked_executor_hot_cells_and_super_slabs(dtype, block_rows):
                 y = torch.full((m,), float("nan"), dtype=tdt, device=dev)
                 with api.Handle(m, n, rp32, ci, va, M.Method_Balanced2) as h:
                     info = h.info()
-                    assert info["cache_blocked"] == 1 and info["kernel_name"] == "blk_kernel", info
+                    assert info["cache_blocked"] == 1 and info["kernel_name"] in ("blk_kernel", "blk_wide_kernel"), info
                     stored[dense] = info["stored_nnz"]
                     h.spmv(x, y)
                     torch.cuda.synchronize()
@@ -620,6 +621,114 @@ def test_blocked_executor_hot_cells_and_super_slabs(dtype, block_rows):
                         torch.cuda.synchronize()
                         assert torch.equal(y, 2 * want), (dense, "update_values")
         assert stored[1] >= nnz
+    finally:
+        for k, v in keep.items():
+            api.set_option(k, v)
+
+
+def _hot_cells_matrix(tdt, dev, seed=77):
+    """hot column ranges (one straddling a super-slab boundary), a uniform background, a partial last slab, empty rows, a hub row; exact data"""
+    import torch
+    m, n = 30_000, 200_037
+    g = torch.Generator(device=dev); g.manual_seed(seed)
+    lens = torch.randint(0, 48, (m,), generator=g, device=dev, dtype=torch.int64)
+    lens[1000:1400] = 0
+    lens[17] = 150_000
+    rp = torch.zeros(m + 1, dtype=torch.int64, device=dev)
+    torch.cumsum(lens, 0, out=rp[1:])
+    nnz = int(rp[-1].item())
+    u = torch.rand(nnz, generator=g, device=dev)
+    hot = torch.randint(0, 700, (nnz,), generator=g, device=dev)
+    hot2 = 131_000 + torch.randint(0, 300, (nnz,), generator=g, device=dev)
+    tail = n - 1 - torch.randint(0, 60, (nnz,), generator=g, device=dev)
+    bg = torch.randint(0, n, (nnz,), generator=g, device=dev)
+    ci = torch.where(u < 0.45, hot, torch.where(u < 0.6, hot2, torch.where(u < 0.7, tail, bg))).to(torch.int32)
+    va = (torch.randint(-8, 9, (nnz,), generator=g, device=dev) * 0.125).to(tdt)
+    x = (torch.randint(-8, 9, (n,), generator=g, device=dev) * 0.125).to(tdt)
+    prod = va.double() * x.double()[ci.long()]
+    cs = torch.cat([torch.zeros(1, dtype=torch.float64, device=dev), torch.cumsum(prod, 0)])
+    want = (cs[rp[1:]] - cs[rp[:-1]]).to(tdt)
+    return m, n, rp.to(torch.int32), ci, va, x, want
+
+
+@pytest.mark.parametrize("dtype", [np.float64, np.float32])
+@pytest.mark.parametrize("waves,det", [(2, 1), (4, 1), (8, 1), (2, 0), (4, 0), (8, 0)])
+def test_wide_blocked_forms_match_the_definition_exactly(dtype, waves, det):
+    """Round 4: ONE row block per CU whose LDS accumulators are shared by 2 / 4 / 8 wavefronts (blocked.hpp: blk_wide_kernel), the waves taking turns
+    at adding (deterministic = 1) or adding in arrival order (0).  Exact data: every form, every groups-per-step value, uniform 512-row blocks and
+    equal-work blocks, sparse cells sorted by column or not -- all equal the definition bit for bit, and so does a values refresh."""
+    import torch
+    dev = torch.device("cuda:0")
+    tdt = torch.float64 if dtype == np.float64 else torch.float32
+    m, n, rp, ci, va, x, want = _hot_cells_matrix(tdt, dev)
+    keys = ("cache_block", "block_rows", "blk_waves", "blk_groups", "blk_subsort", "deterministic")
+    keep = {k: api.get_option(k) for k in keys}
+    try:
+        api.set_option("cache_block", 2)
+        api.set_option("blk_waves", waves)
+        api.set_option("deterministic", det)
+        for block_rows, groups, subsort in ((0, 0, 1), (512, 8, 1), (0, 6 if waves == 8 else 12, 0)):
+            api.set_option("block_rows", block_rows)
+            api.set_option("blk_groups", groups)
+            api.set_option("blk_subsort", subsort)
+            y = torch.full((m,), float("nan"), dtype=tdt, device=dev)
+            with api.Handle(m, n, rp, ci, va, M.Method_Balanced2) as h:
+                info = h.info()
+                assert info["cache_blocked"] == 1 and info["kernel_name"] == "blk_wide_kernel" and info["blk_waves"] == waves, info
+                assert info["reproducible"] == det, info
+                h.spmv(x, y)
+                torch.cuda.synchronize()
+                assert torch.equal(y, want), (block_rows, groups, subsort, int((y != want).sum()))
+                h.update_values(va * 2)
+                h.spmv(x, y)
+                torch.cuda.synchronize()
+                assert torch.equal(y, 2 * want), (block_rows, groups, subsort, "update_values")
+    finally:
+        for k, v in keep.items():
+            api.set_option(k, v)
+
+
+@pytest.mark.parametrize("dtype", [np.float64, np.float32])
+def test_wide_blocked_forms_reproducible_when_the_waves_take_turns(dtype):
+    """Inexact data on power-law rows with hub columns: the ordered wide forms (option deterministic = 1, the default) add every row's products in
+    (phase, wave, instruction, lane) order -- a function of the stored stream -- so two handles give the same bits and so do both groups-per-step
+    forms of one width; the arrival-order forms (deterministic = 0) agree with them to rounding (north_star tolerance, scaled by the row's sum of |a x|)."""
+    import torch
+    dev = torch.device("cuda:0")
+    tdt = torch.float64 if dtype == np.float64 else torch.float32
+    m = n = 1_300_000
+    lens = synth.powerlaw_lengths_device(m, 12.0, 20000, 1.6, dev, 3)
+    _, _, rp, ci, va = synth.from_row_lengths_device(lens, n, "uniform", tdt, dev, 3, cols="rmat")
+    g = torch.Generator(device=dev); g.manual_seed(9)
+    x = torch.rand(n, generator=g, device=dev, dtype=tdt) * 2 - 1
+    prod = va.double() * x.double()[ci.long()]
+    z = torch.zeros(1, dtype=torch.float64, device=dev)
+    cs, ca = torch.cat([z, torch.cumsum(prod, 0)]), torch.cat([z, torch.cumsum(prod.abs(), 0)])
+    want, scale = cs[rp[1:].long()] - cs[rp[:-1].long()], ca[rp[1:].long()] - ca[rp[:-1].long()]
+    tol = 1e-6 if dtype == np.float64 else 1e-3
+    keys = ("cache_block", "blk_waves", "blk_groups", "deterministic")
+    keep = {k: api.get_option(k) for k in keys}
+
+    def run(waves, det, groups):
+        api.set_option("blk_waves", waves); api.set_option("deterministic", det); api.set_option("blk_groups", groups)
+        y = torch.full((m,), float("nan"), dtype=tdt, device=dev)
+        with api.Handle(m, n, rp, ci, va, M.Method_Balanced2) as h:
+            assert h.info()["blk_waves"] == waves and h.info()["reproducible"] == det, h.info()
+            h.spmv(x, y)
+            y2 = torch.empty_like(y)
+            h.spmv(x, y2)
+        torch.cuda.synchronize()
+        assert bool(((y.double() - want).abs() <= tol * scale + 1e-300).all()), (waves, det, groups)
+        return y, y2
+    try:
+        api.set_option("cache_block", 2)
+        for waves, ga, gb in ((2, 8, 12), (4, 8, 12), (8, 6, 8)):
+            ya, ya2 = run(waves, 1, ga)
+            yb, _ = run(waves, 1, gb)
+            yc, _ = run(waves, 1, 0)        # whichever form create() timed faster
+            assert torch.equal(ya, ya2) and torch.equal(ya, yc), f"{waves} waves: not reproducible"
+            assert torch.equal(ya, yb), f"{waves} waves: the two groups-per-step forms differ"
+            run(waves, 0, 0)
     finally:
         for k, v in keep.items():
             api.set_option(k, v)
