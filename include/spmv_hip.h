@@ -149,6 +149,8 @@ typedef struct spmv_hip_info {
     long long run_nnz;          /* CSR-vector / row-block tile kernels, SELL slabs, CSR5 tile groups: entries in RUN tiles / groups -- staged ones whose rows
                                  * each reference one run of consecutive columns (banded matrices; CSR5: of at least sigma entries); their column stream is
                                  * not read at all (16 bits, SELL: a word, per ROW; CSR5: a word per lane and tile instead) */
+    long long byte_nnz;         /* CSR-vector / row-block tile kernels: entries in BYTE tiles -- staged tiles in which every row's LDS slots lie within 255 of the row's
+                                 * smallest (banded matrices with holes, block rows): their column stream is one byte per entry + 16 bits per row */
     int blk_waves;              /* cache_blocked: wavefronts that share one row block's accumulators (1: a wave per block, two blocks per CU; 2 / 4 / 8: the
                                  * wide form, one block of up to ~20 k rows per CU); 0 when another executor runs */
     int reproducible;           /* 1: the executor adds every row's products in an order fixed by the matrix -- identical bits run to run and handle to
@@ -175,11 +177,12 @@ int spmv_hip_multi_uses_rccl(spmv_Handle_t handle);   /* 1: the x exchange runs 
  * full-length copy) and its block of y (rows y_first ... y_first + y_count - 1).  Any out-pointer may be NULL. */
 int spmv_hip_multi_slices(spmv_Handle_t handle, int gpu, void **x_slice, long long *x_first, long long *x_count,
                           void **y_block, long long *y_first, long long *y_count, int *device);
-/* Exchange the x slices between the devices and multiply; y stays distributed.  Synchronous.  The devices' streams are ordered
- * behind the work the caller has submitted to each device's DEFAULT stream (the x slices must have been written there, or be
- * complete); x_exchange = 1 ("range") runs the halo copies beside the multiply and redoes the rows that needed them. */
+/* Exchange the x slices between the devices and multiply; y stays distributed.  Synchronous: every device is drained first
+ * (hipDeviceSynchronize), so the x slices may have been written on any stream; returns when the y blocks are complete.
+ * x_exchange = 1 ("range") runs the halo copies beside the multiply and redoes the rows that needed them. */
 int spmv_hip_multi_step(spmv_Handle_t handle);
-/* The same, enqueued only; spmv_hip_multi_synchronize waits for every device (results in the y blocks).  Steps may be enqueued
+/* The same, enqueued only, ordered behind the work the caller has submitted to each device's DEFAULT stream (the x slices must have
+ * been written there, or be complete); spmv_hip_multi_synchronize waits for every device (results in the y blocks).  Steps may be enqueued
  * back to back (a step's halo copies wait for the previous step's multiplies); the caller writes the NEXT x slices on the default
  * streams, which a step is ordered behind -- but nothing orders those writes behind a step still running: synchronize (or wait on
  * an event of your own) before overwriting x slices a running step reads. */

@@ -29,6 +29,7 @@
 // table per tile.
 #pragma once
 #include <climits>
+#include <type_traits>
 #include "common.hpp"
 #include "csr_vector4.hpp"
 #include "xwindows.hpp"
@@ -53,7 +54,8 @@ static __global__ __launch_bounds__(kBlock) void csr_tile_windows_kernel(int m, 
                                                                   TileWindows *__restrict__ wins,
                                                                   unsigned short *__restrict__ col_local,
                                                                   unsigned short *__restrict__ row_slot /* NULL: no run tiles */,
-                                                                  int *__restrict__ staged /* [0] tiles staged, [1] max total, [2] run tiles, [3] their entries, [4] their rows */)
+                                                                  unsigned char *__restrict__ col8 /* NULL: no byte tiles */,
+                                                                  int *__restrict__ staged /* [0] tiles staged, [1] max total, [2] run tiles, [3] their entries, [4] their rows, [5] byte tiles, [6] their entries, [7] their rows */)
 {
     long long r0, r1;
     tile_rows(blockIdx.x, m, rows_per_tile, split, r0, r1);
@@ -83,7 +85,45 @@ static __global__ __launch_bounds__(kBlock) void csr_tile_windows_kernel(int m, 
             if (l == 0) entries += p1 - p0;
         }
     ok = __syncthreads_and(ok);
-    if (!ok) return;
+    if (!ok) {
+        // BYTE tile?  Every (non-long) row's slots lie within 255 slots of the row's smallest one -- banded matrices with holes, block rows,
+        // anything whose rows span under 256 columns inside one window: the column stream is then ONE byte per entry (the slot's distance from
+        // the row's smallest slot, col8) + 16 bits per row (that smallest slot, row_slot) instead of 16 bits per entry.  Every thread re-reads
+        // the 16-bit slots it stored itself (build_windows ran the same loop), so no fence is needed in front of this.
+        if (!col8 || nwin == 0) return;
+        int okb = 1, nb = 0;
+        for (long long r = r0 + sub; r < r1; r += kBlock / 16) {
+            const int p0 = rowptr[r], p1 = rowptr[r + 1];
+            if (p1 - p0 > long_thr || p1 == p0) continue;
+            int mn = INT_MAX, mx = 0;
+            for (int p = p0 + l; p < p1; p += 16) { const int sl = col_local[p]; mn = sl < mn ? sl : mn; mx = sl > mx ? sl : mx; }
+#pragma unroll
+            for (int o = 8; o > 0; o >>= 1) { mn = min(mn, __shfl_xor(mn, o, 16)); mx = max(mx, __shfl_xor(mx, o, 16)); }
+            okb &= mx - mn <= 255 * slot_bytes;
+            if (l == 0) nb += p1 - p0;
+        }
+        okb = __syncthreads_and(okb);
+        if (!okb) return;
+        for (long long r = r0 + sub; r < r1; r += kBlock / 16) {
+            const int p0 = rowptr[r], p1 = rowptr[r + 1];
+            int mn = INT_MAX;
+            const bool on = p1 - p0 <= long_thr && p1 > p0;
+            if (on) for (int p = p0 + l; p < p1; p += 16) { const int sl = col_local[p]; mn = sl < mn ? sl : mn; }
+#pragma unroll
+            for (int o = 8; o > 0; o >>= 1) mn = min(mn, __shfl_xor(mn, o, 16));
+            if (on) for (int p = p0 + l; p < p1; p += 16) col8[p] = (unsigned char) ((col_local[p] - mn) / slot_bytes);
+            if (l == 0) row_slot[r] = (unsigned short) (on ? mn : 0);
+        }
+#pragma unroll
+        for (int o = kWave / 2; o > 0; o >>= 1) nb += __shfl_xor(nb, o, kWave);
+        if ((threadIdx.x & (kWave - 1)) == 0 && nb) atomicAdd(staged + 6, nb);
+        if (threadIdx.x == 0) {
+            wins[blockIdx.x].runs = 2;
+            atomicAdd(staged + 5, 1);
+            atomicAdd(staged + 7, (int) (r1 - r0));
+        }
+        return;
+    }
     for (long long r = r0 + sub * 16 + l; r < r1; r += kBlock) { // one thread per row now
         const int p0 = rowptr[r], p1 = rowptr[r + 1];
         int slot = 0;
@@ -135,6 +175,21 @@ struct Lane4 {
             c[1] = __builtin_nontemporal_load(reinterpret_cast<const int *>(col + base + 2 * L + 2 * l));
         }
     }
+    // BYTE tiles: one byte per entry (distance from the row's smallest slot); c[0] (fp32: four bytes) or c[0], c[1] (fp64: two bytes each)
+    static __device__ __forceinline__ void load_col8(const unsigned char *__restrict__ col, int base, int l, int (&c)[4])
+    {
+        if constexpr (EPL == 4) {
+            c[0] = __builtin_nontemporal_load(reinterpret_cast<const int *>(col + base + 4 * l));
+        } else {
+            c[0] = (int) __builtin_nontemporal_load(reinterpret_cast<const unsigned short *>(col + base + 2 * l));
+            c[1] = (int) __builtin_nontemporal_load(reinterpret_cast<const unsigned short *>(col + base + 2 * L + 2 * l));
+        }
+    }
+    template <int K> static __device__ __forceinline__ unsigned byte_of(const int (&c)[4])
+    {
+        if constexpr (EPL == 4) return ((unsigned) c[0] >> (8 * K)) & 0xffu;
+        else return ((unsigned) c[K / 2] >> (8 * (K % 2))) & 0xffu;
+    }
     static __device__ __forceinline__ void load_col32(const int *__restrict__ col, int base, int l, int (&c)[4])
     {
         if constexpr (EPL == 4) {
@@ -151,17 +206,26 @@ struct Lane4 {
 // (c, v: already loaded by Lane4 from the chunk starting at the 16 B-aligned position p0 & ~3) and, for
 // rows longer than that chunk, walks on in chunks of 4L.  Returns the lane's partial sum (not yet reduced over the group).
 // MODE 0: unstaged (global columns), 1: staged (16-bit slots from the column stream), 2: staged RUN tile (slots = rs + position in the row;
-// cc0 unused)
+// cc0 unused), 3: staged BYTE tile (slots = rs + the entry's byte of the 8-bit column stream, packed in cc0)
 template <typename T, int L, int MODE, int SHIFT = 0>
 __device__ __forceinline__ T csr_vector_step(int p0, int p1, int l, const int (&cc0)[4], const T (&vv0)[4],
                                              const int *__restrict__ colidx, const unsigned short *__restrict__ col_local,
                                              const T *__restrict__ val, const T *__restrict__ x,
-                                             const unsigned char *__restrict__ xb, unsigned zoff, unsigned rs = 0)
+                                             const unsigned char *__restrict__ xb, unsigned zoff, unsigned rs = 0, const unsigned char *__restrict__ col8 = nullptr)
 {
     constexpr bool STAGED = MODE != 0;
     constexpr unsigned INC = SHIFT ? 1u : (unsigned) sizeof(T); // slot unit of the stream: indices (wide form) or bytes
     // slot of entry e (e - p0 < row length) of a RUN tile's row
     auto run_slot = [&](int e) { return rs + (unsigned) (e - p0) * INC; };
+    using LMB = Lane4<T, L>;
+    // slot of the lane's k-th entry: from the row (RUN), the byte stream (BYTE) or the 16-bit stream
+    auto slot_of = [&](auto kc, int e, const int (&cc)[4]) -> unsigned {
+        constexpr int K = decltype(kc)::value;
+        if constexpr (MODE == 2) return run_slot(e);
+        else if constexpr (MODE == 3) return rs + LMB::template byte_of<K>(cc) * INC;
+        else return lds_slot<K>(cc);
+    };
+    using K0 = std::integral_constant<int, 0>; using K1 = std::integral_constant<int, 1>; using K2 = std::integral_constant<int, 2>; using K3 = std::integral_constant<int, 3>;
     // SHIFT = 0: the stream holds LDS byte offsets; SHIFT = log2(sizeof(T)): slot indices (windows above 64 KiB)
     auto xat = [&](unsigned off) { return *reinterpret_cast<const T *>(xb + ((size_t) off << SHIFT)); };
     using LM = Lane4<T, L>;
@@ -172,8 +236,7 @@ __device__ __forceinline__ T csr_vector_step(int p0, int p1, int l, const int (&
         const bool full = (e0 >= p0) & (e3 < p1), none = e0 >= p1;
         if (__all(full | none)) {
             if (full) {
-                const T x0 = xat(MODE == 2 ? run_slot(e0) : lds_slot<0>(cc0)), x1 = xat(MODE == 2 ? run_slot(e1) : lds_slot<1>(cc0)),
-                        x2 = xat(MODE == 2 ? run_slot(e2) : lds_slot<2>(cc0)), x3 = xat(MODE == 2 ? run_slot(e3) : lds_slot<3>(cc0));
+                const T x0 = xat(slot_of(K0{}, e0, cc0)), x1 = xat(slot_of(K1{}, e1, cc0)), x2 = xat(slot_of(K2{}, e2, cc0)), x3 = xat(slot_of(K3{}, e3, cc0));
                 sum = fmadd(vv0[0], x0, sum);
                 sum = fmadd(vv0[1], x1, sum);
                 sum = fmadd(vv0[2], x2, sum);
@@ -183,8 +246,8 @@ __device__ __forceinline__ T csr_vector_step(int p0, int p1, int l, const int (&
             const unsigned len = (unsigned) (p1 - p0); // entry e is in the row iff e - p0 < len (unsigned)
             const bool k0 = (unsigned) (e0 - p0) < len, k1 = (unsigned) (e1 - p0) < len, k2 = (unsigned) (e2 - p0) < len,
                        k3 = (unsigned) (e3 - p0) < len;
-            const T x0 = xat(k0 ? (MODE == 2 ? run_slot(e0) : lds_slot<0>(cc0)) : zoff), x1 = xat(k1 ? (MODE == 2 ? run_slot(e1) : lds_slot<1>(cc0)) : zoff),
-                    x2 = xat(k2 ? (MODE == 2 ? run_slot(e2) : lds_slot<2>(cc0)) : zoff), x3 = xat(k3 ? (MODE == 2 ? run_slot(e3) : lds_slot<3>(cc0)) : zoff);
+            const T x0 = xat(k0 ? slot_of(K0{}, e0, cc0) : zoff), x1 = xat(k1 ? slot_of(K1{}, e1, cc0) : zoff),
+                    x2 = xat(k2 ? slot_of(K2{}, e2, cc0) : zoff), x3 = xat(k3 ? slot_of(K3{}, e3, cc0) : zoff);
             sum = fmadd(k0 ? vv0[0] : T(0), x0, sum);
             sum = fmadd(k1 ? vv0[1] : T(0), x1, sum);
             sum = fmadd(k2 ? vv0[2] : T(0), x2, sum);
@@ -207,8 +270,14 @@ __device__ __forceinline__ T csr_vector_step(int p0, int p1, int l, const int (&
                 T v2[4];
                 if (MODE == 1) LM::load_col16(col_local, bb, l, cc);
                 else if (MODE == 0) LM::load_col32(colidx, bb, l, cc);
+                else if (MODE == 3) LM::load_col8(col8, bb, l, cc);
                 LM::load_val(val, bb, l, v2);
-                if (MODE == 2) {
+                if (MODE == 3) {
+                    if (bb + LM::pos(l, 0) < p1) sum = fmadd(v2[0], xat(slot_of(K0{}, 0, cc)), sum);
+                    if (bb + LM::pos(l, 1) < p1) sum = fmadd(v2[1], xat(slot_of(K1{}, 0, cc)), sum);
+                    if (bb + LM::pos(l, 2) < p1) sum = fmadd(v2[2], xat(slot_of(K2{}, 0, cc)), sum);
+                    if (bb + LM::pos(l, 3) < p1) sum = fmadd(v2[3], xat(slot_of(K3{}, 0, cc)), sum);
+                } else if (MODE == 2) {
 #pragma unroll
                     for (int k = 0; k < 4; ++k)
                         if (bb + LM::pos(l, k) < p1) sum = fmadd(v2[k], xat(run_slot(bb + LM::pos(l, k))), sum);
@@ -240,7 +309,7 @@ __device__ __forceinline__ void csr_vector_tile_wave(long long row_end, int long
                                                      const int *__restrict__ colidx, const unsigned short *__restrict__ col_local,
                                                      const T *__restrict__ val,
                                                      const T *__restrict__ x, const T *__restrict__ xs, unsigned zoff,
-                                                     T *__restrict__ y, const int (&c0)[4], const T (&v0)[4])
+                                                     T *__restrict__ y, const int (&c0)[4], const T (&v0)[4], const unsigned char *__restrict__ col8 = nullptr)
 {
     constexpr int RW = kWave / L; // rows per step
     constexpr int D = DEPTH < L ? DEPTH : L; // steps of matrix stream in flight per wave
@@ -259,11 +328,12 @@ __device__ __forceinline__ void csr_vector_tile_wave(long long row_end, int long
         pp0[slot] = rp_lds[s * RW + sub];
         pp1[slot] = rp_lds[s * RW + sub + 1];
         if (pp1[slot] - pp0[slot] > long_thr) pp1[slot] = pp0[slot];
-        if (MODE == 2) rs[slot] = rs_lds[s * RW + sub];
+        if (MODE >= 2) rs[slot] = rs_lds[s * RW + sub];
         if (s > 0 || !PRE) {
             const int an = pp0[slot] & ~3;
             if (MODE == 1) Lane4<T, L>::load_col16(col_local, an, l, c[slot]);
             else if (MODE == 0) Lane4<T, L>::load_col32(colidx, an, l, c[slot]);
+            else if (MODE == 3) Lane4<T, L>::load_col8(col8, an, l, c[slot]);
             Lane4<T, L>::load_val(val, an, l, v[slot]);
         }
     };
@@ -273,7 +343,7 @@ __device__ __forceinline__ void csr_vector_tile_wave(long long row_end, int long
     for (int s = 0; s < L; ++s) {
         const int cur = s % D;
         const int p0 = pp0[cur], p1 = pp1[cur];
-        T sum = csr_vector_step<T, L, MODE, SHIFT>(p0, p1, l, c[cur], v[cur], colidx, col_local, val, x, xb, zoff, rs[cur]);
+        T sum = csr_vector_step<T, L, MODE, SHIFT>(p0, p1, l, c[cur], v[cur], colidx, col_local, val, x, xb, zoff, rs[cur], col8);
         sum = group_sum_dpp<L>(sum);
         if (l == 0) y_lds[s * RW + sub] = sum;
         if (s + D < L) issue(s + D); // refill the slot just consumed
@@ -291,6 +361,7 @@ __global__ __launch_bounds__(kVecTileThreads) void csr_vector_tile_kernel(int m,
                                                                           const T *__restrict__ val,
                                                                           const TileWindows *__restrict__ wins,
                                                                           const unsigned short *__restrict__ row_slot,
+                                                                          const unsigned char *__restrict__ col8,
                                                                           const T *__restrict__ x, T *__restrict__ y)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char vec_x_lds[]; // the tile's staged x
@@ -307,7 +378,7 @@ __global__ __launch_bounds__(kVecTileThreads) void csr_vector_tile_kernel(int m,
     const int rp = rowptr[r];
     const int rpe = rowptr[re]; // wave-uniform
     const TileWindows &tw = wins[blockIdx.x];
-    const bool staged = tw.nwin > 0, runs = tw.runs != 0; // runs implies staged
+    const bool staged = tw.nwin > 0, runs = tw.runs == 1, bytes = tw.runs == 2; // runs / bytes imply staged
     // step 0 of the matrix stream is issued straight from registers (RowPtr handed over by
     // shuffles), BEFORE the x staging and the barrier, so neither sits in front of the first loads
     int c0[4] = {0, 0, 0, 0};
@@ -317,19 +388,21 @@ __global__ __launch_bounds__(kVecTileThreads) void csr_vector_tile_kernel(int m,
         const int q0 = __shfl(rp, sub, kWave);
         const int a = q0 & ~3;
         if (runs) {}
+        else if (bytes) Lane4<T, L>::load_col8(col8, a, l, c0);
         else if (staged) Lane4<T, L>::load_col16(col_local, a, l, c0);
         else Lane4<T, L>::load_col32(colidx, a, l, c0);
         Lane4<T, L>::load_val(val, a, l, v0);
     }
     rp_lds[wave][lane] = rp;
     if (lane == 0) rp_lds[wave][kWave] = rpe;
-    if (runs) rs_lds[wave][lane] = row_slot[r]; // r <= m: the array has m + 1 entries
+    if (runs | bytes) rs_lds[wave][lane] = row_slot[r]; // r <= m: the array has m + 1 entries
     stage_windows<kVecTileThreads, T>(tw, x, xs);
     if (threadIdx.x == 0) xs[tw.total] = T(0); // the zero slot of masked entries
     __syncthreads();
     if (rw0 >= m) return;
     const unsigned zoff = (unsigned) tw.total * (unsigned) sizeof(T);
     if (runs) csr_vector_tile_wave<T, L, 2, DEPTH, PRE>((long long) m, long_thr, rw0, lane, rp_lds[wave], rs_lds[wave], y_lds[wave], colidx, col_local, val, x, xs, zoff, y, c0, v0);
+    else if (bytes) csr_vector_tile_wave<T, L, 3, DEPTH, PRE>((long long) m, long_thr, rw0, lane, rp_lds[wave], rs_lds[wave], y_lds[wave], colidx, col_local, val, x, xs, zoff, y, c0, v0, col8);
     else if (staged) csr_vector_tile_wave<T, L, 1, DEPTH, PRE>((long long) m, long_thr, rw0, lane, rp_lds[wave], rs_lds[wave], y_lds[wave], colidx, col_local, val, x, xs, zoff, y, c0, v0);
     else csr_vector_tile_wave<T, L, 0, DEPTH, PRE>((long long) m, long_thr, rw0, lane, rp_lds[wave], rs_lds[wave], y_lds[wave], colidx, col_local, val, x, xs, zoff, y, c0, v0);
 }
@@ -347,6 +420,7 @@ __global__ __launch_bounds__(kVecTileThreads) void csr_vector_rows_kernel(int lo
                                                                           const T *__restrict__ val,
                                                                           const TileWindows *__restrict__ wins,
                                                                           const unsigned short *__restrict__ row_slot,
+                                                                          const unsigned char *__restrict__ col8,
                                                                           const T *__restrict__ x, T *__restrict__ y)
 {
     // WIDE: x windows above 64 KiB (fp64 rows whose columns scatter over thousands of columns): the column
@@ -362,7 +436,7 @@ __global__ __launch_bounds__(kVecTileThreads) void csr_vector_rows_kernel(int lo
     long long r_begin, r_end;
     tile_rows(blockIdx.x, m, rows_per_block, split, r_begin, r_end);
     const TileWindows &tw = wins[blockIdx.x];
-    const bool staged = tw.nwin > 0, runs = tw.runs != 0;
+    const bool staged = tw.nwin > 0, runs = tw.runs == 1, bytes = tw.runs == 2;
     stage_windows<kVecTileThreads, T>(tw, x, xs);
     if (threadIdx.x == 0) xs[tw.total] = T(0); // the zero slot of masked entries
     __syncthreads();
@@ -375,9 +449,10 @@ __global__ __launch_bounds__(kVecTileThreads) void csr_vector_rows_kernel(int lo
         if (re > r_end) re = r_end;
         rp_lds[wave][lane] = rowptr[r];
         if (lane == 0) rp_lds[wave][kWave] = rowptr[re];
-        if (runs) rs_lds[wave][lane] = row_slot[r];
+        if (runs | bytes) rs_lds[wave][lane] = row_slot[r];
         wave_lds_sync();
         if (runs) csr_vector_tile_wave<T, L, 2, DEPTH, false, SHIFT>(r_end, long_thr, rw0, lane, rp_lds[wave], rs_lds[wave], y_lds[wave], colidx, col_local, val, x, xs, zoff, y, c0, v0);
+        else if (bytes) csr_vector_tile_wave<T, L, 3, DEPTH, false, SHIFT>(r_end, long_thr, rw0, lane, rp_lds[wave], rs_lds[wave], y_lds[wave], colidx, col_local, val, x, xs, zoff, y, c0, v0, col8);
         else if (staged) csr_vector_tile_wave<T, L, 1, DEPTH, false, SHIFT>(r_end, long_thr, rw0, lane, rp_lds[wave], rs_lds[wave], y_lds[wave], colidx, col_local, val, x, xs, zoff, y, c0, v0);
         else csr_vector_tile_wave<T, L, 0, DEPTH, false, SHIFT>(r_end, long_thr, rw0, lane, rp_lds[wave], rs_lds[wave], y_lds[wave], colidx, col_local, val, x, xs, zoff, y, c0, v0);
         wave_lds_sync(); // y_lds / rp_lds are reused by the next slab

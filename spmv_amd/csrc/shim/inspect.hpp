@@ -82,7 +82,7 @@ template <typename T>
 static int build_tile_windows(spmv_dev *d, int tiles, const int *split, int rows_per_tile, bool wide)
 {
     int *cnt = nullptr;
-    int host2[5] = {0, 0, 0, 0, 0};
+    int host2[8] = {0, 0, 0, 0, 0, 0, 0, 0};
     d->vt_tiles = tiles;
     ALLOC_TRY(d, &cnt, sizeof host2, true);
     static_assert(kVecXTileBytes <= 65536, "LDS byte offsets must fit 16 bits");
@@ -95,6 +95,10 @@ static int build_tile_windows(spmv_dev *d, int tiles, const int *split, int rows
         ALLOC_TRY(d, &d->vt_rowslot, sizeof(unsigned short) * ((size_t) d->m + kStreamPad), true);
         HIP_TRY(hipMemsetAsync(d->vt_rowslot, 0, sizeof(unsigned short) * ((size_t) d->m + kStreamPad), d->stream));
     }
+    if (!d->vt_col8 && d->vt_rowslot && !getenv("SPMV_HIP_NO_BYTE_TILES")) { // A/B switch: staged tiles that are not RUN tiles read their 16-bit stream
+        ALLOC_TRY(d, &d->vt_col8, (size_t) d->nnz + kStreamPad, true);
+        HIP_TRY(hipMemsetAsync(d->vt_col8, 0, (size_t) d->nnz + kStreamPad, d->stream));
+    }
     if (d->vt_wins) sched_free(d, d->vt_wins);
     ALLOC_TRY(d, &d->vt_wins, sizeof(TileWindows) * (size_t) tiles, true);
     HIP_TRY(hipMemsetAsync(cnt, 0, sizeof host2, d->stream));
@@ -102,7 +106,7 @@ static int build_tile_windows(spmv_dev *d, int tiles, const int *split, int rows
     csr_tile_windows_kernel<<<tiles, kBlock, 0, d->stream>>>(d->m, d->n, rows_per_tile, d->long_thr,
                                                              (int) ((wide ? kVecWideXTileBytes : kVecXTileBytes) / sizeof(T)) - 1, wide ? 1 : (int) sizeof(T),
                                                              split, d->rowptr, d->colidx,
-                                                             d->vt_wins, d->vt_col, d->vt_rowslot, cnt);
+                                                             d->vt_wins, d->vt_col, d->vt_rowslot, d->vt_col8, cnt);
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipMemcpyAsync(host2, cnt, sizeof host2, hipMemcpyDeviceToHost, d->stream));
     HIP_TRY(hipStreamSynchronize(d->stream));
@@ -111,6 +115,10 @@ static int build_tile_windows(spmv_dev *d, int tiles, const int *split, int rows
     d->vt_run_tiles = host2[2];
     d->vt_run_nnz = host2[3];
     d->vt_run_rows = host2[4];
+    d->vt_byte_tiles = host2[5];
+    d->vt_byte_nnz = host2[6];
+    d->vt_byte_rows = host2[7];
+    if (d->vt_col8 && d->vt_byte_tiles == 0) { sched_free(d, d->vt_col8); d->vt_col8 = nullptr; } // no tile qualified: the byte stream is not kept
     d->vt_wide = wide;
     d->vt_rows = rows_per_tile;
     return SPMV_HIP_OK;
@@ -820,6 +828,7 @@ static int account_stream_bytes(spmv_dev *d)
             t.bytes = 4 * (m + 1) + stream_part(d->nnz - d->lsub_nnz, s, fs) + s * (m - d->nlong);
             if (tile_form) { t.bytes += (long long) sizeof(TileWindows) * d->vt_tiles; t.x_elems = welems; }
             if (tile_form) t.bytes += 2ll * d->vt_run_rows - 2ll * d->vt_run_nnz; // RUN tiles: a 16-bit slot per row instead of one per entry
+            if (tile_form) t.bytes += 2ll * d->vt_byte_rows - 1ll * d->vt_byte_nnz; // BYTE tiles: a byte per entry and a 16-bit slot per row instead of 16 bits per entry
             if (d->plan.sched == SPMV_SCHED_ROWBLOCK) t.bytes += 4ll * (d->nblocks + 1);
             if (!tile_form || wtiles < d->vt_tiles) t.gathers_global = true;
             rc = csr5_traffic(d, d->c5_long, t);

@@ -261,6 +261,8 @@ static int launch(spmv_dev *d, const T *x, T *y)
         HIP_TRY(hipGetLastError());
         return SPMV_HIP_OK;
     }
+    // y += A x exists in the blocked executor only: a far half that ever ended on another executor would overwrite A_near x
+    if (d->accumulate && !d->blk_on) return fail(SPMV_HIP_E_RUNTIME, "internal: the accumulating half of a split matrix has no blocked executor");
     const T *val = (const T *) d->val;
     switch (d->plan.sched) {
     case SPMV_SCHED_CSR_SCALAR:

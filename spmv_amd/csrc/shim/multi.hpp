@@ -527,6 +527,18 @@ extern "C" int spmv_shim_multi_sync(spmv_multi *mt)
 // synchronous form (like spmv()): returns when every y block is complete
 extern "C" int spmv_shim_multi_step(spmv_multi *mt)
 {
+    if (!mt) return fail(SPMV_HIP_E_ARG, "multi: NULL");
+    // The synchronous entry keeps its round-2 contract: the x slices may have been written on ANY stream of their device (side streams,
+    // non-blocking streams), so every device is drained first.  Only the _async entry relies on the default-stream ordering.
+    {
+        int cur = -1;
+        if (hipGetDevice(&cur) != hipSuccess) { (void) hipGetLastError(); cur = 0; }
+        for (auto &s : mt->sh) {
+            (void) hipSetDevice(s.device);
+            if (hipDeviceSynchronize() != hipSuccess) { (void) hipGetLastError(); (void) hipSetDevice(cur); return fail(SPMV_HIP_E_RUNTIME, "multi: device %d failed before the step", s.device); }
+        }
+        (void) hipSetDevice(cur);
+    }
     const int rc = spmv_shim_multi_step_async(mt);
     const int rc2 = mt ? spmv_shim_multi_sync(mt) : SPMV_HIP_OK;
     return rc ? rc : rc2;

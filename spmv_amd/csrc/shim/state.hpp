@@ -210,6 +210,8 @@ struct spmv_dev {
     unsigned short *vt_col = nullptr; // tile-local column stream: 16-bit LDS slots (staged tiles only)
     unsigned short *vt_rowslot = nullptr; // RUN tiles (every row one run of consecutive columns): slot of each row's first column; no column stream read
     int vt_run_tiles = 0, vt_run_nnz = 0, vt_run_rows = 0;
+    unsigned char *vt_col8 = nullptr;     // BYTE tiles (every row's slots within 255 of its smallest): one byte per entry, read INSTEAD of vt_col; vt_rowslot holds the smallest slot
+    int vt_byte_tiles = 0, vt_byte_nnz = 0, vt_byte_rows = 0;
     TileWindows *vt_wins = nullptr; // x windows of every tile
     // long rows (csr-vector, sell)
     int nlong = 0, long_thr = INT_MAX;
@@ -289,6 +291,7 @@ static void reset_tile_fields(spmv_dev *d)
     d->long_thr = INT_MAX;
     d->vt_col = nullptr; d->vt_wins = nullptr; d->vt_tiles = d->vt_staged = d->vt_maxspan = 0; d->vt_wide = false; d->vt_rows = 256;
     d->vt_rowslot = nullptr; d->vt_run_tiles = d->vt_run_nnz = d->vt_run_rows = 0;
+    d->vt_col8 = nullptr; d->vt_byte_tiles = d->vt_byte_nnz = d->vt_byte_rows = 0;
     d->c5 = Csr5Plan();
     d->c5_long = Csr5Plan();
     d->ns = Csr5Plan();

@@ -325,15 +325,21 @@ static int state_build(spmv_Handle_t h, spmv_hip_state *st, int m, int n, const 
         spmv_plan best_plan = st->plan;
         SPMV_METHODS best_method = actual;
         double best_ms = spmv_shim_time_self(st->dev, 5);
-        unsigned k;
+        unsigned k, j, nseen = 1;
+        spmv_plan seen[1 + sizeof cand / sizeof cand[0]]; /* schedules already built and timed: several methods may plan the same one (short heavy-tailed rows) */
         int current_is_best = best_ms >= 0.0;
+        seen[0] = st->plan;
         for (k = 0; k < sizeof cand / sizeof cand[0] && best_ms >= 0.0; ++k) {
             spmv_plan p;
             SPMV_METHODS a = cand[k];
             double ms;
+            int dup = 0;
             spmv_plan_choose(cand[k], &stats, (size_t) h->data_size, &st->opts, &p, &a, 0);
-            if (a == actual && p.sched == st->plan.sched) continue; /* the one already built and timed */
-            if (a == best_method && p.sched == best_plan.sched) continue;
+            for (j = 0; j < nseen; ++j) /* the same schedule with the same shape is the same multiply whatever the method is called: timing noise must not choose */
+                if (seen[j].sched == p.sched && seen[j].lanes_per_row == p.lanes_per_row && seen[j].long_thr == p.long_thr && seen[j].sell_sigma == p.sell_sigma &&
+                    seen[j].sell_long_thr == p.sell_long_thr && seen[j].csr5_sigma == p.csr5_sigma && seen[j].rowblock_nnz == p.rowblock_nnz) dup = 1;
+            if (dup) continue;
+            seen[nseen++] = p;
             if (spmv_shim_build(st->dev, &p) != SPMV_HIP_OK) { current_is_best = 0; continue; }
             current_is_best = 0;
             ms = spmv_shim_time_self(st->dev, 5);

@@ -390,8 +390,10 @@ void spmv_plan_choose(SPMV_METHODS requested, const spmv_stats *st, size_t value
      * equal-nnz tiles (nnz / 256 x 1.1 steps) several times cheaper -- measured 0.046 ms (CSR-vector, SELL) against 0.027 ms
      * (nnz-split) on the 1e6-row stand-in.  When the model says "under half", the multiply is handed to the nnz-split executor
      * below the method, like the blocked executor is for matrices without locality: the handle keeps reporting the method asked for.
-     * A forced lanes_per_row (or variant, the A/B selector) keeps the named schedule. */
+     * A forced lanes_per_row (or variant, the A/B selector) keeps the named schedule, and so does an explicit SELL request that sets
+     * any of SELL's own options (sigma, long-row threshold, plain slab kernel): whoever tunes the schedule gets the schedule. */
     if ((plan->sched == SPMV_SCHED_CSR_VECTOR || plan->sched == SPMV_SCHED_SELL) && lanes == 0 && plan->variant == 0 && vector_cost > 0.0 &&
+        !(plan->sched == SPMV_SCHED_SELL && (opt->v[SPMV_OPT_SELL_SIGMA] != 1024 || opt->v[SPMV_OPT_SELL_LONG_THR] != 0 || opt->v[SPMV_OPT_SELL_LDS_X] != 1)) &&
         st->mean_row_len < 8.0 && (double) st->nnz / 256.0 * 1.1 < 0.5 * vector_cost)
         plan->sched = SPMV_SCHED_NNZ_SPLIT;
 }

@@ -376,6 +376,7 @@ extern "C" int spmv_shim_update_values(spmv_dev *d, const void *val)
     DeviceGuard guard(d->device);
     if (!guard.ok) return fail(SPMV_HIP_E_RUNTIME, "hipSetDevice(%d) failed", d->device);
     if (d->sp_near && d->sp_far) { // split handle: the resident values first, then both halves from them (same positions as at create)
+        d->sp_near->stream = d->sp_far->stream = d->stream;
         HIP_TRY(hipMemcpyAsync(d->val, val, d->vsize * (size_t) d->nnz, hipMemcpyDefault, d->stream));
         int rc = d->vsize == sizeof(double) ? split_make<double>(d, nullptr, nullptr, true) : split_make<float>(d, nullptr, nullptr, true);
         if (!rc) rc = spmv_shim_update_values(d->sp_near, d->sp_near->val);
@@ -463,6 +464,9 @@ extern "C" int spmv_shim_set_stream(spmv_dev *d, void *stream)
 {
     if (!d) return fail(SPMV_HIP_E_ARG, "set_stream: NULL");
     d->stream = (hipStream_t) stream;
+    // the halves of a split handle launch on the parent's stream; a values refresh between set_stream and the next multiply must already see it
+    if (d->sp_near) d->sp_near->stream = d->stream;
+    if (d->sp_far) d->sp_far->stream = d->stream;
     return SPMV_HIP_OK;
 }
 
@@ -605,6 +609,7 @@ extern "C" int spmv_shim_info(const spmv_dev *d, spmv_hip_info *o)
     {
         const bool tiles_run = !d->blk_on && ((d->plan.sched == SPMV_SCHED_CSR_VECTOR && d->vt_tiles > 0 && (d->vt_wide || d->vt_staged * 2 >= d->vt_tiles) && d->vec_choice != VEC_PIPE) || d->plan.sched == SPMV_SCHED_ROWBLOCK);
         o->run_nnz = tiles_run ? d->vt_run_nnz : 0;
+        o->byte_nnz = tiles_run ? d->vt_byte_nnz : 0;
         if (!d->blk_on && d->plan.sched == SPMV_SCHED_SELL && d->sell_staged > 0) o->run_nnz = d->sell_run_nnz;
         if (!d->blk_on && d->plan.sched == SPMV_SCHED_CSR5) o->run_nnz = d->c5.run_tiles * kWave * d->c5.sigma;
     }

@@ -195,6 +195,47 @@ def banded_device(m, n, k=32, values="uniform", dtype=None, device="cuda", seed=
     return m, n, rowptr, colidx, val
 
 
+def banded_holes_device(m, n, k=32, holes=0.25, values="uniform", dtype=None, device="cuda", seed=1, row0=0):
+    """Exactly k nnz per row inside a band of width w = round(k / (1 - holes)) around the diagonal: each row keeps k of the band's w
+    columns, chosen at random (sorted) -- BASELINE config 2 with the band no longer one run of consecutive columns per row (mean run
+    length 1 / holes): what a stencil or FEM band with missing couplings looks like.  Columns wrap like banded_device's."""
+    torch = _torch()
+    dtype = dtype or torch.float64
+    assert (m + 1) * k < 2**31, "int32 RowPtr: shard too large"
+    w = max(k, int(round(k / (1.0 - holes))))
+    g = torch.Generator(device=device)
+    g.manual_seed(seed + 707)
+    rowptr = torch.arange(0, (m + 1) * k, k, dtype=torch.int32, device=device)
+    colidx = torch.empty(m * k, dtype=torch.int32, device=device)
+    step = 1 << 20
+    for r0 in range(0, m, step):
+        r1 = min(m, r0 + step)
+        keys = torch.rand(r1 - r0, w, generator=g, device=device)
+        pick = torch.sort(torch.topk(keys, k, dim=1, sorted=False).indices, dim=1).values      # k distinct offsets in [0, w), ascending
+        rows = torch.arange(r0 + row0, r1 + row0, dtype=torch.int64, device=device)
+        cols = (rows[:, None] + pick - w // 2) % n
+        colidx[r0 * k:r1 * k] = torch.sort(cols, dim=1).values.reshape(-1).to(torch.int32)         # the wrapped rows at both ends stay sorted
+    val = _fill_device(m * k, values, dtype, device, seed)
+    return m, n, rowptr, colidx, val
+
+
+def stencil27_device(nx, values="uniform", dtype=None, device="cuda", seed=1):
+    """27-point stencil on an nx^3 periodic grid: 27 nnz per row in 9 runs of 3 consecutive columns, three far-apart bands."""
+    torch = _torch()
+    dtype = dtype or torch.float64
+    m = nx ** 3
+    assert (m + 1) * 27 < 2**31
+    offs = torch.tensor([dz * nx * nx + dy * nx + dx for dz in (-1, 0, 1) for dy in (-1, 0, 1) for dx in (-1, 0, 1)], device=device)
+    rowptr = torch.arange(0, (m + 1) * 27, 27, dtype=torch.int32, device=device)
+    colidx = torch.empty(m * 27, dtype=torch.int32, device=device)
+    for r0 in range(0, m, 1 << 22):
+        r1 = min(m, r0 + (1 << 22))
+        rows = torch.arange(r0, r1, device=device)
+        colidx[r0 * 27:r1 * 27] = torch.sort((rows[:, None] + offs[None, :]) % m, dim=1).values.reshape(-1).to(torch.int32)
+    val = _fill_device(m * 27, values, dtype, device, seed)
+    return m, m, rowptr, colidx, val
+
+
 def uniform_k_device(m, n, k=32, values="uniform", dtype=None, device="cuda", seed=1):
     """Exactly k uniformly random columns per row, sorted within the row (variant (ii) of SURVEY 8d).
     Columns are drawn with replacement; a duplicate column inside a row is legal CSR for SpMV."""

@@ -251,6 +251,48 @@ def test_range_exchange_overlaps_the_halo_with_the_interior_rows(virtual, gpus, 
         h.close()
 
 
+def test_synchronous_step_sees_slices_written_on_a_side_stream_and_stale_halos_do_not_leak(virtual):
+    """spmv_hip_multi_step (the synchronous entry) drains every device first, so x slices written on a NON-BLOCKING side
+    stream are seen; and with the range exchange the whole-shard multiply reads halo columns while they are in flight -- stale halo
+    entries are poisoned with NaN here, and no NaN may survive in y because the boundary rows are recomputed after the halo arrived."""
+    import torch
+    from spmv_amd import synth
+    dtype = np.float64
+    csr = synth.banded(6000, 6000, 40, 40, "eighths", dtype, seed=8)
+    rng = np.random.default_rng(5)
+    h = _multi_handle(csr, M.Method_Parallel, 2, 1)
+    hip = C.CDLL("libamdhip64.so")
+    hip.hipMemcpyAsync.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_int, C.c_void_p]
+    hip.hipMemcpy.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_int]
+    side = torch.cuda.Stream()       # non-blocking with respect to the default stream
+    try:
+        G = h.multi_gpus()
+        for step in range(2):
+            x = (rng.integers(-8, 9, csr.n) * 0.125).astype(dtype)
+            prod = csr.val * x[csr.colidx]
+            cs = np.concatenate([[0.0], np.cumsum(prod)])
+            want = cs[csr.rowptr[1:]] - cs[csr.rowptr[:-1]]
+            keep = []
+            for g in range(G):       # poison the other shards' part of this device's x copy (the stale halo), then write the own slice on the side stream
+                s = h.multi_slices(g)
+                full = np.full(csr.n, np.nan, dtype=dtype)
+                assert hip.hipMemcpy(s["x_ptr"] - 8 * s["x_first"], full.ctypes.data, full.nbytes, 1) == 0
+                part = np.ascontiguousarray(x[s["x_first"]: s["x_first"] + s["x_count"]])
+                keep.append(part)
+                assert hip.hipMemcpyAsync(s["x_ptr"], part.ctypes.data, part.nbytes, 1, C.c_void_p(side.cuda_stream)) == 0
+            h.multi_step()
+            y = np.full(csr.m, np.nan, dtype=dtype)
+            for g in range(G):
+                s = h.multi_slices(g)
+                blk = np.empty(s["y_count"], dtype=dtype)
+                assert hip.hipMemcpy(blk.ctypes.data, s["y_ptr"], blk.nbytes, 2) == 0
+                y[s["y_first"]: s["y_first"] + s["y_count"]] = blk
+            assert not np.isnan(y).any(), (step, int(np.isnan(y).sum()))
+            assert np.array_equal(y, want), (step, int((y != want).sum()))
+    finally:
+        h.close()
+
+
 def test_async_steps_enqueued_back_to_back(virtual):
     """three spmv_hip_multi_step_async calls without a synchronize in between (the same x: the caller may not overwrite slices a
     running step reads), one synchronize: the halo copies of a step are ordered behind the previous step's multiplies"""

@@ -1083,6 +1083,112 @@ def test_run_tiles_need_no_column_stream(shape, dtype, method):
         assert torch.equal(y, 2 * want)
 
 
+def _holes_rows_matrix(m, n, lens, start, span, dtype, dev, seed, reverse=False):
+    """CSR whose row i holds lens[i] DISTINCT columns drawn from [start[i], start[i] + span[i]) -- first and last column of the range always present
+    when lens[i] >= 2, so the row's column span is exactly span[i] --, ascending (or descending: unsorted rows are legal CSR); exact values"""
+    import torch
+    g = torch.Generator(device=dev); g.manual_seed(seed)
+    W = int(span.max())
+    keys = torch.rand(m, W, generator=g, device=dev)
+    cols = torch.arange(W, device=dev)[None, :]
+    keys = torch.where(cols < span[:, None], keys, torch.full_like(keys, 2.0))         # outside the row's range: never picked
+    keys[:, 0] = -1.0                                                                  # the range's first column: always
+    keys[torch.arange(m, device=dev), (span - 1).clamp_(min=0)] = -0.5                 # ... and its last
+    order = torch.argsort(keys, dim=1)                                                 # row i keeps the lens[i] smallest keys
+    keep = torch.arange(W, device=dev)[None, :] < lens[:, None]
+    picked = torch.where(keep, order, torch.full_like(order, W + 1))
+    picked = torch.sort(picked, dim=1, descending=reverse).values
+    rp = torch.zeros(m + 1, dtype=torch.int64, device=dev)
+    torch.cumsum(lens, 0, out=rp[1:])
+    mask = picked <= W
+    ci = (start[:, None] + picked)[mask].to(torch.int32)
+    nnz = int(rp[-1])
+    assert ci.numel() == nnz and int(ci.min()) >= 0 and int(ci.max()) < n
+    va = (torch.randint(-8, 9, (nnz,), generator=g, device=dev) * 0.125).to(dtype)
+    return rp.to(torch.int32), ci, va
+
+
+@pytest.mark.parametrize("method", [M.Method_Parallel, M.Method_Balanced], ids=lambda m: m.name)
+@pytest.mark.parametrize("dtype", ["f64", "f32"])
+@pytest.mark.parametrize("shape", ["holes", "ragged", "unsorted", "two_bands", "chunks", "span_edge", "wide"])
+def test_byte_tiles_read_one_byte_per_entry(shape, dtype, method):
+    """BYTE tiles (round 4, csr_vector_tile.hpp): a staged tile in which every row's LDS slots lie within 255 of the row's smallest slot -- bands with
+    holes, block rows, anything whose rows span under 256 columns of one window -- reads a BYTE per entry + 16 bits per row instead of 16 bits per
+    entry.  Exact data: the sums equal the definition bit for bit; info.byte_nnz says how many entries took the byte stream.
+      holes      32 of the 43 columns of a band (BASELINE config 2 with 25 % holes)
+      ragged     0..40 entries per row out of ranges of 1..200 columns that start within +-600 of the diagonal (empty rows, single entries)
+      unsorted   the same with every row's columns in DESCENDING order: the row's smallest slot is not its first entry's
+      two_bands  odd rows 200 000 columns away: two x windows per tile, every row inside one of them
+      chunks     64..200 entries per row from ranges of up to 255 columns: several chunks per row
+      span_edge  ranges of exactly 256 columns (span 255: the largest byte) everywhere but in every 40th 256-row tile, where one row spans 257
+                 columns: those tiles keep the 16-bit stream, the others are BYTE tiles
+      wide       8 entries from ranges of 20 columns starting within +-5000 columns of the diagonal: fp64 -> wide form (slot indices, 1024-row blocks)"""
+    import torch
+    dev = torch.device("cuda:0")
+    tdt = torch.float64 if dtype == "f64" else torch.float32
+    m = n = 300_000
+    g = torch.Generator(device=dev); g.manual_seed(21)
+    rows = torch.arange(m, device=dev)
+    reverse = shape == "unsorted"
+    if shape == "holes":
+        m, n, rp, ci, va = synth.banded_holes_device(m, n, 32, 0.25, "eighths", tdt, dev, 3)
+    else:
+        if shape in ("ragged", "unsorted"):
+            span = torch.randint(1, 201, (m,), generator=g, device=dev)
+            lens = torch.minimum(torch.randint(0, 41, (m,), generator=g, device=dev), span)
+            start = (rows + torch.randint(-600, 601, (m,), generator=g, device=dev)).clamp_(0, n - 201)
+        elif shape == "two_bands":
+            span = torch.full((m,), 40, device=dev)
+            lens = torch.full((m,), 12, device=dev)
+            start = torch.where(rows % 2 == 0, rows, (rows + 200_000) % n).clamp_(0, n - 41)
+        elif shape == "chunks":
+            span = torch.randint(200, 256, (m,), generator=g, device=dev)
+            lens = torch.randint(64, 201, (m,), generator=g, device=dev)
+            start = (rows - 100).clamp_(0, n - 257)
+        elif shape == "span_edge":
+            span = torch.full((m,), 256, device=dev)
+            span[(rows % (40 * 256)) == 77] = 257
+            lens = torch.full((m,), 10, device=dev)
+            start = (rows - 100).clamp_(0, n - 258)
+        else:
+            span = torch.full((m,), 20, device=dev)
+            lens = torch.full((m,), 8, device=dev)
+            start = (rows + torch.randint(-5000, 5001, (m,), generator=g, device=dev)).clamp_(0, n - 21)
+        rp, ci, va = _holes_rows_matrix(m, n, lens, start, span, tdt, dev, 6, reverse)
+    nnz = int(rp[-1])
+    x = (torch.randint(-8, 9, (n,), generator=g, device=dev) * 0.125).to(tdt)
+    want = _segment_sums(va.double() * x.double()[ci.long()], rp).to(tdt)
+    y = torch.full((m,), float("nan"), dtype=tdt, device=dev)
+    if shape == "chunks":
+        api.set_thread_option("lanes_per_row", 4)
+    try:
+        h = api.Handle(m, n, rp, ci, va, method)
+    finally:
+        api.clear_thread_options()
+    with h:
+        h.spmv(x, y)
+        info = h.info()
+        torch.cuda.synchronize()
+        assert torch.equal(y, want), (info["kernel_name"], int((y != want).sum()))
+        assert info["kernel_name"] in ("csr_vector_tile_kernel", "csr_vector_rows_kernel") and info["cache_blocked"] == 0, info
+        assert info["run_nnz"] + info["byte_nnz"] <= nnz
+        if shape == "span_edge":
+            if method == M.Method_Parallel:   # every 40th tile holds a 257-column row
+                assert 0.96 * nnz <= info["byte_nnz"] <= 0.985 * nnz, (info["byte_nnz"], nnz)
+            else:
+                assert 0 < info["byte_nnz"] < nnz, (info["byte_nnz"], nnz)
+        elif shape == "holes":     # the band wraps at both ends of the matrix: the first and the last tile see columns at both ends of x (two windows)
+            assert nnz - 4 * 256 * 32 <= info["byte_nnz"] < nnz, (info["byte_nnz"], nnz)
+        else:
+            assert info["byte_nnz"] + info["run_nnz"] == nnz, (info["byte_nnz"], info["run_nnz"], nnz, info["x_groups"], info["x_groups_staged"])
+            assert info["byte_nnz"] >= 0.9 * nnz
+        va2 = (va * 2).contiguous()
+        h.update_values(va2)
+        h.spmv(x, y)
+        torch.cuda.synchronize()
+        assert torch.equal(y, 2 * want)
+
+
 @pytest.mark.parametrize("method", [M.Method_CSR5SPMV, M.Method_SellCSigma, M.Method_Balanced_Yid, M.Method_Parallel], ids=lambda m: m.name)
 @pytest.mark.parametrize("dtype", ["f64", "f32"])
 def test_wide_x_windows_are_staged_from_any_element_alignment(dtype, method):

@@ -20,6 +20,8 @@ M = api.SPMV_METHODS
 CONFIGS = {
     "2": ("config 2: 1e7 x 1e7, 32 nnz/row banded, fp64", M.Method_Parallel),
     "2r": ("config 2 variant (ii): uniformly random columns, fp64", M.Method_Parallel),
+    "2h": ("config 2 with holes: 32 of the 43 columns of a band per row (mean run length 4), fp64", M.Method_Parallel),
+    "s27": ("27-point stencil 215^3 (9.9e6 rows, 2.7e8 nnz), fp64", M.Method_Parallel),
     "3w": ("config 3 stand-in webbase-1M-style: 1e6 rows, mean 3.1, max 4.7k, R-MAT columns, fp64", M.Method_Balanced2),
     "3w-uniform": ("config 3 stand-in webbase-1M-style, uniform columns, fp64", M.Method_Balanced2),
     "3w-web": ("config 3 stand-in webbase-1M-style, web-like columns (90 % within +-2000 of the row, 10 % R-MAT hubs), fp64", M.Method_Balanced2),
@@ -34,6 +36,10 @@ def make(config, dev):
     f64 = torch.float64
     if config == "2":
         return synth.banded_device(10_000_000, 10_000_000, 32, "uniform", f64, dev, 1)
+    if config == "2h":
+        return synth.banded_holes_device(10_000_000, 10_000_000, 32, 0.25, "uniform", f64, dev, 1)
+    if config == "s27":
+        return synth.stencil27_device(215, "uniform", f64, dev, 1)
     if config == "2r":
         return synth.uniform_k_device(10_000_000, 10_000_000, 32, "uniform", f64, dev, 1)
     if config in ("3w", "3w-uniform", "3w-web"):
