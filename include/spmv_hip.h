@@ -153,6 +153,7 @@ typedef struct spmv_hip_info {
                                  * smallest (banded matrices with holes, block rows): their column stream is one byte per entry + 16 bits per row */
     int blk_waves;              /* cache_blocked: wavefronts that share one row block's accumulators (1: a wave per block, two blocks per CU; 2 / 4 / 8: the
                                  * wide form, one block of up to ~20 k rows per CU); 0 when another executor runs */
+    char launch_kernels[160];   /* every kernel ONE spmv() launches, in order, '+'-separated (e.g. "sell_window_kernel+csr5_group_pipe_kernel+csr5_fixup_kernel") */
     int reproducible;           /* 1: the executor adds every row's products in an order fixed by the matrix -- identical bits run to run and handle to
                                  * handle; 0 only for the wide blocked form under option "deterministic" = 0 */
 } spmv_hip_info;

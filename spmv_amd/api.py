@@ -68,7 +68,7 @@ class spmv_hip_info(C.Structure):
                 ("tuned_choice", C.c_int), ("tune_ms", C.c_float * 3),
                 ("x_groups", C.c_int), ("x_groups_staged", C.c_int), ("cache_blocked", C.c_int),
                 ("stream_bytes", C.c_longlong), ("x_bytes", C.c_longlong), ("route_ms", C.c_float * 2), ("split_ms", C.c_float * 2), ("far_nnz", C.c_longlong), ("run_nnz", C.c_longlong), ("byte_nnz", C.c_longlong),
-                ("blk_waves", C.c_int), ("reproducible", C.c_int)]
+                ("blk_waves", C.c_int), ("launch_kernels", C.c_char * 160), ("reproducible", C.c_int)]
 
 
 # Every symbol include/*.h declares: functions with their prototypes, then data symbols.
@@ -250,6 +250,7 @@ def get_info(handle):
     out = {k: getattr(info, k) for k, _ in spmv_hip_info._fields_}
     out["schedule_name"] = (out["schedule_name"] or b"").decode()
     out["kernel_name"] = (out["kernel_name"] or b"").decode()
+    out["launch_kernels"] = [k for k in (out["launch_kernels"] or b"").decode().split("+") if k]
     out["tune_ms"] = [float(v) for v in out["tune_ms"]]
     out["route_ms"] = [float(v) for v in out["route_ms"]]
     out["split_ms"] = [float(v) for v in out["split_ms"]]

@@ -28,6 +28,7 @@ ARCH = "gfx950"
 
 C_SOURCES = ["spmv_api.c", "spmv_plan.c", "host_rows.c", os.path.join("io", "mtx_io.c"), os.path.join("reorder", "rcm.c")]
 TOOL_SOURCES = {"test_spmv": os.path.join("tools", "test_spmv_csv.c")}   # -> spmv_amd/bin/<name>
+HIP_TOOLS = {"gbench": os.path.join(ROOT, "tools", "gbench.hip")}          # measurement programs (bench.py's same-box read ceiling); not part of the library
 BINDIR = os.path.join(PKG, "bin")
 ROCM = os.environ.get("ROCM_PATH", "/opt/rocm")
 # (source, extra defines, object name): compiled side by side.  The CSR-vector family's executors (seven lanes-per-row values x five
@@ -97,8 +98,8 @@ def build(force=False, verbose=False):
     os.makedirs(LIBDIR, exist_ok=True)
     os.makedirs(OBJDIR, exist_ok=True)
     os.makedirs(BINDIR, exist_ok=True)
-    tools = [os.path.join(BINDIR, t) for t in TOOL_SOURCES]
-    if not force and all(os.path.exists(p) for p in [LIB] + tools) and min(os.path.getmtime(p) for p in [LIB] + tools) >= _newest(_deps()):
+    tools = [os.path.join(BINDIR, t) for t in list(TOOL_SOURCES) + list(HIP_TOOLS)]
+    if not force and all(os.path.exists(p) for p in [LIB] + tools) and min(os.path.getmtime(p) for p in [LIB] + tools) >= _newest(_deps() + list(HIP_TOOLS.values())):
         return LIB
     if not os.path.exists(HIPCC):
         raise RuntimeError(f"hipcc not found ({HIPCC}); libspmv_hip.so cannot be built")
@@ -118,6 +119,8 @@ def build(force=False, verbose=False):
             print(" ".join(cmd))
         cmds.append(cmd)
         objs.append(obj)
+    for name, src in HIP_TOOLS.items():
+        cmds.append([HIPCC, "-O3", "-std=c++17", f"--offload-arch={ARCH}", src, "-o", os.path.join(BINDIR, name)])
     _run_all(cmds)
     # host_rows.c is compiled with -fopenmp by gcc: link GNU libgomp by path (hipcc's own -fopenmp would pull LLVM's runtime)
     gomp = subprocess.run([CC, "-print-file-name=libgomp.so"], capture_output=True, text=True).stdout.strip()

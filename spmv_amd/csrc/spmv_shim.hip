@@ -547,6 +547,23 @@ static const char *kSchedNames[] = {"csr-scalar", "csr-vector", "row-block", "nn
 static const char *kKernelNames[] = {"csr_scalar_kernel", "csr_vector_pipe_kernel", "csr_vector_rows_kernel",
                                      "nat_kernel", "sell_kernel", "csr5_kernel"};
 
+// kernels of one CSR5 / nnz-split plan's multiply, appended to `buf` ('+'-separated, in launch order)
+static void append_name(char *buf, size_t cap, const char *name)
+{
+    const size_t n = strlen(buf);
+    if (n + strlen(name) + 2 >= cap) return;
+    if (n) strcat(buf, "+");
+    strcat(buf, name);
+}
+
+static void csr5_kernel_names(const spmv_dev *d, const Csr5Plan &P, char *buf, size_t cap)
+{
+    if (P.nnz == 0) return;
+    if (P.staged > 0) append_name(buf, cap, P.natural ? "nat_group_kernel" : (csr5_two_deep(d, P) ? "csr5_group_pipe_kernel" : "csr5_group_kernel"));
+    else append_name(buf, cap, P.natural ? "nat_kernel" : "csr5_kernel");
+    if (P.fixup && P.tiles > 1) append_name(buf, cap, "csr5_fixup_kernel");
+}
+
 extern "C" int spmv_shim_info(const spmv_dev *d, spmv_hip_info *o)
 {
     if (!d || !o) return fail(SPMV_HIP_E_ARG, "info: NULL");
@@ -569,6 +586,7 @@ extern "C" int spmv_shim_info(const spmv_dev *d, spmv_hip_info *o)
         o->far_nnz = d->sp_far->nnz;
         o->blk_waves = f.blk_waves;
         o->reproducible = o->reproducible && f.reproducible;
+        append_name(o->launch_kernels, sizeof o->launch_kernels, f.launch_kernels);
         return SPMV_HIP_OK;
     }
     memset(o, 0, sizeof *o);
@@ -629,6 +647,22 @@ extern "C" int spmv_shim_info(const spmv_dev *d, spmv_hip_info *o)
         o->kernel_name = d->ns.staged > 0 ? "nat_group_kernel" : "nat_kernel";
     if (d->plan.sched == SPMV_SCHED_CSR5 && d->c5.staged > 0) o->kernel_name = csr5_two_deep(d, d->c5) ? "csr5_group_pipe_kernel" : "csr5_group_kernel";
     if (d->plan.sched == SPMV_SCHED_SELL && d->sell_staged > 0) o->kernel_name = "sell_window_kernel";
+    { // every kernel of one multiply, in launch order
+        char *b = o->launch_kernels;
+        const size_t cap = sizeof o->launch_kernels;
+        b[0] = 0;
+        if (d->nnz == 0) { if (!d->accumulate && d->m > 0) append_name(b, cap, "fill_zero_kernel"); }
+        else if (d->blk_on) append_name(b, cap, o->kernel_name);
+        else switch (d->plan.sched) {
+        case SPMV_SCHED_NNZ_SPLIT: csr5_kernel_names(d, d->ns, b, cap); break;
+        case SPMV_SCHED_CSR5: csr5_kernel_names(d, d->c5, b, cap); break;
+        case SPMV_SCHED_CSR_SCALAR: append_name(b, cap, o->kernel_name); break;
+        default: // CSR-vector, row blocks, SELL: the row-granular kernel, then the long rows' CSR5 sub-matrix
+            append_name(b, cap, o->kernel_name);
+            if (d->nlong > 0) csr5_kernel_names(d, d->c5_long, b, cap);
+            break;
+        }
+    }
     return SPMV_HIP_OK;
 }
 

@@ -207,6 +207,18 @@ template <typename F> static float time_ms(F f, int reps)
 
 int main(int argc, char **argv)
 {
+    if (argc > 2 && strcmp(argv[1], "read") == 0) { // same-box ceiling for bench.py: a pure 16-byte-per-lane in-order read of `bytes` (one line of JSON)
+        size_t bytes = (size_t) strtoull(argv[2], nullptr, 10);
+        if (bytes < (1u << 20)) bytes = 1u << 20;
+        const size_t n2 = bytes / 16;
+        const int reps = argc > 3 ? atoi(argv[3]) : 10;
+        double *a, *o;
+        CK(hipMalloc(&a, n2 * 16)); CK(hipMalloc(&o, 1 << 20));
+        CK(hipMemset(a, 0, n2 * 16));
+        const float t = time_ms([&] { calib_read<<<(int) ((n2 + 1023) / 1024), 256>>>(a, n2, o); }, reps);
+        printf("{\"kernel\": \"calib_read\", \"bytes\": %zu, \"launches\": %d, \"ms_min\": %.5f, \"read_gbps\": %.1f}\n", n2 * 16, reps, t, n2 * 16 / t / 1e6);
+        return 0;
+    }
     if (argc > 1 && strcmp(argv[1], "calib") == 0) { // known-bytes read for the FETCH_SIZE calibration
         const size_t n2 = (size_t) 240 << 20;       // 16-byte elements: 3.75 GiB, far beyond the 256 MiB Infinity Cache
         double *a, *o;

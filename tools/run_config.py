@@ -15,6 +15,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 import torch  # noqa: E402
 from spmv_amd import api, build, synth  # noqa: E402
+from spmv_amd.srchash import csrc_sha  # noqa: E402
 
 M = api.SPMV_METHODS
 CONFIGS = {
@@ -92,6 +93,8 @@ def main():
            "x_groups_staged": info["x_groups_staged"], "alg_bytes": info["alg_bytes"], "stream_bytes": info["stream_bytes"],
            "x_bytes": info["x_bytes"], "ms_min": round(float(ms.min()), 5), "ms_mean": round(float(mean), 5),
            "create_s": round(create_s, 3), "inspect_ms": round(info["inspect_ms"], 2), "options": a.opt,
+           "launch_kernels": info["launch_kernels"], "blk_waves": info["blk_waves"], "reproducible": info["reproducible"], "run_nnz": info["run_nnz"],
+           "byte_nnz": info["byte_nnz"], "csrc_sha": csrc_sha(),
            "gflops": round(2 * info["nnz"] / float(ms.min()) / 1e6, 1),
            "moved_gbps": round(info["stream_bytes"] / float(ms.min()) / 1e6, 1), "frac_moved": round(info["stream_bytes"] / float(ms.min()) / 1e6 / 8000, 4),
            "alg_gbps": round(info["alg_bytes"] / float(ms.min()) / 1e6, 1), "frac_alg": round(info["alg_bytes"] / float(ms.min()) / 1e6 / 8000, 4)}

@@ -70,10 +70,11 @@ def stats_table(base, out_csv):
 
 STATS_ITERS, STATS_WARMUP = 20, 3   # tools/profile_configs.sh: run_config.py --iters 20 (warm-up 3) in the stats pass
 MULTIPLY = ("csr_vector_tile_kernel", "csr_vector_pipe_kernel", "csr_vector_rows_kernel", "csr_scalar_kernel", "nat_group_kernel", "nat_kernel",
-            "csr5_group_kernel", "csr5_group_pipe_kernel", "csr5_kernel", "csr5_fixup_kernel", "sell_window_kernel", "sell_kernel", "blk_kernel", "fill_zero_kernel")
+            "csr5_group_kernel", "csr5_group_pipe_kernel", "csr5_kernel", "csr5_fixup_kernel", "sell_window_kernel", "sell_kernel", "sell_fused_kernel", "blk_kernel", "blk_wide_kernel", "fill_zero_kernel")
 summary = {"tag": tag, "units": "FETCH_SIZE / WRITE_SIZE in KiB (rocprofv3) -> bytes = KiB x 1024; hbm_bytes = 2 x FETCH + WRITE (gfx950 wide-read "
            "under-count, MI355X_MICROARCH.md 'HBM'); fractions are of 8.0 TB/s", "configs": {}}
 entries = []
+shas = set()
 for log in sorted(glob.glob(os.path.join(src, "*.stats.log"))):
     cfg = os.path.basename(log)[: -len(".stats.log")]
     if cfg == "bench":
@@ -128,9 +129,13 @@ for log in sorted(glob.glob(os.path.join(src, "*.stats.log"))):
             "frac_pmc_bytes": tot_bytes / tot_ns / 8000.0, "frac_model_bytes": run["stream_bytes"] / tot_ns / 8000.0,
             "frac_alg_bytes": run["alg_bytes"] / tot_ns / 8000.0,
             "l2_hit_rate_dominant": d["l2_hit_rate"] if d else None}
-    if d and len(kernels) == 1:
+    if d and tot_bytes > 0:   # what bench.py reads: the whole multiply (every kernel of one spmv(), summed) and its parts
+        shas.add(run.get("csrc_sha"))
         entries.append({"config": cfg, "kernel_short": dom, "m": run["m"], "nnz": run["nnz"], "dtype": run["dtype"],
-                        "hbm_bytes_per_launch": d["hbm_bytes_per_launch"], "fetch_bytes_raw": d["fetch_bytes_raw"], "write_bytes": d["write_bytes"],
+                        "hbm_bytes_per_launch": tot_bytes, "fetch_bytes_raw": d["fetch_bytes_raw"], "write_bytes": d["write_bytes"],
+                        "kernels": [{"kernel": kn.split("#")[0], "avg_ms": kv["avg_ns"] * kv["launches_per_multiply"] / 1e6, "hbm_bytes": kv["hbm_bytes_per_launch"] * kv["launches_per_multiply"]}
+                                    for kn, kv in kernels.items()],
+                        "ms_rocprof_sum_of_kernels": tot_ns / 1e6, "csrc_sha": run.get("csrc_sha"),
                         "source": f"profiles/{tag}_configs_pmc.json#{cfg}"})
     summary["configs"][cfg] = cfg_out
 
@@ -162,6 +167,7 @@ with open(os.path.join(dst, f"{tag}_configs_pmc.json"), "w") as f:
     json.dump(summary, f, indent=1)
 with open(os.path.join(dst, f"traffic_{tag}.json"), "w") as f:
     json.dump({"tag": tag, "correction": "2 x FETCH_SIZE (gfx950 wide-read under-count) + WRITE_SIZE, KiB -> bytes; separate --pmc passes",
+               "csrc_sha": (shas.pop() if len(shas) == 1 else None),   # the source tree the passes ran on (spmv_amd/srchash.py); bench.py ignores the file when its tree differs
                "entries": entries}, f, indent=1)
 for cfg, c in summary["configs"].items():
     print(cfg, json.dumps(c.get("multiply", c.get("error")), indent=None)[:700])
