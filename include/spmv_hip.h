@@ -54,9 +54,10 @@ void spmv_hip_trim_pool(void);
 /* The reference re-reads Matrix_Val on every spmv() (common.c:286-298); this library multiplies its
  * HBM-resident copy.  After changing values IN PLACE (same pattern) call this with the array (host or device
  * pointer, RowPtr[m] entries in CSR order): the values are copied to HBM and re-permuted into the schedule's
- * private layouts by device kernels -- no re-inspection, no autotune.  Alternatively option "check_values"
- * (env SPMV_HIP_CHECK_VALUES=1) makes spmv() checksum Matrix_Val on every call and refresh by itself: a pure
- * drop-in, at the price of reading the values once more per call.  Not available on handles created with
+ * private layouts by device kernels -- no re-inspection, no autotune.  spmv() also watches the array by itself (option
+ * "check_values"): by default a HOST Matrix_Val -- the reference's only mode -- is sample-checksummed on every call and a change of the
+ * whole array is picked up without any call; SPMV_HIP_CHECK_VALUES=1 makes that a full checksum (device arrays too), at the price of
+ * reading the values once more per call.  Not available on handles created with
  * option "reorder".  Returns 0 or an SPMV_HIP_E_* code. */
 int spmv_hip_update_values(spmv_Handle_t handle, const void *Matrix_Val);
 
@@ -98,7 +99,10 @@ int spmv_hip_update_values(spmv_Handle_t handle, const void *Matrix_Val);
  *       "host_rows" (0/1, default 0: 1 = handles created with VECTOR_NONE and Method_Serial / Method_Parallel run
  *                    a plain-C row loop on the HOST over the caller's arrays (BASELINE config 1: the reference's
  *                    plumbing case); never selected automatically -- without it a missing GPU is an error)
- *       "check_values" (0/1, default 0: see spmv_hip_update_values)
+ *       "check_values" (0/1/2, default 2: spmv() watches Matrix_Val for in-place changes and refreshes the resident copies by itself.  2: HOST arrays
+                       only, by a SAMPLED checksum (every 64th word, at most 65536, and both ends: sees any update of the whole array, misses most
+                       single-entry edits; under a millisecond per call); 1: the full position-weighted checksum on every call, host or device array
+                       (reads the values once more per call); 0: never.  Works on multi-GPU handles (option "gpus") too.)
  *       "gpus" (0 = this handle lives on the current device; G > 0: row blocks over min(G, visible devices) GPUs
  *               of this process, see "multi-GPU" below)   "x_exchange" (multi-GPU: 0 allgather, 1 range, 2 broadcast)
  * Each key can also be preset with the environment variable SPMV_HIP_<KEY IN CAPS>.

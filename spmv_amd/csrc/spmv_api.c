@@ -113,13 +113,51 @@ void spmv_destory_handle(spmv_Handle_t h) /* common.c:54-61 */
  * path (common.c:144-156: permuted copy + index; test_spmv.c:95-101,130-137: the caller gathers
  * XX[i] = X[index[i]] before spmv() and scatters Y[index[i]] = YY[i] after).  Returns 0 when the
  * permuted matrix is resident, non-zero to fall back to the unpermuted upload. */
-static int upload_reordered(spmv_Handle_t h, spmv_hip_state *st, int m, int n, const int *RowPtr,
-                            const int *ColIdx, const void *Val)
+/* ---------------------------------------------------------------- values changed in place
+ * The reference multiplies the arrays passed to THIS call (common.c:286-298); this library multiplies its HBM-resident copy.  Option
+ * "check_values" closes the gap: at create a checksum of Matrix_Val is kept, spmv() recomputes it and refreshes the resident copies when
+ * it differs.  Mode 1: the full position-weighted sum (shim; host loop or one device reduction).  Mode 2 (default, HOST arrays -- the
+ * reference's only mode, where a call already moves x and y over PCIe): the same sum over a SAMPLE -- every 64th 32-bit word (at most
+ * 65536 of them) plus the first and last 1024 words -- certain to see an update that touches the whole array (a Newton or time step),
+ * blind to most single-entry edits (spmv_hip_update_values or mode 1 are for those). */
+static unsigned long long sampled_host_checksum(const void *val, long long words)
 {
-    const size_t vs = h->data_size == sizeof(double) ? sizeof(double) : sizeof(float);
-    int *rp = (int *) malloc(sizeof(int) * ((size_t) m + 1)), *ci = NULL, *perm = NULL, *rp2 = NULL, *ci2 = NULL;
-    void *va = NULL, *va2 = NULL;
+    const unsigned *w = (const unsigned *) val;
+    unsigned long long s = 0;
+    long long i;
+    const long long edge = words < 2048 ? words : 1024;
+    for (i = 0; i < edge; ++i) s += ((unsigned long long) w[i] + 0x9E3779B97F4A7C15ull) * (2ull * (unsigned long long) i + 1ull);
+    if (words >= 2048) {
+        /* every 64th word, but never more than 65536 samples: a 2.56 GB value array (config 2) costs 65 k cache lines per call, under a millisecond */
+        const long long stride = (words - 2048) / 65536 > 64 ? (words - 2048) / 65536 : 64;
+        for (i = words - 1024; i < words; ++i) s += ((unsigned long long) w[i] + 0x9E3779B97F4A7C15ull) * (2ull * (unsigned long long) i + 1ull);
+        for (i = 1024; i < words - 1024; i += stride) s += ((unsigned long long) w[i] + 0x9E3779B97F4A7C15ull) * (2ull * (unsigned long long) i + 1ull);
+    }
+    return s;
+}
+
+/* take the checksum the handle's options ask for (create, re-inspection, update_values) */
+static void watch_values(spmv_Handle_t h, spmv_hip_state *st, const void *Val, long long nnz)
+{
+    const long mode = st->opts.v[SPMV_OPT_CHECK_VALUES];
+    st->val_sum_valid = 0;
+    st->val_words = nnz * (long long) ((h->data_size == sizeof(double) ? sizeof(double) : sizeof(float)) / 4);
+    if (!Val || st->val_words <= 0 || mode == 0) return;
+    if (mode == 1) {
+        if (spmv_shim_checksum_words(Val, st->val_words, &st->val_sum) == SPMV_HIP_OK) st->val_sum_valid = 1;
+    } else if (!spmv_shim_is_device_ptr(Val)) {
+        st->val_sum = sampled_host_checksum(Val, st->val_words);
+        st->val_sum_valid = 2;
+    }
+}
+
+/* host copies of P A P^T and the permutation (all malloc'ed; 0 on success) */
+static int reorder_on_host(size_t vs, int m, const int *RowPtr, const int *ColIdx, const void *Val, int **rp2, int **ci2, void **va2, int **perm_out)
+{
+    int *rp = (int *) malloc(sizeof(int) * ((size_t) m + 1)), *ci = NULL, *perm = NULL;
+    void *va = NULL;
     int rc = 1, nnz;
+    *rp2 = *ci2 = NULL; *va2 = NULL; *perm_out = NULL;
     if (!rp || spmv_shim_copy_to_host(rp, RowPtr, sizeof(int) * ((size_t) m + 1))) goto out;
     nnz = rp[m];
     if (rp[0] != 0 || nnz < 0) goto out;
@@ -133,14 +171,30 @@ static int upload_reordered(spmv_Handle_t h, spmv_hip_state *st, int m, int n, c
     perm = (int *) malloc(sizeof(int) * (size_t) m);
     if (!ci || !va || !perm) goto out;
     if (spmv_shim_copy_to_host(ci, ColIdx, sizeof(int) * (size_t) nnz) || spmv_shim_copy_to_host(va, Val, vs * (size_t) nnz)) goto out;
-    if (spmv_rcm_order(m, rp, ci, perm) || spmv_permute_csr(m, rp, ci, va, vs, perm, &rp2, &ci2, &va2)) goto out;
+    if (spmv_rcm_order(m, rp, ci, perm) || spmv_permute_csr(m, rp, ci, va, vs, perm, rp2, ci2, va2)) goto out;
+    *perm_out = perm;
+    perm = NULL;
+    rc = 0;
+out:
+    free(rp); free(ci); free(va); free(perm);
+    return rc;
+}
+
+static int upload_reordered(spmv_Handle_t h, spmv_hip_state *st, int m, int n, const int *RowPtr,
+                            const int *ColIdx, const void *Val)
+{
+    const size_t vs = h->data_size == sizeof(double) ? sizeof(double) : sizeof(float);
+    int *rp2 = NULL, *ci2 = NULL, *perm = NULL;
+    void *va2 = NULL;
+    int rc = 1;
+    if (reorder_on_host(vs, m, RowPtr, ColIdx, Val, &rp2, &ci2, &va2, &perm)) goto out;
     if (spmv_shim_matrix_create(&st->dev, m, n, rp2, ci2, va2, vs) != SPMV_HIP_OK) goto out;
     h->index = perm;
     h->Level_3_opt_used = 1;
     perm = NULL;
     rc = 0;
 out:
-    free(rp); free(ci); free(va); free(perm); free(rp2); free(ci2); free(va2);
+    free(perm); free(rp2); free(ci2); free(va2);
     return rc;
 }
 
@@ -180,14 +234,32 @@ static int state_build_multi(spmv_Handle_t h, spmv_hip_state *st, int m, int n, 
     int rc;
     if (st->multi) { spmv_shim_multi_destroy(st->multi); st->multi = NULL; }
     index_free(h);
-    rc = spmv_shim_multi_create(&st->multi, (int) st->opts.v[SPMV_OPT_GPUS], (int) st->opts.v[SPMV_OPT_X_EXCHANGE], m, n, RowPtr, ColIdx, Val,
-                                (size_t) h->data_size);
+    rc = -1;
+    if (st->opts.v[SPMV_OPT_REORDER] == 1 && m == n && m > 1 && RowPtr && ColIdx && Val) {
+        /* Option "reorder" on a multi-GPU handle: P A P^T is what gets cut into equal-nnz row blocks -- the reason a partitioner exists in the
+         * reference at all (fewer off-block columns: HyperGraphInterface.cpp:60-147 feeding the NUMA row blocks, numa.c:277-304).  The
+         * caller-side protocol is the single-GPU one: XX[i] = X[index[i]], Y[index[i]] = YY[i] (test_spmv.c:95-101, 130-137). */
+        const size_t vs = h->data_size == sizeof(double) ? sizeof(double) : sizeof(float);
+        int *rp2 = NULL, *ci2 = NULL, *perm = NULL;
+        void *va2 = NULL;
+        if (reorder_on_host(vs, m, RowPtr, ColIdx, Val, &rp2, &ci2, &va2, &perm) == 0) {
+            rc = spmv_shim_multi_create(&st->multi, (int) st->opts.v[SPMV_OPT_GPUS], (int) st->opts.v[SPMV_OPT_X_EXCHANGE], m, n, rp2, ci2, va2, vs);
+            if (rc == SPMV_HIP_OK) { h->index = perm; h->Level_3_opt_used = 1; perm = NULL; }
+        } else {
+            /* never silently: the caller asked for a permutation and will gather x / scatter y by handle->index -- which stays NULL, i.e. identity */
+            spmv_set_error(SPMV_HIP_E_ARG, "create/multi", "option reorder: the matrix could not be reordered (bad RowPtr or out of host memory); created unpermuted, handle->index = NULL");
+        }
+        free(perm); free(rp2); free(ci2); free(va2);
+    }
+    if (rc != SPMV_HIP_OK)
+        rc = spmv_shim_multi_create(&st->multi, (int) st->opts.v[SPMV_OPT_GPUS], (int) st->opts.v[SPMV_OPT_X_EXCHANGE], m, n, RowPtr, ColIdx, Val,
+                                    (size_t) h->data_size);
     if (rc) { spmv_set_error(rc, "create/multi", spmv_shim_error_text()); return rc; }
     rc = multi_plan_shards(h, st, &actual);
     if (rc) return rc;
     st->m = m;
     st->n = n;
-    st->val_sum_valid = 0;
+    watch_values(h, st, Val, spmv_shim_multi_nnz(st->multi));
     st->from_blocks = 0;
     h->spmvMethod = actual; /* shard 0's: the shards of a skewed matrix may differ (Balanced vs Balanced2) */
     h->RowPtr = (BASIC_INT_TYPE *) RowPtr;
@@ -362,9 +434,7 @@ static int state_build(spmv_Handle_t h, spmv_hip_state *st, int m, int n, const 
     spmv_shim_set_async(st->dev, st->async);
     st->m = m;
     st->n = n;
-    st->val_sum_valid = 0;
-    if (st->opts.v[SPMV_OPT_CHECK_VALUES] == 1 && spmv_shim_checksum(st->dev, Val, &st->val_sum) == SPMV_HIP_OK)
-        st->val_sum_valid = 1;
+    watch_values(h, st, Val, stats.nnz);
     h->spmvMethod = actual;
     h->RowPtr = (BASIC_INT_TYPE *) RowPtr;
     h->ColIdx = (BASIC_INT_TYPE *) ColIdx;
@@ -467,8 +537,15 @@ void spmv(const spmv_Handle_t handle, BASIC_INT_TYPE m, const BASIC_INT_TYPE *Ro
          * values in place between calls (Newton steps, time stepping).  Detect that by checksum and refresh
          * the resident copies (no re-inspection: the pattern is the same). */
         unsigned long long sum = 0;
-        if (spmv_shim_checksum(st->dev, Matrix_Val, &sum) == SPMV_HIP_OK && sum != st->val_sum) {
-            if (handle->Level_3_opt_used) {
+        int have = 1;
+        if (st->val_sum_valid == 2) sum = sampled_host_checksum(Matrix_Val, st->val_words);
+        else have = spmv_shim_checksum_words(Matrix_Val, st->val_words, &sum) == SPMV_HIP_OK;
+        if (have && sum != st->val_sum) {
+            if (st->multi && !handle->Level_3_opt_used) { /* every shard refreshes its slice of the values in place */
+                rc = spmv_shim_multi_update_values(st->multi, Matrix_Val);
+                if (rc) { spmv_set_error(rc, "spmv/refresh values", spmv_shim_error_text()); return; }
+                st->val_sum = sum;
+            } else if (handle->Level_3_opt_used) {
                 /* option "reorder": the resident matrix is P A P^T, whose value order is not the caller's -- the values
                  * cannot be refreshed in place; upload, reorder and inspect the caller's matrix again (state_build
                  * takes a new checksum) */
@@ -653,9 +730,14 @@ int spmv_hip_update_values(spmv_Handle_t h, const void *Val)
     if (st && st->host_rows) { h->Matrix_Val = (void *) Val; return SPMV_HIP_OK; } /* borrowed arrays: nothing resident */
     if (st && st->multi) {
         if (!Val) { spmv_set_error(SPMV_HIP_E_ARG, "update_values", "Val is NULL"); return SPMV_HIP_E_ARG; }
+        if (h->Level_3_opt_used) {
+            spmv_set_error(SPMV_HIP_E_ARG, "update_values", "not available on a reordered handle (option \"reorder\")");
+            return SPMV_HIP_E_ARG;
+        }
         rc = spmv_shim_multi_update_values(st->multi, Val);
         if (rc) { spmv_set_error(rc, "update_values", spmv_shim_error_text()); return rc; }
         h->Matrix_Val = (void *) Val;
+        watch_values(h, st, Val, spmv_shim_multi_nnz(st->multi));
         return SPMV_HIP_OK;
     }
     st = state_of(h, "update_values");
@@ -668,8 +750,7 @@ int spmv_hip_update_values(spmv_Handle_t h, const void *Val)
     rc = spmv_shim_update_values(st->dev, Val);
     if (rc) { spmv_set_error(rc, "update_values", spmv_shim_error_text()); return rc; }
     h->Matrix_Val = (void *) Val;
-    if (st->opts.v[SPMV_OPT_CHECK_VALUES] == 1)
-        st->val_sum_valid = spmv_shim_checksum(st->dev, Val, &st->val_sum) == SPMV_HIP_OK;
+    watch_values(h, st, Val, st->val_words / (long long) ((h->data_size == sizeof(double) ? sizeof(double) : sizeof(float)) / 4));
     return SPMV_HIP_OK;
 }
 

@@ -33,7 +33,8 @@ typedef struct spmv_hip_state {
     void *stream;
     int stream_set, async, warned_rebuild;
     unsigned long long val_sum; /* option "check_values": checksum of Matrix_Val as last uploaded */
-    int val_sum_valid;
+    int val_sum_valid;      /* 0: values are not watched; 1: full checksum (option check_values = 1); 2: SAMPLED checksum of a HOST array (the default) */
+    long long val_words;    /* 32-bit words of Matrix_Val (nnz x size / 4) */
     int from_blocks;        /* multi-GPU handle created from separate row blocks (spmv_hip_create_handle_from_blocks): spmv() ignores its CSR arguments */
 } spmv_hip_state;
 

@@ -55,8 +55,10 @@ static opt_t g_opts[SPMV_N_OPTS] = {
     [SPMV_OPT_REORDER] = {"reorder", 0, 0, 1, 0, 0},                  /* 1: square matrices are RCM-reordered at create; handle->index = permutation */
     [SPMV_OPT_HOST_ROWS] = {"host_rows", 0, 0, 1, 0, 0},              /* 1: VECTOR_NONE + Method_Serial / Method_Parallel run the plain-C row loop on
                                                                        * the host (host_rows.c; BASELINE config 1).  Never chosen by itself. */
-    [SPMV_OPT_CHECK_VALUES] = {"check_values", 0, 0, 1, 0, 0},        /* 1: spmv() checksums Matrix_Val on every call and refreshes the resident
-                                                                       * copy when it changed behind an unchanged pointer (common.c:286-298 semantics) */
+    [SPMV_OPT_CHECK_VALUES] = {"check_values", 2, 0, 2, 0, 0},        /* spmv() watches Matrix_Val for changes IN PLACE behind an unchanged pointer (the reference re-reads it on
+                                                                       * every call, common.c:286-298) and refreshes the resident copies: 1 = full position-weighted checksum on
+                                                                       * every call (host or device array); 2 (default) = HOST arrays only, a SAMPLED checksum -- every 64th word
+                                                                       * and both ends: any whole-array update (Newton step, time step) is seen for 1/64 of the read; 0 = never */
     [SPMV_OPT_GPUS] = {"gpus", 0, 0, 64, 0, 0},                       /* > 0: row blocks over min(gpus, visible devices) GPUs in this one process (multi.hpp) */
     [SPMV_OPT_BLK_WAVES] = {"blk_waves", 0, 0, 8, 1, 0},              /* row-block x column-slab executor: wavefronts that share ONE row block's accumulators: 1 = a wave per block, two blocks
                                                                        * per CU (rounds 2-3); 4 / 8 = one block of up to ~20 k rows per CU (kernels/blocked.hpp "wide form"); 0 = automatic */

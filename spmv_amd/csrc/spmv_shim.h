@@ -86,6 +86,8 @@ int spmv_shim_is_device_ptr(const void *p);
 int spmv_shim_update_values(spmv_dev *d, const void *val);
 /* Order-independent 64-bit checksum (sum of the 32-bit words) of nnz values at `val` (host or device). */
 int spmv_shim_checksum(spmv_dev *d, const void *val, unsigned long long *out);
+/* the same sum over `words` 32-bit words at `val` (host or device) without a matrix: multi-GPU handles */
+int spmv_shim_checksum_words(const void *val, long long words, unsigned long long *out);
 
 /* ---- A = A_near + A_far (shim/split.hpp): a matrix with locality in part of its entries ---- */
 int spmv_shim_split_candidate(spmv_dev *d);                                   /* 1: worth building and timing */

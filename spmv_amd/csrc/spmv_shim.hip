@@ -429,6 +429,37 @@ extern "C" int spmv_shim_checksum(spmv_dev *d, const void *val, unsigned long lo
     return SPMV_HIP_OK;
 }
 
+extern "C" int spmv_shim_checksum_words(const void *val, long long words, unsigned long long *out)
+{
+    if (!out) return fail(SPMV_HIP_E_ARG, "checksum: NULL");
+    *out = 0;
+    if (words <= 0) return SPMV_HIP_OK;
+    if (!val) return fail(SPMV_HIP_E_ARG, "checksum: NULL values");
+    if (!is_device_ptr(val)) {
+        const unsigned *w = (const unsigned *) val;
+        unsigned long long s = 0;
+        for (long long i = 0; i < words; ++i) s += checksum_term(w[i], i);
+        *out = s;
+        return SPMV_HIP_OK;
+    }
+    hipPointerAttribute_t attr;
+    int dev = 0;
+    if (hipPointerGetAttributes(&attr, val) == hipSuccess) dev = attr.device; else (void) hipGetLastError();
+    DeviceGuard guard(dev);
+    if (!guard.ok) return fail(SPMV_HIP_E_RUNTIME, "hipSetDevice(%d) failed", dev);
+    unsigned long long *acc = nullptr;
+    HIP_TRY(pool_malloc((void **) &acc, 8));
+    hipError_t e = hipMemset(acc, 0, 8);
+    if (e == hipSuccess) {
+        checksum_kernel<<<grid_for(words, kBlock * 8, 2048), kBlock>>>(words, (const unsigned *) val, acc);
+        e = hipGetLastError();
+    }
+    if (e == hipSuccess) e = hipMemcpy(out, acc, 8, hipMemcpyDeviceToHost);
+    (void) pool_free(acc);
+    if (e != hipSuccess) return fail(SPMV_HIP_E_RUNTIME, "checksum: %s", hipGetErrorString(e));
+    return SPMV_HIP_OK;
+}
+
 extern "C" int spmv_shim_is_device_ptr(const void *p) { return is_device_ptr(p) ? 1 : 0; }
 
 #include "shim/launch.hpp"

@@ -365,3 +365,41 @@ def test_empty_matrix_and_info_totals_on_a_sharded_handle(virtual):
         assert info["stored_nnz"] >= csr.nnz and info["stream_bytes"] >= 0.9 * one["stream_bytes"]     # summed over the three shards, not shard 0's third
     finally:
         h.close()
+
+
+@pytest.mark.parametrize("xchg", [0, 1])
+def test_reorder_option_on_a_multi_gpu_handle(virtual, xchg):
+    """VERDICT r3 #5c: option reorder used to be ignored when gpus > 0.  Now P A P^T is what gets cut into equal-nnz row blocks (the reason the
+    reference has a partitioner: fewer off-block columns, numa.c:277-304 / HyperGraphInterface.cpp:60-147), handle->index holds the permutation and
+    the caller gathers x / scatters y as in test_spmv.c:95-101, 130-137."""
+    from spmv_amd import synth
+    import oracle
+    rng = np.random.default_rng(4)
+    m = 12000
+    band = synth.banded(m, m, 6, 5, "eighths", np.float64, seed=9)
+    sc = rng.permutation(m)
+    inv = np.empty(m, dtype=np.int64); inv[sc] = np.arange(m)
+    lens = np.diff(band.rowptr)[sc]
+    rp = np.zeros(m + 1, dtype=np.int32); np.cumsum(lens, out=rp[1:])
+    ci = np.empty(band.nnz, dtype=np.int32); va = np.empty(band.nnz)
+    for r in range(m):
+        s0, s1 = band.rowptr[sc[r]], band.rowptr[sc[r] + 1]
+        ci[rp[r]:rp[r + 1]] = inv[band.colidx[s0:s1]]
+        va[rp[r]:rp[r + 1]] = band.val[s0:s1]
+    A = synth.CSR(m, m, rp, ci, va)
+    x = synth.fill_x(m, "eighths", np.float64, 6)
+    want = oracle.spmv_serial(A, x)
+    api.set_thread_option("reorder", 1)
+    api.set_thread_option("gpus", 3)
+    api.set_thread_option("x_exchange", xchg)
+    try:
+        h = api.Handle(m, m, A.rowptr, A.colidx, A.val, M.Method_Parallel)
+    finally:
+        api.clear_thread_options()
+    with h:
+        index = h.index
+        assert h.multi_gpus() == 3 and index is not None and h.h.contents.Level_3_opt_used == 1
+        assert np.array_equal(np.sort(index), np.arange(m))
+        yy = h.spmv(x[index], np.full(m, np.nan))
+        y = np.empty(m); y[index] = yy
+        assert np.array_equal(y, want)

@@ -744,6 +744,7 @@ def test_update_values_refreshes_every_private_layout(name, method, blocked):
     csr, x, _ = load_golden(name)
     val = csr.val.copy()
     api.set_option("cache_block", 2 if blocked else 1)
+    api.set_option("check_values", 0)       # this test is about the explicit call: spmv() does not watch the array
     h = None
     try:
         h = api.Handle(csr.m, csr.n, csr.rowptr, csr.colidx, val, method)
@@ -763,8 +764,44 @@ def test_update_values_refreshes_every_private_layout(name, method, blocked):
         assert np.array_equal(h.spmv(x, np.empty(csr.m, dtype=val.dtype)), y0)
     finally:
         api.set_option("cache_block", 1)
+        api.set_option("check_values", 2)
         if h is not None:
             h.close()
+
+
+@pytest.mark.parametrize("method", [M.Method_Parallel, M.Method_SellCSigma, M.Method_CSR5SPMV, M.Method_Balanced2], ids=lambda m: m.name)
+@pytest.mark.parametrize("gpus", [0, 3])
+def test_host_values_changed_in_place_are_seen_with_no_option_set(method, gpus, monkeypatch):
+    """the reference multiplies the arrays of THIS call (common.c:286-298).  With HOST arrays -- its only mode -- an in-place
+    change of Matrix_Val behind the same pointer is picked up by spmv() by default (sampled checksum, option check_values = 2), on ordinary
+    and on multi-GPU handles; nothing to call, no option to set.  A device array is not watched by default (documented)."""
+    import torch
+    csr, x, _ = load_golden("skewed_f64_uniform")
+    val = csr.val.copy()
+    if gpus:
+        monkeypatch.setenv("SPMV_HIP_GPUS_VIRTUAL", "1")
+        api.set_thread_option("gpus", gpus)
+    try:
+        h = api.Handle(csr.m, csr.n, csr.rowptr, csr.colidx, val, method)
+    finally:
+        api.clear_thread_options()
+    with h:
+        assert h.option("check_values") == 2
+        y0 = h.spmv(x, np.full(csr.m, np.nan))
+        val *= -0.5                                                 # a whole-array update in place (Newton / time step); a power of two: exact
+        y1 = h.spmv(x, np.full(csr.m, np.nan))
+        assert np.array_equal(y1, -0.5 * y0) and not np.array_equal(y1, y0)
+        y2 = h.spmv(x, np.full(csr.m, np.nan))                      # unchanged since: same result, no refresh
+        assert np.array_equal(y2, y1)
+    if gpus == 0:
+        dev = torch.device("cuda:0")
+        rp, ci, va = (torch.from_numpy(a).to(dev) for a in (csr.rowptr, csr.colidx, csr.val.copy()))
+        xd = torch.from_numpy(x).to(dev)
+        with api.Handle(csr.m, csr.n, rp, ci, va, method) as h:
+            ya = h.spmv(xd, torch.empty(csr.m, dtype=torch.float64, device=dev)).clone()
+            va.mul_(-0.5)
+            yb = h.spmv(xd, torch.empty(csr.m, dtype=torch.float64, device=dev))
+            assert torch.equal(ya, yb)                              # device arrays: spmv_hip_update_values or check_values = 1
 
 
 @pytest.mark.parametrize("devptr", [False, True])
