@@ -8,7 +8,7 @@
  *   - the reference has no notion of a device or a stream      -> spmv_hip_set_stream / _set_async / _synchronize
  *   - SELL's C and sigma and CSR5's sigma are hard-wired in the reference (common.c:139-140,
  *     csr5_spmv.cpp:30)                                         -> spmv_hip_set_option (also env SPMV_HIP_<KEY>)
- *   - measurement (hipEvent per launch on the launch stream)    -> spmv_hip_time_launches
+ *   - measurement (hipEvent per launch on the launch stream)    -> include/spmv_hip_tools.h (bench.py and tools/ only)
  */
 #include "spmv_Defines.h"
 #if defined(__cplusplus)
@@ -70,7 +70,10 @@ int spmv_hip_update_values(spmv_Handle_t handle, const void *Matrix_Val);
  *       "sell_long_thr" (rows longer than this stay out of the slabs; 0 = from the row-length histogram: length classes with
  *                        less than a chunk's worth of rows per sigma window leave, at most max(64, 8 x mean row length) stays)
  *       "csr5_sigma" (0 = auto)  "rowblock_nnz" (equal-nnz share of one Balanced row block, 0 = auto = 8192)
- *       "variant" (kernel variant selector used by the tuning harness, 0 = default)
+ *       executor-form selectors (what create() otherwise chooses by rule or by timing; tests force every form through them):
+ *       "vector_form" (CSR-vector: 0 timed at create, 4 pipe, 5 / 12 tile two deep, 10 / 11 tile four deep, 6 tile eight deep)
+ *       "x_windows" (0/1, default 1: stage the tile groups' x windows in LDS)   "xcd_order" (0/1, default 1)   "csr5_two_deep" (0 auto / 1 never / 2 always)
+ *       "run_tiles" (0/1, default 1: RUN / BYTE tiles -- spmv_hip_info.run_nnz, byte_nnz)
  *       "autotune" (0/1, default 1: for matrices above 2^24 nnz create() times the applicable CSR-vector
  *                   kernel forms once on the resident matrix and keeps the fastest, ~10 ms)
  *       "reorder" (0/1, default 0: square matrices are RCM-reordered at create, B = P A P^T is what stays
@@ -203,13 +206,6 @@ int spmv_hip_multi_synchronize(spmv_Handle_t handle);
 void spmv_hip_create_handle_from_blocks(spmv_Handle_t *Handle, int blocks, const BASIC_INT_TYPE *rows, BASIC_INT_TYPE n,
                                         BASIC_INT_TYPE *const *RowPtr, BASIC_INT_TYPE *const *ColIdx, void *const *Matrix_Val,
                                         SPMV_METHODS Function, BASIC_SIZE_TYPE size);
-
-/* ---- measurement -------------------------------------------------------------------------- */
-/* `warmup` untimed + `iters` timed spmv() launches back to back on the handle's stream, each
- * timed launch bracketed by hipEvents recorded on that stream; ms_out[i] (may be NULL) receives
- * launch i's duration.  x and y must be DEVICE pointers.  Returns the mean in ms, < 0 on error. */
-double spmv_hip_time_launches(spmv_Handle_t handle, const void *x, void *y,
-                              int warmup, int iters, float *ms_out);
 
 #endif /* SPMV_HIP_EXT_H */
 

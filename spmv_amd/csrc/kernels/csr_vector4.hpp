@@ -61,7 +61,7 @@ constexpr int kStreamPad = 4 * kWave + 8;
 // line (masks by select, clamped row index) so the compiler can hoist every load; rows longer than
 // 4L fall into the loop at the end of each group, rows longer than long_thr are left to the
 // whole-wavefront long-row kernels (kernels/long_rows.hpp).
-template <typename T, int L, int NB, bool NTSTORE = false, int ABL = 0>
+template <typename T, int L, int NB, bool NTSTORE = false>
 __global__ __launch_bounds__(kBlock) void csr_vector_pipe_kernel(int m, int long_thr, const int *__restrict__ rowptr,
                                                                  const int *__restrict__ colidx,
                                                                  const T *__restrict__ val,
@@ -77,8 +77,8 @@ __global__ __launch_bounds__(kBlock) void csr_vector_pipe_kernel(int m, int long
     for (int j = 0; j < NB; ++j) {
         long long r = row0 + (long long) j * kRows;
         if (r > m - 1) { r = m - 1; skip |= 1u << j; }
-        if (ABL & 1) { p0[j] = (int) r * 32; p1[j] = (int) r * 32 + 32; } // ablation: no RowPtr chain
-        else { p0[j] = rowptr[r]; p1[j] = rowptr[r + 1]; }
+        p0[j] = rowptr[r];
+        p1[j] = rowptr[r + 1];
         if (p1[j] - p0[j] > long_thr) { p1[j] = p0[j]; skip |= 1u << j; }
     }
     int c[2][4];
@@ -101,7 +101,7 @@ __global__ __launch_bounds__(kBlock) void csr_vector_pipe_kernel(int m, int long
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
             const bool ok = (a + k >= p0[j]) & (a + k < p1[j]);
-            const T xl = (ABL & 8) ? (T) c[cur][k] : ((ABL & 2) ? x[(c[cur][k] & 1) + threadIdx.x] : x[ok ? c[cur][k] : 0]);
+            const T xl = x[ok ? c[cur][k] : 0];
             xv[k] = ok ? xl : T(0); // a masked slot contributes 0 * 0, never 0 * x[0] (x[0] may be NaN/Inf)
             vv[k] = ok ? v[cur][k] : T(0);
         }
@@ -121,9 +121,9 @@ __global__ __launch_bounds__(kBlock) void csr_vector_pipe_kernel(int m, int long
                 }
             }
         }
-        if (!(ABL & 4)) sum = group_sum_dpp<L>(sum);
+        sum = group_sum_dpp<L>(sum);
         const long long row = row0 + (long long) j * kRows;
-        if ((ABL & 16) ? (sum == T(1.2345)) : (lane == 0 && !((skip >> j) & 1u))) {
+        if (lane == 0 && !((skip >> j) & 1u)) {
             if (NTSTORE) __builtin_nontemporal_store(sum, y + row);
             else y[row] = sum;
         }

@@ -69,7 +69,7 @@ static int build_rowblock_tiles(spmv_dev *d)
     if (rc) return rc;
     rc = build_tile_windows<T>(d, d->nblocks, d->rb_split);
     if (rc) return rc;
-    if (d->vt_staged * 2 < d->vt_tiles && d->plan.variant == 0) { // wide windows: slot indices, 96 KiB budget (same blocks)
+    if (d->vt_staged * 2 < d->vt_tiles && !d->plan.forced) { // wide windows: slot indices, 96 KiB budget (same blocks)
         rc = build_tile_windows<T>(d, d->nblocks, d->rb_split, kVecTileRows, true);
         if (rc) return rc;
         if (d->vt_staged * 2 < d->vt_tiles) rc = build_tile_windows<T>(d, d->nblocks, d->rb_split);
@@ -91,11 +91,11 @@ static int build_tile_windows(spmv_dev *d, int tiles, const int *split, int rows
         ALLOC_TRY(d, &d->vt_col, sizeof(unsigned short) * ((size_t) d->nnz + kStreamPad), true);
         HIP_TRY(hipMemsetAsync(d->vt_col, 0, sizeof(unsigned short) * ((size_t) d->nnz + kStreamPad), d->stream));
     }
-    if (!d->vt_rowslot && !getenv("SPMV_HIP_NO_RUN_TILES")) { // A/B switch of tools/: every staged tile reads its column stream
+    if (!d->vt_rowslot && d->plan.run_tiles) { // option run_tiles = 0 (A/B): every staged tile reads its 16-bit column stream
         ALLOC_TRY(d, &d->vt_rowslot, sizeof(unsigned short) * ((size_t) d->m + kStreamPad), true);
         HIP_TRY(hipMemsetAsync(d->vt_rowslot, 0, sizeof(unsigned short) * ((size_t) d->m + kStreamPad), d->stream));
     }
-    if (!d->vt_col8 && d->vt_rowslot && !getenv("SPMV_HIP_NO_BYTE_TILES")) { // A/B switch: staged tiles that are not RUN tiles read their 16-bit stream
+    if (!d->vt_col8 && d->vt_rowslot && !getenv("SPMV_HIP_NO_BYTE_TILES")) { // A/B switch of tools/: staged tiles that are not RUN tiles read their 16-bit stream
         ALLOC_TRY(d, &d->vt_col8, (size_t) d->nnz + kStreamPad, true);
         HIP_TRY(hipMemsetAsync(d->vt_col8, 0, (size_t) d->nnz + kStreamPad, d->stream));
     }
@@ -191,7 +191,7 @@ static int build_vector_tiles(spmv_dev *d)
     d->vt_tiles = (int) (((long long) d->m + rows - 1) / rows);
     if (d->vt_tiles == 0 || d->nnz == 0) return SPMV_HIP_OK;
     int rc = build_tile_windows<T>(d, d->vt_tiles, nullptr, rows);
-    if (rc || d->plan.variant != 0) return rc;
+    if (rc || d->plan.forced) return rc;
     if (d->vt_staged * 2 >= d->vt_tiles) {
         // The narrow tiles stage -- but at what price?  Rows scattered +-4096 columns around the diagonal make every 256-row tile stage 8 448
         // columns for 256 rows' worth of entries: with 16 entries per row the windows are 1.4 x the bytes the tile streams (fp32), read from L2,
@@ -267,7 +267,7 @@ static int build_sell(spmv_dev *d)
     d->sell_nwin = nwin;
     d->sell_staged = 0;
     d->sell_group = 1;
-    if (d->plan.sell_lds_x && d->plan.variant != 3) { // x windows of every sigma window, in place on scol (xwindows.hpp)
+    if (d->plan.sell_lds_x && d->plan.x_windows) { // x windows of every sigma window, in place on scol (xwindows.hpp)
         static_assert(kSellXTileBytes / sizeof(float) <= 65536, "LDS slots must fit 16 bits");
         d->sell_xcap = (int) (kSellXTileBytes / sizeof(T)) - 1; // one slot stays free: the zero slot of padding entries
         ALLOC_TRY(d, &d->sell_wins, sizeof(TileWindows) * (size_t) nwin, true);
@@ -373,7 +373,7 @@ static int build_csr5_sigma(spmv_dev *d, Csr5Plan &P, const int *rp, int m2, con
     auto inspect = [&](int gt) -> int {
         P.group_tiles = gt;
         P.groups = (p + gt - 1) / gt;
-        return build_range_windows(d, d->plan.variant == 3 ? 0 : P.groups, total, (long long) gt * TN, nullptr, 1, 1, max_cols, P.col, P.wins,
+        return build_range_windows(d, !d->plan.x_windows ? 0 : P.groups, total, (long long) gt * TN, nullptr, 1, 1, max_cols, P.col, P.wins,
                                    &P.staged, &P.maxspan, P.col16, P.natural ? 0 : SIGMA);
     };
     int rc = inspect(base_gt);
@@ -403,7 +403,7 @@ static int build_csr5_sigma(spmv_dev *d, Csr5Plan &P, const int *rp, int m2, con
     }
     P.run_groups = 0;
     P.run_tiles = 0;
-    if (P.staged > 0 && !P.natural && d->plan.variant != 63 && !getenv("SPMV_HIP_NO_RUN_TILES")) { // RUN groups: a word per lane and tile instead of SIGMA slots (csr5.hpp; not for the natural layout: no gain); variant 63: off (tests)
+    if (P.staged > 0 && !P.natural && d->plan.run_tiles) { // RUN groups: a word per lane and tile instead of SIGMA slots (csr5.hpp; not for the natural layout: no gain); option run_tiles = 0: off
         unsigned long long *cnt = nullptr, h[2] = {0, 0};
         ALLOC_TRY(d, &P.lane_run, sizeof(unsigned) * (size_t) p * kWave, true);
         HIP_TRY(pool_malloc((void **) &cnt, sizeof h));
@@ -701,7 +701,7 @@ static bool blocked_size_ok(const spmv_dev *d)
 static int blocked_mode(const spmv_dev *d, int staged, int groups)
 {
     if (d->plan.cache_block == 2) return d->nnz > 0 && blocked_possible(d) ? 1 : 0;
-    if (d->plan.cache_block != 1 || d->plan.variant == 3) return 0; // variant 3: A/B, the tile executors with global gathers
+    if (d->plan.cache_block != 1 || !d->plan.x_windows) return 0; // x_windows = 0: the tile executors with global gathers (A/B)
     if (!blocked_size_ok(d) || groups <= 0 || staged >= groups) return 0;
     if ((long long) staged * 2 < groups) return 1;                   // most groups gather globally: no contest (the tile inspectors do not even stage the rest then)
     if ((long long) (groups - staged) * 200 < groups) return 0;      // under 0.5 % of the groups: at most a few percent of the time

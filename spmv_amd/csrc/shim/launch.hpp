@@ -19,7 +19,7 @@ template <typename T>
 static int autotune_vector(spmv_dev *d)
 {
     d->vec_choice = VEC_AUTO;
-    if (d->nnz < (1ll << 24) || d->plan.variant != 0 || d->vt_tiles <= 0) return SPMV_HIP_OK;
+    if (d->nnz < (1ll << 24) || d->plan.forced || d->vt_tiles <= 0) return SPMV_HIP_OK;
     if (d->vt_wide || d->vt_staged * 2 < d->vt_tiles) return SPMV_HIP_OK; // wide form: one kernel form; x windows not staged: the pipe form runs, nothing to choose (and 45 gather-bound launches would cost ~0.3 s)
     T *x = nullptr, *y = nullptr;
     if (pool_malloc((void **) &x, sizeof(T) * (size_t) d->n) != hipSuccess || pool_malloc((void **) &y, sizeof(T) * (size_t) d->m) != hipSuccess) {
@@ -98,14 +98,15 @@ static void launch_blocked(spmv_dev *d, const T *x, T *y)
         blk_wide_kernel<T, UN, W, ORD><<<S.B, kWave * W, lds, d->stream>>>(S.row0, S.R, S.dir, (const T *) S.val, S.meta, S.hdr, S.order, x, y, d->accumulate ? 1 : 0); \
     } while (0)
 #define SPMV_BLK_WFORM(UN, W) do { if (S.ordered) SPMV_BLK_WLAUNCH(UN, W, true); else SPMV_BLK_WLAUNCH(UN, W, false); } while (0)
-#ifdef SPMV_BLK_DEBUG_FORMS // A/B builds of tools/ only (wrong results): variant 51 / 52 / 53 = no gathers / no LDS adds / neither, 8 groups per step
-    if (d->plan.variant == 51) { SPMV_BLK_LAUNCH(8, 1); return; }
-    if (d->plan.variant == 52) { SPMV_BLK_LAUNCH(8, 2); return; }
-    if (d->plan.variant == 53) { SPMV_BLK_LAUNCH(8, 3); return; }
+#ifdef SPMV_BLK_DEBUG_FORMS // A/B builds of tools/ only (wrong results): SPMV_HIP_BLK_DEBUG_FORM = 1 / 2 / 3 = no gathers / no LDS adds / neither, 8 groups per step
+    static const int dbg_form = getenv("SPMV_HIP_BLK_DEBUG_FORM") ? atoi(getenv("SPMV_HIP_BLK_DEBUG_FORM")) : 0;
+    if (dbg_form == 1) { SPMV_BLK_LAUNCH(8, 1); return; }
+    if (dbg_form == 2) { SPMV_BLK_LAUNCH(8, 2); return; }
+    if (dbg_form == 3) { SPMV_BLK_LAUNCH(8, 3); return; }
 #endif
     int un[2];
     blocked_forms(S, un);
-    const int form = d->plan.variant == 35 ? 0 : (d->plan.variant == 37 ? 1 : S.form);
+    const int form = S.form;
     const int g = d->plan.blk_groups > 0 ? d->plan.blk_groups : un[form];
     if (S.waves == 2) {
         if (g == 12) SPMV_BLK_WFORM(12, 2); else SPMV_BLK_WFORM(8, 2);
@@ -128,7 +129,7 @@ static int autotune_blocked(spmv_dev *d)
 {
     d->blk.form = 0;
     d->blk.tune_ms[0] = d->blk.tune_ms[1] = d->blk.tune_ms[2] = 0;
-    if (!d->blk_on || !d->plan.autotune || d->plan.variant != 0 || d->plan.blk_groups != 0) return SPMV_HIP_OK;
+    if (!d->blk_on || !d->plan.autotune || d->plan.blk_groups != 0) return SPMV_HIP_OK;
     T *x = nullptr, *y = nullptr;
     if (pool_malloc((void **) &x, sizeof(T) * (size_t) d->n) != hipSuccess || pool_malloc((void **) &y, sizeof(T) * (size_t) d->m) != hipSuccess) {
         (void) hipGetLastError();
@@ -166,11 +167,11 @@ static int autotune_blocked(spmv_dev *d)
 
 // The staged CSR5 group kernel two tiles deep (csr5_group_pipe_kernel)?  When EVERY group is staged (the pipelined kernel has no
 // global-column path) and the values are fp32: in fp64 the second register set costs a wave per SIMD and measured no gain (config 2
-// under CSR5: 0.511 vs 0.515 ms).  plan.variant 61 / 62: never / also for fp64 (A/B).
+// under CSR5: 0.511 vs 0.515 ms).  Option csr5_two_deep 1 / 2: never / also for fp64 (A/B).
 static bool csr5_two_deep(const spmv_dev *d, const Csr5Plan &P)
 {
-    if (P.natural || P.staged <= 0 || P.staged != P.groups || P.group_tiles > kCsr5PipeMaxGroupTiles || d->plan.variant == 61) return false;
-    return d->vsize == sizeof(float) || d->plan.variant == 62;
+    if (P.natural || P.staged <= 0 || P.staged != P.groups || P.group_tiles > kCsr5PipeMaxGroupTiles || d->plan.csr5_two_deep == 1) return false;
+    return d->vsize == sizeof(float) || d->plan.csr5_two_deep == 2;
 }
 
 template <typename T, int SIGMA, bool MAPPED>
@@ -212,7 +213,7 @@ static void launch_csr5_form(spmv_dev *d, const Csr5Plan &P, const T *x, T *y)
         return;
     }
     const int grid = grid_for(P.tiles, kBlock / kWave, INT_MAX);
-    const int xcd = d->plan.variant == 30 ? 0 : 1; // XCD-aware block order (common.hpp: xcd_block); variant 30 = dispatch order, for A/B
+    const int xcd = d->plan.xcd_order ? 1 : 0; // XCD-aware block order (common.hpp: xcd_block); option xcd_order = 0: dispatch order, for A/B
     if (P.natural)
         nat_kernel<T, SIGMA, MAPPED><<<grid, kBlock, rmb, d->stream>>>(P.tiles, (int) P.nnz, P.tile_ptr, P.desc, P.col, (const T *) P.val, P.row_map, x, y, (T *) P.carry, P.n_empty,
                                                                       P.empty_list, rm_stride, xcd);

@@ -18,7 +18,7 @@ static void launch_vector_tile(spmv_dev *d, const T *x, T *y, int long_thr)
 template <typename T, int L>
 static void launch_vector(spmv_dev *d, const T *x, T *y)
 {
-    const int v = d->plan.variant ? d->plan.variant : d->vec_choice;
+    const int v = d->plan.vector_form ? d->plan.vector_form : d->vec_choice;
     const int long_thr = d->long_thr;
     const bool tile_default = d->vt_staged * 2 >= d->vt_tiles; // most x tiles fit LDS
     const bool tile_forced = v == VEC_TILE_D2 || v == VEC_TILE_D4 || v == VEC_TILE_D8 || v == VEC_TILE_D4_NOPRE || v == VEC_TILE_D2_NOPRE;

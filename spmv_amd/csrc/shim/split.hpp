@@ -31,7 +31,7 @@ static float sample_near_share(spmv_dev *d)
 extern "C" int spmv_shim_split_candidate(spmv_dev *d)
 {
     if (!d || !d->built || d->sp_near || d->accumulate) return 0;
-    if (d->plan.sched == SPMV_SCHED_CSR_SCALAR || d->plan.cache_block != 1 || d->plan.variant != 0 || !d->plan.autotune || d->plan.block_rows != 0) return 0;
+    if (d->plan.sched == SPMV_SCHED_CSR_SCALAR || d->plan.cache_block != 1 || d->plan.forced || !d->plan.autotune || d->plan.block_rows != 0) return 0;
     if (!blocked_size_ok(d) || d->nnz < (1ll << 22)) return 0;
     if (!d->blk_on && d->route_ms[0] == 0.f) return 0; // every group stages (or under 0.5 % do not): nothing to gain
     DeviceGuard guard(d->device);

@@ -22,6 +22,7 @@
 
 #include "spmv.h"
 #include "spmv_hip.h"
+#include "spmv_hip_tools.h"
 #include "spmv_internal.h"
 #include "spmv_shim.h"
 #include "reorder/rcm.h"

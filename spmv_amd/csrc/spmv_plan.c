@@ -48,7 +48,16 @@ static opt_t g_opts[SPMV_N_OPTS] = {
     [SPMV_OPT_BLOCK_ROWS] = {"block_rows", 0, 0, 16384, 1, 0},        /* ... uniform blocks of that many rows (0 = equal-work blocks, two per CU) */
     [SPMV_OPT_SPLIT] = {"split", 1, 0, 1, 0, 0},                      /* 1: a matrix with locality in PART of its entries may be multiplied as A_near (tile schedule) +
                                                                        * A_far (blocked executor) when create() measures that faster (kernels/split.hpp); 0: never */
-    [SPMV_OPT_VARIANT] = {"variant", 0, 0, 1 << 20, 0, 0},            /* kernel-form selector of the A/B harness and the variant tests, 0 = default */
+    /* executor-form selectors: what create() would otherwise choose by rule or by timing.  Tests force every form through them; setting any of
+     * them switches the create-time timing of alternatives off for that handle. */
+    [SPMV_OPT_VECTOR_FORM] = {"vector_form", 0, 0, 12, 0, 0},         /* CSR-vector kernel form: 0 = timed at create; 4 pipe, 5 / 12 tile two steps deep (with / without the
+                                                                       * pre-issued step), 10 / 11 tile four deep, 6 tile eight deep (shim/vector_forms.hpp) */
+    [SPMV_OPT_X_WINDOWS] = {"x_windows", 1, 0, 1, 0, 0},              /* 1: tile schedules stage the x windows of their tile groups in LDS; 0: never (global gathers; the blocked
+                                                                       * executor does not take over either) */
+    [SPMV_OPT_XCD_ORDER] = {"xcd_order", 1, 0, 1, 0, 0},              /* tile kernels that gather x through L2: 1 = XCD-aware block order, 0 = dispatch order */
+    [SPMV_OPT_CSR5_TWO_DEEP] = {"csr5_two_deep", 0, 0, 2, 0, 0},      /* staged CSR5 group kernel two tiles deep: 0 = fp32 only (measured), 1 = never, 2 = also fp64 */
+    [SPMV_OPT_RUN_TILES] = {"run_tiles", 1, 0, 1, 0, 0},              /* 1: tiles / groups whose rows are runs of consecutive columns read no column stream (RUN), tiles whose rows span
+                                                                       * under 256 slots a byte per entry (BYTE); 0: every staged tile reads its 16-bit slot stream */
     [SPMV_OPT_AUTO_METHOD] = {"auto_method", 0, 0, 2, 0, 0},          /* 1: create() picks the schedule from the matrix by rules (two stages, spmv_api.c);
                                                                        * 2: ... by building the candidate schedules and timing them */
     [SPMV_OPT_AUTOTUNE] = {"autotune", 1, 0, 1, 0, 0},                /* 1: create() times the CSR-vector kernel forms on matrices >= 2^24 nnz */
@@ -287,7 +296,12 @@ void spmv_plan_choose(SPMV_METHODS requested, const spmv_stats *st, size_t value
     long rb = opt->v[SPMV_OPT_ROWBLOCK_NNZ];
     double vector_cost = -1.0; /* wave steps of the best CSR-vector shape (choose_vector_shape's model) */
     memset(plan, 0, sizeof *plan);
-    plan->variant = (int) opt->v[SPMV_OPT_VARIANT];
+    plan->vector_form = (int) opt->v[SPMV_OPT_VECTOR_FORM];
+    plan->x_windows = (int) opt->v[SPMV_OPT_X_WINDOWS];
+    plan->xcd_order = (int) opt->v[SPMV_OPT_XCD_ORDER];
+    plan->csr5_two_deep = (int) opt->v[SPMV_OPT_CSR5_TWO_DEEP];
+    plan->run_tiles = (int) opt->v[SPMV_OPT_RUN_TILES];
+    plan->forced = plan->vector_form != 0 || plan->x_windows != 1 || plan->xcd_order != 1 || plan->csr5_two_deep != 0 || plan->run_tiles != 1;
     plan->autotune = (int) opt->v[SPMV_OPT_AUTOTUNE];
     plan->sell_c = (int) opt->v[SPMV_OPT_SELL_C];
     plan->sell_sigma = (int) opt->v[SPMV_OPT_SELL_SIGMA];
@@ -392,9 +406,9 @@ void spmv_plan_choose(SPMV_METHODS requested, const spmv_stats *st, size_t value
      * equal-nnz tiles (nnz / 256 x 1.1 steps) several times cheaper -- measured 0.046 ms (CSR-vector, SELL) against 0.027 ms
      * (nnz-split) on the 1e6-row stand-in.  When the model says "under half", the multiply is handed to the nnz-split executor
      * below the method, like the blocked executor is for matrices without locality: the handle keeps reporting the method asked for.
-     * A forced lanes_per_row (or variant, the A/B selector) keeps the named schedule, and so does an explicit SELL request that sets
+     * A forced lanes_per_row (or executor form) keeps the named schedule, and so does an explicit SELL request that sets
      * any of SELL's own options (sigma, long-row threshold, plain slab kernel): whoever tunes the schedule gets the schedule. */
-    if ((plan->sched == SPMV_SCHED_CSR_VECTOR || plan->sched == SPMV_SCHED_SELL) && lanes == 0 && plan->variant == 0 && vector_cost > 0.0 &&
+    if ((plan->sched == SPMV_SCHED_CSR_VECTOR || plan->sched == SPMV_SCHED_SELL) && lanes == 0 && !plan->forced && vector_cost > 0.0 &&
         !(plan->sched == SPMV_SCHED_SELL && (opt->v[SPMV_OPT_SELL_SIGMA] != 1024 || opt->v[SPMV_OPT_SELL_LONG_THR] != 0 || opt->v[SPMV_OPT_SELL_LDS_X] != 1)) &&
         st->mean_row_len < 8.0 && (double) st->nnz / 256.0 * 1.1 < 0.5 * vector_cost)
         plan->sched = SPMV_SCHED_NNZ_SPLIT;

@@ -189,7 +189,7 @@ extern "C" int spmv_shim_build(spmv_dev *d, const spmv_plan *plan)
     // cache_block = 2), or a sample of the columns shows that no tile group could stage its x windows -- then the tile schedule's
     // inspector is skipped altogether (round 2 built windows / CSR5 transposes / SELL slabs and dropped them: 40-80 ms for 3e8 nnz).
     bool tiles = true;
-    if (plan->sched != SPMV_SCHED_CSR_SCALAR && d->nnz > 0 && plan->variant != 3 &&
+    if (plan->sched != SPMV_SCHED_CSR_SCALAR && d->nnz > 0 && plan->x_windows &&
         ((plan->cache_block == 2 && blocked_possible(d)) || (plan->cache_block == 1 && blocked_size_ok(d) && !(plan->sched == SPMV_SCHED_SELL && !plan->sell_lds_x) && sample_says_no_locality(d))))
         tiles = false;
     auto build_tiles = [&]() -> int { // the inspector of the method's own tile schedule
@@ -304,7 +304,7 @@ extern "C" int spmv_shim_build(spmv_dev *d, const spmv_plan *plan)
             }
         }
         if (!rc && d->blk_on) drop_tile_schedule(d, keep_from);
-        const bool may_try = !rc && d->blk_on && plan->autotune && plan->variant == 0 && plan->block_rows == 0 && forced == 0 && d->nnz >= (1ll << 22);
+        const bool may_try = !rc && d->blk_on && plan->autotune && !plan->forced && plan->blk_groups == 0 && plan->block_rows == 0 && forced == 0 && d->nnz >= (1ll << 22);
         const double rate = may_try && blk_best(d->blk) > 0 ? (double) d->nnz * ((double) d->vsize + 4.0) / ((double) blk_best(d->blk) * 1e-3) : 0.0; // the streams' bytes per second
         // Stream-bound under rule 0 (the streams alone move >= 3.6 TB/s; web-like 4e6 x 24 in fp32 sits at 4.2)?  Then thinner blocks may do better: build the
         // rule-1 set next to this one, time it, keep the faster (one more inspector pass, only for such matrices).

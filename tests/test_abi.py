@@ -21,7 +21,7 @@ def lib():
 
 def _declared_functions():
     names = set()
-    for hdr in ("spmv.h", "spmv_hip.h", "spmv_io.h"):
+    for hdr in ("spmv.h", "spmv_hip.h", "spmv_io.h", "spmv_hip_tools.h"):
         text = open(os.path.join(ROOT, "include", hdr)).read()
         text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
         names |= set(re.findall(r"\b(spmv\w*)\s*\(", text))

@@ -85,7 +85,8 @@ def _definition(csr, x):
 
 
 OPTIONS = {"csr5_sigma": [0, 4, 8, 16], "sell_sigma": [64, 1024], "rowblock_nnz": [0, 64, 700], "lanes_per_row": [0, 1, 4, 64],
-           "cache_block": [1, 2], "variant": [0, 0, 0, 3, 35, 30, 37], "block_rows": [0, 0, 256, 4096]}
+           "cache_block": [1, 2], "x_windows": [1, 1, 1, 0], "blk_groups": [0, 0, 8, 12], "xcd_order": [1, 1, 0], "run_tiles": [1, 1, 1, 0], "blk_waves": [0, 0, 1, 2, 4, 8],
+           "deterministic": [1, 1, 0], "block_rows": [0, 0, 256, 4096]}
 
 
 # SPMV_FUZZ_FIRST / SPMV_FUZZ_SEEDS widen the sweep (seeds 48..847 were run once on the final kernels of round 2, seeds 0..399 with the run-structured cases on those of round 3)

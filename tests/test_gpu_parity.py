@@ -240,10 +240,15 @@ def test_auto_method_picks_schedule_from_row_statistics():
     ("csr5_sigma", [4, 8, 16], M.Method_CSR5SPMV),
     ("rowblock_nnz", [64, 333, 4096, 100000], M.Method_Balanced),
     ("csr5_sigma", [4, 8, 16], M.Method_Balanced_Yid),           # nnz-split = natural-layout tiles of 64 x sigma
-    ("variant", [3], M.Method_Balanced_Yid),                     # no x windows (global gathers)
-    ("variant", [4, 5, 6, 10, 11, 12], M.Method_Parallel),       # CSR-vector kernel forms
-    ("variant", [3, 61, 62], M.Method_SellCSigma),               # 61 / 62: the staged CSR5 group kernel one tile / two tiles deep (long rows)
-    ("variant", [3, 61, 62, 63], M.Method_CSR5SPMV),             # 63: no RUN groups (the 16-bit slot stream is read everywhere)
+    ("x_windows", [0], M.Method_Balanced_Yid),                   # no x windows (global gathers)
+    ("vector_form", [4, 5, 6, 10, 11, 12], M.Method_Parallel),   # CSR-vector kernel forms
+    ("x_windows", [0], M.Method_SellCSigma),
+    ("csr5_two_deep", [1, 2], M.Method_SellCSigma),              # the staged CSR5 group kernel one tile / two tiles deep (long rows)
+    ("x_windows", [0], M.Method_CSR5SPMV),
+    ("csr5_two_deep", [1, 2], M.Method_CSR5SPMV),
+    ("run_tiles", [0], M.Method_CSR5SPMV),                       # no RUN groups (the 16-bit slot stream is read everywhere)
+    ("run_tiles", [0], M.Method_Parallel),                       # no RUN / BYTE tiles
+    ("xcd_order", [0], M.Method_Balanced_Yid),
 ])
 @pytest.mark.parametrize("name", ["skewed_f64_eighths", "empty_mix_f32_eighths", "banded_wide_f64_eighths"])
 def test_tuning_options_do_not_change_results(key, values, method, name):
@@ -544,13 +549,13 @@ def test_blocked_executor_forms_give_the_same_bits_and_create_picks_one_by_timin
     _, _, rp, ci, va = synth.from_row_lengths_device(lens, n, "uniform", tdt, dev, 3, cols="rmat")
     g = torch.Generator(device=dev); g.manual_seed(9)
     x = torch.rand(n, generator=g, device=dev, dtype=tdt) * 2 - 1
-    keep = {k: api.get_option(k) for k in ("cache_block", "variant", "blk_waves")}
+    keep = {k: api.get_option(k) for k in ("cache_block", "blk_groups", "blk_waves")}
     ys = {}
     try:
         api.set_option("cache_block", 2)
         api.set_option("blk_waves", 1)      # the one-wave layout (create() may otherwise keep a wide one: another stored order)
-        for variant in (0, 35, 37):
-            api.set_option("variant", variant)
+        for variant in (0, 8, 12):
+            api.set_option("blk_groups", variant)
             y = torch.full((m,), float("nan"), dtype=tdt, device=dev)
             with api.Handle(m, n, rp, ci, va, M.Method_Balanced2) as h:
                 info = h.info()
@@ -599,14 +604,14 @@ def test_blocked_executor_hot_cells_and_super_slabs(dtype, block_rows):
     cs = torch.cat([torch.zeros(1, dtype=torch.float64, device=dev), torch.cumsum(prod, 0)])
     want = (cs[rp[1:]] - cs[rp[:-1]]).to(tdt)
     rp32 = rp.to(torch.int32)
-    keep = {k: api.get_option(k) for k in ("cache_block", "variant", "block_rows")}
+    keep = {k: api.get_option(k) for k in ("cache_block", "blk_groups", "block_rows")}
     try:
         api.set_option("cache_block", 2)
         api.set_option("block_rows", block_rows)
         stored = {}
         for dense in (1,):
-            for variant in (0, 35, 37):
-                api.set_option("variant", variant)
+            for variant in (0, 8, 12):
+                api.set_option("blk_groups", variant)
                 y = torch.full((m,), float("nan"), dtype=tdt, device=dev)
                 with api.Handle(m, n, rp32, ci, va, M.Method_Balanced2) as h:
                     info = h.info()
@@ -1283,10 +1288,10 @@ def test_two_deep_csr5_group_kernel(shape):
     x = (torch.randint(-8, 9, (n,), generator=g, device=dev) * 0.125).to(torch.float32)
     want = _segment_sums(va.double() * x.double()[ci.long()], rp).to(torch.float32)
     ys = {}
-    keep = api.get_option("variant")
+    keep = api.get_option("csr5_two_deep")
     try:
-        for variant in (0, 61):
-            api.set_option("variant", variant)
+        for variant in (0, 1):
+            api.set_option("csr5_two_deep", variant)
             with api.Handle(m, n, rp, ci, va, M.Method_CSR5SPMV) as h:
                 info = h.info()
                 y = torch.full((m,), float("nan"), dtype=torch.float32, device=dev)
@@ -1296,6 +1301,6 @@ def test_two_deep_csr5_group_kernel(shape):
                 assert torch.equal(y, want), (shape, variant, int((y != want).sum()))
                 ys[variant] = y
     finally:
-        api.set_option("variant", keep)
+        api.set_option("csr5_two_deep", keep)
     with api.Handle(m, n, rp, ci, va.double(), M.Method_CSR5SPMV) as h:
         assert h.info()["kernel_name"] == "csr5_group_kernel"

@@ -130,3 +130,25 @@ def test_split_off_gives_the_unsplit_executors(x):
         assert info["far_nnz"] == 0 and info["split_ms"] == [0.0, 0.0] and torch.equal(y, _definition(ci, va, x))
     finally:
         h.close()
+
+
+@pytest.mark.parametrize("family", ["tile", "csr5", "blocked"])
+def test_inspector_time_is_bounded_per_nonzero(family):
+    """the inspector's cost is reported (spmv_hip_info.inspect_ms) -- and bounded here.  Every inspector is a handful of device passes
+    over the matrix plus the create-time timing of a few executor forms: under 0.5 ns per non-zero + 40 ms of fixed cost (allocations, ~30 timed
+    launches) at 6.4e7 non-zeros for each executor family -- CSR-vector tiles (windows, slot streams, autotune), CSR5 (transposes, descriptors,
+    windows) and row blocks x column slabs (two layouts built and timed).  Measured: 0.06 / 0.09 / 0.25 ns per non-zero at 3.2e8."""
+    m, k = 2_000_000, 32
+    if family == "blocked":
+        _, _, rp, ci, va = synth.uniform_k_device(m, m, k, "eighths", torch.float64, DEV, seed=5)
+        method = M.Method_Parallel
+    else:
+        _, _, rp, ci, va = synth.banded_device(m, m, k, "eighths", torch.float64, DEV, seed=5)
+        method = M.Method_Parallel if family == "tile" else M.Method_CSR5SPMV
+    with api.Handle(m, m, rp, ci, va, method) as h:      # first create of the process pays allocator warm-up: measure the second
+        pass
+    with api.Handle(m, m, rp, ci, va, method) as h:
+        info = h.info()
+    nnz = m * k
+    assert info["cache_blocked"] == (1 if family == "blocked" else 0)
+    assert info["inspect_ms"] <= 0.5e-6 * nnz + 40.0, (family, info["inspect_ms"], info["kernel_name"])

@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""Developer tool: interleaved A/B of (method, variant) pairs on one matrix in ONE process
+"""Developer tool: interleaved A/B of (method, vector_form) pairs on one matrix in ONE process
 (cdna_hip_programming.md 5.4 rule 24): all handles are created first, then R rounds visit them in
 turn; min and median over rounds are reported, which removes the thermal drift a sequential run shows."""
 import argparse, json, os, sys, time
@@ -13,7 +13,7 @@ ap.add_argument("--m", type=int, default=10_000_000)
 ap.add_argument("--k", type=int, default=32)
 ap.add_argument("--dtype", default="f64")
 ap.add_argument("--kind", default="banded")
-ap.add_argument("--pairs", default="1:10,1:11,1:5,1:4,6:0,5:0,2:0", help="method:variant,...")
+ap.add_argument("--pairs", default="1:10,1:11,1:5,1:4,6:0,5:0,2:0", help="method:vector_form,...")
 ap.add_argument("--rounds", type=int, default=8)
 ap.add_argument("--iters", type=int, default=5)
 a = ap.parse_args()
@@ -29,7 +29,7 @@ y = torch.empty(m, dtype=dt, device=dev)
 hs = []
 for pr in a.pairs.split(","):
     meth, var = (int(v) for v in pr.split(":"))
-    api.set_option("variant", var)
+    api.set_option("vector_form", var)
     api.set_option("autotune", 0)
     h = api.Handle(m, n, rp, ci, va, meth)
     hs.append((f"{pr}#{len(hs)}", h, h.info()))

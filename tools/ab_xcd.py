@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""A/B of the XCD-aware block mapping (the default; variant 30 = dispatch order) on the tile kernels that gather x through L2:
+"""A/B of the XCD-aware block mapping (the default; option xcd_order = 0 = dispatch order) on the tile kernels that gather x through L2:
 webbase-style power-law matrices with the three column models, 3e5 ... 4e6 rows (tile executors forced)."""
 import os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -18,10 +18,10 @@ for cols in ("web", "rmat", "uniform"):
         row = []
         for meth in (M.Method_Balanced2, M.Method_CSR5SPMV):
             for var in (0, 30):
-                api.set_option("variant", var)
+                api.set_option("xcd_order", 0 if var == 30 else 1)
                 h = api.Handle(m, m, rp, ci, va, meth)
                 _, ms = api.time_launches(h.h, x, y, 5, 30)
                 row.append("%s v%d %s %.4f" % (M(meth).name[7:], var, h.info()["kernel_name"], float(ms.min())))
                 h.close()
-        api.set_option("variant", 0)
+        api.set_option("xcd_order", 1)
         print(cols, m, int(rp[-1]), " | ".join(row), flush=True)

@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Row-block x column-slab executor on the shapes without column locality: ms (min of 20), B_alg fraction, inspector time,
 stored entries and the dense share, per option set.
-    python tools/blk_bench.py 2r 3o 3o-uniform web24 [--sets "variant=35;variant=37"]      (SPMV_LIB=<another build>: same-box A/B)"""
+    python tools/blk_bench.py 2r 3o 3o-uniform web24 [--sets "blk_groups=8;blk_waves=4,deterministic=0"]      (SPMV_LIB=<another build>: same-box A/B)"""
 import argparse, json, os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tools"))

@@ -77,7 +77,7 @@ for meth in [int(s) for s in a.methods.split(",")]:
        for reo in [int(s) for s in a.reorder.split(",")]:
         api.set_option("reorder", reo)
         api.set_option("lanes_per_row", lanes)
-        api.set_option("variant", var)
+        api.set_option("vector_form", var)
         tcr = time.time()
         try:
             h = api.Handle(m, n, rp, ci, va, meth)
