@@ -235,7 +235,7 @@ def column_stream_bytes(info):
     if info["cache_blocked"]:
         return 4.0
     staged = info["x_groups_staged"] / max(info["x_groups"], 1) if info["x_groups"] else 0.0
-    run, byte = int(info.get("run_nnz", 0)), int(info.get("byte_nnz", 0))
+    run, byte = int(info.get("run_nnz", 0)) + int(info.get("tmpl_nnz", 0)), int(info.get("byte_nnz", 0))
     rest = max(nnz - run - byte, 0)
     return round((run * 0.0 + byte * 1.0 + rest * (2.0 * staged + 4.0 * (1.0 - staged))) / nnz, 3)
 

@@ -158,6 +158,8 @@ typedef struct spmv_hip_info {
                                  * not read at all (16 bits, SELL: a word, per ROW; CSR5: a word per lane and tile instead) */
     long long byte_nnz;         /* CSR-vector / row-block tile kernels: entries in BYTE tiles -- staged tiles in which every row's LDS slots lie within 255 of the row's
                                  * smallest (banded matrices with holes, block rows): their column stream is one byte per entry + 16 bits per row */
+    long long tmpl_nnz;         /* ... entries in TEMPLATE tiles -- staged tiles whose rows all have the same slot offsets from their first entry (stencil interiors,
+                                 * block rows): no column stream either, 16 bits per row + one offset list per tile */
     int blk_waves;              /* cache_blocked: wavefronts that share one row block's accumulators (1: a wave per block, two blocks per CU; 2 / 4 / 8: the
                                  * wide form, one block of up to ~20 k rows per CU); 0 when another executor runs */
     char launch_kernels[160];   /* every kernel ONE spmv() launches, in order, '+'-separated (e.g. "sell_window_kernel+csr5_group_pipe_kernel+csr5_fixup_kernel") */

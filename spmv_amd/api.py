@@ -67,7 +67,7 @@ class spmv_hip_info(C.Structure):
                 ("schedule_name", C.c_char_p), ("kernel_name", C.c_char_p),
                 ("tuned_choice", C.c_int), ("tune_ms", C.c_float * 3),
                 ("x_groups", C.c_int), ("x_groups_staged", C.c_int), ("cache_blocked", C.c_int),
-                ("stream_bytes", C.c_longlong), ("x_bytes", C.c_longlong), ("route_ms", C.c_float * 2), ("split_ms", C.c_float * 2), ("far_nnz", C.c_longlong), ("run_nnz", C.c_longlong), ("byte_nnz", C.c_longlong),
+                ("stream_bytes", C.c_longlong), ("x_bytes", C.c_longlong), ("route_ms", C.c_float * 2), ("split_ms", C.c_float * 2), ("far_nnz", C.c_longlong), ("run_nnz", C.c_longlong), ("byte_nnz", C.c_longlong), ("tmpl_nnz", C.c_longlong),
                 ("blk_waves", C.c_int), ("launch_kernels", C.c_char * 160), ("reproducible", C.c_int)]
 
 

@@ -38,6 +38,9 @@ namespace spmv {
 
 constexpr int kVecTileThreads = 256;           // 4 wavefronts per workgroup (512 measured no better)
 constexpr int kVecTileRows = kVecTileThreads;  // rows per workgroup slab (64 per wave)
+constexpr int kTmplMax = 64;                   // TEMPLATE tiles: most entries of a row (a power of two: positions are masked with kTmplMax - 1),
+constexpr int kTmplCount = 8;                  // ... different offset lists per tile,
+constexpr int kTmplRows = 1024;                // ... rows of a tile (the wide form's blocks; Balanced's equal-nnz blocks may hold more: those keep their stream)
 // Row range of tile b: fixed 256-row tiles, or the equal-nnz blocks of `split` (Method_Balanced).
 __device__ __forceinline__ void tile_rows(int b, int m, int rows_per_tile, const int *__restrict__ split, long long &r0, long long &r1)
 {
@@ -55,7 +58,10 @@ static __global__ __launch_bounds__(kBlock) void csr_tile_windows_kernel(int m, 
                                                                   unsigned short *__restrict__ col_local,
                                                                   unsigned short *__restrict__ row_slot /* NULL: no run tiles */,
                                                                   unsigned char *__restrict__ col8 /* NULL: no byte tiles */,
-                                                                  int *__restrict__ staged /* [0] tiles staged, [1] max total, [2] run tiles, [3] their entries, [4] their rows, [5] byte tiles, [6] their entries, [7] their rows */)
+                                                                  unsigned short *__restrict__ tmpl /* NULL: no template tiles; else kTmplCount lists of kTmplMax offsets per tile */,
+                                                                  unsigned char *__restrict__ row_tid /* template tiles: the list number of every row */,
+                                                                  int *__restrict__ staged /* [0] tiles staged, [1] max total, [2] run tiles, [3] their entries, [4] their rows, [5] byte tiles, [6] their entries, [7] their rows,
+                                                                                              [8] template tiles, [9] their entries, [10] their rows */)
 {
     long long r0, r1;
     tile_rows(blockIdx.x, m, rows_per_tile, split, r0, r1);
@@ -90,6 +96,96 @@ static __global__ __launch_bounds__(kBlock) void csr_tile_windows_kernel(int m, 
         // anything whose rows span under 256 columns inside one window: the column stream is then ONE byte per entry (the slot's distance from
         // the row's smallest slot, col8) + 16 bits per row (that smallest slot, row_slot) instead of 16 bits per entry.  Every thread re-reads
         // the 16-bit slots it stored itself (build_windows ran the same loop), so no fence is needed in front of this.
+        // TEMPLATE tile?  The tile's (non-long, non-empty) rows use at most kTmplCount different lists of slot offsets from their first entry (each of
+        // at most kTmplMax entries) -- the interior of any stencil (a 27-point row: three windows, nine runs of three, the same 27 offsets in every
+        // row) plus the few other lists of the rows at the grid's edges, block rows, anything assembled from a few element patterns.  Like a RUN tile
+        // it reads no column stream at all: 16 bits (row_slot: the slot of the row's first entry) + 8 bits (row_tid: which list) per ROW and the
+        // lists once per tile (tmpl); the slot of a row's k-th entry is row_slot + list[k].  RUN = the one list 0, 1, 2, ...
+        if (tmpl && nwin > 0 && r1 - r0 <= kTmplRows) {
+            __shared__ unsigned s_hash[kTmplCount];
+            __shared__ int s_tlen[kTmplCount], s_first[kTmplCount], s_tm[kTmplCount][kTmplMax];
+            __shared__ unsigned char s_ids[kTmplRows];
+            for (int i = threadIdx.x; i < kTmplCount * kTmplMax; i += kBlock) s_tm[i / kTmplMax][i % kTmplMax] = 0;
+            if (threadIdx.x < kTmplCount) { s_hash[threadIdx.x] = 0u; s_tlen[threadIdx.x] = 0; s_first[threadIdx.x] = INT_MAX; }
+            __syncthreads();
+            int okt = 1, nt = 0;
+            auto on_row = [&](int len) { return len > 0 && len <= long_thr; };
+            // A: every row hashes its list (length and offsets) and claims or finds one of the kTmplCount list numbers
+            for (long long r = r0 + sub; r < r1; r += kBlock / 16) {
+                const int p0 = rowptr[r], len = rowptr[r + 1] - p0;
+                int id = 0;
+                if (on_row(len)) {
+                    if (len > kTmplMax) okt = 0;
+                    else {
+                        const int s0 = col_local[p0];
+                        unsigned h = 0x9E3779B9u * (unsigned) len;
+                        for (int k = l; k < len; k += 16) {
+                            const int dlt = (int) col_local[p0 + k] - s0;
+                            okt &= dlt >= 0;
+                            h += ((unsigned) dlt + 0x7F4A7C15u) * (2u * (unsigned) k + 1u) * 0x85EBCA6Bu;
+                        }
+#pragma unroll
+                        for (int o = 8; o > 0; o >>= 1) h += __shfl_xor(h, o, 16);
+                        h |= 1u; // 0 = a free list number
+                        id = -1;
+                        if (l == 0)
+                            for (int i = 0; i < kTmplCount && id < 0; ++i) {
+                                const unsigned old = atomicCAS(&s_hash[i], 0u, h);
+                                if (old == 0u || old == h) id = i;
+                            }
+                        id = __shfl(id, 0, 16);
+                        if (id < 0) { okt = 0; id = 0; } // more than kTmplCount different lists in this tile
+                    }
+                    if (l == 0) nt += len;
+                }
+                if (l == 0) s_ids[r - r0] = (unsigned char) id;
+            }
+            __syncthreads();
+            // B, C: list i is written by the FIRST row (in row order) that carries it
+            for (long long r = r0 + sub; r < r1; r += kBlock / 16) {
+                const int len = rowptr[r + 1] - rowptr[r];
+                if (l == 0 && on_row(len) && len <= kTmplMax) atomicMin(&s_first[s_ids[r - r0]], (int) (r - r0));
+            }
+            __syncthreads();
+            for (long long r = r0 + sub; r < r1; r += kBlock / 16) {
+                const int p0 = rowptr[r], len = rowptr[r + 1] - p0;
+                if (!on_row(len) || len > kTmplMax) continue;
+                const int id = s_ids[r - r0];
+                if (s_first[id] == (int) (r - r0)) {
+                    const int s0 = col_local[p0];
+                    for (int k = l; k < len; k += 16) s_tm[id][k] = (int) col_local[p0 + k] - s0;
+                    if (l == 0) s_tlen[id] = len;
+                }
+            }
+            __syncthreads();
+            // D: every row against its list (a hash is not a proof)
+            for (long long r = r0 + sub; r < r1; r += kBlock / 16) {
+                const int p0 = rowptr[r], len = rowptr[r + 1] - p0;
+                if (!on_row(len) || len > kTmplMax) continue;
+                const int id = s_ids[r - r0], s0 = col_local[p0];
+                okt &= s_tlen[id] == len;
+                for (int k = l; k < len; k += 16) okt &= (int) col_local[p0 + k] - s0 == s_tm[id][k];
+            }
+            okt = __syncthreads_and(okt);
+            if (okt) {
+                for (long long r = r0 + sub * 16 + l; r < r1; r += kBlock) { // one thread per row
+                    const int p0 = rowptr[r], len = rowptr[r + 1] - p0;
+                    row_slot[r] = (unsigned short) (on_row(len) ? col_local[p0] : 0);
+                    row_tid[r] = on_row(len) ? s_ids[r - r0] : (unsigned char) 0;
+                }
+                for (int i = threadIdx.x; i < kTmplCount * kTmplMax; i += kBlock)
+                    tmpl[(size_t) blockIdx.x * (kTmplCount * kTmplMax) + i] = (unsigned short) s_tm[i / kTmplMax][i % kTmplMax];
+#pragma unroll
+                for (int o = kWave / 2; o > 0; o >>= 1) nt += __shfl_xor(nt, o, kWave);
+                if ((threadIdx.x & (kWave - 1)) == 0 && nt) atomicAdd(staged + 9, nt);
+                if (threadIdx.x == 0) {
+                    wins[blockIdx.x].runs = 3;
+                    atomicAdd(staged + 8, 1);
+                    atomicAdd(staged + 10, (int) (r1 - r0));
+                }
+                return;
+            }
+        }
         if (!col8 || nwin == 0) return;
         int okb = 1, nb = 0;
         for (long long r = r0 + sub; r < r1; r += kBlock / 16) {
@@ -206,12 +302,14 @@ struct Lane4 {
 // (c, v: already loaded by Lane4 from the chunk starting at the 16 B-aligned position p0 & ~3) and, for
 // rows longer than that chunk, walks on in chunks of 4L.  Returns the lane's partial sum (not yet reduced over the group).
 // MODE 0: unstaged (global columns), 1: staged (16-bit slots from the column stream), 2: staged RUN tile (slots = rs + position in the row;
-// cc0 unused), 3: staged BYTE tile (slots = rs + the entry's byte of the 8-bit column stream, packed in cc0)
+// cc0 unused), 3: staged BYTE tile (slots = rs + the entry's byte of the 8-bit column stream, packed in cc0), 4: staged TEMPLATE tile (slots = rs +
+// tm[position in the row], tm = the tile's offset list in LDS; cc0 unused)
 template <typename T, int L, int MODE, int SHIFT = 0>
 __device__ __forceinline__ T csr_vector_step(int p0, int p1, int l, const int (&cc0)[4], const T (&vv0)[4],
                                              const int *__restrict__ colidx, const unsigned short *__restrict__ col_local,
                                              const T *__restrict__ val, const T *__restrict__ x,
-                                             const unsigned char *__restrict__ xb, unsigned zoff, unsigned rs = 0, const unsigned char *__restrict__ col8 = nullptr)
+                                             const unsigned char *__restrict__ xb, unsigned zoff, unsigned rs = 0, const unsigned char *__restrict__ col8 = nullptr,
+                                             const unsigned short *__restrict__ tm = nullptr)
 {
     constexpr bool STAGED = MODE != 0;
     constexpr unsigned INC = SHIFT ? 1u : (unsigned) sizeof(T); // slot unit of the stream: indices (wide form) or bytes
@@ -222,6 +320,7 @@ __device__ __forceinline__ T csr_vector_step(int p0, int p1, int l, const int (&
     auto slot_of = [&](auto kc, int e, const int (&cc)[4]) -> unsigned {
         constexpr int K = decltype(kc)::value;
         if constexpr (MODE == 2) return run_slot(e);
+        else if constexpr (MODE == 4) return (rs & 0xffffu) + tm[(rs >> 16) + ((unsigned) (e - p0) & (unsigned) (kTmplMax - 1))]; // rs = slot | list number * kTmplMax << 16; out-of-row positions read a slot they never use
         else if constexpr (MODE == 3) return rs + LMB::template byte_of<K>(cc) * INC;
         else return lds_slot<K>(cc);
     };
@@ -272,7 +371,11 @@ __device__ __forceinline__ T csr_vector_step(int p0, int p1, int l, const int (&
                 else if (MODE == 0) LM::load_col32(colidx, bb, l, cc);
                 else if (MODE == 3) LM::load_col8(col8, bb, l, cc);
                 LM::load_val(val, bb, l, v2);
-                if (MODE == 3) {
+                if (MODE == 4) {
+#pragma unroll
+                    for (int k = 0; k < 4; ++k)
+                        if (bb + LM::pos(l, k) < p1) sum = fmadd(v2[k], xat((rs & 0xffffu) + tm[(rs >> 16) + ((unsigned) (bb + LM::pos(l, k) - p0) & (unsigned) (kTmplMax - 1))]), sum);
+                } else if (MODE == 3) {
                     if (bb + LM::pos(l, 0) < p1) sum = fmadd(v2[0], xat(slot_of(K0{}, 0, cc)), sum);
                     if (bb + LM::pos(l, 1) < p1) sum = fmadd(v2[1], xat(slot_of(K1{}, 0, cc)), sum);
                     if (bb + LM::pos(l, 2) < p1) sum = fmadd(v2[2], xat(slot_of(K2{}, 0, cc)), sum);
@@ -304,12 +407,13 @@ __device__ __forceinline__ T csr_vector_step(int p0, int p1, int l, const int (&
 // takes the unmasked path.  The order of the fused multiply-adds is the same on both paths.
 template <typename T, int L, int MODE, int DEPTH, bool PRE = true, int SHIFT = 0>
 __device__ __forceinline__ void csr_vector_tile_wave(long long row_end, int long_thr, long long rw0, int lane,
-                                                     const int *__restrict__ rp_lds, const unsigned short *__restrict__ rs_lds /* MODE 2: slot of each row's first column */,
+                                                     const int *__restrict__ rp_lds, const unsigned *__restrict__ rs_lds /* MODE >= 2: slot of each row's first column (MODE 4: | list number * kTmplMax << 16) */,
                                                      T *__restrict__ y_lds,
                                                      const int *__restrict__ colidx, const unsigned short *__restrict__ col_local,
                                                      const T *__restrict__ val,
                                                      const T *__restrict__ x, const T *__restrict__ xs, unsigned zoff,
-                                                     T *__restrict__ y, const int (&c0)[4], const T (&v0)[4], const unsigned char *__restrict__ col8 = nullptr)
+                                                     T *__restrict__ y, const int (&c0)[4], const T (&v0)[4], const unsigned char *__restrict__ col8 = nullptr,
+                                                     const unsigned short *__restrict__ tm = nullptr)
 {
     constexpr int RW = kWave / L; // rows per step
     constexpr int D = DEPTH < L ? DEPTH : L; // steps of matrix stream in flight per wave
@@ -343,7 +447,7 @@ __device__ __forceinline__ void csr_vector_tile_wave(long long row_end, int long
     for (int s = 0; s < L; ++s) {
         const int cur = s % D;
         const int p0 = pp0[cur], p1 = pp1[cur];
-        T sum = csr_vector_step<T, L, MODE, SHIFT>(p0, p1, l, c[cur], v[cur], colidx, col_local, val, x, xb, zoff, rs[cur], col8);
+        T sum = csr_vector_step<T, L, MODE, SHIFT>(p0, p1, l, c[cur], v[cur], colidx, col_local, val, x, xb, zoff, rs[cur], col8, tm);
         sum = group_sum_dpp<L>(sum);
         if (l == 0) y_lds[s * RW + sub] = sum;
         if (s + D < L) issue(s + D); // refill the slot just consumed
@@ -362,12 +466,14 @@ __global__ __launch_bounds__(kVecTileThreads) void csr_vector_tile_kernel(int m,
                                                                           const TileWindows *__restrict__ wins,
                                                                           const unsigned short *__restrict__ row_slot,
                                                                           const unsigned char *__restrict__ col8,
+                                                                          const unsigned short *__restrict__ tmpl, const unsigned char *__restrict__ row_tid,
                                                                           const T *__restrict__ x, T *__restrict__ y)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char vec_x_lds[]; // the tile's staged x
+    __shared__ unsigned short tm_lds[kTmplCount * kTmplMax];
     T *xs = reinterpret_cast<T *>(vec_x_lds);
     __shared__ int rp_lds[kVecTileThreads / kWave][kWave + 2];
-    __shared__ unsigned short rs_lds[kVecTileThreads / kWave][kWave];
+    __shared__ unsigned rs_lds[kVecTileThreads / kWave][kWave];
     __shared__ T y_lds[kVecTileThreads / kWave][kWave];
     const int lane = threadIdx.x & (kWave - 1), wave = threadIdx.x / kWave;
     const long long rw0 = (long long) blockIdx.x * kVecTileRows + wave * kWave;
@@ -378,7 +484,7 @@ __global__ __launch_bounds__(kVecTileThreads) void csr_vector_tile_kernel(int m,
     const int rp = rowptr[r];
     const int rpe = rowptr[re]; // wave-uniform
     const TileWindows &tw = wins[blockIdx.x];
-    const bool staged = tw.nwin > 0, runs = tw.runs == 1, bytes = tw.runs == 2; // runs / bytes imply staged
+    const bool staged = tw.nwin > 0, runs = tw.runs == 1, bytes = tw.runs == 2, templ = tw.runs == 3; // runs / bytes / templ imply staged
     // step 0 of the matrix stream is issued straight from registers (RowPtr handed over by
     // shuffles), BEFORE the x staging and the barrier, so neither sits in front of the first loads
     int c0[4] = {0, 0, 0, 0};
@@ -387,7 +493,7 @@ __global__ __launch_bounds__(kVecTileThreads) void csr_vector_tile_kernel(int m,
         const int sub = lane / L, l = lane % L;
         const int q0 = __shfl(rp, sub, kWave);
         const int a = q0 & ~3;
-        if (runs) {}
+        if (runs | templ) {}
         else if (bytes) Lane4<T, L>::load_col8(col8, a, l, c0);
         else if (staged) Lane4<T, L>::load_col16(col_local, a, l, c0);
         else Lane4<T, L>::load_col32(colidx, a, l, c0);
@@ -396,6 +502,10 @@ __global__ __launch_bounds__(kVecTileThreads) void csr_vector_tile_kernel(int m,
     rp_lds[wave][lane] = rp;
     if (lane == 0) rp_lds[wave][kWave] = rpe;
     if (runs | bytes) rs_lds[wave][lane] = row_slot[r]; // r <= m: the array has m + 1 entries
+    if (templ) {
+        rs_lds[wave][lane] = (unsigned) row_slot[r] | ((unsigned) row_tid[r] * kTmplMax << 16);
+        for (int i = threadIdx.x; i < kTmplCount * kTmplMax; i += kVecTileThreads) tm_lds[i] = tmpl[(size_t) blockIdx.x * (kTmplCount * kTmplMax) + i];
+    }
     stage_windows<kVecTileThreads, T>(tw, x, xs);
     if (threadIdx.x == 0) xs[tw.total] = T(0); // the zero slot of masked entries
     __syncthreads();
@@ -403,6 +513,7 @@ __global__ __launch_bounds__(kVecTileThreads) void csr_vector_tile_kernel(int m,
     const unsigned zoff = (unsigned) tw.total * (unsigned) sizeof(T);
     if (runs) csr_vector_tile_wave<T, L, 2, DEPTH, PRE>((long long) m, long_thr, rw0, lane, rp_lds[wave], rs_lds[wave], y_lds[wave], colidx, col_local, val, x, xs, zoff, y, c0, v0);
     else if (bytes) csr_vector_tile_wave<T, L, 3, DEPTH, PRE>((long long) m, long_thr, rw0, lane, rp_lds[wave], rs_lds[wave], y_lds[wave], colidx, col_local, val, x, xs, zoff, y, c0, v0, col8);
+    else if (templ) csr_vector_tile_wave<T, L, 4, DEPTH, PRE>((long long) m, long_thr, rw0, lane, rp_lds[wave], rs_lds[wave], y_lds[wave], colidx, col_local, val, x, xs, zoff, y, c0, v0, col8, tm_lds);
     else if (staged) csr_vector_tile_wave<T, L, 1, DEPTH, PRE>((long long) m, long_thr, rw0, lane, rp_lds[wave], rs_lds[wave], y_lds[wave], colidx, col_local, val, x, xs, zoff, y, c0, v0);
     else csr_vector_tile_wave<T, L, 0, DEPTH, PRE>((long long) m, long_thr, rw0, lane, rp_lds[wave], rs_lds[wave], y_lds[wave], colidx, col_local, val, x, xs, zoff, y, c0, v0);
 }
@@ -421,8 +532,10 @@ __global__ __launch_bounds__(kVecTileThreads) void csr_vector_rows_kernel(int lo
                                                                           const TileWindows *__restrict__ wins,
                                                                           const unsigned short *__restrict__ row_slot,
                                                                           const unsigned char *__restrict__ col8,
+                                                                          const unsigned short *__restrict__ tmpl, const unsigned char *__restrict__ row_tid,
                                                                           const T *__restrict__ x, T *__restrict__ y)
 {
+    __shared__ unsigned short tm_lds[kTmplCount * kTmplMax];
     // WIDE: x windows above 64 KiB (fp64 rows whose columns scatter over thousands of columns): the column
     // stream holds slot INDICES instead of byte offsets; blocks are `rows_per_block` consecutive rows
     // (split == NULL) so that one staging serves more rows.
@@ -430,13 +543,14 @@ __global__ __launch_bounds__(kVecTileThreads) void csr_vector_rows_kernel(int lo
     extern __shared__ __attribute__((aligned(16))) unsigned char vec_x_lds[];
     T *xs = reinterpret_cast<T *>(vec_x_lds);
     __shared__ int rp_lds[kVecTileThreads / kWave][kWave + 2];
-    __shared__ unsigned short rs_lds[kVecTileThreads / kWave][kWave];
+    __shared__ unsigned rs_lds[kVecTileThreads / kWave][kWave];
     __shared__ T y_lds[kVecTileThreads / kWave][kWave];
     const int lane = threadIdx.x & (kWave - 1), wave = threadIdx.x / kWave;
     long long r_begin, r_end;
     tile_rows(blockIdx.x, m, rows_per_block, split, r_begin, r_end);
     const TileWindows &tw = wins[blockIdx.x];
-    const bool staged = tw.nwin > 0, runs = tw.runs == 1, bytes = tw.runs == 2;
+    const bool staged = tw.nwin > 0, runs = tw.runs == 1, bytes = tw.runs == 2, templ = tw.runs == 3;
+    if (templ) for (int i = threadIdx.x; i < kTmplCount * kTmplMax; i += kVecTileThreads) tm_lds[i] = tmpl[(size_t) blockIdx.x * (kTmplCount * kTmplMax) + i];
     stage_windows<kVecTileThreads, T>(tw, x, xs);
     if (threadIdx.x == 0) xs[tw.total] = T(0); // the zero slot of masked entries
     __syncthreads();
@@ -450,9 +564,11 @@ __global__ __launch_bounds__(kVecTileThreads) void csr_vector_rows_kernel(int lo
         rp_lds[wave][lane] = rowptr[r];
         if (lane == 0) rp_lds[wave][kWave] = rowptr[re];
         if (runs | bytes) rs_lds[wave][lane] = row_slot[r];
+        if (templ) rs_lds[wave][lane] = (unsigned) row_slot[r] | ((unsigned) row_tid[r] * kTmplMax << 16);
         wave_lds_sync();
         if (runs) csr_vector_tile_wave<T, L, 2, DEPTH, false, SHIFT>(r_end, long_thr, rw0, lane, rp_lds[wave], rs_lds[wave], y_lds[wave], colidx, col_local, val, x, xs, zoff, y, c0, v0);
         else if (bytes) csr_vector_tile_wave<T, L, 3, DEPTH, false, SHIFT>(r_end, long_thr, rw0, lane, rp_lds[wave], rs_lds[wave], y_lds[wave], colidx, col_local, val, x, xs, zoff, y, c0, v0, col8);
+        else if (templ) csr_vector_tile_wave<T, L, 4, DEPTH, false, SHIFT>(r_end, long_thr, rw0, lane, rp_lds[wave], rs_lds[wave], y_lds[wave], colidx, col_local, val, x, xs, zoff, y, c0, v0, col8, tm_lds);
         else if (staged) csr_vector_tile_wave<T, L, 1, DEPTH, false, SHIFT>(r_end, long_thr, rw0, lane, rp_lds[wave], rs_lds[wave], y_lds[wave], colidx, col_local, val, x, xs, zoff, y, c0, v0);
         else csr_vector_tile_wave<T, L, 0, DEPTH, false, SHIFT>(r_end, long_thr, rw0, lane, rp_lds[wave], rs_lds[wave], y_lds[wave], colidx, col_local, val, x, xs, zoff, y, c0, v0);
         wave_lds_sync(); // y_lds / rp_lds are reused by the next slab

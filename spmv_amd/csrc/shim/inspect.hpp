@@ -82,7 +82,7 @@ template <typename T>
 static int build_tile_windows(spmv_dev *d, int tiles, const int *split, int rows_per_tile, bool wide)
 {
     int *cnt = nullptr;
-    int host2[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    int host2[11] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
     d->vt_tiles = tiles;
     ALLOC_TRY(d, &cnt, sizeof host2, true);
     static_assert(kVecXTileBytes <= 65536, "LDS byte offsets must fit 16 bits");
@@ -99,6 +99,14 @@ static int build_tile_windows(spmv_dev *d, int tiles, const int *split, int rows
         ALLOC_TRY(d, &d->vt_col8, (size_t) d->nnz + kStreamPad, true);
         HIP_TRY(hipMemsetAsync(d->vt_col8, 0, (size_t) d->nnz + kStreamPad, d->stream));
     }
+    if (d->vt_tmpl) { sched_free(d, d->vt_tmpl); d->vt_tmpl = nullptr; } // sized by the tile count, which differs between the narrow and the wide attempt
+    if (d->vt_rowslot && !getenv("SPMV_HIP_NO_TEMPLATE_TILES")) {
+        ALLOC_TRY(d, &d->vt_tmpl, sizeof(unsigned short) * kTmplCount * kTmplMax * (size_t) tiles, true);
+        if (!d->vt_rowtid) {
+            ALLOC_TRY(d, &d->vt_rowtid, (size_t) d->m + kStreamPad, true);
+            HIP_TRY(hipMemsetAsync(d->vt_rowtid, 0, (size_t) d->m + kStreamPad, d->stream));
+        }
+    }
     if (d->vt_wins) sched_free(d, d->vt_wins);
     ALLOC_TRY(d, &d->vt_wins, sizeof(TileWindows) * (size_t) tiles, true);
     HIP_TRY(hipMemsetAsync(cnt, 0, sizeof host2, d->stream));
@@ -106,7 +114,7 @@ static int build_tile_windows(spmv_dev *d, int tiles, const int *split, int rows
     csr_tile_windows_kernel<<<tiles, kBlock, 0, d->stream>>>(d->m, d->n, rows_per_tile, d->long_thr,
                                                              (int) ((wide ? kVecWideXTileBytes : kVecXTileBytes) / sizeof(T)) - 1, wide ? 1 : (int) sizeof(T),
                                                              split, d->rowptr, d->colidx,
-                                                             d->vt_wins, d->vt_col, d->vt_rowslot, d->vt_col8, cnt);
+                                                             d->vt_wins, d->vt_col, d->vt_rowslot, d->vt_col8, d->vt_tmpl, d->vt_rowtid, cnt);
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipMemcpyAsync(host2, cnt, sizeof host2, hipMemcpyDeviceToHost, d->stream));
     HIP_TRY(hipStreamSynchronize(d->stream));
@@ -118,6 +126,10 @@ static int build_tile_windows(spmv_dev *d, int tiles, const int *split, int rows
     d->vt_byte_tiles = host2[5];
     d->vt_byte_nnz = host2[6];
     d->vt_byte_rows = host2[7];
+    d->vt_tmpl_tiles = host2[8];
+    d->vt_tmpl_nnz = host2[9];
+    d->vt_tmpl_rows = host2[10];
+    if (d->vt_tmpl && d->vt_tmpl_tiles == 0) { sched_free(d, d->vt_tmpl); d->vt_tmpl = nullptr; sched_free(d, d->vt_rowtid); d->vt_rowtid = nullptr; }
     if (d->vt_col8 && d->vt_byte_tiles == 0) { sched_free(d, d->vt_col8); d->vt_col8 = nullptr; } // no tile qualified: the byte stream is not kept
     d->vt_wide = wide;
     d->vt_rows = rows_per_tile;
@@ -828,6 +840,7 @@ static int account_stream_bytes(spmv_dev *d)
             t.bytes = 4 * (m + 1) + stream_part(d->nnz - d->lsub_nnz, s, fs) + s * (m - d->nlong);
             if (tile_form) { t.bytes += (long long) sizeof(TileWindows) * d->vt_tiles; t.x_elems = welems; }
             if (tile_form) t.bytes += 2ll * d->vt_run_rows - 2ll * d->vt_run_nnz; // RUN tiles: a 16-bit slot per row instead of one per entry
+            if (tile_form) t.bytes += 3ll * d->vt_tmpl_rows + 2ll * kTmplCount * kTmplMax * d->vt_tmpl_tiles - 2ll * d->vt_tmpl_nnz; // TEMPLATE tiles: a 16-bit slot and a list number per row, the lists once per tile
             if (tile_form) t.bytes += 2ll * d->vt_byte_rows - 1ll * d->vt_byte_nnz; // BYTE tiles: a byte per entry and a 16-bit slot per row instead of 16 bits per entry
             if (d->plan.sched == SPMV_SCHED_ROWBLOCK) t.bytes += 4ll * (d->nblocks + 1);
             if (!tile_form || wtiles < d->vt_tiles) t.gathers_global = true;

@@ -12,7 +12,7 @@ static void launch_vector_tile(spmv_dev *d, const T *x, T *y, int long_thr)
     const size_t lds = ((((size_t) d->vt_maxspan + 1) * sizeof(T)) + 1023) & ~(size_t) 1023; // + the zero slot
     ensure_lds<csr_vector_tile_kernel<T, L, DEPTH, PRE>>(d, lds);
     csr_vector_tile_kernel<T, L, DEPTH, PRE><<<d->vt_tiles, kVecTileThreads, lds, d->stream>>>(d->m, long_thr, d->rowptr, d->colidx, d->vt_col, (const T *) d->val,
-                                                                                           d->vt_wins, d->vt_rowslot, d->vt_col8, x, y);
+                                                                                           d->vt_wins, d->vt_rowslot, d->vt_col8, d->vt_tmpl, d->vt_rowtid, x, y);
 }
 
 template <typename T, int L>
@@ -59,12 +59,12 @@ static void launch_rows(spmv_dev *d, const T *x, T *y, const int *split)
     if (d->vt_wide) {
         ensure_lds<csr_vector_rows_kernel<T, L, DEPTH, true>>(d, lds);
         csr_vector_rows_kernel<T, L, DEPTH, true><<<d->vt_tiles, kVecTileThreads, lds, d->stream>>>(
-            d->long_thr, split, d->vt_rows, d->m, d->rowptr, d->colidx, d->vt_col, (const T *) d->val, d->vt_wins, d->vt_rowslot, d->vt_col8, x, y);
+            d->long_thr, split, d->vt_rows, d->m, d->rowptr, d->colidx, d->vt_col, (const T *) d->val, d->vt_wins, d->vt_rowslot, d->vt_col8, d->vt_tmpl, d->vt_rowtid, x, y);
         return;
     }
     ensure_lds<csr_vector_rows_kernel<T, L, DEPTH, false>>(d, lds);
     csr_vector_rows_kernel<T, L, DEPTH><<<d->vt_tiles, kVecTileThreads, lds, d->stream>>>(
-        d->long_thr, split, d->vt_rows, d->m, d->rowptr, d->colidx, d->vt_col, (const T *) d->val, d->vt_wins, d->vt_rowslot, d->vt_col8, x, y);
+        d->long_thr, split, d->vt_rows, d->m, d->rowptr, d->colidx, d->vt_col, (const T *) d->val, d->vt_wins, d->vt_rowslot, d->vt_col8, d->vt_tmpl, d->vt_rowtid, x, y);
 }
 
 template <typename T>

@@ -212,6 +212,9 @@ struct spmv_dev {
     int vt_run_tiles = 0, vt_run_nnz = 0, vt_run_rows = 0;
     unsigned char *vt_col8 = nullptr;     // BYTE tiles (every row's slots within 255 of its smallest): one byte per entry, read INSTEAD of vt_col; vt_rowslot holds the smallest slot
     int vt_byte_tiles = 0, vt_byte_nnz = 0, vt_byte_rows = 0;
+    unsigned short *vt_tmpl = nullptr;    // TEMPLATE tiles (rows share a few lists of slot offsets from their first entry): kTmplCount lists of kTmplMax offsets per tile, read INSTEAD of any column stream
+    unsigned char *vt_rowtid = nullptr;   // ... and the list number of every row
+    int vt_tmpl_tiles = 0, vt_tmpl_nnz = 0, vt_tmpl_rows = 0;
     TileWindows *vt_wins = nullptr; // x windows of every tile
     // long rows (csr-vector, sell)
     int nlong = 0, long_thr = INT_MAX;
@@ -292,6 +295,7 @@ static void reset_tile_fields(spmv_dev *d)
     d->vt_col = nullptr; d->vt_wins = nullptr; d->vt_tiles = d->vt_staged = d->vt_maxspan = 0; d->vt_wide = false; d->vt_rows = 256;
     d->vt_rowslot = nullptr; d->vt_run_tiles = d->vt_run_nnz = d->vt_run_rows = 0;
     d->vt_col8 = nullptr; d->vt_byte_tiles = d->vt_byte_nnz = d->vt_byte_rows = 0;
+    d->vt_tmpl = nullptr; d->vt_rowtid = nullptr; d->vt_tmpl_tiles = d->vt_tmpl_nnz = d->vt_tmpl_rows = 0;
     d->c5 = Csr5Plan();
     d->c5_long = Csr5Plan();
     d->ns = Csr5Plan();

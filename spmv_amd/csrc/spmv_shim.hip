@@ -659,6 +659,7 @@ extern "C" int spmv_shim_info(const spmv_dev *d, spmv_hip_info *o)
         const bool tiles_run = !d->blk_on && ((d->plan.sched == SPMV_SCHED_CSR_VECTOR && d->vt_tiles > 0 && (d->vt_wide || d->vt_staged * 2 >= d->vt_tiles) && d->vec_choice != VEC_PIPE) || d->plan.sched == SPMV_SCHED_ROWBLOCK);
         o->run_nnz = tiles_run ? d->vt_run_nnz : 0;
         o->byte_nnz = tiles_run ? d->vt_byte_nnz : 0;
+        o->tmpl_nnz = tiles_run ? d->vt_tmpl_nnz : 0;
         if (!d->blk_on && d->plan.sched == SPMV_SCHED_SELL && d->sell_staged > 0) o->run_nnz = d->sell_run_nnz;
         if (!d->blk_on && d->plan.sched == SPMV_SCHED_CSR5) o->run_nnz = d->c5.run_tiles * kWave * d->c5.sigma;
     }

@@ -387,9 +387,16 @@ def test_multi_window_x_tiles_on_stencil_structure(method, dtype):
     y = np.full(m, np.nan, dtype=dtype)
     with api.Handle(m, m, csr.rowptr, csr.colidx, csr.val, method) as h:
         h.spmv(x, y)
-        name = h.info()["kernel_name"]
-    assert np.array_equal(y, want)
-    assert name in ("csr_vector_tile_kernel", "csr_vector_rows_kernel")
+        info = h.info()
+        name = info["kernel_name"]
+        assert np.array_equal(y, want)
+        assert name in ("csr_vector_tile_kernel", "csr_vector_rows_kernel")
+        if method == M.Method_Parallel:
+            # round 4: every interior row has the same 27 slot offsets from its first entry -> TEMPLATE tiles (no column stream at all); only the
+            # tiles in which the periodic grid wraps keep a stream
+            assert info["tmpl_nnz"] >= 0.9 * csr.nnz, (info["tmpl_nnz"], csr.nnz)
+        h.update_values(csr.val * 2)
+        assert np.array_equal(h.spmv(x, np.full(m, np.nan, dtype=dtype)), 2 * want)
 
 
 def test_create_destroy_cycles_return_all_device_memory():
@@ -1120,6 +1127,91 @@ def test_run_tiles_need_no_column_stream(shape, dtype, method):
             assert info["run_nnz"] == nnz, (info["run_nnz"], nnz, info["x_groups"], info["x_groups_staged"])
         va2 = (va * 2).contiguous()                       # values only: the row slots stay
         h.update_values(va2)
+        h.spmv(x, y)
+        torch.cuda.synchronize()
+        assert torch.equal(y, 2 * want)
+
+
+@pytest.mark.parametrize("method", [M.Method_Parallel, M.Method_Balanced], ids=lambda m: m.name)
+@pytest.mark.parametrize("dtype", ["f64", "f32"])
+@pytest.mark.parametrize("shape", ["stencil5", "pattern40", "pattern64", "pattern65", "one_odd_row", "nine_lists", "empty_rows", "far_bands"])
+def test_template_tiles_need_no_column_stream(shape, dtype, method):
+    """TEMPLATE tiles (round 4, csr_vector_tile.hpp): a staged tile whose rows use at most 8 different lists of slot offsets from their first entry --
+    stencils (interior rows + the few edge patterns), rows assembled from a few element patterns -- reads 16 + 8 bits per ROW and the lists once per
+    TILE, no column stream (RUN tiles are the one list 0, 1, 2, ...).  Exact data: bit-equal to the definition; info.tmpl_nnz counts the entries.
+      stencil5     2-D 5-point stencil on a 600 x 500 grid, NOT periodic: rows at the grid's edges have 3 or 4 entries -- more lists, still template tiles
+      nine_lists   rows cycle through nine different lists: one too many -> BYTE / 16-bit tiles
+      pattern40    every row: the same 40 offsets within +-300 of the diagonal (two 4L chunks per row at 8 lanes per row)
+      pattern64    64 offsets: the largest template            pattern65   65 offsets: one too many -> BYTE / 16-bit tiles
+      one_odd_row  pattern40 with one entry of every 5000th row moved: a second list in those tiles
+      empty_rows   pattern40 with every 7th row empty: empty rows read nothing and do not break the template
+      far_bands    12 offsets in three bands 150 000 columns apart: three x windows per tile, one template"""
+    import torch
+    dev = torch.device("cuda:0")
+    tdt = torch.float64 if dtype == "f64" else torch.float32
+    g = torch.Generator(device=dev); g.manual_seed(31)
+    if shape == "stencil5":
+        nx, ny = 600, 500
+        m = n = nx * ny
+        rows = torch.arange(m, device=dev)
+        ix, iy = rows % nx, rows // nx
+        cand = torch.stack([rows - nx, rows - 1, rows, rows + 1, rows + nx], 1)
+        ok = torch.stack([iy > 0, ix > 0, torch.ones_like(ix, dtype=torch.bool), ix < nx - 1, iy < ny - 1], 1)
+        lens = ok.sum(1)
+        ci = cand[ok].to(torch.int32)
+    else:
+        m = n = 600_000 if shape == "far_bands" else 300_000
+        rows = torch.arange(m, device=dev)
+        k = {"pattern40": 40, "pattern64": 64, "pattern65": 65, "one_odd_row": 40, "nine_lists": 20, "empty_rows": 40, "far_bands": 12}[shape]
+        if shape == "far_bands":
+            offs = torch.tensor([-150_001, -150_000, -149_998, -149_990, -3, -1, 0, 2, 149_990, 150_000, 150_003, 150_007], device=dev)
+        else:
+            offs = torch.sort(torch.randperm(601, generator=g, device=dev)[:k] - 300).values
+        lo, hi = int(-offs.min()), int(n - 1 - offs.max()) - 9
+        base = rows.clamp(lo, hi)               # the first and last rows repeat a neighbour's columns: still the same offsets
+        cand = base[:, None] + offs[None, :]
+        if shape == "nine_lists":           # the last column of the list moves with the row number modulo 9
+            cand[:, -1] = cand[:, -1] + rows % 9
+        lens = torch.full((m,), k, device=dev)
+        if shape == "empty_rows":
+            lens[rows % 7 == 3] = 0
+        keep = torch.arange(k, device=dev)[None, :] < lens[:, None]
+        ci = cand[keep].to(torch.int32)
+    rp = torch.zeros(m + 1, dtype=torch.int64, device=dev)
+    torch.cumsum(lens, 0, out=rp[1:])
+    nnz = int(rp[-1])
+    odd = 0
+    if shape == "one_odd_row":
+        pick = torch.nonzero(rows % 5000 == 11).flatten()
+        pos = rp[pick] + 5
+        ci[pos] = ci[pos] + 1 if False else ci[pos - 1]            # a duplicate of the previous column: legal CSR, another offset list
+        odd = int(pick.numel())
+    va = (torch.randint(-8, 9, (nnz,), generator=g, device=dev) * 0.125).to(tdt)
+    x = (torch.randint(-8, 9, (n,), generator=g, device=dev) * 0.125).to(tdt)
+    rp32 = rp.to(torch.int32)
+    want = _segment_sums(va.double() * x.double()[ci.long()], rp32).to(tdt)
+    y = torch.full((m,), float("nan"), dtype=tdt, device=dev)
+    api.set_thread_option("lanes_per_row", 8)
+    try:
+        h = api.Handle(m, n, rp32, ci, va, method)
+    finally:
+        api.clear_thread_options()
+    with h:
+        h.spmv(x, y)
+        info = h.info()
+        torch.cuda.synchronize()
+        assert torch.equal(y, want), (info["kernel_name"], int((y != want).sum()))
+        assert info["kernel_name"] in ("csr_vector_tile_kernel", "csr_vector_rows_kernel") and info["cache_blocked"] == 0, info
+        t = info["tmpl_nnz"]
+        if shape == "pattern65":
+            assert t == 0 and info["byte_nnz"] + info["run_nnz"] <= nnz, info
+        elif shape == "nine_lists":
+            assert t == 0, info
+        elif shape == "far_bands" and dtype == "f64" and method == M.Method_Balanced:
+            assert t <= nnz                                             # block spans decide what stages: exactness is the test
+        else:
+            assert t >= 0.99 * nnz, (t, nnz, info["x_groups"], info["x_groups_staged"])
+        h.update_values((va * 2).contiguous())
         h.spmv(x, y)
         torch.cuda.synchronize()
         assert torch.equal(y, 2 * want)

@@ -94,7 +94,7 @@ def main():
            "x_bytes": info["x_bytes"], "ms_min": round(float(ms.min()), 5), "ms_mean": round(float(mean), 5),
            "create_s": round(create_s, 3), "inspect_ms": round(info["inspect_ms"], 2), "options": a.opt,
            "launch_kernels": info["launch_kernels"], "blk_waves": info["blk_waves"], "reproducible": info["reproducible"], "run_nnz": info["run_nnz"],
-           "byte_nnz": info["byte_nnz"], "csrc_sha": csrc_sha(),
+           "byte_nnz": info["byte_nnz"], "tmpl_nnz": info["tmpl_nnz"], "csrc_sha": csrc_sha(),
            "gflops": round(2 * info["nnz"] / float(ms.min()) / 1e6, 1),
            "moved_gbps": round(info["stream_bytes"] / float(ms.min()) / 1e6, 1), "frac_moved": round(info["stream_bytes"] / float(ms.min()) / 1e6 / 8000, 4),
            "alg_gbps": round(info["alg_bytes"] / float(ms.min()) / 1e6, 1), "frac_alg": round(info["alg_bytes"] / float(ms.min()) / 1e6 / 8000, 4)}
