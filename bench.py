@@ -254,7 +254,7 @@ def kernel_shares(names, parts):
 
 
 def extra_configs(args, dev):
-    """BASELINE configs 2-ii, 2 with holes, 3 (both stand-ins) and 4 under their named schedules, on this run's clock (the reference's harness
+    """BASELINE configs 2-ii, 2 with holes, a 27-point stencil, 3 (both stand-ins) and 4 under their named schedules, on this run's clock (the reference's harness
     times every method on the matrix it is given, test_spmv.c:103-127, 238-244).  Sizes scale with --rows / 1e7 so that a small
     --rows run stays small.  Per config: >= --config-iters launches timed one by one with HIP events on the launch stream
     (spmv_hip_time_launches), min and mean; the three fractions of roofline_fields; every kernel of one multiply; parity against the fp64 torch
@@ -274,6 +274,10 @@ def extra_configs(args, dev):
         m = max(1024, int(10_000_000 * scale))
         return synth.banded_holes_device(m, m, 32, 0.25, "uniform", f64, dev, 1)
 
+    def cfg_s27():
+        nx = max(16, int(round(215 * scale ** (1.0 / 3.0))))
+        return synth.stencil27_device(nx, "uniform", f64, dev, 1)
+
     def cfg_3o():
         m = max(1024, int(3_070_000 * scale))
         lens = synth.powerlaw_lengths_device(m, 76, min(33000, m), 1.5, dev, 1)
@@ -292,6 +296,8 @@ def extra_configs(args, dev):
     table = [
         ("2-ii", "config 2 variant (ii): uniformly random columns, 32 nnz/row, fp64", M.Method_Parallel, cfg_2ii),
         ("2-holes", "config 2 with holes: 32 of the 43 columns of a band per row (mean run length 4: no row is one run of consecutive columns), fp64", M.Method_Parallel, cfg_2h),
+        ("stencil27", "27-point stencil on a periodic 215^3 grid (9.9e6 rows, 2.7e8 nnz: nine runs of three per row in three far-apart bands), fp64 -- the other "
+                      "regular shape beside config 2: rows are not runs, but every row uses the same slot offsets (TEMPLATE tiles)", M.Method_Parallel, cfg_s27),
         ("3-orkut-style", "config 3 stand-in com-Orkut-style: power-law rows (mean 76, max 33 k), R-MAT columns, fp64", M.Method_Balanced2, cfg_3o),
         ("3-webbase-style", "config 3 stand-in webbase-1M-style: power-law rows (mean 3.1, max 4.7 k), R-MAT columns, fp64", M.Method_Balanced2, cfg_3w),
         ("4", "config 4: skewed rows (90 % 8-24, 9 % 64-256, 1 % 1 k-4 k), columns within +-4096, fp32, SELL C=64 sigma=1024", M.Method_SellCSigma, cfg_4),

@@ -36,7 +36,7 @@ def test_bench_line_has_the_contract_keys_and_sane_values():
     assert rf["read_calibration"] is None or rf["read_calibration"].get("read_gbps", 1) > 0
     cb = d["cpu_baseline"]
     assert cb["parity_ok"] is True and cb["kind"] in ("reference", "port") and cb["cores"] >= 1 and cb["value"] > 0
-    assert set(d["configs"]) == {"2-ii", "2-holes", "3-orkut-style", "3-webbase-style", "4"}
+    assert set(d["configs"]) == {"2-ii", "2-holes", "stencil27", "3-orkut-style", "3-webbase-style", "4"}
     for name, c in d["configs"].items():
         assert c["parity_ok"] is True and c["rows_unwritten"] == 0, (name, c)
         assert c["ms_min"] > 0 and c["ms_min"] <= c["ms_mean"] and c["frac"] > 0 and c["launches"] == 3, (name, c)

@@ -24,9 +24,11 @@ import run_config as rc  # noqa: E402
 
 M = api.SPMV_METHODS
 tag = sys.argv[1] if len(sys.argv) > 1 else "r02"
-wanted = sys.argv[2:] or ["2", "2r", "3w", "3w-uniform", "3w-web", "3o", "3o-uniform", "4", "5shard"]
+wanted = sys.argv[2:] or ["2", "2h", "s27", "2r", "3w", "3w-uniform", "3w-web", "3o", "3o-uniform", "4", "5shard"]
 METHODS = {
     "2": [M.Method_Parallel, M.Method_Balanced, M.Method_Balanced_Yid, M.Method_SellCSigma, M.Method_CSR5SPMV],
+    "2h": [M.Method_Parallel, M.Method_Balanced, M.Method_Balanced_Yid, M.Method_SellCSigma, M.Method_CSR5SPMV],
+    "s27": [M.Method_Parallel, M.Method_Balanced, M.Method_Balanced_Yid, M.Method_SellCSigma, M.Method_CSR5SPMV],
     "2r": [M.Method_Parallel, M.Method_Balanced2, M.Method_CSR5SPMV, M.Method_SellCSigma],
     "3w": [M.Method_Balanced2, M.Method_CSR5SPMV, M.Method_Parallel, M.Method_SellCSigma],
     "3w-uniform": [M.Method_Balanced2, M.Method_CSR5SPMV, M.Method_Parallel],
@@ -48,7 +50,11 @@ for cfg in wanted:
     x = torch.rand(n, dtype=va.dtype, device=dev) * 2 - 1
     y = torch.empty(m, dtype=va.dtype, device=dev)
     rows = []
-    for meth in METHODS[cfg]:
+    runs = [(meth, 1) for meth in METHODS[cfg]]
+    if cfg in ("2r", "3o", "3o-uniform"):   # the blocked executor with reproducibility waived (wide form, arrival order)
+        runs.append((METHODS[cfg][0], 0))
+    for meth, det in runs:
+        api.set_option("deterministic", det)
         t0 = time.time()
         h = api.Handle(m, n, rp, ci, va, meth)
         create_s = time.time() - t0
@@ -57,7 +63,10 @@ for cfg in wanted:
         used = h.method.name
         h.close()
         t = float(ms.min()) / 1e3
-        rows.append({"method": M(meth).name, "method_used": used, "schedule": info["schedule_name"], "kernel": info["kernel_name"],
+        api.set_option("deterministic", 1)
+        rows.append({"method": M(meth).name, "deterministic": det, "blk_waves": info["blk_waves"], "reproducible": info["reproducible"],
+                     "launch_kernels": info["launch_kernels"], "run_nnz": info["run_nnz"], "tmpl_nnz": info["tmpl_nnz"], "byte_nnz": info["byte_nnz"],
+                     "device_bytes": info["device_bytes"], "method_used": used, "schedule": info["schedule_name"], "kernel": info["kernel_name"],
                      "cache_blocked": info["cache_blocked"], "ms_min": round(t * 1e3, 4), "ms_mean": round(float(mean), 4),
                      "gflops": round(2 * info["nnz"] / t / 1e9, 1),
                      "stream_bytes": info["stream_bytes"], "alg_bytes": info["alg_bytes"],

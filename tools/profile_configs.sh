@@ -7,7 +7,7 @@
 #   usage: tools/profile_configs.sh r02 "2 2r 3w 3o 4"      (NOBENCH=1: configs only; KEEP=1: add to an existing output directory)
 set -u
 TAG=${1:-r02}
-CONFIGS=${2:-"2 2r 3w 3o 3o-uniform 4"}
+CONFIGS=${2:-"2 2h s27 2r 3w 3o 3o-uniform 4"}
 REPO=$PWD
 OUT=$REPO/gpurun_out/prof_$TAG
 [ -n "${KEEP:-}" ] || rm -rf "$OUT"   # KEEP=1: second call of a split run
@@ -24,8 +24,8 @@ done
 if [ -z "${NOBENCH:-}" ]; then
 echo "== bench.py"; date +%T
 timeout -k 10 280 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/bench/stats" -- python3 "$REPO/bench.py" --steps 30 --warmup 5 --no-cpu > "$OUT/bench.stats.log" 2>&1 || echo "bench stats pass failed"
-if [ -x "$REPO/build/gbench" ]; then   # hipcc -O3 --offload-arch=gfx950 tools/gbench.hip -o build/gbench
-  timeout -k 10 280 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d "$OUT/calib/fetch" -- "$REPO/build/gbench" calib > "$OUT/calib.log" 2>&1 || echo "calib pass failed"
+if [ -x "$REPO/spmv_amd/bin/gbench" ]; then   # built by spmv_amd/build.py from tools/gbench.hip
+  timeout -k 10 280 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d "$OUT/calib/fetch" -- "$REPO/spmv_amd/bin/gbench" calib > "$OUT/calib.log" 2>&1 || echo "calib pass failed"
 fi
 fi
 cd "$REPO"
