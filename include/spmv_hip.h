@@ -76,7 +76,9 @@ int spmv_hip_update_values(spmv_Handle_t handle, const void *Matrix_Val);
  *       "run_tiles" (0/1, default 1: RUN / BYTE tiles -- spmv_hip_info.run_nnz, byte_nnz)
  *       "autotune" (0/1, default 1: for matrices above 2^24 nnz create() times the applicable CSR-vector
  *                   kernel forms once on the resident matrix and keeps the fastest, ~10 ms)
- *       "reorder" (0/1, default 0: square matrices are RCM-reordered at create, B = P A P^T is what stays
+ *       "reorder" (0/1/2, default 0; 1: reverse Cuthill-McKee on the device (kernels/rcm.hpp), 2: the host BFS of round 1.  For matrices whose band was lost to
+                  a bad numbering; NOT for power-law matrices: the blocked executor is indifferent to vertex numbers and RCM scatters the hubs (measured
+                  slower, profiles/r04_reorder.txt).  Square matrices are reordered at create, B = P A P^T is what stays
  *                  resident, and handle->index holds the permutation -- the caller gathers
  *                  XX[i] = X[index[i]] and scatters Y[index[i]] = YY[i] exactly as the reference's harness
  *                  does for its OPT_LEVEL 3 path, test_spmv.c:95-101, 130-137)

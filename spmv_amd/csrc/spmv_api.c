@@ -236,7 +236,7 @@ static int state_build_multi(spmv_Handle_t h, spmv_hip_state *st, int m, int n, 
     if (st->multi) { spmv_shim_multi_destroy(st->multi); st->multi = NULL; }
     index_free(h);
     rc = -1;
-    if (st->opts.v[SPMV_OPT_REORDER] == 1 && m == n && m > 1 && RowPtr && ColIdx && Val) {
+    if (st->opts.v[SPMV_OPT_REORDER] >= 1 && m == n && m > 1 && RowPtr && ColIdx && Val) {
         /* Option "reorder" on a multi-GPU handle: P A P^T is what gets cut into equal-nnz row blocks -- the reason a partitioner exists in the
          * reference at all (fewer off-block columns: HyperGraphInterface.cpp:60-147 feeding the NUMA row blocks, numa.c:277-304).  The
          * caller-side protocol is the single-GPU one: XX[i] = X[index[i]], Y[index[i]] = YY[i] (test_spmv.c:95-101, 130-137). */
@@ -371,10 +371,23 @@ static int state_build(spmv_Handle_t h, spmv_hip_state *st, int m, int n, const 
     }
     index_free(h);
     rc = -1;
-    if (st->opts.v[SPMV_OPT_REORDER] == 1 && m == n && m > 1 && RowPtr && ColIdx && Val)
-        rc = upload_reordered(h, st, m, n, RowPtr, ColIdx, Val); /* 0 = uploaded the permuted matrix */
+    if (st->opts.v[SPMV_OPT_REORDER] == 2 && m == n && m > 1 && RowPtr && ColIdx && Val)
+        rc = upload_reordered(h, st, m, n, RowPtr, ColIdx, Val); /* the host BFS of round 1 (reorder/rcm.c), kept for comparison; 0 = uploaded the permuted matrix */
     if (rc != 0) rc = spmv_shim_matrix_create(&st->dev, m, n, RowPtr, ColIdx, Val, (size_t) h->data_size);
     if (rc) { spmv_set_error(rc, "create/upload", spmv_shim_error_text()); return rc; }
+    if (st->opts.v[SPMV_OPT_REORDER] == 1 && m == n && m > 1) {
+        /* reverse Cuthill-McKee ON THE DEVICE over the matrix just uploaded (kernels/rcm.hpp): P A P^T replaces it, handle->index = the
+         * permutation (test_spmv.c:95-101, 130-137: the caller gathers x and scatters y).  A failure leaves the unpermuted matrix resident
+         * and index NULL -- and says so. */
+        int *perm = (int *) malloc(sizeof(int) * (size_t) m);
+        if (perm && spmv_shim_reorder_rcm(st->dev, perm) == SPMV_HIP_OK) {
+            h->index = perm;
+            h->Level_3_opt_used = 1;
+        } else {
+            free(perm);
+            spmv_set_error(SPMV_HIP_E_RUNTIME, "create/reorder", perm ? spmv_shim_error_text() : "malloc(perm)");
+        }
+    }
     rc = spmv_shim_matrix_stats(st->dev, &stats);
     if (rc) { spmv_set_error(rc, "create/stats", spmv_shim_error_text()); return rc; }
     spmv_plan_choose(st->requested, &stats, (size_t) h->data_size, &st->opts, &st->plan, &actual, 1);

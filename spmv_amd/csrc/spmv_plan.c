@@ -61,7 +61,8 @@ static opt_t g_opts[SPMV_N_OPTS] = {
     [SPMV_OPT_AUTO_METHOD] = {"auto_method", 0, 0, 2, 0, 0},          /* 1: create() picks the schedule from the matrix by rules (two stages, spmv_api.c);
                                                                        * 2: ... by building the candidate schedules and timing them */
     [SPMV_OPT_AUTOTUNE] = {"autotune", 1, 0, 1, 0, 0},                /* 1: create() times the CSR-vector kernel forms on matrices >= 2^24 nnz */
-    [SPMV_OPT_REORDER] = {"reorder", 0, 0, 1, 0, 0},                  /* 1: square matrices are RCM-reordered at create; handle->index = permutation */
+    [SPMV_OPT_REORDER] = {"reorder", 0, 0, 2, 0, 0},                  /* 1: square matrices are RCM-reordered at create, on the device (kernels/rcm.hpp); handle->index = permutation;
+                                                                       * 2: the host BFS of round 1 (reorder/rcm.c; also what multi-GPU handles use) */
     [SPMV_OPT_HOST_ROWS] = {"host_rows", 0, 0, 1, 0, 0},              /* 1: VECTOR_NONE + Method_Serial / Method_Parallel run the plain-C row loop on
                                                                        * the host (host_rows.c; BASELINE config 1).  Never chosen by itself. */
     [SPMV_OPT_CHECK_VALUES] = {"check_values", 2, 0, 2, 0, 0},        /* spmv() watches Matrix_Val for changes IN PLACE behind an unchanged pointer (the reference re-reads it on

@@ -90,6 +90,10 @@ int spmv_shim_checksum(spmv_dev *d, const void *val, unsigned long long *out);
 /* the same sum over `words` 32-bit words at `val` (host or device) without a matrix: multi-GPU handles */
 int spmv_shim_checksum_words(const void *val, long long words, unsigned long long *out);
 
+/* Reverse Cuthill-McKee of the resident (square) matrix on the device; P A P^T replaces it, perm (m ints, host) receives the permutation
+ * (row i of the new matrix = row perm[i] of the old).  Before spmv_shim_build. */
+int spmv_shim_reorder_rcm(spmv_dev *d, int *perm_host);
+
 /* ---- A = A_near + A_far (shim/split.hpp): a matrix with locality in part of its entries ---- */
 int spmv_shim_split_candidate(spmv_dev *d);                                   /* 1: worth building and timing */
 int spmv_shim_split(spmv_dev *d, spmv_dev **near_out, spmv_dev **far_out);    /* the two halves, unplanned; far multiplies accumulating */

@@ -31,6 +31,7 @@
 #include "kernels/long_rows.hpp"
 #include "kernels/blocked.hpp"
 #include "kernels/split.hpp"
+#include "kernels/rcm.hpp"
 #include "kernels/csr_vector_tile.hpp"
 
 using namespace spmv;
@@ -706,4 +707,5 @@ extern "C" int spmv_shim_debug_blk_times(unsigned long long *out)
 }
 #endif
 
+#include "shim/reorder.hpp"
 #include "shim/multi.hpp"

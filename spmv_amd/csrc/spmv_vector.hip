@@ -17,6 +17,8 @@
 #include "kernels/xwindows.hpp"
 #include "kernels/csr5.hpp"
 #include "kernels/blocked.hpp"
+#include "kernels/split.hpp"
+#include "kernels/rcm.hpp"
 #include "kernels/csr_vector_tile.hpp"
 
 using namespace spmv;

@@ -351,6 +351,113 @@ def test_reorder_option_follows_the_reference_index_protocol():
         assert h.info()["kernel_name"] == "csr_vector_pipe_kernel"               # scrambled: spans too wide
 
 
+def _scrambled(csr, rng):
+    """rows and columns of a square CSR under one random symmetric permutation (row r of the result = row sc[r] of csr)"""
+    m = csr.m
+    sc = rng.permutation(m)
+    inv = np.empty(m, dtype=np.int64); inv[sc] = np.arange(m)
+    lens = np.diff(csr.rowptr)[sc]
+    rp = np.zeros(m + 1, dtype=np.int32); np.cumsum(lens, out=rp[1:])
+    starts = csr.rowptr[:-1][sc].astype(np.int64)
+    src = np.repeat(starts - rp[:-1], lens) + np.arange(int(rp[-1]))
+    return synth.CSR(m, m, rp, inv[csr.colidx[src]].astype(np.int32), csr.val[src])
+
+
+@pytest.mark.parametrize("shape", ["band", "nonsymmetric", "components", "powerlaw"])
+def test_device_rcm_orders_like_a_bfs_and_is_reproducible(shape):
+    """Round 4 (kernels/rcm.hpp): option reorder = 1 runs reverse Cuthill-McKee on the DEVICE -- A^T's pattern, a queue BFS whose small frontiers are
+    walked level after level by one persistent workgroup, a (level, degree, id) sort, the permuted matrix in place of the uploaded one.  Checked:
+    the product through the handle->index protocol is exact; the permutation is a permutation and the same from handle to handle; the
+    bandwidth of P A P^T is what a BFS ordering gives (band: within 4 x the band's; host RCM, reorder = 2, is the yardstick).
+      band          a scrambled band (half-width 6): ~3000 BFS levels, all of them inside one launch of the small-frontier kernel
+      nonsymmetric  the band with its lower triangle only: A alone cannot be walked backwards -- the BFS pushes along A^T as well
+      components    three scrambled bands side by side + 500 isolated rows/columns + empty rows: component after component, isolated ones at once
+      powerlaw      heavy-tailed rows with R-MAT columns: frontiers of 1e4-1e5 vertices, expanded by the whole grid"""
+    rng = np.random.default_rng(8)
+    if shape in ("band", "nonsymmetric"):
+        base = synth.banded(40_000, 40_000, 6, 6, "eighths", np.float64, seed=3)
+        if shape == "nonsymmetric":
+            keep = base.colidx <= np.repeat(np.arange(base.m), np.diff(base.rowptr))
+            rp = np.zeros(base.m + 1, dtype=np.int32); np.cumsum(np.add.reduceat(keep.astype(np.int32), base.rowptr[:-1]), out=rp[1:])
+            base = synth.CSR(base.m, base.n, rp, base.colidx[keep], base.val[keep])
+        A = _scrambled(base, rng)
+    elif shape == "components":
+        b = synth.banded(9_000, 9_000, 4, 4, "eighths", np.float64, seed=4)
+        m = 3 * b.m + 500
+        rp = np.concatenate([b.rowptr[:-1], b.rowptr[:-1] + b.nnz, b.rowptr[:-1] + 2 * b.nnz, np.full(501, 3 * b.nnz)]).astype(np.int32)
+        ci = np.concatenate([b.colidx, b.colidx + b.m, b.colidx + 2 * b.m]).astype(np.int32)
+        A = _scrambled(synth.CSR(m, m, rp, ci, np.tile(b.val, 3)), rng)
+    else:
+        A = synth.powerlaw(60_000, 60_000, 6.0, 3000, 1.5, "eighths", np.float64, seed=5)
+    m = A.m
+    x = synth.fill_x(m, "eighths", np.float64, 6)
+    want = oracle.spmv_serial(A, x)
+
+    def bandwidth(index):
+        inv = np.empty(m, dtype=np.int64); inv[index] = np.arange(m)
+        rows = inv[np.repeat(np.arange(m), np.diff(A.rowptr))]
+        return int(np.abs(inv[A.colidx] - rows).max()) if A.nnz else 0
+    got = {}
+    for mode in (1, 1, 2):
+        api.set_thread_option("reorder", mode)
+        try:
+            h = api.Handle(m, m, A.rowptr, A.colidx, A.val, M.Method_CSR5SPMV)
+        finally:
+            api.clear_thread_options()
+        with h:
+            index = h.index
+            assert index is not None and h.h.contents.Level_3_opt_used == 1
+            assert np.array_equal(np.sort(index), np.arange(m)), mode
+            yy = h.spmv(x[index], np.full(m, np.nan))
+            y = np.empty(m); y[index] = yy
+            assert np.array_equal(y, want), (shape, mode)
+            got.setdefault(mode, []).append(index)
+    assert np.array_equal(got[1][0], got[1][1]), "the device ordering differs from handle to handle"
+    bw_dev, bw_host = bandwidth(got[1][0]), bandwidth(got[2][0])
+    if shape in ("band", "nonsymmetric"):
+        assert bw_dev <= 4 * 12 and bw_dev <= 2 * bw_host + 16, (bw_dev, bw_host)
+    elif shape == "components":
+        assert bw_dev <= 4 * 8 + 2, (bw_dev, bw_host)
+
+
+def test_device_rcm_at_size_is_fast(capsys):
+    """2e6 rows x 32 of a band under a random symmetric permutation (62 500 BFS levels): round 1's host RCM added 3.3 s to create(); on the device the
+    whole reordering -- transpose, two BFS sweeps, sort, permute -- is bounded here by 1.5 s, and the multiply gets its banded rate back (x tiles staged)."""
+    import time
+    import torch
+    dev = torch.device("cuda:0")
+    m, k = 2_000_000, 32
+    g = torch.Generator(device=dev); g.manual_seed(5)
+    sc = torch.randperm(m, generator=g, device=dev)
+    inv = torch.empty_like(sc); inv[sc] = torch.arange(m, device=dev)
+    offs = torch.arange(k, device=dev) - k // 2
+    ci = inv[(sc[:, None] + offs[None, :]) % m].reshape(-1).to(torch.int32)
+    rp = torch.arange(0, (m + 1) * k, k, dtype=torch.int32, device=dev)
+    va = (torch.randint(-8, 9, (m * k,), generator=g, device=dev) * 0.125).double()
+    x = (torch.randint(-8, 9, (m,), generator=g, device=dev) * 0.125).double()
+    want = (va * x[ci.long()]).view(m, k).sum(1)
+    api.set_thread_option("reorder", 1)
+    try:
+        with api.Handle(m, m, rp, ci, va, M.Method_Parallel) as h0:     # the first create of a process pays allocator warm-up
+            pass
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        h = api.Handle(m, m, rp, ci, va, M.Method_Parallel)
+        create_s = time.perf_counter() - t0
+    finally:
+        api.clear_thread_options()
+    with h:
+        index = torch.from_numpy(h.index).to(dev).long()
+        info = h.info()
+        yy = torch.full((m,), float("nan"), dtype=torch.float64, device=dev)
+        h.spmv(x[index].contiguous(), yy)
+        y = torch.empty_like(yy); y[index] = yy
+        assert torch.equal(y, want)
+        assert info["kernel_name"] == "csr_vector_tile_kernel" and info["x_groups_staged"] >= 0.99 * info["x_groups"], info
+    print(f"device RCM: create {create_s:.3f} s at {m} rows x {k}")
+    assert create_s <= 1.5, create_s
+
+
 def test_out_of_range_column_index_is_rejected_at_create(monkeypatch):
     """An index outside [0, n) makes the reference read out of bounds; on a GPU it would fault, so
     create() validates ColIdx and reports SPMV_HIP_E_ARG instead."""

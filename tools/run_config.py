@@ -28,6 +28,7 @@ CONFIGS = {
     "3w-web": ("config 3 stand-in webbase-1M-style, web-like columns (90 % within +-2000 of the row, 10 % R-MAT hubs), fp64", M.Method_Balanced2),
     "3o": ("config 3 stand-in com-Orkut-style: 3.07e6 rows, ~2.3e8 nnz, R-MAT columns, fp64", M.Method_Balanced2),
     "3o-uniform": ("config 3 stand-in com-Orkut-style, uniform columns, fp64", M.Method_Balanced2),
+    "3o-scrambled": ("config 3 stand-in com-Orkut-style (R-MAT) with its vertices renumbered at random: hubs scattered over the index range, fp64", M.Method_Balanced2),
     "4": ("config 4: 1e7 rows skewed nnz, fp32, columns within +-4096", M.Method_SellCSigma),
     "5shard": ("config 5 shard: 1e7 of 8e7 rows, global columns, fp64", M.Method_Parallel),
 }
@@ -49,6 +50,20 @@ def make(config, dev):
     if config in ("3o", "3o-uniform"):
         lens = synth.powerlaw_lengths_device(3_070_000, 76, 33000, 1.5, dev, 1)
         return synth.from_row_lengths_device(lens, 3_070_000, "uniform", f64, dev, 1, cols="rmat" if config == "3o" else "uniform")
+    if config == "3o-scrambled":
+        lens = synth.powerlaw_lengths_device(3_070_000, 76, 33000, 1.5, dev, 1)
+        m, n, rp, ci, va = synth.from_row_lengths_device(lens, 3_070_000, "uniform", f64, dev, 1, cols="rmat")
+        g = torch.Generator(device=dev); g.manual_seed(99)
+        sc = torch.randperm(m, generator=g, device=dev)
+        inv = torch.empty_like(sc); inv[sc] = torch.arange(m, device=dev)
+        lens2 = lens[sc]
+        rp2 = torch.zeros(m + 1, dtype=torch.int64, device=dev)
+        torch.cumsum(lens2, 0, out=rp2[1:])
+        src = torch.repeat_interleave(rp.long()[:-1][sc] - rp2[:-1], lens2) + torch.arange(int(rp2[-1]), device=dev)
+        ci2 = inv[ci.long()[src]].to(torch.int32)
+        va2 = va[src]
+        del src, ci, va
+        return m, n, rp2.to(torch.int32), ci2, va2
     if config == "4":
         lens = synth.skewed_lengths_device(10_000_000, dev, 1)
         return synth.from_row_lengths_device(lens, 10_000_000, "uniform", torch.float32, dev, 1, local=4096)
