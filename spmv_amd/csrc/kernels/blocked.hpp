@@ -512,6 +512,9 @@ __global__ __launch_bounds__(kWave * W) void blk_wide_kernel(const int *__restri
     const int tid = threadIdx.x, lane = tid & (kWave - 1);
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int blk = order[blockIdx.x];
+#ifdef SPMV_BLK_DEBUG_FORMS
+    const unsigned long long dbg_t0 = __builtin_amdgcn_s_memrealtime();
+#endif
     const BlkDir d = dir[blk];
     if (accumulate && d.ns == 0) return;
     for (int i = tid; i <= R; i += NT) ys[i] = 0.0;
@@ -575,6 +578,17 @@ __global__ __launch_bounds__(kWave * W) void blk_wide_kernel(const int *__restri
     const int nr = row0[blk + 1] - (int) r0;
     if (accumulate) for (int i = tid; i < nr; i += NT) y[r0 + i] += (T) ys[i];
     else for (int i = tid; i < nr; i += NT) y[r0 + i] = (T) ys[i];
+#ifdef SPMV_BLK_DEBUG_FORMS
+    if (tid == 0 && blockIdx.x < 8192) {
+        unsigned xcc, hw;
+        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hw));
+        blk_dbg_times[4 * blockIdx.x] = dbg_t0;
+        blk_dbg_times[4 * blockIdx.x + 1] = __builtin_amdgcn_s_memrealtime();
+        blk_dbg_times[4 * blockIdx.x + 2] = (xcc & 0xf) | ((unsigned long long) hw << 8);
+        blk_dbg_times[4 * blockIdx.x + 3] = (unsigned long long) blk | ((unsigned long long) d.ns << 32);
+    }
+#endif
 }
 
 } // namespace spmv

@@ -37,7 +37,7 @@ for cdir in sorted(glob.glob(os.path.join(out, "*/"))):
             acc[k.split("(")[0][:60]][row["Counter_Name"]].append(float(row["Counter_Value"]))
     print("==", os.path.basename(cdir.rstrip("/")))
     for k, cs in acc.items():
-        if not any("blk_kernel" in k or "nat" in k or "sell" in k or "csr" in k for _ in [0]): continue
+        if not any("blk_" in k or "nat" in k or "sell" in k or "csr" in k for _ in [0]): continue
         print(" ", k)
         for c, v in sorted(cs.items()):
             v = v[len(v) // 2:]   # later dispatches: the timed launches
