@@ -207,7 +207,7 @@ def roofline_fields(info, ms, dtype, nnz=None, alg_bytes=None):
     alg = int(alg_bytes if alg_bytes is not None else info["alg_bytes"])
     moved = int(info["stream_bytes"])
     sec = float(ms) * 1e-3
-    traffic, src, parts = traffic_from_profiles(info["kernel_name"], info["m"], info["nnz"], dtype)
+    traffic, src, parts = traffic_from_profiles(info["kernel_name"], info["m"], info["nnz"], dtype, moved)
     frac_alg = alg / sec / 1e9 / HBM_PEAK_GBPS
     frac_model = moved / sec / 1e9 / HBM_PEAK_GBPS
     frac_counter = (traffic / sec / 1e9 / HBM_PEAK_GBPS) if traffic else None
@@ -526,7 +526,7 @@ def run_c_leg(args, world):
 _TRAFFIC = None
 
 
-def traffic_from_profiles(kernel_name, m, nnz, dtype):
+def traffic_from_profiles(kernel_name, m, nnz, dtype, model_bytes):
     """HBM bytes per launch measured by rocprofv3 --pmc (separate FETCH_SIZE / WRITE_SIZE passes, tools/profile_configs.sh ->
     profiles/traffic_rNN.json) for THIS kernel on THIS shape, built from THIS source tree (csrc hash): (bytes, source, per-kernel parts);
     (None, None, None) when no committed entry matches -- a profile of other code says nothing about this run."""
@@ -543,8 +543,9 @@ def traffic_from_profiles(kernel_name, m, nnz, dtype):
                 continue
             if d.get("csrc_sha") == sha:
                 _TRAFFIC += d.get("entries", [])
-    for e in _TRAFFIC:
-        if e.get("kernel_short") == kernel_name and e.get("m") == m and e.get("nnz") == nnz and e.get("dtype") == dtype:
+    for e in _TRAFFIC:   # two matrices of one shape (config 2 and config 2 with holes) differ in what their schedule has to move: the model's byte count is part of the key
+        if (e.get("kernel_short") == kernel_name and e.get("m") == m and e.get("nnz") == nnz and e.get("dtype") == dtype
+                and abs(int(e.get("model_stream_bytes", -1)) - int(model_bytes)) <= 0.005 * int(model_bytes)):
             return e.get("hbm_bytes_per_launch"), e.get("source"), e.get("kernels")
     return None, None, None
 

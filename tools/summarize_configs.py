@@ -131,7 +131,7 @@ for log in sorted(glob.glob(os.path.join(src, "*.stats.log"))):
             "l2_hit_rate_dominant": d["l2_hit_rate"] if d else None}
     if d and tot_bytes > 0:   # what bench.py reads: the whole multiply (every kernel of one spmv(), summed) and its parts
         shas.add(run.get("csrc_sha"))
-        entries.append({"config": cfg, "kernel_short": dom, "m": run["m"], "nnz": run["nnz"], "dtype": run["dtype"],
+        entries.append({"config": cfg, "kernel_short": dom, "m": run["m"], "nnz": run["nnz"], "dtype": run["dtype"], "model_stream_bytes": run["stream_bytes"],
                         "hbm_bytes_per_launch": tot_bytes, "fetch_bytes_raw": d["fetch_bytes_raw"], "write_bytes": d["write_bytes"],
                         "kernels": [{"kernel": kn.split("#")[0], "avg_ms": kv["avg_ns"] * kv["launches_per_multiply"] / 1e6, "hbm_bytes": kv["hbm_bytes_per_launch"] * kv["launches_per_multiply"]}
                                     for kn, kv in kernels.items()],
