@@ -305,7 +305,7 @@ static int build_sell(spmv_dev *d)
         }
         if (d->sell_staged == d->sell_nwin) { sched_free(d, d->scol); d->scol = nullptr; } // no window reads global columns
         else if (d->sell_staged == 0) { sched_free(d, d->scol16); d->scol16 = nullptr; }
-        if (d->sell_staged > 0 && !getenv("SPMV_HIP_NO_RUN_TILES")) { // RUN groups: rows that are runs of consecutive columns need no slot slab (sell.hpp)
+        if (d->sell_staged > 0 && d->plan.run_tiles) { // RUN groups: rows that are runs of consecutive columns need no slot slab (sell.hpp)
             unsigned long long *cnt = nullptr, h[4] = {0, 0, 0, 0};
             ALLOC_TRY(d, &d->sell_run, sizeof(unsigned) * (size_t) d->nchunks * kSellC, true);
             HIP_TRY(pool_malloc((void **) &cnt, sizeof h));

@@ -328,3 +328,83 @@ def test_rounding_at_size_config4_named_schedule(dtype, tol):
     lens = synth.skewed_lengths_device(m, DEV, 1)
     _, _, rp, ci, va = synth.from_row_lengths_device(lens, m, "uniform", dtype, DEV, 1, local=4096)
     _check_rounding(m, m, rp, ci, va, [M.Method_SellCSigma, M.Method_CSR5SPMV, M.Method_Balanced_Yid], tol)
+
+
+def test_round4_column_stream_forms_at_full_size():
+    """BASELINE config 2's partners of round 4 at full size, exact arithmetic, against the torch fp64 definition: the band with 25 % holes (BYTE
+    tiles: a byte of column stream per entry) and the 27-point stencil 215^3 (TEMPLATE tiles: none), under the schedule BASELINE names for config 2
+    and one other; plus linearity of the holes matrix on inexact data (size-independent property)."""
+    m, n, rp, ci, va = synth.banded_holes_device(10_000_000, 10_000_000, 32, 0.25, "eighths", torch.float64, DEV, 3)
+    x = _exact_x(n, 31)
+    want = _definition_regular(m, 32, ci, va, x)
+    for method in (M.Method_Parallel, M.Method_Balanced):
+        y = torch.full((m,), float("nan"), dtype=torch.float64, device=DEV)
+        with api.Handle(m, n, rp, ci, va, method) as h:
+            h.spmv(x, y)
+            info = h.info()
+        torch.cuda.synchronize()
+        assert torch.equal(y, want), method
+        assert info["byte_nnz"] >= 0.999 * info["nnz"] and info["run_nnz"] == 0, info
+    g = torch.Generator(device=DEV); g.manual_seed(5)
+    va2 = torch.rand(m * 32, generator=g, device=DEV, dtype=torch.float64) * 2 - 1
+    xa, xb = (torch.rand(n, generator=g, device=DEV, dtype=torch.float64) * 2 - 1 for _ in range(2))
+    with api.Handle(m, n, rp, ci, va2, M.Method_Parallel) as h:
+        ya, yb, yc = (torch.empty(m, dtype=torch.float64, device=DEV) for _ in range(3))
+        h.spmv(xa, ya); h.spmv(xb, yb); h.spmv((0.5 * xa - 2.0 * xb).contiguous(), yc)
+    torch.cuda.synchronize()
+    assert float((yc - (0.5 * ya - 2.0 * yb)).abs().max()) <= 64 * 2.3e-16 * 32 * 3
+    del rp, ci, va, va2, want
+    torch.cuda.empty_cache()
+    m, n, rp, ci, va = synth.stencil27_device(215, "eighths", torch.float64, DEV, 4)
+    x = _exact_x(n, 32)
+    want = _definition_regular(m, 27, ci, va, x)
+    for method in (M.Method_Parallel, M.Method_SellCSigma):
+        y = torch.full((m,), float("nan"), dtype=torch.float64, device=DEV)
+        with api.Handle(m, n, rp, ci, va, method) as h:
+            h.spmv(x, y)
+            info = h.info()
+        torch.cuda.synchronize()
+        assert torch.equal(y, want), method
+        if method == M.Method_Parallel:
+            assert info["tmpl_nnz"] >= 0.97 * info["nnz"], info      # every tile but those where the periodic grid wraps
+
+
+def test_round4_wide_blocked_forms_at_full_size():
+    """Config 2-ii at full size under the wide forms of the row-block x column-slab executor (one ~19.5 k-row block per CU): exact inputs -> the bits of
+    the definition for two ordered waves (what create() picks by itself), four ordered waves and four waves in arrival order; inexact inputs -> the
+    ordered forms agree bit for bit with each other and from handle to handle, the arrival-order form within the north_star tolerance."""
+    m = n = 10_000_000
+    k = 32
+    _, _, rp, ci, va = synth.uniform_k_device(m, n, k, "eighths", torch.float64, DEV, seed=23)
+    x = _exact_x(n, 33)
+    want = _definition_regular(m, k, ci, va, x)
+    keep = {key: api.get_option(key) for key in ("blk_waves", "deterministic")}
+    try:
+        for waves, det in ((0, 1), (4, 1), (4, 0)):
+            api.set_option("blk_waves", waves); api.set_option("deterministic", det)
+            y = torch.full((m,), float("nan"), dtype=torch.float64, device=DEV)
+            with api.Handle(m, n, rp, ci, va, M.Method_Parallel) as h:
+                h.spmv(x, y)
+                info = h.info()
+            torch.cuda.synchronize()
+            assert info["cache_blocked"] == 1 and info["reproducible"] == det, info
+            if waves:
+                assert info["kernel_name"] == "blk_wide_kernel" and info["blk_waves"] == waves, info
+            assert torch.equal(y, want), (waves, det)
+        _, _, rp, ci, va = synth.uniform_k_device(m, n, k, "uniform", torch.float64, DEV, seed=29)
+        g = torch.Generator(device=DEV); g.manual_seed(6)
+        xr = torch.rand(n, generator=g, device=DEV, dtype=torch.float64) * 2 - 1
+        ref = _definition_regular(m, k, ci, va, xr)
+        ys = {}
+        for waves, det in ((2, 1), (2, 1), (4, 1), (4, 0)):
+            api.set_option("blk_waves", waves); api.set_option("deterministic", det)
+            y = torch.empty(m, dtype=torch.float64, device=DEV)
+            with api.Handle(m, n, rp, ci, va, M.Method_Parallel) as h:
+                h.spmv(xr, y)
+            torch.cuda.synchronize()
+            assert float((y - ref).abs().max()) <= 64 * 2.3e-16 * k
+            ys.setdefault((waves, det), []).append(y)
+        assert torch.equal(ys[(2, 1)][0], ys[(2, 1)][1]) and torch.equal(ys[(2, 1)][0], ys[(4, 1)][0])
+    finally:
+        for key, v in keep.items():
+            api.set_option(key, v)
