@@ -99,6 +99,8 @@ int spmv_hip_update_values(spmv_Handle_t handle, const void *Matrix_Val);
        "blk_waves" (0 automatic / 1 / 2 / 4 / 8: wavefronts sharing ONE row block's LDS accumulators; 0: create() builds the one-wave form and, on large
                     matrices, the wide form that fits option "deterministic", times them and keeps the faster)
        "blk_groups" (groups of 128 fp64 / 256 fp32 entries per pipeline step, 0 = timed at create)   "blk_subsort" (0/1, default 1)
+       "keep_columns" (0/1, default 0: at the end of create() the HBM-resident int32 ColIdx copy is released when the built schedule's multiply never reads it --
+                       every tile / group staged, SELL slabs, CSR5 tiles -- 4 B per non-zero less (spmv_hip_info.device_bytes); 1 keeps it)
        "deterministic" (0/1, default 1: every executor adds a row's products in an order fixed by the matrix, so results are bit-identical run to
                         run; 0 lets the wide blocked form add in arrival order -- 10-16 % faster on matrices without column locality, equal to rounding)
  *       "host_rows" (0/1, default 0: 1 = handles created with VECTOR_NONE and Method_Serial / Method_Parallel run

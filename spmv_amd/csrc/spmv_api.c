@@ -444,6 +444,7 @@ static int state_build(spmv_Handle_t h, spmv_hip_state *st, int m, int n, const 
         actual = best_method;
     }
     try_split(h, st, actual);
+    if (st->opts.v[SPMV_OPT_KEEP_COLUMNS] == 0) (void) spmv_shim_release_columns(st->dev); /* the last build of this create is done */
     if (st->stream_set) spmv_shim_set_stream(st->dev, st->stream);
     spmv_shim_set_async(st->dev, st->async);
     st->m = m;

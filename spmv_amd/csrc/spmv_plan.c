@@ -70,6 +70,8 @@ static opt_t g_opts[SPMV_N_OPTS] = {
                                                                        * every call (host or device array); 2 (default) = HOST arrays only, a SAMPLED checksum -- every 64th word
                                                                        * and both ends: any whole-array update (Newton step, time step) is seen for 1/64 of the read; 0 = never */
     [SPMV_OPT_GPUS] = {"gpus", 0, 0, 64, 0, 0},                       /* > 0: row blocks over min(gpus, visible devices) GPUs in this one process (multi.hpp) */
+    [SPMV_OPT_KEEP_COLUMNS] = {"keep_columns", 0, 0, 1, 0, 0},        /* 0: the resident int32 ColIdx copy is released at the end of create() when the schedule's multiply never reads it
+                                                                       * (every tile / group staged: 4 B per non-zero less); 1: always kept */
     [SPMV_OPT_BLK_WAVES] = {"blk_waves", 0, 0, 8, 1, 0},              /* row-block x column-slab executor: wavefronts that share ONE row block's accumulators: 1 = a wave per block, two blocks
                                                                        * per CU (rounds 2-3); 4 / 8 = one block of up to ~20 k rows per CU (kernels/blocked.hpp "wide form"); 0 = automatic */
     [SPMV_OPT_BLK_GROUPS] = {"blk_groups", 0, 0, 12, 0, 0},           /* ... groups per pipeline step, 0 = create() times the forms of the chosen width and keeps the faster */

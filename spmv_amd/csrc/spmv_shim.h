@@ -82,6 +82,8 @@ int spmv_shim_copy_to_host(void *dst, const void *src, size_t bytes);
 void spmv_shim_trim_pool(void);
 /* 1 if a kernel can use the pointer as is (device or managed memory), else 0 (also without any device) */
 int spmv_shim_is_device_ptr(const void *p);
+/* After the last spmv_shim_build of a create: give the resident ColIdx copy back when the built schedule's multiply never reads it */
+int spmv_shim_release_columns(spmv_dev *d);
 /* New values (host or device, nnz entries in CSR order) behind the same pattern: copied to HBM and
  * re-permuted into the schedule's private value layouts; nothing else is rebuilt. */
 int spmv_shim_update_values(spmv_dev *d, const void *val);

@@ -37,6 +37,7 @@
 using namespace spmv;
 
 #include "shim/state.hpp"
+#include "shim/vector_forms.hpp"
 
 // row statistics of the resident RowPtr (also validates it): d->nnz, d->stats
 static int matrix_row_stats(spmv_dev *d)
@@ -167,9 +168,37 @@ extern "C" void spmv_shim_matrix_destroy(spmv_dev *d)
 
 #include "shim/inspect.hpp"
 
+// The resident int32 ColIdx copy (4 B per non-zero: 1.28 GB on config 2) is read by the inspectors -- and afterwards only by executors that
+// gather through global columns.  Once create() has settled on a schedule whose multiply never touches it (every tile / group staged: the 16-bit
+// slot streams, RUN / BYTE / TEMPLATE data, SELL slabs and CSR5 tiles are copies of their own), it goes back to the pool.  Kept: CSR-scalar, the pipe
+// form, any schedule with unstaged groups, the blocked executor (its values refresh re-derives the cells from the columns), split handles.
+extern "C" int spmv_shim_release_columns(spmv_dev *d)
+{
+    if (!d || !d->built || !d->colidx || d->nnz == 0) return SPMV_HIP_OK;
+    if (d->sp_near || d->sp_far || d->accumulate || d->blk_on) return SPMV_HIP_OK;
+    bool unused = false;
+    switch (d->plan.sched) {
+    case SPMV_SCHED_CSR_VECTOR:
+        unused = d->vt_tiles > 0 && d->vt_staged == d->vt_tiles && d->plan.vector_form != VEC_PIPE && d->vec_choice != VEC_PIPE;
+        break;
+    case SPMV_SCHED_ROWBLOCK: unused = d->vt_tiles > 0 && d->vt_staged == d->vt_tiles; break;
+    case SPMV_SCHED_NNZ_SPLIT: unused = d->ns.groups > 0 && d->ns.staged == d->ns.groups; break; // natural layout: unstaged groups read the matrix's own columns
+    case SPMV_SCHED_SELL:
+    case SPMV_SCHED_CSR5: unused = true; break;                                                    // slabs / transposed tiles are copies
+    default: break;
+    }
+    if (!unused) return SPMV_HIP_OK;
+    quiesce(d);
+    (void) pool_free(d->colidx);
+    d->colidx = nullptr;
+    d->device_bytes -= (long long) (sizeof(int) * ((size_t) d->nnz + kStreamPad));
+    return SPMV_HIP_OK;
+}
+
 extern "C" int spmv_shim_build(spmv_dev *d, const spmv_plan *plan)
 {
     if (!d || !plan) return fail(SPMV_HIP_E_ARG, "build: NULL");
+    if (!d->colidx && d->nnz > 0) return fail(SPMV_HIP_E_NOSTATE, "build: the column indices of this matrix were released after create (option keep_columns = 1 keeps them)");
     if (plan->sched < 0 || plan->sched >= SPMV_SCHED_COUNT) return fail(SPMV_HIP_E_ARG, "unknown schedule %d", plan->sched);
     if (d->sp_near || d->sp_far) { // a rebuild starts from the unsplit matrix
         if (d->sp_near) spmv_shim_matrix_destroy(d->sp_near);

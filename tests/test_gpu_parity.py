@@ -458,6 +458,49 @@ def test_device_rcm_at_size_is_fast(capsys):
     assert create_s <= 1.5, create_s
 
 
+@pytest.mark.parametrize("method", [M.Method_Parallel, M.Method_Balanced, M.Method_Balanced_Yid, M.Method_SellCSigma, M.Method_CSR5SPMV], ids=lambda m: m.name)
+def test_column_indices_are_released_when_the_multiply_never_reads_them(method):
+    """the resident int32 ColIdx copy (4 B per non-zero) goes back to the pool at the end of create() when the built schedule
+    reads only its own slot streams / slabs / tiles (every tile staged) -- spmv_hip_info.device_bytes drops by 4 nnz, the multiply and a values refresh are
+    unaffected; option keep_columns = 1 keeps it; a matrix whose tiles do not stage (global gathers) keeps it whatever the option."""
+    import torch
+    dev = torch.device("cuda:0")
+    m, n, rp, ci, va = synth.banded_holes_device(400_000, 400_000, 24, 0.25, "eighths", torch.float64, dev, 7)
+    g = torch.Generator(device=dev); g.manual_seed(2)
+    x = (torch.randint(-8, 9, (n,), generator=g, device=dev) * 0.125).double()
+    want = (va * x[ci.long()]).view(m, 24).sum(1)
+    held = {}
+    for keep in (1, 0):
+        api.set_thread_option("keep_columns", keep)
+        try:
+            h = api.Handle(m, n, rp, ci, va, method)
+        finally:
+            api.clear_thread_options()
+        with h:
+            held[keep] = h.info()["device_bytes"]
+            y = torch.full((m,), float("nan"), dtype=torch.float64, device=dev)
+            h.spmv(x, y)
+            torch.cuda.synchronize()
+            assert torch.equal(y, want), (method, keep)
+            h.update_values((va * 2).contiguous())
+            h.spmv(x, y)
+            torch.cuda.synchronize()
+            assert torch.equal(y, 2 * want), (method, keep, "update_values")
+    assert held[1] - held[0] >= 4 * m * 24, (method, held)          # the int32 column copy (+ its padding)
+    # no locality: the tile kernels gather through the global columns -> nothing is released
+    _, _, rp2, ci2, va2 = synth.uniform_k_device(60_000, 60_000, 8, "eighths", torch.float64, dev, 9)
+    sizes = []
+    for keep in (1, 0):
+        api.set_thread_option("keep_columns", keep)
+        api.set_thread_option("cache_block", 0)
+        try:
+            with api.Handle(60_000, 60_000, rp2, ci2, va2, M.Method_Parallel) as h:
+                sizes.append(h.info()["device_bytes"])
+        finally:
+            api.clear_thread_options()
+    assert sizes[0] == sizes[1], sizes
+
+
 def test_out_of_range_column_index_is_rejected_at_create(monkeypatch):
     """An index outside [0, n) makes the reference read out of bounds; on a GPU it would fault, so
     create() validates ColIdx and reports SPMV_HIP_E_ARG instead."""
