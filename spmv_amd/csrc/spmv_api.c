@@ -243,13 +243,23 @@ static int state_build_multi(spmv_Handle_t h, spmv_hip_state *st, int m, int n, 
         const size_t vs = h->data_size == sizeof(double) ? sizeof(double) : sizeof(float);
         int *rp2 = NULL, *ci2 = NULL, *perm = NULL;
         void *va2 = NULL;
-        if (reorder_on_host(vs, m, RowPtr, ColIdx, Val, &rp2, &ci2, &va2, &perm) == 0) {
+        spmv_dev *tmp = NULL;
+        if (st->opts.v[SPMV_OPT_REORDER] == 1 && (perm = (int *) malloc(sizeof(int) * (size_t) m)) != NULL &&
+            spmv_shim_matrix_create(&tmp, m, n, RowPtr, ColIdx, Val, vs) == SPMV_HIP_OK && spmv_shim_reorder_rcm(tmp, perm) == SPMV_HIP_OK) {
+            /* reorder = 1: on the device (kernels/rcm.hpp) -- the whole matrix on the current device for a moment, P A P^T handed to the sharding as device arrays */
+            const int *drp = NULL, *dci = NULL;
+            const void *dva = NULL;
+            spmv_shim_matrix_arrays(tmp, &drp, &dci, &dva);
+            rc = spmv_shim_multi_create(&st->multi, (int) st->opts.v[SPMV_OPT_GPUS], (int) st->opts.v[SPMV_OPT_X_EXCHANGE], m, n, drp, dci, dva, vs);
+            if (rc == SPMV_HIP_OK) { h->index = perm; h->Level_3_opt_used = 1; perm = NULL; }
+        } else if ((free(perm), perm = NULL, spmv_hip_clear_error(), 1) && reorder_on_host(vs, m, RowPtr, ColIdx, Val, &rp2, &ci2, &va2, &perm) == 0) {
             rc = spmv_shim_multi_create(&st->multi, (int) st->opts.v[SPMV_OPT_GPUS], (int) st->opts.v[SPMV_OPT_X_EXCHANGE], m, n, rp2, ci2, va2, vs);
             if (rc == SPMV_HIP_OK) { h->index = perm; h->Level_3_opt_used = 1; perm = NULL; }
         } else {
             /* never silently: the caller asked for a permutation and will gather x / scatter y by handle->index -- which stays NULL, i.e. identity */
             spmv_set_error(SPMV_HIP_E_ARG, "create/multi", "option reorder: the matrix could not be reordered (bad RowPtr or out of host memory); created unpermuted, handle->index = NULL");
         }
+        if (tmp) spmv_shim_matrix_destroy(tmp);
         free(perm); free(rp2); free(ci2); free(va2);
     }
     if (rc != SPMV_HIP_OK)

@@ -96,6 +96,9 @@ int spmv_shim_checksum_words(const void *val, long long words, unsigned long lon
  * (row i of the new matrix = row perm[i] of the old).  Before spmv_shim_build. */
 int spmv_shim_reorder_rcm(spmv_dev *d, int *perm_host);
 
+/* the resident CSR arrays (device pointers; ColIdx may be NULL after spmv_shim_release_columns) */
+void spmv_shim_matrix_arrays(const spmv_dev *d, const int **rowptr, const int **colidx, const void **val);
+
 /* ---- A = A_near + A_far (shim/split.hpp): a matrix with locality in part of its entries ---- */
 int spmv_shim_split_candidate(spmv_dev *d);                                   /* 1: worth building and timing */
 int spmv_shim_split(spmv_dev *d, spmv_dev **near_out, spmv_dev **far_out);    /* the two halves, unplanned; far multiplies accumulating */

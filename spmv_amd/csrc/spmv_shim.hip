@@ -134,6 +134,13 @@ extern "C" int spmv_shim_matrix_create(spmv_dev **out, int m, int n, const int *
     return SPMV_HIP_OK;
 }
 
+extern "C" void spmv_shim_matrix_arrays(const spmv_dev *d, const int **rowptr, const int **colidx, const void **val)
+{
+    if (rowptr) *rowptr = d ? d->rowptr : nullptr;
+    if (colidx) *colidx = d ? d->colidx : nullptr;
+    if (val) *val = d ? d->val : nullptr;
+}
+
 extern "C" int spmv_shim_copy_to_host(void *dst, const void *src, size_t bytes)
 {
     if (bytes == 0) return SPMV_HIP_OK;
