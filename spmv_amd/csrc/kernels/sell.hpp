@@ -262,12 +262,44 @@ __device__ __forceinline__ void sell_chunk_run(unsigned run, const T *__restrict
     }
 }
 
+// TEMPLATE groups (round 4; csr_vector_tile.hpp's TEMPLATE tiles for the SELL slabs): the rows of a staged window group use at most kSellTmplCount
+// lists of slot offsets from their first entry (stencils: every interior row the same 27 offsets): no slot slab either; the word per row slot is
+// first slot | row length << 16 | list number << 24, the lists (kSellTmplMax offsets each) sit in LDS.
+constexpr int kSellTmplMax = 64, kSellTmplCount = 8;
+template <typename T>
+__device__ __forceinline__ void sell_chunk_tmpl(unsigned run, const T *__restrict__ pv, int width, const T *__restrict__ xs, unsigned zslot,
+                                                const unsigned short *__restrict__ tm, T &sum)
+{
+    constexpr int U = 8;
+    const unsigned s0 = run & 0xffffu, len = (run >> 16) & 0xffu;
+    const unsigned short *__restrict__ list = tm + (run >> 24) * kSellTmplMax;
+    int j = 0;
+    for (; j + U <= width; j += U) {
+        T vv[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) vv[u] = ld_stream(pv + (size_t) (j + u) * kSellC);
+#pragma unroll
+        for (int u = 0; u < U; ++u) sum = fmadd(vv[u], xs[(unsigned) (j + u) < len ? s0 + list[(j + u) & (kSellTmplMax - 1)] : zslot], sum);
+    }
+    const int r = __builtin_amdgcn_readfirstlane(width - j);
+    if (r > 0) {
+        T vv[U - 1];
+#pragma unroll
+        for (int u = 0; u < U - 1; ++u)
+            if (u < r) vv[u] = ld_stream(pv + (size_t) (j + u) * kSellC);
+#pragma unroll
+        for (int u = 0; u < U - 1; ++u)
+            if (u < r) sum = fmadd(vv[u], xs[(unsigned) (j + u) < len ? s0 + list[(j + u) & (kSellTmplMax - 1)] : zslot], sum);
+    }
+}
+
 // Inspector: is window group w a RUN group?  One workgroup per group, a wave per chunk (lane = row slot) walks the row's slots in the
 // slab.  counters[0] += groups, [1] += entries (real ones), [2] += stored slab entries, [3] += row slots of the RUN groups.
 static __global__ __launch_bounds__(kBlock) void sell_runs_kernel(int chunks_per_win, long long nchunks, const long long *__restrict__ chunk_ptr,
                                                            const unsigned short *__restrict__ scol16, const int *__restrict__ perm,
                                                            const int *__restrict__ rowptr, TileWindows *__restrict__ wins,
-                                                           unsigned *__restrict__ sell_run, unsigned long long *__restrict__ counters)
+                                                           unsigned *__restrict__ sell_run, unsigned long long *__restrict__ counters,
+                                                           unsigned short *__restrict__ tmpl /* NULL: RUN groups only; else kSellTmplCount lists of kSellTmplMax offsets per group */)
 {
     const int w = blockIdx.x, lane = threadIdx.x & (kWave - 1), wave = threadIdx.x / kWave;
     const TileWindows &tw = wins[w];
@@ -289,7 +321,89 @@ static __global__ __launch_bounds__(kBlock) void sell_runs_kernel(int chunks_per
             if (lane == 0) { stored += (unsigned long long) width * kSellC; slots += kSellC; }
         }
     ok = __syncthreads_and(ok);
-    if (!ok) return;
+    if (!ok) {
+        if (!tmpl || tw.nwin == 0) return;
+        // TEMPLATE group?  every row hashes (length, offsets from its first slot), claims or finds one of kSellTmplCount list numbers; list i is written
+        // from the FIRST row slot (chunk, lane order) that carries it; every row is then compared with its list.
+        __shared__ unsigned s_hash[kSellTmplCount];
+        __shared__ int s_tlen[kSellTmplCount], s_first[kSellTmplCount], s_tm[kSellTmplCount][kSellTmplMax];
+        for (int i = threadIdx.x; i < kSellTmplCount * kSellTmplMax; i += kBlock) s_tm[i / kSellTmplMax][i % kSellTmplMax] = 0;
+        if (threadIdx.x < kSellTmplCount) { s_hash[threadIdx.x] = 0u; s_tlen[threadIdx.x] = 0; s_first[threadIdx.x] = INT_MAX; }
+        __syncthreads();
+        int okt = 1;
+        unsigned long long tent = 0;
+        auto row_of = [&](int k, long long &c0, int &width, int &len) { // lane's row slot in chunk k of the group; false past the matrix
+            const long long c = (long long) w * chunks_per_win + k;
+            if (c >= nchunks) return false;
+            c0 = chunk_ptr[c];
+            width = (int) (chunk_ptr[c + 1] - c0);
+            const int row = perm[c * kSellC + lane];
+            len = row >= 0 ? rowptr[row + 1] - rowptr[row] : 0;
+            return true;
+        };
+        auto hash_of = [&](const unsigned short *pc, int len, unsigned s0) {
+            unsigned h = 0x9E3779B9u * (unsigned) len;
+            for (int j = 0; j < len; ++j) h += ((unsigned) pc[(size_t) j * kSellC] - s0 + 0x7F4A7C15u) * (2u * (unsigned) j + 1u) * 0x85EBCA6Bu;
+            return h | 1u;
+        };
+        for (int k = wave; k < chunks_per_win; k += kBlock / kWave) {
+            long long c0; int width, len;
+            if (!row_of(k, c0, width, len)) break;
+            if (len == 0) continue;
+            if (len > kSellTmplMax || len > width) { okt = 0; continue; }
+            const unsigned short *pc = scol16 + (size_t) c0 * kSellC + lane;
+            const unsigned s0 = pc[0], h = hash_of(pc, len, s0);
+            int id = -1;
+            for (int i = 0; i < kSellTmplCount && id < 0; ++i) {
+                const unsigned old = atomicCAS(&s_hash[i], 0u, h);
+                if (old == 0u || old == h) id = i;
+            }
+            if (id < 0) okt = 0;
+            else atomicMin(&s_first[id], k * kSellC + lane);
+            tent += (unsigned long long) len;
+        }
+        okt = __syncthreads_and(okt);
+        if (!okt) return;
+        for (int k = wave; k < chunks_per_win; k += kBlock / kWave) { // the first carrier of each list writes it
+            long long c0; int width, len;
+            if (!row_of(k, c0, width, len)) break;
+            if (len == 0) continue;
+            const unsigned short *pc = scol16 + (size_t) c0 * kSellC + lane;
+            const unsigned s0 = pc[0], h = hash_of(pc, len, s0);
+            for (int i = 0; i < kSellTmplCount; ++i)
+                if (s_hash[i] == h && s_first[i] == k * kSellC + lane) {
+                    for (int j = 0; j < len; ++j) s_tm[i][j] = (int) pc[(size_t) j * kSellC] - (int) s0;
+                    s_tlen[i] = len;
+                }
+        }
+        __syncthreads();
+        for (int k = wave; k < chunks_per_win; k += kBlock / kWave) { // every row against its list; its word
+            long long c0; int width, len;
+            if (!row_of(k, c0, width, len)) break;
+            const long long c = (long long) w * chunks_per_win + k;
+            unsigned word = (unsigned) tw.total;
+            if (len > 0) {
+                const unsigned short *pc = scol16 + (size_t) c0 * kSellC + lane;
+                const unsigned s0 = pc[0], h = hash_of(pc, len, s0);
+                int id = -1;
+                for (int i = 0; i < kSellTmplCount; ++i) if (s_hash[i] == h) id = i;
+                if (id < 0 || s_tlen[id] != len) okt = 0;
+                else {
+                    for (int j = 0; j < len; ++j) okt &= (int) pc[(size_t) j * kSellC] - (int) s0 == s_tm[id][j] && s_tm[id][j] >= 0;
+                    word = s0 | ((unsigned) len << 16) | ((unsigned) id << 24);
+                }
+            }
+            sell_run[c * kSellC + lane] = word;
+        }
+        okt = __syncthreads_and(okt);
+        if (!okt) return; // sell_run was scribbled on: harmless, only RUN / TEMPLATE groups read it
+        for (int i = threadIdx.x; i < kSellTmplCount * kSellTmplMax; i += kBlock) tmpl[(size_t) w * (kSellTmplCount * kSellTmplMax) + i] = (unsigned short) s_tm[i / kSellTmplMax][i % kSellTmplMax];
+#pragma unroll
+        for (int o = kWave / 2; o > 0; o >>= 1) { tent += __shfl_xor(tent, o, kWave); stored += __shfl_xor(stored, o, kWave); slots += __shfl_xor(slots, o, kWave); }
+        if (lane == 0) { atomicAdd(counters + 1, tent); atomicAdd(counters + 2, stored); atomicAdd(counters + 3, slots); atomicAdd(counters + 4, tent); }
+        if (threadIdx.x == 0) { wins[w].runs = 3; atomicAdd(counters, 1ull); }
+        return;
+    }
     for (int k = wave; k < chunks_per_win; k += kBlock / kWave) {
         const long long c = (long long) w * chunks_per_win + k;
         if (c >= nchunks) break;
@@ -313,16 +427,18 @@ __global__ __launch_bounds__(kSellWinThreads) void sell_window_kernel(int chunks
                                                                       const T *__restrict__ sval,
                                                                       const int *__restrict__ perm,
                                                                       const TileWindows *__restrict__ wins,
-                                                                      const unsigned *__restrict__ sell_run,
+                                                                      const unsigned *__restrict__ sell_run, const unsigned short *__restrict__ sell_tmpl,
                                                                       const T *__restrict__ x, T *__restrict__ y, int ys_offset)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char sell_x_lds[];
     __shared__ int next_chunk;
+    __shared__ unsigned short tm_lds[kSellTmplCount * kSellTmplMax];
     T *xs = reinterpret_cast<T *>(sell_x_lds);
     T *ys = reinterpret_cast<T *>(sell_x_lds + ys_offset);
     const int w = blockIdx.x;
     const TileWindows &tw = wins[w];
-    const bool staged = tw.nwin > 0, runs = tw.runs != 0; // runs implies staged
+    const bool staged = tw.nwin > 0, runs = tw.runs == 1, templ = tw.runs == 3; // runs / templ imply staged
+    if (templ) for (int i = threadIdx.x; i < kSellTmplCount * kSellTmplMax; i += kSellWinThreads) tm_lds[i] = sell_tmpl[(size_t) blockIdx.x * (kSellTmplCount * kSellTmplMax) + i];
     const int rows_per_group = chunks_per_win * kSellC;
     const long long row0 = (long long) w * rows_per_group;
     for (int i = threadIdx.x; i < rows_per_group; i += kSellWinThreads) ys[i] = T(0);
@@ -345,6 +461,7 @@ __global__ __launch_bounds__(kSellWinThreads) void sell_window_kernel(int chunks
         const int row = perm[c * kSellC + lane];
         T sum = 0;
         if (runs) sell_chunk_run<T>(sell_run[c * kSellC + lane], pv, width, xs, (unsigned) tw.total, sum);
+        else if (templ) sell_chunk_tmpl<T>(sell_run[c * kSellC + lane], pv, width, xs, (unsigned) tw.total, tm_lds, sum);
         else if (staged) sell_chunk<T, true>(pc, pc16, pv, width, xs, x, sum);
         else sell_chunk<T, false>(pc, pc16, pv, width, xs, x, sum);
         if (row >= 0) ys[row - row0] = sum;

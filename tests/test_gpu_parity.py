@@ -1367,6 +1367,63 @@ def test_template_tiles_need_no_column_stream(shape, dtype, method):
         assert torch.equal(y, 2 * want)
 
 
+@pytest.mark.parametrize("dtype", ["f64", "f32"])
+@pytest.mark.parametrize("shape", ["stencil27", "pattern40", "nine_lists", "edges"])
+def test_sell_template_groups_need_no_slot_slab(shape, dtype):
+    """TEMPLATE groups of the SELL slabs (sell.hpp, round 4): when the rows of a staged window group use at most 8 lists of slot offsets, a word per row
+    slot (first slot | length | list number) replaces the 16-bit slot slab -- the SELL counterpart of the CSR-vector TEMPLATE tiles.  Exact data.
+      stencil27   27-point stencil on a periodic 48^3 grid              pattern40  every row the same 40 offsets within +-300 of the diagonal
+      nine_lists  rows cycle through nine lists: one too many -> the slot slab is read          edges  2-D 5-point stencil, NOT periodic: rows of 3-5 entries"""
+    import torch
+    dev = torch.device("cuda:0")
+    tdt = torch.float64 if dtype == "f64" else torch.float32
+    g = torch.Generator(device=dev); g.manual_seed(41)
+    if shape == "stencil27":
+        m, n, rp, ci, va = synth.stencil27_device(48, "eighths", tdt, dev, 5)
+    elif shape == "edges":
+        nx, ny = 300, 400
+        m = n = nx * ny
+        rows = torch.arange(m, device=dev)
+        ix, iy = rows % nx, rows // nx
+        cand = torch.stack([rows - nx, rows - 1, rows, rows + 1, rows + nx], 1)
+        ok = torch.stack([iy > 0, ix > 0, torch.ones_like(ix, dtype=torch.bool), ix < nx - 1, iy < ny - 1], 1)
+        rp = torch.zeros(m + 1, dtype=torch.int64, device=dev); torch.cumsum(ok.sum(1), 0, out=rp[1:])
+        ci = cand[ok].to(torch.int32); rp = rp.to(torch.int32)
+        va = (torch.randint(-8, 9, (ci.numel(),), generator=g, device=dev) * 0.125).to(tdt)
+    else:
+        m = n = 200_000
+        rows = torch.arange(m, device=dev)
+        k = 40 if shape == "pattern40" else 20
+        offs = torch.sort(torch.randperm(601, generator=g, device=dev)[:k] - 300).values
+        base = rows.clamp(300, n - 1 - 300 - 9)
+        cand = base[:, None] + offs[None, :]
+        if shape == "nine_lists":
+            cand[:, -1] = cand[:, -1] + rows % 9
+        ci = cand.reshape(-1).to(torch.int32)
+        rp = torch.arange(0, (m + 1) * k, k, dtype=torch.int32, device=dev)
+        va = (torch.randint(-8, 9, (m * k,), generator=g, device=dev) * 0.125).to(tdt)
+    nnz = int(rp[-1])
+    x = (torch.randint(-8, 9, (n,), generator=g, device=dev) * 0.125).to(tdt)
+    want = _segment_sums(va.double() * x.double()[ci.long()], rp).to(tdt)
+    y = torch.full((m,), float("nan"), dtype=tdt, device=dev)
+    with api.Handle(m, n, rp, ci, va, M.Method_SellCSigma) as h:
+        h.spmv(x, y)
+        info = h.info()
+        torch.cuda.synchronize()
+        assert torch.equal(y, want), (info["kernel_name"], int((y != want).sum()))
+        assert info["kernel_name"] == "sell_window_kernel", info
+        if shape == "nine_lists":
+            assert info["tmpl_nnz"] == 0, info
+        elif shape == "stencil27":
+            assert info["tmpl_nnz"] >= 0.8 * nnz, (info["tmpl_nnz"], nnz)       # groups in which the periodic grid wraps hold more lists
+        else:
+            assert info["tmpl_nnz"] >= 0.95 * nnz, (info["tmpl_nnz"], nnz)
+        h.update_values((va * 2).contiguous())
+        h.spmv(x, y)
+        torch.cuda.synchronize()
+        assert torch.equal(y, 2 * want)
+
+
 def _holes_rows_matrix(m, n, lens, start, span, dtype, dev, seed, reverse=False):
     """CSR whose row i holds lens[i] DISTINCT columns drawn from [start[i], start[i] + span[i]) -- first and last column of the range always present
     when lens[i] >= 2, so the row's column span is exactly span[i] --, ascending (or descending: unsorted rows are legal CSR); exact values"""
