@@ -1072,7 +1072,8 @@ def test_stream_bytes_model_of_the_storage_format():
     ci2 = torch.sort(ci2, dim=1).values.reshape(-1).contiguous()
     with api.Handle(m, n, rp, ci2, va, M.Method_Parallel) as h:
         i2 = h.info()
-    assert i2["kernel_name"] == "csr_vector_tile_kernel" and i2["run_nnz"] == 0 and i2["stream_bytes"] > i["stream_bytes"] + nnz
+    # two runs per row: no RUN tile -- every row the same 32 offsets: TEMPLATE tiles (no column stream either, a wider x window)
+    assert i2["kernel_name"] == "csr_vector_tile_kernel" and i2["run_nnz"] == 0 and i2["tmpl_nnz"] >= 0.99 * nnz and i2["stream_bytes"] > i["stream_bytes"], i2
     with api.Handle(m, n, rp, ci, va, M.Method_Serial) as h:
         i = h.info()
     assert i["stream_bytes"] == i["alg_bytes"]
@@ -1080,9 +1081,16 @@ def test_stream_bytes_model_of_the_storage_format():
         i = h.info()
     # banded: nearly every sigma window is a RUN group (a word per row slot instead of 16 bits per stored entry); padding still counts
     assert i["run_nnz"] >= 0.99 * nnz and i["stored_nnz"] * 8 + 12 * m <= i["stream_bytes"] < i["stored_nnz"] * 10 + 8 * m, i
-    with api.Handle(m, n, rp, ci2, va, M.Method_SellCSigma) as h:       # two runs per row: the 16-bit slot slabs are read
+    with api.Handle(m, n, rp, ci2, va, M.Method_SellCSigma) as h:       # two runs per row: not RUN groups -- but every row the same offsets: TEMPLATE groups (round 4)
         i = h.info()
-    assert i["run_nnz"] == 0 and i["stream_bytes"] >= i["stored_nnz"] * 10 + 8 * m
+    assert i["run_nnz"] == 0 and i["tmpl_nnz"] >= 0.99 * nnz and i["stored_nnz"] * 8 + 12 * m <= i["stream_bytes"] < i["stored_nnz"] * 10 + 8 * m, i
+    api.set_option("run_tiles", 0)                                      # ... and with the RUN / TEMPLATE checks off the 16-bit slot slabs are read
+    try:
+        with api.Handle(m, n, rp, ci2, va, M.Method_SellCSigma) as h:
+            i = h.info()
+    finally:
+        api.set_option("run_tiles", 1)
+    assert i["run_nnz"] == 0 and i["tmpl_nnz"] == 0 and i["stream_bytes"] >= i["stored_nnz"] * 10 + 8 * m, i
 
 
 def test_auto_method_measured_mode_builds_times_and_keeps_a_candidate():
