@@ -90,7 +90,8 @@ int spmv_hip_update_values(spmv_Handle_t handle, const void *Matrix_Val);
  *       "cache_block" (0 never / 1 automatic (default) / 2 always: every schedule but the debug kernel CSR-scalar hands the
  *                      multiply to the row-block x column-slab executor when no x window of the matrix fits LDS,
  *                      nnz >= 2^21 and n * size >= 4 MiB (x as large as an XCD's L2; 12 MiB when rows average fewer than 8 entries): ~3x faster on columns
- *                      without locality.  One wavefront owns a row block, so results are bit-reproducible.)
+ *                      without locality.  A row block's products are added in an order fixed by the matrix -- one wavefront per block, or the waves
+ *                      of the wide form taking turns --, so results are bit-reproducible unless option "deterministic" = 0 waives that.)
  *       "split" (0/1, default 1: a matrix whose entries are partly local, partly scattered may be multiplied as A_near + A_far when
  *               create() measures that faster -- spmv_hip_info.split_ms, far_nnz)
  *       "slab_kib" (KiB of x per column slab, 0 = as narrow as the cell table allows)
@@ -138,9 +139,9 @@ typedef struct spmv_hip_info {
     const char *schedule_name;
     const char *kernel_name;    /* symbol of the dominant kernel (as rocprofv3 shows it) */
     int tuned_choice;           /* csr-vector autotune: 0 none, 10/11 tile 4-deep, 5/12 tile 2-deep, 4 pipe; cache_blocked: 100 / 101 =
-                                   8 / 12 groups per pipeline step */
+                                   the smaller / larger groups-per-pipeline-step form (8 / 12; 6 / 8 with blk_waves = 8) */
     float tune_ms[3];           /* measured ms of {tile/4-deep, tile/2-deep, pipe} at create (0 if not tuned; pipe: 0 when 99 % of the tiles stage their x windows -- not timed); cache_blocked: of the
-                                   row-block executor's {8, 12} groups-per-step forms ([2] unused) */
+                                   row-block executor's two groups-per-step forms ([2] unused) */
     int x_groups;               /* tiles / tile groups / sigma windows the inspector analysed for x windows */
     int x_groups_staged;        /* ... of which have their x windows staged in LDS (0: every gather goes to L1/L2) */
     int cache_blocked;          /* 1: the row-block x column-slab executor runs (option "cache_block") */
