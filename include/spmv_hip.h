@@ -74,6 +74,7 @@ int spmv_hip_update_values(spmv_Handle_t handle, const void *Matrix_Val);
  *       "vector_form" (CSR-vector: 0 timed at create, 4 pipe, 5 / 12 tile two deep, 10 / 11 tile four deep, 6 tile eight deep)
  *       "x_windows" (0/1, default 1: stage the tile groups' x windows in LDS)   "xcd_order" (0/1, default 1)   "csr5_two_deep" (0 auto / 1 never / 2 always)
  *       "run_tiles" (0/1, default 1: RUN / BYTE tiles -- spmv_hip_info.run_nnz, byte_nnz)
+ *       "row_forward" (0/1, default 1: nnz-split tiles that gather through L2 finish the rows they start -- one launch, no carry fix-up; spmv_hip_info.launch_kernels)
  *       "autotune" (0/1, default 1: for matrices above 2^24 nnz create() times the applicable CSR-vector
  *                   kernel forms once on the resident matrix and keeps the fastest, ~10 ms)
  *       "reorder" (0/1/2, default 0; 1: reverse Cuthill-McKee on the device (kernels/rcm.hpp), 2: the host BFS of round 1.  For matrices whose band was lost to

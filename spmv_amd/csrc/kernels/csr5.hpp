@@ -365,11 +365,27 @@ __device__ __forceinline__ void csr5_stage_row_map(int lane, int r0, int r1, con
     wave_lds_sync();
 }
 
-template <typename T, int SIGMA, bool MAPPED, bool STAGED>
+// The forward part of a tile (nat_kernel<.., FWD>, "forward completion"): the row that is open at the tile's END is finished by the tile it
+// STARTS in -- count entries of the next tile (count < the tile size: longer rows are on the long-row list, count = -1, and a workgroup of their own
+// writes them).  The first 64 of them arrive in v / c, one per lane (0 / column 0 beyond count), loaded and gathered with the tile's own entries;
+// the rest are read in place from base (rare with short rows).  Variants measured on the webbase-style stand-in and not kept: the first FOUR entries
+// only, by wave-uniform loads (the compiler makes them s_loads, whose waits drain the tile's LDS hand-over) or by four lanes + DPP (more tiles take
+// the in-place loop: two more round trips for those waves, and the launch is as long as its slowest wave).
+template <typename T>
+struct TileForward {
+    int count = 0;
+    T v = 0;
+    int c = 0;
+    const int *__restrict__ colidx = nullptr;
+    const T *__restrict__ val = nullptr;
+    long long base = 0; // position of the next tile's first entry
+};
+
+template <typename T, int SIGMA, bool MAPPED, bool STAGED, bool FWD = false>
 __device__ __forceinline__ void csr5_tile_compute(int t, int lane, const int (&c)[SIGMA], const T (&v)[SIGMA],
                                                   unsigned d, int r0, const int *__restrict__ rm /* MAPPED: the tile's row map in LDS */,
                                                   const T *__restrict__ x, const T *__restrict__ xs,
-                                                  T *__restrict__ y, T *__restrict__ carry)
+                                                  T *__restrict__ y, T *__restrict__ carry, const TileForward<T> &fw = TileForward<T>())
 {
     const unsigned flags = d & kCsr5FlagMask;
     // row of the tile's first row start: r0 itself if the tile begins on a row boundary
@@ -381,6 +397,8 @@ __device__ __forceinline__ void csr5_tile_compute(int t, int lane, const int (&c
         if (STAGED) xv[i] = xs[c[i]];
         else xv[i] = x[c[i] >= 0 ? c[i] : 0];
     }
+    T fx = 0;
+    if constexpr (FWD) fx = x[fw.c]; // with the tile's own gathers: the forward part adds no round trip
 
     T head = 0, acc = 0;
     bool started = false;
@@ -410,7 +428,20 @@ __device__ __forceinline__ void csr5_tile_compute(int t, int lane, const int (&c
     }
     T next = __shfl_down(B, 1, kWave);
     if (lane == kWave - 1) next = 0;
-    if (started) y[MAPPED ? rm[seg_row - r0] : seg_row] = acc + next;
+    T out = acc + next;
+    bool write = started;
+    if constexpr (FWD) {
+        if (fw.count != 0) { // wave-uniform: the tile's last row goes on behind the tile
+            T fs = fw.v * fx;
+            for (int k = kWave + lane; k < fw.count; k += kWave) fs = fmadd(fw.val[fw.base + k], x[fw.colidx[fw.base + k]], fs); // more than 64 entries behind the cut: rare
+            fs = lane0_value(group_sum_dpp<kWave>(fs));
+            if (lane == 63 - __clzll((long long) starts)) { // the lane that holds the row's start
+                out += fs;
+                write = fw.count > 0; // a long row: its own workgroup writes it (nat_long_row)
+            }
+        }
+    }
+    if (write) y[MAPPED ? rm[seg_row - r0] : seg_row] = out;
     if (lane == 0) carry[t] = B;
 }
 
@@ -676,18 +707,28 @@ struct NatLds {
     static constexpr int kBytes = kValBytes + kColBytes;         // per wavefront: 11.5 KiB (5.8 KiB HALF) for fp64, sigma = 16
 };
 
-template <typename T, int SIGMA, bool MAPPED, bool STAGED, bool HALF>
+template <typename T, int SIGMA, bool MAPPED, bool STAGED, bool HALF, bool FWD = false>
 __device__ __forceinline__ void nat_tile(int t, int lane, int nnz, unsigned zslot, unsigned char *__restrict__ wl,
                                          const int *__restrict__ tile_ptr, const unsigned *__restrict__ desc,
                                          const int *__restrict__ colidx, const unsigned short *__restrict__ col16,
                                          const T *__restrict__ val, const int *__restrict__ row_map, int *__restrict__ rm,
                                          const T *__restrict__ x, const T *__restrict__ xs,
-                                         T *__restrict__ y, T *__restrict__ carry)
+                                         T *__restrict__ y, T *__restrict__ carry, const int *__restrict__ fwd = nullptr)
 {
     using NL = NatLds<T, SIGMA, HALF>;
     const unsigned d = desc[(long long) t * kWave + lane]; // descriptor and row range first: in flight with the tile itself
     const int r0 = tile_ptr[t], r1 = MAPPED ? tile_ptr[t + 1] : 0;
     constexpr int TN = kWave * SIGMA;
+    TileForward<T> fw;
+    if constexpr (FWD) { // the first entries behind the tile, loaded whether or not they are needed (fwd[t] decides when it arrives): no round trip of their own
+        fw.base = (long long) (t + 1) * TN;
+        fw.count = fwd[t];
+        const long long q = fw.base + lane < nnz ? fw.base + lane : nnz - 1;
+        fw.v = val[q];
+        fw.c = colidx[q];
+        fw.colidx = colidx;
+        fw.val = val;
+    }
     constexpr int EPL = 16 / (int) sizeof(T);              // values per 16-byte load
     constexpr int VL = SIGMA / EPL;                        // value loads per lane
     constexpr int CB = SIGMA * 2 < 16 ? SIGMA * 2 : 16;    // bytes of slot stream per lane and load
@@ -750,6 +791,9 @@ __device__ __forceinline__ void nat_tile(int t, int lane, int nnz, unsigned zslo
             for (int i = 0; i < SIGMA; ++i) c[i] = lane * SIGMA + i < left ? colidx[tb + lane * SIGMA + i] : -1;
         }
     }
+    if constexpr (FWD) { // checked behind the tile's own loads, so that waiting for fwd[t] costs no round trip
+        if (__builtin_amdgcn_readfirstlane(fw.count) == -2) return; // the tile lies inside a long row (nat_long_row writes it): no hand-over, no gathers
+    }
     // 2. hand-over through LDS in two halves (lane rows 0..31, then 32..63: half the buffer, twice the syncs):
     //    entry p of the tile belongs to lane row p / SIGMA, position p % SIGMA
     T v[SIGMA];
@@ -795,24 +839,111 @@ __device__ __forceinline__ void nat_tile(int t, int lane, int nnz, unsigned zslo
         wave_lds_sync(); // the buffer is free for the other half / the wave's next tile
     }
     if constexpr (MAPPED) csr5_stage_row_map<SIGMA>(lane, r0, r1, row_map, rm);
-    csr5_tile_compute<T, SIGMA, MAPPED, STAGED>(t, lane, c, v, d, r0, rm, x, xs, y, carry);
+    if constexpr (FWD) {
+        fw.count = __builtin_amdgcn_readfirstlane(fw.count);
+        if (lane >= fw.count) { fw.v = T(0); fw.c = 0; }
+    }
+    csr5_tile_compute<T, SIGMA, MAPPED, STAGED, FWD>(t, lane, c, v, d, r0, rm, x, xs, y, carry, fw);
 }
 
-template <typename T, int SIGMA, bool MAPPED>
+// Forward completion: which tiles finish their last row, and which rows are too long for that (inspector, one thread per tile).
+// fwd[t] = entries of tile t + 1 (.. further tiles: never, such rows are long) that belong to the row open at the end of tile t, if that row STARTS
+// in tile t and is at most one tile long; -1 if it starts in tile t and is longer (row appended to long_list, counters[0] / [1] = number / longest);
+// -2 if the whole tile lies inside a long row (the wave returns before it gathers anything); else 0.
+static __global__ __launch_bounds__(kBlock) void nat_forward_kernel(int p, int tile_nnz, const int *__restrict__ rp, const int *__restrict__ tile_ptr, const int *__restrict__ row_map,
+                                                                    int *__restrict__ fwd, int4 *__restrict__ long_list, int cap, int *__restrict__ counters)
+{
+    auto list = [&](int r, long long b, long long e) { // (y row, first entry, end): everything the row's workgroup needs, in one load
+        const int k = atomicAdd(&counters[0], 1);
+        if (k < cap) long_list[k] = make_int4(row_map ? row_map[r] : r, (int) b, (int) e, 0);
+        atomicMax(&counters[1], (int) (e - b < INT_MAX ? e - b : INT_MAX));
+    };
+    const int t = blockIdx.x * kBlock + threadIdx.x;
+    if (t >= p) return;
+    int f = 0;
+    {
+        const int r0 = tile_ptr[t];
+        const long long b0 = rp[r0], e0 = rp[r0 + 1], lo = (long long) t * tile_nnz;
+        if (b0 <= lo && e0 >= lo + tile_nnz && e0 - b0 > tile_nnz) { // the whole tile lies inside a long row: nothing for the tile to do
+            if (b0 == lo) list(r0, b0, e0); // ... which starts with the tile: list it here
+            fwd[t] = -2;
+            return;
+        }
+    }
+    if (t + 1 < p) {
+        const long long cut = (long long) (t + 1) * tile_nnz;
+        const int r = tile_ptr[t + 1];
+        const long long b = rp[r], e = rp[r + 1];
+        if (b < cut && e > cut && b >= cut - tile_nnz) {
+            if (e - b <= tile_nnz) f = (int) (e - cut);
+            else {
+                f = -1;
+                list(r, b, e);
+            }
+        }
+    }
+    fwd[t] = f;
+}
+
+// One long row by one workgroup: thread i takes entries i, i + 256, ... -- kNatLongU in flight, so that a row of up to 256 kNatLongU entries is two memory round
+// trips behind the list entry, like a tile (the launch is one round of workgroups, all in flight together: a round trip takes microseconds, and a row that
+// needed five would be the launch's tail) --, fixed-shape combine: the same bits on every run.
+constexpr int kNatLongU = 20;    // 5120 entries per pass (webbase-1M's longest row: 4700).  fp64: 98 registers instead of 70, five workgroups per CU instead of six -- measured against
+                                 // 14 per thread (74 registers, two passes for the longest rows): 25.9 vs 28.2 us on the stand-in; the row with two passes is the launch's tail
+template <typename T>
+__device__ __forceinline__ void nat_long_row(int4 row, const int *__restrict__ colidx, const T *__restrict__ val, const T *__restrict__ x, T *__restrict__ y)
+{
+    __shared__ T part[kBlock / kWave];
+    const int e = row.z;
+    constexpr int U = kNatLongU;
+    T acc = 0;
+    for (int k = row.y + (int) threadIdx.x; k < e; k += U * kBlock) {
+        int c[U];
+        T v[U];
+#pragma unroll
+        for (int j = 0; j < U; ++j) {
+            const int q = k + j * kBlock;
+            c[j] = q < e ? colidx[q] : 0;
+            v[j] = q < e ? val[q] : T(0);
+        }
+#pragma unroll
+        for (int j = 0; j < U; ++j) acc = fmadd(v[j], x[c[j]], acc);
+    }
+#pragma unroll
+    for (int o = kWave / 2; o > 0; o >>= 1) acc += __shfl_xor(acc, o, kWave);
+    if ((threadIdx.x & (kWave - 1)) == 0) part[threadIdx.x / kWave] = acc;
+    __syncthreads();
+    if (threadIdx.x == 0) y[row.x] = (part[0] + part[1]) + (part[2] + part[3]);
+}
+
+template <typename T, int SIGMA, bool MAPPED, bool FWD = false>
 __global__ __launch_bounds__(kBlock) void nat_kernel(int p, int nnz, const int *__restrict__ tile_ptr,
                                                      const unsigned *__restrict__ desc,
                                                      const int *__restrict__ colidx, const T *__restrict__ val,
                                                      const int *__restrict__ row_map,
                                                      const T *__restrict__ x, T *__restrict__ y, T *__restrict__ carry, int n_empty, const int *__restrict__ empty_list,
-                                                     int rm_stride, int xcd)
+                                                     int rm_stride, int xcd,
+                                                     // FWD ("forward completion": no carry fix-up launch): a row cut by a tile boundary is finished by the tile it starts in
+                                                     // (fwd[t] entries of the next tile); rows longer than a tile by the first long_blocks workgroups (a multiple of 8:
+                                                     // the tiles' XCD order stays), one row each
+                                                     const int *__restrict__ fwd = nullptr, const int4 *__restrict__ long_list = nullptr, int n_long = 0, int long_blocks = 0)
 {
     if (MAPPED) zero_empty_rows(n_empty, empty_list, y);
     extern __shared__ __attribute__((aligned(16))) unsigned char csr5_x_lds[]; // MAPPED: the waves' row maps (rm_stride ints each)
     __shared__ __attribute__((aligned(16))) unsigned char nat_lds[kBlock / kWave][NatLds<T, SIGMA, false>::kBytes];
     const int lane = threadIdx.x & (kWave - 1), wave = threadIdx.x / kWave;
-    const int t = (xcd ? xcd_block(blockIdx.x, gridDim.x) : (int) blockIdx.x) * (kBlock / kWave) + wave;
+    int b = (int) blockIdx.x, nb = (int) gridDim.x;
+    if constexpr (FWD) {
+        if (b < long_blocks) {
+            if (b < n_long) nat_long_row<T>(long_list[b], colidx, val, x, y);
+            return;
+        }
+        b -= long_blocks;
+        nb -= long_blocks;
+    }
+    const int t = (xcd ? xcd_block(b, nb) : b) * (kBlock / kWave) + wave;
     if (t >= p) return;
-    nat_tile<T, SIGMA, MAPPED, false, false>(t, lane, nnz, 0u, nat_lds[wave], tile_ptr, desc, colidx, nullptr, val, row_map, wave_row_map(csr5_x_lds, 0, rm_stride), x, nullptr, y, carry);
+    nat_tile<T, SIGMA, MAPPED, false, false, FWD>(t, lane, nnz, 0u, nat_lds[wave], tile_ptr, desc, colidx, nullptr, val, row_map, wave_row_map(csr5_x_lds, 0, rm_stride), x, nullptr, y, carry, fwd);
 }
 
 // HALF: two-half hand-over (half the tile buffers, twice the wave syncs: ~8 % slower per tile) -- chosen by

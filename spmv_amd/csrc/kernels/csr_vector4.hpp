@@ -17,35 +17,6 @@
 
 namespace spmv {
 
-// ---- DPP butterfly pieces (all lanes of the group end up with the group total) ----------------
-template <int CTRL>
-__device__ __forceinline__ float dpp_mov(float v)
-{
-    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, 0xF, 0xF, true));
-}
-template <int CTRL>
-__device__ __forceinline__ double dpp_mov(double v)
-{
-    const long long b = __builtin_bit_cast(long long, v);
-    const int lo = __builtin_amdgcn_update_dpp(0, (int) (b & 0xFFFFFFFFll), CTRL, 0xF, 0xF, true);
-    const int hi = __builtin_amdgcn_update_dpp(0, (int) (b >> 32), CTRL, 0xF, 0xF, true);
-    return __builtin_bit_cast(double, ((long long) hi << 32) | (unsigned) lo);
-}
-
-// Sum over groups of W consecutive lanes, W in {1,2,4,8,16,32,64}; result valid in every lane of the
-// group for W <= 16, and at least in the group's first lane for W = 32 / 64.
-template <int W, typename T>
-__device__ __forceinline__ T group_sum_dpp(T v)
-{
-    if (W >= 2) v += dpp_mov<0xB1>(v);   // quad_perm [1,0,3,2]
-    if (W >= 4) v += dpp_mov<0x4E>(v);   // quad_perm [2,3,0,1]
-    if (W >= 8) v += dpp_mov<0x141>(v);  // row_half_mirror: the other quad of each 8
-    if (W >= 16) v += dpp_mov<0x140>(v); // row_mirror: the other half of each 16
-    if (W >= 32) v += __shfl_xor(v, 16, kWave);
-    if (W >= 64) v += __shfl_xor(v, 32, kWave);
-    return v;
-}
-
 } // namespace spmv
 
 namespace spmv {

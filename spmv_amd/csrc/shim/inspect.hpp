@@ -434,6 +434,32 @@ static int build_csr5_sigma(spmv_dev *d, Csr5Plan &P, const int *rp, int m2, con
     }
     if (P.staged == 0) { sched_free(d, P.col16); P.col16 = nullptr; }
     else if (!P.natural && P.staged == P.groups) { sched_free(d, P.col); P.col = nullptr; } // no group reads global columns
+    // Forward completion (nat_kernel, csr5.hpp): short heavy-tailed rows in ONE launch.  Where no group stages (the tiles gather through L2 and a multiply is a
+    // few tens of microseconds) the fix-up launch is a fifth of the time: tiles finish the rows they start, the few rows longer than a tile get a workgroup each.
+    // Not with many or very long long rows (they would be the launch's tail): those keep carries + fix-up.
+    P.forward = 0;
+    if (P.natural && P.staged == 0 && P.fixup && p > 1 && d->plan.row_forward) {
+        constexpr int kLongCap = 1024, kLongMax = 2 * (kNatLongU) * kBlock; // a long row's workgroup: at most two passes
+        int *cnt = nullptr, h[2] = {0, 0};
+        ALLOC_TRY(d, &P.fwd, sizeof(int) * (size_t) p, true);
+        ALLOC_TRY(d, &P.long_list, sizeof(int4) * kLongCap, true);
+        HIP_TRY(pool_malloc((void **) &cnt, sizeof h));
+        hipError_t e = hipMemsetAsync(cnt, 0, sizeof h, d->stream);
+        nat_forward_kernel<<<grid_for(p, kBlock, INT_MAX), kBlock, 0, d->stream>>>(p, TN, rp, P.tile_ptr, P.row_map, P.fwd, P.long_list, kLongCap, cnt);
+        if (e == hipSuccess) e = hipGetLastError();
+        if (e == hipSuccess) e = hipMemcpyAsync(h, cnt, sizeof h, hipMemcpyDeviceToHost, d->stream);
+        if (e == hipSuccess) e = hipStreamSynchronize(d->stream);
+        (void) pool_free(cnt);
+        if (e != hipSuccess) return fail(SPMV_HIP_E_RUNTIME, "forward-completion inspector: %s", hipGetErrorString(e));
+        if (getenv("SPMV_HIP_CSR5_DEBUG")) fprintf(stderr, "[spmv_hip] forward completion: %d tiles, %d rows longer than a tile (longest %d)\n", p, h[0], h[1]);
+        if (h[0] <= kLongCap && h[1] <= kLongMax) {
+            P.forward = 1;
+            P.n_long = h[0];
+        } else {
+            sched_free(d, P.fwd); P.fwd = nullptr;
+            sched_free(d, P.long_list); P.long_list = nullptr;
+        }
+    }
     return SPMV_HIP_OK;
 }
 
@@ -813,7 +839,8 @@ static int csr5_traffic(spmv_dev *d, const Csr5Plan &P, Traffic &t)
     const double fs = P.groups > 0 ? (double) wtiles / (double) P.groups : 0.0;
     t.bytes += stream_part(P.natural ? P.nnz : p * TN, s, fs);
     t.bytes += 4 * (p + 1) + 4 * kWave * p + s * p;            // tile_ptr, descriptors, carries written
-    if (P.fixup && p > 1) t.bytes += (s + 8) * p;               // fix-up launch: carries, tile_ptr, run_len
+    if (P.forward) t.bytes += 4ll * p;                          // forward completion: a count per tile, no fix-up launch
+    else if (P.fixup && p > 1) t.bytes += (s + 8) * p;          // fix-up launch: carries, tile_ptr, run_len
     if (P.staged > 0) t.bytes += (long long) sizeof(TileWindows) * P.groups;
     t.bytes += P.run_tiles * (4ll * kWave - 2ll * TN); // RUN groups: a word per lane and tile instead of 16 bits per entry
     if (P.row_map) t.bytes += 4ll * P.m2;

@@ -214,7 +214,11 @@ static void launch_csr5_form(spmv_dev *d, const Csr5Plan &P, const T *x, T *y)
     }
     const int grid = grid_for(P.tiles, kBlock / kWave, INT_MAX);
     const int xcd = d->plan.xcd_order ? 1 : 0; // XCD-aware block order (common.hpp: xcd_block); option xcd_order = 0: dispatch order, for A/B
-    if (P.natural)
+    if (P.natural && P.forward) {
+        const int long_blocks = (P.n_long + 7) & ~7;
+        nat_kernel<T, SIGMA, MAPPED, true><<<grid + long_blocks, kBlock, rmb, d->stream>>>(P.tiles, (int) P.nnz, P.tile_ptr, P.desc, P.col, (const T *) P.val, P.row_map, x, y, (T *) P.carry,
+                                                                                          P.n_empty, P.empty_list, rm_stride, xcd, P.fwd, P.long_list, P.n_long, long_blocks);
+    } else if (P.natural)
         nat_kernel<T, SIGMA, MAPPED><<<grid, kBlock, rmb, d->stream>>>(P.tiles, (int) P.nnz, P.tile_ptr, P.desc, P.col, (const T *) P.val, P.row_map, x, y, (T *) P.carry, P.n_empty,
                                                                       P.empty_list, rm_stride, xcd);
     else
@@ -239,7 +243,7 @@ static int launch_csr5(spmv_dev *d, const Csr5Plan &P, const T *x, T *y)
     case 8: launch_csr5_sigma<T, 8>(d, P, x, y); break;
     default: launch_csr5_sigma<T, 16>(d, P, x, y); break;
     }
-    if (P.fixup && P.tiles > 1) {
+    if (P.fixup && P.tiles > 1 && !P.forward) {
         const int g = grid_for(P.tiles - 1, kBlock, INT_MAX);
         if (P.row_map) csr5_fixup_kernel<T, true><<<g, kBlock, 0, d->stream>>>(P.tiles, P.tile_ptr, P.run_len, P.row_map, (const T *) P.carry, y);
         else csr5_fixup_kernel<T, false><<<g, kBlock, 0, d->stream>>>(P.tiles, P.tile_ptr, P.run_len, nullptr, (const T *) P.carry, y);

@@ -163,6 +163,10 @@ struct Csr5Plan {
     const int *row_map = nullptr; // CSR5 row -> y row (NULL: identity)
     unsigned *desc = nullptr;
     void *val = nullptr, *carry = nullptr;
+    // forward completion (csr5.hpp, nat_kernel<.., FWD>): no fix-up launch -- a row cut by a tile boundary is finished by the tile it starts in
+    int forward = 0, n_long = 0;  // on / rows longer than a tile (a workgroup each, in front of the tiles)
+    int *fwd = nullptr;           // per tile: entries behind the tile that finish its last row (-1 / -2: long-row cases, csr5.hpp)
+    int4 *long_list = nullptr;    // per long row: y row, first entry, end
 };
 
 // One row-block x column-slab layout (kernels/blocked.hpp; built by build_blocked).

@@ -9,7 +9,7 @@
 enum {
     SPMV_OPT_LANES_PER_ROW, SPMV_OPT_SELL_C, SPMV_OPT_SELL_SIGMA, SPMV_OPT_SELL_LDS_X, SPMV_OPT_SELL_LONG_THR,
     SPMV_OPT_CSR5_SIGMA, SPMV_OPT_ROWBLOCK_NNZ, SPMV_OPT_CACHE_BLOCK, SPMV_OPT_SLAB_KIB, SPMV_OPT_BLOCK_ROWS,
-    SPMV_OPT_VECTOR_FORM, SPMV_OPT_X_WINDOWS, SPMV_OPT_XCD_ORDER, SPMV_OPT_CSR5_TWO_DEEP, SPMV_OPT_RUN_TILES, SPMV_OPT_AUTO_METHOD, SPMV_OPT_AUTOTUNE, SPMV_OPT_REORDER, SPMV_OPT_HOST_ROWS,
+    SPMV_OPT_VECTOR_FORM, SPMV_OPT_X_WINDOWS, SPMV_OPT_XCD_ORDER, SPMV_OPT_CSR5_TWO_DEEP, SPMV_OPT_RUN_TILES, SPMV_OPT_ROW_FORWARD, SPMV_OPT_AUTO_METHOD, SPMV_OPT_AUTOTUNE, SPMV_OPT_REORDER, SPMV_OPT_HOST_ROWS,
     SPMV_OPT_CHECK_VALUES, SPMV_OPT_GPUS, SPMV_OPT_X_EXCHANGE, SPMV_OPT_SPLIT,
     SPMV_OPT_KEEP_COLUMNS, SPMV_OPT_BLK_WAVES, SPMV_OPT_BLK_GROUPS, SPMV_OPT_BLK_SUBSORT, SPMV_OPT_DETERMINISTIC,
     SPMV_N_OPTS

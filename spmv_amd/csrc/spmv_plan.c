@@ -58,6 +58,8 @@ static opt_t g_opts[SPMV_N_OPTS] = {
     [SPMV_OPT_CSR5_TWO_DEEP] = {"csr5_two_deep", 0, 0, 2, 0, 0},      /* staged CSR5 group kernel two tiles deep: 0 = fp32 only (measured), 1 = never, 2 = also fp64 */
     [SPMV_OPT_RUN_TILES] = {"run_tiles", 1, 0, 1, 0, 0},              /* 1: tiles / groups whose rows are runs of consecutive columns read no column stream (RUN), tiles whose rows span
                                                                        * under 256 slots a byte per entry (BYTE); 0: every staged tile reads its 16-bit slot stream */
+    [SPMV_OPT_ROW_FORWARD] = {"row_forward", 1, 0, 1, 0, 0},          /* nnz-split tiles that gather through L2 (short heavy-tailed rows): 1 = a row cut by a tile boundary is finished by the tile
+                                                                       * it starts in, rows longer than a tile by a workgroup each -- ONE launch; 0 = carries + fix-up launch (kernels/csr5.hpp) */
     [SPMV_OPT_AUTO_METHOD] = {"auto_method", 0, 0, 2, 0, 0},          /* 1: create() picks the schedule from the matrix by rules (two stages, spmv_api.c);
                                                                        * 2: ... by building the candidate schedules and timing them */
     [SPMV_OPT_AUTOTUNE] = {"autotune", 1, 0, 1, 0, 0},                /* 1: create() times the CSR-vector kernel forms on matrices >= 2^24 nnz */
@@ -304,7 +306,8 @@ void spmv_plan_choose(SPMV_METHODS requested, const spmv_stats *st, size_t value
     plan->xcd_order = (int) opt->v[SPMV_OPT_XCD_ORDER];
     plan->csr5_two_deep = (int) opt->v[SPMV_OPT_CSR5_TWO_DEEP];
     plan->run_tiles = (int) opt->v[SPMV_OPT_RUN_TILES];
-    plan->forced = plan->vector_form != 0 || plan->x_windows != 1 || plan->xcd_order != 1 || plan->csr5_two_deep != 0 || plan->run_tiles != 1;
+    plan->row_forward = (int) opt->v[SPMV_OPT_ROW_FORWARD];
+    plan->forced = plan->vector_form != 0 || plan->x_windows != 1 || plan->xcd_order != 1 || plan->csr5_two_deep != 0 || plan->run_tiles != 1 || plan->row_forward != 1;
     plan->autotune = (int) opt->v[SPMV_OPT_AUTOTUNE];
     plan->sell_c = (int) opt->v[SPMV_OPT_SELL_C];
     plan->sell_sigma = (int) opt->v[SPMV_OPT_SELL_SIGMA];

@@ -50,7 +50,7 @@ typedef struct spmv_plan {
     int deterministic;  /* 1: bit-reproducible results required (default) */
     int cache_block;    /* nnz-split family: 0 never, 1 automatic, 2 always use the row-block x column-slab executor */
     int rowblock_nnz;
-    int vector_form, x_windows, xcd_order, csr5_two_deep, run_tiles; /* executor-form selectors (spmv_plan.c option table) */
+    int vector_form, x_windows, xcd_order, csr5_two_deep, run_tiles, row_forward; /* executor-form selectors (spmv_plan.c option table) */
     int forced;         /* any of them differs from its default: create() does not time alternatives */
     int autotune;       /* csr-vector: time the applicable kernel forms at create and keep the fastest */
 } spmv_plan;

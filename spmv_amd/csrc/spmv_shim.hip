@@ -629,7 +629,7 @@ static void csr5_kernel_names(const spmv_dev *d, const Csr5Plan &P, char *buf, s
     if (P.nnz == 0) return;
     if (P.staged > 0) append_name(buf, cap, P.natural ? "nat_group_kernel" : (csr5_two_deep(d, P) ? "csr5_group_pipe_kernel" : "csr5_group_kernel"));
     else append_name(buf, cap, P.natural ? "nat_kernel" : "csr5_kernel");
-    if (P.fixup && P.tiles > 1) append_name(buf, cap, "csr5_fixup_kernel");
+    if (P.fixup && P.tiles > 1 && !P.forward) append_name(buf, cap, "csr5_fixup_kernel");
 }
 
 extern "C" int spmv_shim_info(const spmv_dev *d, spmv_hip_info *o)

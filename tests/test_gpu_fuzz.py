@@ -85,7 +85,7 @@ def _definition(csr, x):
 
 
 OPTIONS = {"csr5_sigma": [0, 4, 8, 16], "sell_sigma": [64, 1024], "rowblock_nnz": [0, 64, 700], "lanes_per_row": [0, 1, 4, 64],
-           "cache_block": [1, 2], "x_windows": [1, 1, 1, 0], "blk_groups": [0, 0, 8, 12], "xcd_order": [1, 1, 0], "run_tiles": [1, 1, 1, 0], "blk_waves": [0, 0, 1, 2, 4, 8],
+           "cache_block": [1, 2], "x_windows": [1, 1, 1, 0], "blk_groups": [0, 0, 8, 12], "xcd_order": [1, 1, 0], "run_tiles": [1, 1, 1, 0], "row_forward": [1, 1, 0], "blk_waves": [0, 0, 1, 2, 4, 8],
            "deterministic": [1, 1, 0], "block_rows": [0, 0, 256, 4096]}
 
 

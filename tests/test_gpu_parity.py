@@ -1611,3 +1611,76 @@ def test_two_deep_csr5_group_kernel(shape):
         api.set_option("csr5_two_deep", keep)
     with api.Handle(m, n, rp, ci, va.double(), M.Method_CSR5SPMV) as h:
         assert h.info()["kernel_name"] == "csr5_group_kernel"
+
+
+def _edge_lengths(tn, rng, filler):
+    """Row lengths that put every forward-completion case on a tile boundary (tiles of tn entries): a row ending exactly on a cut and one starting on it,
+    rows with 1 .. tn - 1 entries behind the cut (more than 64: the in-place loop), a row of exactly tn entries started mid-tile, rows of tn + 1 and
+    3 tn + 5 entries (long: a workgroup each), short rows in between."""
+    lens, pos = [], 0
+
+    def short_until(target):          # 1-3-entry rows up to position `target`
+        nonlocal pos
+        while pos < target:
+            k = int(min(rng.integers(1, 4), target - pos))
+            lens.append(k); pos += k
+
+    def row(k):
+        nonlocal pos
+        lens.append(int(k)); pos += int(k)
+
+    cut = tn
+    short_until(cut)                                   # a row ends exactly on the first cut, the next starts on it
+    for back, fwd in [(1, 1), (3, 63), (2, 64), (5, 65), (7, 130), (1, tn - 1), (tn // 2, tn // 2), (tn - 1, 1), (10, tn - 10 + 1), (4, 3 * tn + 1), (tn - 3, 8)]:
+        cut = (pos // tn + 2) * tn
+        short_until(cut - back)
+        row(back + fwd)                                # starts `back` entries before the cut, `fwd` behind it
+    short_until(pos + filler)
+    return np.asarray(lens, dtype=np.int64)
+
+
+@pytest.mark.parametrize("dtype", [np.float64, np.float32])
+@pytest.mark.parametrize("sigma", [0, 4, 8, 16])
+@pytest.mark.parametrize("shape", ["edges", "edges_empty_rows", "powerlaw", "many_long_rows"])
+def test_short_rows_in_one_launch_forward_completion(shape, sigma, dtype):
+    """nnz-split tiles that gather through L2 (short heavy-tailed rows, no x window stages) run ONE kernel -- the tile that holds a row's
+    start finishes it from the next tile's entries, rows longer than a tile get a workgroup each -- and option row_forward = 0 brings back carries +
+    fix-up launch.  Exact data: the reference's bits either way (parallel_balanced_Yid_spmv.c:151-156 is the serial fix-up this replaces); random
+    data: the row-relative bar.  More long rows than the list holds: the fix-up form stays."""
+    rng = np.random.default_rng(1234 + sigma)
+    tn = 64 * (sigma if sigma else 4)                   # auto: sigma = 4 below 2^19 entries
+    n = 1 << 21                                         # columns scattered over 2 M: no window stages
+    if shape.startswith("edges"):
+        lens = _edge_lengths(tn, rng, 40 * tn)
+    elif shape == "powerlaw":
+        lens = synth.powerlaw_lengths(60000, 3.1, 4700, 1.6, seed=9)
+    else:
+        lens = rng.integers(1, 4, 40000)
+        lens[rng.choice(lens.shape[0], 1500, replace=False)] = tn + 1 + rng.integers(0, 40, 1500)
+    if shape == "edges_empty_rows":                     # empty rows in front, behind and in between (the tiles then run over the compacted row space)
+        lens = np.concatenate([np.zeros(3, np.int64), np.insert(lens, rng.choice(lens.shape[0], lens.shape[0] // 9), 0), np.zeros(5, np.int64)])
+    for kind in ("eighths", "uniform"):
+        csr = synth.from_row_lengths(lens, n, kind, dtype, seed=31)
+        x = synth.fill_x(n, kind, dtype, 77)
+        y_ref = oracle.spmv_serial(csr, x)
+        got = {}
+        for fwd in (1, 0):
+            api.set_option("row_forward", fwd)
+            api.set_option("csr5_sigma", sigma)
+            try:
+                y = np.full(csr.m, np.nan, dtype=dtype)
+                with api.Handle(csr.m, csr.n, csr.rowptr, csr.colidx, csr.val, M.Method_Balanced2) as h:
+                    h.spmv(x, y)
+                    info = h.info()
+                    y2 = np.full(csr.m, np.nan, dtype=dtype)
+                    h.spmv(x, y2)
+            finally:
+                api.set_option("row_forward", 1)
+                api.set_option("csr5_sigma", 0)
+            one_launch = fwd == 1 and shape != "many_long_rows"
+            assert info["launch_kernels"] == (["nat_kernel"] if one_launch else ["nat_kernel", "csr5_fixup_kernel"]), (info["launch_kernels"], fwd)
+            check(y, csr, x, y_ref, exact=kind == "eighths")
+            assert np.array_equal(y.view(np.uint8), y2.view(np.uint8))        # bit-reproducible call to call
+            got[fwd] = y
+        if kind == "eighths":
+            assert np.array_equal(got[0].view(np.uint8), got[1].view(np.uint8))
