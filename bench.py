@@ -311,6 +311,12 @@ def extra_configs(args, dev):
         create_s = time.perf_counter() - t1
         info = h.info()
         mean, ms = api.time_launches(h.h, x, y, 3, max(args.config_iters, 1))
+        retimed = 0
+        if mean > 1.5 * float(ms.min()):     # a launch or two took many times the others (seen once: one 30 ms launch among twenty of 0.5 ms): time the set again, keep the calmer one, say so
+            mean2, ms2 = api.time_launches(h.h, x, y, 3, max(args.config_iters, 1))
+            retimed = 1
+            if mean2 < mean:
+                mean, ms = mean2, ms2
         used = h.method.name
         h.close()
         tol = 1e-6 if dtype == "f64" else 1e-3
@@ -319,7 +325,7 @@ def extra_configs(args, dev):
         rf = roofline_fields(info, float(mean), dtype)
         r = {"method_used": used, "schedule": info["schedule_name"], "kernel": info["kernel_name"], "kernels": rf["kernels"],
              "cache_blocked": int(info["cache_blocked"]), "blk_waves": int(info["blk_waves"]), "reproducible": bool(info["reproducible"]),
-             "stored_nnz": int(info["stored_nnz"]), "launches": int(ms.size), "ms_min": round(float(ms.min()), 5), "ms_mean": round(float(mean), 5),
+             "stored_nnz": int(info["stored_nnz"]), "launches": int(ms.size), "ms_min": round(float(ms.min()), 5), "ms_mean": round(float(mean), 5), "ms_max": round(float(ms.max()), 5), "retimed": retimed,
              "gflops": round(2.0 * info["nnz"] / (float(mean) * 1e-3) / 1e9, 1),
              "bytes_moved_per_launch": rf["bytes_moved_per_launch"], "alg_bytes_per_launch": rf["alg_bytes_per_launch"],
              "frac": rf["frac"], "frac_source": rf["frac_source"], "frac_counter": rf["frac_counter"], "frac_model": rf["frac_model"], "frac_alg": rf["frac_alg"],
@@ -543,10 +549,14 @@ def traffic_from_profiles(kernel_name, m, nnz, dtype, model_bytes):
                 continue
             if d.get("csrc_sha") == sha:
                 _TRAFFIC += d.get("entries", [])
-    for e in _TRAFFIC:   # two matrices of one shape (config 2 and config 2 with holes) differ in what their schedule has to move: the model's byte count is part of the key
-        if (e.get("kernel_short") == kernel_name and e.get("m") == m and e.get("nnz") == nnz and e.get("dtype") == dtype
-                and abs(int(e.get("model_stream_bytes", -1)) - int(model_bytes)) <= 0.005 * int(model_bytes)):
-            return e.get("hbm_bytes_per_launch"), e.get("source"), e.get("kernels")
+    best = None   # two matrices of one shape (config 2 and config 2 with holes; the Orkut-style stand-in with R-MAT and with uniform columns) differ in what their
+    for e in _TRAFFIC:   # schedule has to move: the model's byte count is part of the key, and the closest entry within 0.5 % wins
+        if e.get("kernel_short") == kernel_name and e.get("m") == m and e.get("nnz") == nnz and e.get("dtype") == dtype:
+            diff = abs(int(e.get("model_stream_bytes", -1)) - int(model_bytes))
+            if diff <= 0.005 * int(model_bytes) and (best is None or diff < best[0]):
+                best = (diff, e)
+    if best is not None:
+        return best[1].get("hbm_bytes_per_launch"), best[1].get("source"), best[1].get("kernels")
     return None, None, None
 
 

@@ -45,6 +45,11 @@ def test_fractions_side_by_side_and_frac_is_the_counter_one_only_when_the_profil
     # another matrix of the same shape (config 2 vs config 2 with holes): the model's byte count differs -> no match
     rf = bench.roofline_fields(_info(stream_bytes=330_000), 0.001, "f64")
     assert rf["frac_source"] == "model" and rf["traffic"] is None and rf["frac"] == rf["frac_model"] and rf["frac_counter"] is None
+    # two matrices whose byte counts differ by less than the tolerance (the Orkut-style stand-in with R-MAT and with uniform columns): the closest entry wins
+    near = dict(entry, model_stream_bytes=300_020, hbm_bytes_per_launch=310_000.0, source="profiles/near")
+    write(sha, [near, entry])
+    assert bench.roofline_fields(_info(), 0.001, "f64")["traffic"] == 290_000.0
+    assert bench.roofline_fields(_info(stream_bytes=300_019), 0.001, "f64")["traffic"] == 310_000.0
     # a profile taken on another source tree says nothing about this run
     write("0" * 16, [entry])
     rf = bench.roofline_fields(_info(), 0.001, "f64")
