@@ -162,8 +162,9 @@ typedef struct spmv_hip_info {
     long long run_nnz;          /* CSR-vector / row-block tile kernels, SELL slabs, CSR5 tile groups: entries in RUN tiles / groups -- staged ones whose rows
                                  * each reference one run of consecutive columns (banded matrices; CSR5: of at least sigma entries); their column stream is
                                  * not read at all (16 bits, SELL: a word, per ROW; CSR5: a word per lane and tile instead) */
-    long long byte_nnz;         /* CSR-vector / row-block tile kernels: entries in BYTE tiles -- staged tiles in which every row's LDS slots lie within 255 of the row's
-                                 * smallest (banded matrices with holes, block rows): their column stream is one byte per entry + 16 bits per row */
+    long long byte_nnz;         /* CSR-vector / row-block tile kernels, SELL window groups: entries in BYTE tiles / groups -- staged ones in which every row's LDS slots lie
+                                 * within 255 of the row's smallest (SELL: first) slot (banded matrices with holes, block rows): their column stream is one byte per entry
+                                 * + 16 bits (SELL: a word) per row */
     long long tmpl_nnz;         /* ... entries in TEMPLATE tiles -- staged tiles whose rows all have the same slot offsets from their first entry (stencil interiors,
                                  * block rows): no column stream either, 16 bits per row + one offset list per tile */
     int blk_waves;              /* cache_blocked: wavefronts that share one row block's accumulators (1: a wave per block, two blocks per CU; 2 / 4 / 8: the

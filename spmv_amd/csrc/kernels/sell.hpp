@@ -293,14 +293,55 @@ __device__ __forceinline__ void sell_chunk_tmpl(unsigned run, const T *__restric
     }
 }
 
-// Inspector: is window group w a RUN group?  One workgroup per group, a wave per chunk (lane = row slot) walks the row's slots in the
-// slab.  counters[0] += groups, [1] += entries (real ones), [2] += stored slab entries, [3] += row slots of the RUN groups.
+// BYTE groups (round 4; csr_vector_tile.hpp's BYTE tiles for the SELL slabs): every row of a staged window group keeps its slots within 255 of its first one
+// (bands with holes): an 8-bit slab of offsets from the row's first slot (scol8, same positions as the 16-bit slab) + the word per row slot
+// (first slot | row length << 16) -- 1 B per stored entry instead of 2.
+template <typename T>
+__device__ __forceinline__ void sell_chunk_byte(unsigned run, const unsigned char *__restrict__ pc8, const T *__restrict__ pv, int width, const T *__restrict__ xs,
+                                                unsigned zslot, T &sum)
+{
+    constexpr int U = 8;
+    const unsigned s0 = run & 0xffffu, len = run >> 16;
+    int j = 0;
+    for (; j + U <= width; j += U) {
+        unsigned cc[U];
+        T vv[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            cc[u] = ld_stream(pc8 + (size_t) (j + u) * kSellC);
+            vv[u] = ld_stream(pv + (size_t) (j + u) * kSellC);
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u) sum = fmadd(vv[u], xs[(unsigned) (j + u) < len ? s0 + cc[u] : zslot], sum);
+    }
+    const int r = __builtin_amdgcn_readfirstlane(width - j);
+    if (r > 0) {
+        unsigned cc[U - 1];
+        T vv[U - 1];
+#pragma unroll
+        for (int u = 0; u < U - 1; ++u)
+            if (u < r) {
+                cc[u] = ld_stream(pc8 + (size_t) (j + u) * kSellC);
+                vv[u] = ld_stream(pv + (size_t) (j + u) * kSellC);
+            }
+#pragma unroll
+        for (int u = 0; u < U - 1; ++u)
+            if (u < r) sum = fmadd(vv[u], xs[(unsigned) (j + u) < len ? s0 + cc[u] : zslot], sum);
+    }
+}
+
+// Inspector: is window group w a RUN group (wins[w].runs = 1), else a TEMPLATE group (3), else a BYTE group (2)?  One workgroup per group, a wave per chunk
+// (lane = row slot) walks the row's slots in the slab.  counters[0] += groups, [1] += entries (real ones), [2] += stored slab entries, [3] += row slots of the
+// RUN / TEMPLATE groups, [4] += entries of the TEMPLATE groups; BYTE groups: [5] += entries, [6] += stored slab entries, [7] += row slots.
 static __global__ __launch_bounds__(kBlock) void sell_runs_kernel(int chunks_per_win, long long nchunks, const long long *__restrict__ chunk_ptr,
                                                            const unsigned short *__restrict__ scol16, const int *__restrict__ perm,
                                                            const int *__restrict__ rowptr, TileWindows *__restrict__ wins,
                                                            unsigned *__restrict__ sell_run, unsigned long long *__restrict__ counters,
-                                                           unsigned short *__restrict__ tmpl /* NULL: RUN groups only; else kSellTmplCount lists of kSellTmplMax offsets per group */)
+                                                           unsigned short *__restrict__ tmpl /* NULL: no TEMPLATE groups; else kSellTmplCount lists of kSellTmplMax offsets per group */,
+                                                           unsigned char *__restrict__ scol8 /* NULL: no BYTE groups; else the 8-bit slab */)
 {
+    __shared__ unsigned s_hash[kSellTmplCount];
+    __shared__ int s_tlen[kSellTmplCount], s_first[kSellTmplCount], s_tm[kSellTmplCount][kSellTmplMax];
     const int w = blockIdx.x, lane = threadIdx.x & (kWave - 1), wave = threadIdx.x / kWave;
     const TileWindows &tw = wins[w];
     int ok = tw.nwin > 0;
@@ -322,16 +363,7 @@ static __global__ __launch_bounds__(kBlock) void sell_runs_kernel(int chunks_per
         }
     ok = __syncthreads_and(ok);
     if (!ok) {
-        if (!tmpl || tw.nwin == 0) return;
-        // TEMPLATE group?  every row hashes (length, offsets from its first slot), claims or finds one of kSellTmplCount list numbers; list i is written
-        // from the FIRST row slot (chunk, lane order) that carries it; every row is then compared with its list.
-        __shared__ unsigned s_hash[kSellTmplCount];
-        __shared__ int s_tlen[kSellTmplCount], s_first[kSellTmplCount], s_tm[kSellTmplCount][kSellTmplMax];
-        for (int i = threadIdx.x; i < kSellTmplCount * kSellTmplMax; i += kBlock) s_tm[i / kSellTmplMax][i % kSellTmplMax] = 0;
-        if (threadIdx.x < kSellTmplCount) { s_hash[threadIdx.x] = 0u; s_tlen[threadIdx.x] = 0; s_first[threadIdx.x] = INT_MAX; }
-        __syncthreads();
-        int okt = 1;
-        unsigned long long tent = 0;
+        if (tw.nwin == 0) return;
         auto row_of = [&](int k, long long &c0, int &width, int &len) { // lane's row slot in chunk k of the group; false past the matrix
             const long long c = (long long) w * chunks_per_win + k;
             if (c >= nchunks) return false;
@@ -341,6 +373,14 @@ static __global__ __launch_bounds__(kBlock) void sell_runs_kernel(int chunks_per
             len = row >= 0 ? rowptr[row + 1] - rowptr[row] : 0;
             return true;
         };
+        // TEMPLATE group?  every row hashes (length, offsets from its first slot), claims or finds one of kSellTmplCount list numbers; list i is written
+        // from the FIRST row slot (chunk, lane order) that carries it; every row is then compared with its list.
+        auto template_stage = [&]() -> bool {
+        for (int i = threadIdx.x; i < kSellTmplCount * kSellTmplMax; i += kBlock) s_tm[i / kSellTmplMax][i % kSellTmplMax] = 0;
+        if (threadIdx.x < kSellTmplCount) { s_hash[threadIdx.x] = 0u; s_tlen[threadIdx.x] = 0; s_first[threadIdx.x] = INT_MAX; }
+        __syncthreads();
+        int okt = 1;
+        unsigned long long tent = 0;
         auto hash_of = [&](const unsigned short *pc, int len, unsigned s0) {
             unsigned h = 0x9E3779B9u * (unsigned) len;
             for (int j = 0; j < len; ++j) h += ((unsigned) pc[(size_t) j * kSellC] - s0 + 0x7F4A7C15u) * (2u * (unsigned) j + 1u) * 0x85EBCA6Bu;
@@ -363,7 +403,7 @@ static __global__ __launch_bounds__(kBlock) void sell_runs_kernel(int chunks_per
             tent += (unsigned long long) len;
         }
         okt = __syncthreads_and(okt);
-        if (!okt) return;
+        if (!okt) return false;
         for (int k = wave; k < chunks_per_win; k += kBlock / kWave) { // the first carrier of each list writes it
             long long c0; int width, len;
             if (!row_of(k, c0, width, len)) break;
@@ -396,12 +436,45 @@ static __global__ __launch_bounds__(kBlock) void sell_runs_kernel(int chunks_per
             sell_run[c * kSellC + lane] = word;
         }
         okt = __syncthreads_and(okt);
-        if (!okt) return; // sell_run was scribbled on: harmless, only RUN / TEMPLATE groups read it
+        if (!okt) return false; // sell_run was scribbled on: harmless, only RUN / TEMPLATE / BYTE groups read it (and a BYTE group writes it again)
         for (int i = threadIdx.x; i < kSellTmplCount * kSellTmplMax; i += kBlock) tmpl[(size_t) w * (kSellTmplCount * kSellTmplMax) + i] = (unsigned short) s_tm[i / kSellTmplMax][i % kSellTmplMax];
 #pragma unroll
         for (int o = kWave / 2; o > 0; o >>= 1) { tent += __shfl_xor(tent, o, kWave); stored += __shfl_xor(stored, o, kWave); slots += __shfl_xor(slots, o, kWave); }
         if (lane == 0) { atomicAdd(counters + 1, tent); atomicAdd(counters + 2, stored); atomicAdd(counters + 3, slots); atomicAdd(counters + 4, tent); }
         if (threadIdx.x == 0) { wins[w].runs = 3; atomicAdd(counters, 1ull); }
+        return true;
+        };
+        if (tmpl && template_stage()) return;
+        if (!scol8) return;
+        // BYTE group?  every slot of a row within 255 of the row's first (slots of a row ascend: sorted columns inside sorted windows; anything else fails the test)
+        int okb = 1;
+        unsigned long long bent = 0;
+        for (int k = wave; k < chunks_per_win; k += kBlock / kWave) {
+            long long c0; int width, len;
+            if (!row_of(k, c0, width, len)) break;
+            if (len == 0) continue;
+            if (len > width || len >= 65536) { okb = 0; continue; }
+            const unsigned short *pc = scol16 + (size_t) c0 * kSellC + lane;
+            const unsigned s0 = pc[0];
+            for (int j = 1; j < len; ++j) okb &= (unsigned) pc[(size_t) j * kSellC] - s0 < 256u;
+            bent += (unsigned long long) len;
+        }
+        okb = __syncthreads_and(okb);
+        if (!okb) return;
+        for (int k = wave; k < chunks_per_win; k += kBlock / kWave) {
+            long long c0; int width, len;
+            if (!row_of(k, c0, width, len)) break;
+            const long long c = (long long) w * chunks_per_win + k;
+            const unsigned short *pc = scol16 + (size_t) c0 * kSellC + lane;
+            unsigned char *p8 = scol8 + (size_t) c0 * kSellC + lane;
+            const unsigned s0 = len > 0 ? pc[0] : (unsigned) tw.total;
+            for (int j = 0; j < width; ++j) p8[(size_t) j * kSellC] = j < len ? (unsigned char) (pc[(size_t) j * kSellC] - s0) : (unsigned char) 0;
+            sell_run[c * kSellC + lane] = s0 | ((unsigned) len << 16);
+        }
+#pragma unroll
+        for (int o = kWave / 2; o > 0; o >>= 1) { bent += __shfl_xor(bent, o, kWave); stored += __shfl_xor(stored, o, kWave); slots += __shfl_xor(slots, o, kWave); }
+        if (lane == 0) { atomicAdd(counters + 5, bent); atomicAdd(counters + 6, stored); atomicAdd(counters + 7, slots); }
+        if (threadIdx.x == 0) { wins[w].runs = 2; atomicAdd(counters, 1ull); }
         return;
     }
     for (int k = wave; k < chunks_per_win; k += kBlock / kWave) {
@@ -428,6 +501,7 @@ __global__ __launch_bounds__(kSellWinThreads) void sell_window_kernel(int chunks
                                                                       const int *__restrict__ perm,
                                                                       const TileWindows *__restrict__ wins,
                                                                       const unsigned *__restrict__ sell_run, const unsigned short *__restrict__ sell_tmpl,
+                                                                      const unsigned char *__restrict__ scol8,
                                                                       const T *__restrict__ x, T *__restrict__ y, int ys_offset)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char sell_x_lds[];
@@ -437,7 +511,7 @@ __global__ __launch_bounds__(kSellWinThreads) void sell_window_kernel(int chunks
     T *ys = reinterpret_cast<T *>(sell_x_lds + ys_offset);
     const int w = blockIdx.x;
     const TileWindows &tw = wins[w];
-    const bool staged = tw.nwin > 0, runs = tw.runs == 1, templ = tw.runs == 3; // runs / templ imply staged
+    const bool staged = tw.nwin > 0, runs = tw.runs == 1, bytes = tw.runs == 2, templ = tw.runs == 3; // runs / bytes / templ imply staged
     if (templ) for (int i = threadIdx.x; i < kSellTmplCount * kSellTmplMax; i += kSellWinThreads) tm_lds[i] = sell_tmpl[(size_t) blockIdx.x * (kSellTmplCount * kSellTmplMax) + i];
     const int rows_per_group = chunks_per_win * kSellC;
     const long long row0 = (long long) w * rows_per_group;
@@ -462,6 +536,7 @@ __global__ __launch_bounds__(kSellWinThreads) void sell_window_kernel(int chunks
         T sum = 0;
         if (runs) sell_chunk_run<T>(sell_run[c * kSellC + lane], pv, width, xs, (unsigned) tw.total, sum);
         else if (templ) sell_chunk_tmpl<T>(sell_run[c * kSellC + lane], pv, width, xs, (unsigned) tw.total, tm_lds, sum);
+        else if (bytes) sell_chunk_byte<T>(sell_run[c * kSellC + lane], scol8 + (size_t) c0 * kSellC + lane, pv, width, xs, (unsigned) tw.total, sum);
         else if (staged) sell_chunk<T, true>(pc, pc16, pv, width, xs, x, sum);
         else sell_chunk<T, false>(pc, pc16, pv, width, xs, x, sum);
         if (row >= 0) ys[row - row0] = sum;

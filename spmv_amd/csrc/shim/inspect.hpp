@@ -306,13 +306,14 @@ static int build_sell(spmv_dev *d)
         if (d->sell_staged == d->sell_nwin) { sched_free(d, d->scol); d->scol = nullptr; } // no window reads global columns
         else if (d->sell_staged == 0) { sched_free(d, d->scol16); d->scol16 = nullptr; }
         if (d->sell_staged > 0 && d->plan.run_tiles) { // RUN groups: rows that are runs of consecutive columns need no slot slab (sell.hpp)
-            unsigned long long *cnt = nullptr, h[5] = {0, 0, 0, 0, 0};
+            unsigned long long *cnt = nullptr, h[8] = {0, 0, 0, 0, 0, 0, 0, 0};
             ALLOC_TRY(d, &d->sell_run, sizeof(unsigned) * (size_t) d->nchunks * kSellC, true);
             if (!getenv("SPMV_HIP_NO_TEMPLATE_TILES")) ALLOC_TRY(d, &d->sell_tmpl, sizeof(unsigned short) * kSellTmplCount * kSellTmplMax * (size_t) d->sell_nwin, true);
+            if (!getenv("SPMV_HIP_NO_BYTE_TILES")) ALLOC_TRY(d, &d->scol8, (size_t) slots + 16, true);
             HIP_TRY(pool_malloc((void **) &cnt, sizeof h));
             hipError_t e = hipMemsetAsync(cnt, 0, sizeof h, d->stream);
             sell_runs_kernel<<<d->sell_nwin, kBlock, 0, d->stream>>>(d->sell_group * (sigma / kSellC), (long long) d->nchunks, d->chunk_ptr, d->scol16, d->perm, d->rowptr,
-                                                                    d->sell_wins, d->sell_run, cnt, d->sell_tmpl);
+                                                                    d->sell_wins, d->sell_run, cnt, d->sell_tmpl, d->scol8);
             if (e == hipSuccess) e = hipGetLastError();
             if (e == hipSuccess) e = hipMemcpyAsync(h, cnt, sizeof h, hipMemcpyDeviceToHost, d->stream);
             if (e == hipSuccess) e = hipStreamSynchronize(d->stream);
@@ -323,7 +324,12 @@ static int build_sell(spmv_dev *d)
             d->sell_run_stored = (long long) h[2];
             d->sell_run_slots = (long long) h[3];
             d->sell_tmpl_nnz = (long long) h[4];
+            d->sell_byte_nnz = (long long) h[5];
+            d->sell_byte_stored = (long long) h[6];
+            d->sell_byte_slots = (long long) h[7];
             if (d->sell_tmpl && d->sell_tmpl_nnz == 0) { sched_free(d, d->sell_tmpl); d->sell_tmpl = nullptr; }
+            if (d->scol8 && d->sell_byte_nnz == 0) { sched_free(d, d->scol8); d->scol8 = nullptr; }
+            if (d->sell_run_groups == d->sell_nwin && d->scol16) { sched_free(d, d->scol16); d->scol16 = nullptr; } // every group is RUN / TEMPLATE / BYTE: nobody reads the 16-bit slab
             if (getenv("SPMV_HIP_SELL_DEBUG")) fprintf(stderr, "[spmv_hip] sell: groups %d staged %d RUN %d (entries %lld, stored %lld, row slots %lld)\n", d->sell_nwin, d->sell_staged, d->sell_run_groups, d->sell_run_nnz, d->sell_run_stored, d->sell_run_slots);
         }
     }
@@ -885,6 +891,7 @@ static int account_stream_bytes(spmv_dev *d)
             const double fs = d->sell_nwin > 0 ? (double) wtiles / (double) d->sell_nwin : 0.0;
             t.bytes = stream_part(d->sell_cols * kSellC, s, fs) + 8ll * (d->nchunks + 1) + 4ll * d->nchunks * kSellC + s * (m - d->nlong);
             t.bytes += 4ll * d->sell_run_slots - 2ll * d->sell_run_stored; // RUN groups: a word per row slot instead of a 16-bit slot per stored entry
+            t.bytes += 4ll * d->sell_byte_slots - d->sell_byte_stored;    // BYTE groups: the word + 1 B per stored entry instead of 2
             if (d->sell_staged > 0) t.bytes += (long long) sizeof(TileWindows) * d->sell_nwin;
             t.x_elems = welems;
             if (wtiles < d->sell_nwin) t.gathers_global = true;

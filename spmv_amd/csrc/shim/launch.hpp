@@ -300,7 +300,7 @@ static int launch(spmv_dev *d, const T *x, T *y)
             const size_t lds = xbytes + sizeof(T) * (size_t) cpw * kSellC;                                  // + the group's row sums
             ensure_lds<sell_window_kernel<T>>(d, lds);
             sell_window_kernel<T><<<d->sell_nwin, kSellWinThreads, lds, d->stream>>>(cpw, (long long) d->nchunks, d->m, d->chunk_ptr, d->scol, d->scol16, (const T *) d->sval,
-                                                                                     d->perm, d->sell_wins, d->sell_run, d->sell_tmpl, x, y, (int) xbytes);
+                                                                                     d->perm, d->sell_wins, d->sell_run, d->sell_tmpl, d->scol8, x, y, (int) xbytes);
         }
         else
             sell_kernel<T><<<grid_for(d->nchunks, kBlock / kWave, INT_MAX), kBlock, 0, d->stream>>>(

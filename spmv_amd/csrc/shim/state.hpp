@@ -232,6 +232,8 @@ struct spmv_dev {
     unsigned *sell_run = nullptr;      // RUN groups (sell.hpp): per row slot, first LDS slot | row length << 16
     unsigned short *sell_tmpl = nullptr; // TEMPLATE groups: kSellTmplCount lists of kSellTmplMax slot offsets per window group
     long long sell_tmpl_nnz = 0;
+    unsigned char *scol8 = nullptr;   // BYTE window groups (sell.hpp): 8-bit offsets from the row's first slot, at the 16-bit slab's positions
+    long long sell_byte_nnz = 0, sell_byte_stored = 0, sell_byte_slots = 0;
     int sell_run_groups = 0;
     long long sell_run_nnz = 0, sell_run_stored = 0, sell_run_slots = 0;
     unsigned short *scol16 = nullptr; // 16-bit LDS slots of the staged sigma windows
@@ -294,7 +296,7 @@ static void sched_free(spmv_dev *d, void *p)
 static void reset_tile_fields(spmv_dev *d)
 {
     d->rb_split = nullptr;
-    d->perm = d->scol = d->long_rows = nullptr; d->sell_wins = nullptr; d->scol16 = nullptr; d->sell_run = nullptr; d->sell_tmpl = nullptr; d->sell_tmpl_nnz = 0; d->sell_run_groups = 0; d->sell_run_nnz = d->sell_run_stored = d->sell_run_slots = 0; d->sell_staged = d->sell_nwin = 0; d->chunk_ptr = d->lr_seg_start = nullptr;
+    d->perm = d->scol = d->long_rows = nullptr; d->sell_wins = nullptr; d->scol16 = nullptr; d->sell_run = nullptr; d->sell_tmpl = nullptr; d->sell_tmpl_nnz = 0; d->scol8 = nullptr; d->sell_byte_nnz = d->sell_byte_stored = d->sell_byte_slots = 0; d->sell_run_groups = 0; d->sell_run_nnz = d->sell_run_stored = d->sell_run_slots = 0; d->sell_staged = d->sell_nwin = 0; d->chunk_ptr = d->lr_seg_start = nullptr;
     d->sval = nullptr;
     d->nblocks = d->nchunks = d->nlong = 0;
     d->long_thr = INT_MAX;

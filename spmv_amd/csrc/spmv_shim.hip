@@ -697,7 +697,7 @@ extern "C" int spmv_shim_info(const spmv_dev *d, spmv_hip_info *o)
         o->run_nnz = tiles_run ? d->vt_run_nnz : 0;
         o->byte_nnz = tiles_run ? d->vt_byte_nnz : 0;
         o->tmpl_nnz = tiles_run ? d->vt_tmpl_nnz : 0;
-        if (!d->blk_on && d->plan.sched == SPMV_SCHED_SELL && d->sell_staged > 0) { o->run_nnz = d->sell_run_nnz - d->sell_tmpl_nnz; o->tmpl_nnz = d->sell_tmpl_nnz; }
+        if (!d->blk_on && d->plan.sched == SPMV_SCHED_SELL && d->sell_staged > 0) { o->run_nnz = d->sell_run_nnz - d->sell_tmpl_nnz; o->tmpl_nnz = d->sell_tmpl_nnz; o->byte_nnz = d->sell_byte_nnz; }
         if (!d->blk_on && d->plan.sched == SPMV_SCHED_CSR5) o->run_nnz = d->c5.run_tiles * kWave * d->c5.sigma;
     }
     if (d->blk_on) { o->stored_nnz = d->blk.groups << d->blk.ge; o->x_groups = d->x_groups_seen; o->x_groups_staged = 0; }

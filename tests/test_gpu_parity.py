@@ -1475,6 +1475,12 @@ def test_byte_tiles_read_one_byte_per_entry(shape, dtype, method):
     import torch
     dev = torch.device("cuda:0")
     tdt = torch.float64 if dtype == "f64" else torch.float32
+    m, n, rp, ci, va, g = _byte_shape_matrix(shape, tdt, dev)
+    _byte_tiles_body(shape, method, m, n, rp, ci, va, g, tdt, dev)
+
+
+def _byte_shape_matrix(shape, tdt, dev):
+    import torch
     m = n = 300_000
     g = torch.Generator(device=dev); g.manual_seed(21)
     rows = torch.arange(m, device=dev)
@@ -1504,6 +1510,11 @@ def test_byte_tiles_read_one_byte_per_entry(shape, dtype, method):
             lens = torch.full((m,), 8, device=dev)
             start = (rows + torch.randint(-5000, 5001, (m,), generator=g, device=dev)).clamp_(0, n - 21)
         rp, ci, va = _holes_rows_matrix(m, n, lens, start, span, tdt, dev, 6, reverse)
+    return m, n, rp, ci, va, g
+
+
+def _byte_tiles_body(shape, method, m, n, rp, ci, va, g, tdt, dev):
+    import torch
     nnz = int(rp[-1])
     x = (torch.randint(-8, 9, (n,), generator=g, device=dev) * 0.125).to(tdt)
     want = _segment_sums(va.double() * x.double()[ci.long()], rp).to(tdt)
@@ -1536,6 +1547,46 @@ def test_byte_tiles_read_one_byte_per_entry(shape, dtype, method):
         h.spmv(x, y)
         torch.cuda.synchronize()
         assert torch.equal(y, 2 * want)
+
+
+@pytest.mark.parametrize("dtype", ["f64", "f32"])
+@pytest.mark.parametrize("shape", ["holes", "ragged", "unsorted", "two_bands", "span_edge"])
+def test_sell_byte_groups_read_one_byte_per_entry(shape, dtype):
+    """BYTE window groups of the SELL slabs (round 4, sell.hpp): when every row of a staged group keeps its slots within 255 of its FIRST one, the group reads
+    an 8-bit slab + a word per row slot instead of the 16-bit slab.  Shapes as in test_byte_tiles_read_one_byte_per_entry; rows with descending columns
+    ('unsorted') fail the test by construction and keep the 16-bit slab.  Exact data: the definition's bits, with the forms on and off (run_tiles = 0)."""
+    import torch
+    dev = torch.device("cuda:0")
+    tdt = torch.float64 if dtype == "f64" else torch.float32
+    m, n, rp, ci, va, g = _byte_shape_matrix(shape, tdt, dev)
+    nnz = int(rp[-1])
+    x = (torch.randint(-8, 9, (n,), generator=g, device=dev) * 0.125).to(tdt)
+    want = _segment_sums(va.double() * x.double()[ci.long()], rp).to(tdt)
+    for on in (1, 0):
+        api.set_option("run_tiles", on)
+        try:
+            h = api.Handle(m, n, rp, ci, va, M.Method_SellCSigma)
+        finally:
+            api.set_option("run_tiles", 1)
+        with h:
+            y = torch.full((m,), float("nan"), dtype=tdt, device=dev)
+            h.spmv(x, y)
+            info = h.info()
+            torch.cuda.synchronize()
+            assert torch.equal(y, want), (info["kernel_name"], int((y != want).sum()))
+            assert info["kernel_name"] == "sell_window_kernel" and info["x_groups_staged"] == info["x_groups"], info
+            if not on or shape == "unsorted":
+                assert info["byte_nnz"] == 0, info
+            elif shape == "span_edge":          # one row in 10 240 spans 257 columns: its window group keeps the 16-bit slab
+                assert 0.4 * nnz <= info["byte_nnz"] < nnz, (info["byte_nnz"], nnz)
+            elif shape == "holes":              # the band wraps at both ends of the matrix
+                assert info["byte_nnz"] >= 0.98 * nnz, (info["byte_nnz"], nnz)
+            else:
+                assert info["byte_nnz"] + info["run_nnz"] + info["tmpl_nnz"] == nnz and info["byte_nnz"] >= 0.9 * nnz, info
+            h.update_values((va * 2).contiguous())
+            h.spmv(x, y)
+            torch.cuda.synchronize()
+            assert torch.equal(y, 2 * want)
 
 
 @pytest.mark.parametrize("method", [M.Method_CSR5SPMV, M.Method_SellCSigma, M.Method_Balanced_Yid, M.Method_Parallel], ids=lambda m: m.name)
