@@ -314,9 +314,22 @@ extern "C" int spmv_shim_build(spmv_dev *d, const spmv_plan *plan)
         d->x_groups_seen = groups;
         double tile_ms = -1.0;
         if (mode == 2) tile_ms = f64 ? time_schedule<double>(d, 5) : time_schedule<float>(d, 5);
-        // forced width (option blk_waves) or the one-wave form first; the wide forms are tried against it below
+        // forced width (option blk_waves) or the one-wave form first; the wide forms are tried against it below.  Where the one-wave form would surely be gather-bound
+        // -- under one entry per 128-byte line of x and block if the columns were uniform (config 2-ii: 0.5) -- the wide form is built FIRST and the one-wave form only
+        // if the measurement contradicts the estimate (config 2-ii: create 66 -> 40 ms; nothing changes for the others)
         const int forced = plan->blk_waves;
-        int rcb = blk_build(0, forced > 0 ? forced : 1, plan->deterministic != 0);
+        const bool can_try = plan->autotune && !plan->forced && plan->blk_groups == 0 && plan->block_rows == 0 && forced == 0 && d->nnz >= (1ll << 22);
+        const double rows_one = std::min(9982.0, std::max(1.0, (double) d->m / (2.0 * (double) d->cus)));
+        const double lambda_one = rows_one * ((double) d->nnz / (double) d->m) * (128.0 / (double) d->vsize) / (double) d->n;
+        const bool wide_first = can_try && plan->deterministic != 0 && (long long) d->m >= 2048ll * d->cus && lambda_one < 1.0;
+        int rcb = blk_build(0, forced > 0 ? forced : (wide_first ? 2 : 1), plan->deterministic != 0);
+        if (rcb && wide_first) { // the wide layout could not be built: the one-wave form before anything is given up
+            blk_release(d->blk);
+            d->blk = BlkSet();
+            d->blk_on = false;
+            (void) hipGetLastError();
+            rcb = blk_build(0, 1, true);
+        }
         if (!rcb && d->blk_on) rcb = blk_tune();
         if (rcb) {
             // The blocked executor could not be built (device memory, or padded positions beyond 32 bits).  It is an alternative, not a
@@ -341,19 +354,25 @@ extern "C" int spmv_shim_build(spmv_dev *d, const spmv_plan *plan)
             }
         }
         if (!rc && d->blk_on) drop_tile_schedule(d, keep_from);
-        const bool may_try = !rc && d->blk_on && plan->autotune && !plan->forced && plan->blk_groups == 0 && plan->block_rows == 0 && forced == 0 && d->nnz >= (1ll << 22);
-        const double rate = may_try && blk_best(d->blk) > 0 ? (double) d->nnz * ((double) d->vsize + 4.0) / ((double) blk_best(d->blk) * 1e-3) : 0.0; // the streams' bytes per second
+        const bool may_try = !rc && d->blk_on && can_try;
+        auto stream_rate = [&]() { return may_try && blk_best(d->blk) > 0 ? (double) d->nnz * ((double) d->vsize + 4.0) / ((double) blk_best(d->blk) * 1e-3) : 0.0; }; // the streams' bytes per second
+        double rate = stream_rate();
+        if (may_try && wide_first && d->blk.waves > 1 && rate >= 4.2e12) { // not gather-bound after all: the one-wave form against it
+            blk_try(0, 1, true);
+            rate = stream_rate();
+        }
+        const bool one_wave = d->blk.waves <= 1;
         // Stream-bound under rule 0 (the streams alone move >= 3.6 TB/s; web-like 4e6 x 24 in fp32 sits at 4.2)?  Then thinner blocks may do better: build the
         // rule-1 set next to this one, time it, keep the faster (one more inspector pass, only for such matrices).
-        if (may_try && blocked_differs(d) && rate >= 3.6e12) blk_try(1, 1, true);
+        if (may_try && one_wave && blocked_differs(d) && rate >= 3.6e12) blk_try(1, 1, true);
         // The wide forms: ONE block of up to ~20 k rows per CU, its accumulators shared by the waves of a workgroup -- fewer cache lines of x per
         // entry (kernels/blocked.hpp).  Reproducible results required (default): two waves taking turns at adding, tried where the one-wave
         // form is gather-bound (config 2-ii: 1.40 -> 1.19 ms; stream-bound shapes lose 3-5 % to the turns and are not tried).  Option
         // deterministic = 0: four waves adding as their products arrive (config 2-ii 1.22, Orkut-style R-MAT 0.55 -> 0.49, uniform
         // 0.66 -> 0.54, web-like 4e6 x 24 0.243 -> 0.216).
-        if (may_try && (long long) d->m >= 2048ll * d->cus) {
+        if (may_try && one_wave && (long long) d->m >= 2048ll * d->cus) {
             if (plan->deterministic == 0) blk_try(0, 4, false);
-            else if (rate < 4.2e12) blk_try(0, 2, true);
+            else if (rate < 4.2e12 && !wide_first) blk_try(0, 2, true);
         }
     }
     if (!rc) rc = account_stream_bytes(d);
