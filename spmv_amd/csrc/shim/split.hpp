@@ -34,6 +34,7 @@ extern "C" int spmv_shim_split_candidate(spmv_dev *d)
     if (d->plan.sched == SPMV_SCHED_CSR_SCALAR || d->plan.cache_block != 1 || d->plan.forced || !d->plan.autotune || d->plan.block_rows != 0) return 0;
     if (!blocked_size_ok(d) || d->nnz < (1ll << 22)) return 0;
     if (!d->blk_on && d->route_ms[0] == 0.f) return 0; // every group stages (or under 0.5 % do not): nothing to gain
+    if (!d->blk_on && d->route_ms[0] > 0.f && (double) d->stream_bytes >= 5.6e12 * (double) d->route_ms[0] * 1e-3) return 0; // the tile schedule moves its own bytes at >= 0.70 of the HBM peak: no split can be worth its create time
     DeviceGuard guard(d->device);
     if (!guard.ok) return 0;
     if (d->near_share < 0.f) d->near_share = sample_near_share(d);

@@ -314,6 +314,11 @@ extern "C" int spmv_shim_build(spmv_dev *d, const spmv_plan *plan)
         d->x_groups_seen = groups;
         double tile_ms = -1.0;
         if (mode == 2) tile_ms = f64 ? time_schedule<double>(d, 5) : time_schedule<float>(d, 5);
+        // The blocked executor streams vsize + 4 bytes per entry and has never moved them faster than 5.0 TB/s next to its gathers: a tile schedule that is already
+        // faster than 5.5 TB/s of THOSE bytes cannot lose to it -- neither executor is built nor timed (27-point stencil with periodic boundaries, 1 % of the tile
+        // groups unstaged: create 33 -> 17 ms)
+        const bool tiles_win_anyway = mode == 2 && tile_ms > 0 && plan->cache_block == 1 && tile_ms * 1e-3 * 5.5e12 <= (double) d->nnz * ((double) d->vsize + 4.0);
+        if (tiles_win_anyway) d->route_ms[0] = (float) tile_ms;
         // forced width (option blk_waves) or the one-wave form first; the wide forms are tried against it below.  Where the one-wave form would surely be gather-bound
         // -- under one entry per 128-byte line of x and block if the columns were uniform (config 2-ii: 0.5) -- the wide form is built FIRST and the one-wave form only
         // if the measurement contradicts the estimate (config 2-ii: create 66 -> 40 ms; nothing changes for the others)
@@ -322,7 +327,7 @@ extern "C" int spmv_shim_build(spmv_dev *d, const spmv_plan *plan)
         const double rows_one = std::min(9982.0, std::max(1.0, (double) d->m / (2.0 * (double) d->cus)));
         const double lambda_one = rows_one * ((double) d->nnz / (double) d->m) * (128.0 / (double) d->vsize) / (double) d->n;
         const bool wide_first = can_try && plan->deterministic != 0 && (long long) d->m >= 2048ll * d->cus && lambda_one < 1.0;
-        int rcb = blk_build(0, forced > 0 ? forced : (wide_first ? 2 : 1), plan->deterministic != 0);
+        int rcb = tiles_win_anyway ? SPMV_HIP_OK : blk_build(0, forced > 0 ? forced : (wide_first ? 2 : 1), plan->deterministic != 0);
         if (rcb && wide_first) { // the wide layout could not be built: the one-wave form before anything is given up
             blk_release(d->blk);
             d->blk = BlkSet();
