@@ -89,7 +89,7 @@ OPTIONS = {"csr5_sigma": [0, 4, 8, 16], "sell_sigma": [64, 1024], "rowblock_nnz"
            "deterministic": [1, 1, 0], "block_rows": [0, 0, 256, 4096]}
 
 
-# SPMV_FUZZ_FIRST / SPMV_FUZZ_SEEDS widen the sweep (seeds 48..847 were run once on the final kernels of round 2, seeds 0..399 with the run-structured cases on those of round 3, seeds 1000..7999 on those of round 4 -- forward completion included)
+# SPMV_FUZZ_FIRST / SPMV_FUZZ_SEEDS widen the sweep (seeds 48..847 were run once on the final kernels of round 2, seeds 0..399 with the run-structured cases on those of round 3, seeds 1000..19999 on those of round 4 -- forward completion and SELL's BYTE groups included)
 _FIRST, _COUNT = int(os.environ.get("SPMV_FUZZ_FIRST", "0")), int(os.environ.get("SPMV_FUZZ_SEEDS", "48"))
 
 
