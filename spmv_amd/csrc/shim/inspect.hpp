@@ -40,6 +40,7 @@ template <typename T>
 static int build_csr5(spmv_dev *d, Csr5Plan &P, int m, long long nnz, const int *rowptr, const int *colidx, const T *val, int empty_rows,
                       double mean_row_len, const int *out_rows, bool natural = false);
 template <typename T> static int autotune_vector(spmv_dev *d);
+template <typename T> static int autotune_rows(spmv_dev *d, const int *split);
 template <typename T> static int autotune_blocked(spmv_dev *d);
 template <typename T> static double time_schedule(spmv_dev *d, int iters);
 template <typename T> static int split_make(spmv_dev *d, spmv_dev **near_out, spmv_dev **far_out, bool values_only);

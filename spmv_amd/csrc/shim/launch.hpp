@@ -164,6 +164,48 @@ static int autotune_blocked(spmv_dev *d)
     return SPMV_HIP_OK;
 }
 
+// The rows kernel (Balanced's row blocks with `split`, CSR-vector's wide form without): two or four steps in flight?  Timed like the tile forms, on matrices of
+// >= 2^24 entries whose blocks mostly stage (27-point stencil under Method_Balanced: 0.55 ms four deep, the fp64 default, 0.47 two deep).
+template <typename T>
+static int autotune_rows(spmv_dev *d, const int *split)
+{
+    d->rows_depth = 0;
+    if (d->nnz < (1ll << 24) || d->plan.forced || d->vt_tiles <= 0 || d->vt_staged * 2 < d->vt_tiles) return SPMV_HIP_OK;
+    T *x = nullptr, *y = nullptr;
+    if (pool_malloc((void **) &x, sizeof(T) * (size_t) d->n) != hipSuccess || pool_malloc((void **) &y, sizeof(T) * (size_t) d->m) != hipSuccess) {
+        (void) hipGetLastError();
+        if (x) (void) pool_free(x);
+        return SPMV_HIP_OK;
+    }
+    fill_value_kernel<T><<<grid_for(d->n, kBlock, d->cus * 8), kBlock, 0, d->stream>>>(d->n, x, T(1));
+    hipEvent_t e0, e1;
+    (void) hipEventCreate(&e0);
+    (void) hipEventCreate(&e1);
+    const int depth[2] = {4, 2};
+    float tmin[2] = {1e30f, 1e30f};
+    for (int k = 0; k < 2; ++k) { d->rows_depth = depth[k]; launch_rows_any<T>(d, x, y, split); }
+    for (int round = 0; round < 2; ++round)
+        for (int k = 0; k < 2; ++k) {
+            d->rows_depth = depth[k];
+            (void) hipEventRecord(e0, d->stream);
+            launch_rows_any<T>(d, x, y, split);
+            (void) hipEventRecord(e1, d->stream);
+            (void) hipEventSynchronize(e1);
+            float ms = 0;
+            (void) hipEventElapsedTime(&ms, e0, e1);
+            if (ms < tmin[k]) tmin[k] = ms;
+        }
+    d->tune_ms[0] = tmin[0];
+    d->tune_ms[1] = tmin[1];
+    d->rows_depth = tmin[1] < tmin[0] ? 2 : 4;
+    (void) hipEventDestroy(e0);
+    (void) hipEventDestroy(e1);
+    (void) pool_free(x);
+    (void) pool_free(y);
+    if (hipGetLastError() != hipSuccess) d->rows_depth = 0;
+    return SPMV_HIP_OK;
+}
+
 // The staged CSR5 group kernel two tiles deep (csr5_group_pipe_kernel)?  When EVERY group is staged (the pipelined kernel has no
 // global-column path) and the values are fp32: in fp64 the second register set costs a wave per SIMD and measured no gain (config 2
 // under CSR5: 0.511 vs 0.515 ms).  Option csr5_two_deep 1 / 2: never / also for fp64 (A/B).

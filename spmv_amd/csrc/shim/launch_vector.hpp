@@ -51,10 +51,9 @@ void launch_vector_any(spmv_dev *d, const T *x, T *y)
 }
 
 // The rows kernel: Balanced's equal-nnz row blocks (split), or CSR-vector's wide form (uniform blocks).
-template <typename T, int L>
-static void launch_rows(spmv_dev *d, const T *x, T *y, const int *split)
+template <typename T, int L, int DEPTH>
+static void launch_rows_depth(spmv_dev *d, const T *x, T *y, const int *split)
 {
-    constexpr int DEPTH = sizeof(T) == 8 ? 4 : 2;
     const size_t lds = ((((size_t) d->vt_maxspan + 1) * sizeof(T)) + 1023) & ~(size_t) 1023; // + the zero slot
     if (d->vt_wide) {
         ensure_lds<csr_vector_rows_kernel<T, L, DEPTH, true>>(d, lds);
@@ -65,6 +64,18 @@ static void launch_rows(spmv_dev *d, const T *x, T *y, const int *split)
     ensure_lds<csr_vector_rows_kernel<T, L, DEPTH, false>>(d, lds);
     csr_vector_rows_kernel<T, L, DEPTH><<<d->vt_tiles, kVecTileThreads, lds, d->stream>>>(
         d->long_thr, split, d->vt_rows, d->m, d->rowptr, d->colidx, d->vt_col, (const T *) d->val, d->vt_wins, d->vt_rowslot, d->vt_col8, d->vt_tmpl, d->vt_rowtid, x, y);
+}
+
+// Steps in flight: what create() measured (rows_depth, autotune_rows), what option vector_form names (5 / 12: two, 10 / 11: four), else the dtype's default.
+template <typename T, int L>
+static void launch_rows(spmv_dev *d, const T *x, T *y, const int *split)
+{
+    const int v = d->plan.vector_form;
+    int depth = d->rows_depth ? d->rows_depth : (sizeof(T) == 8 ? 4 : 2);
+    if (v == VEC_TILE_D2 || v == VEC_TILE_D2_NOPRE) depth = 2;
+    if (v == VEC_TILE_D4 || v == VEC_TILE_D4_NOPRE) depth = 4;
+    if (depth == 2) launch_rows_depth<T, L, 2>(d, x, y, split);
+    else launch_rows_depth<T, L, 4>(d, x, y, split);
 }
 
 template <typename T>

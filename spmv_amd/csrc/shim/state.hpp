@@ -208,6 +208,7 @@ struct spmv_dev {
     int *rb_split = nullptr;
     // csr-vector x tiles
     int vt_tiles = 0, vt_staged = 0, vt_maxspan = 0, vec_choice = 0;
+    int rows_depth = 0;           // rows kernel (Balanced's row blocks, CSR-vector's wide form): steps in flight, 2 / 4; 0 = the dtype's default (autotune_rows)
     bool vt_wide = false;           // windows above 64 KiB: slot-index stream, blocks of vt_rows rows, rows kernel
     int vt_rows = 256;
     float tune_ms[3] = {0, 0, 0}; // tile D4, tile D2, pipe (autotune_vector)
@@ -301,7 +302,7 @@ static void reset_tile_fields(spmv_dev *d)
     d->nblocks = d->nchunks = d->nlong = 0;
     d->long_thr = INT_MAX;
     d->vt_col = nullptr; d->vt_wins = nullptr; d->vt_tiles = d->vt_staged = d->vt_maxspan = 0; d->vt_wide = false; d->vt_rows = 256;
-    d->vt_rowslot = nullptr; d->vt_run_tiles = d->vt_run_nnz = d->vt_run_rows = 0;
+    d->vt_rowslot = nullptr; d->vt_run_tiles = d->vt_run_nnz = d->vt_run_rows = 0; d->rows_depth = 0;
     d->vt_col8 = nullptr; d->vt_byte_tiles = d->vt_byte_nnz = d->vt_byte_rows = 0;
     d->vt_tmpl = nullptr; d->vt_rowtid = nullptr; d->vt_tmpl_tiles = d->vt_tmpl_nnz = d->vt_tmpl_rows = 0;
     d->c5 = Csr5Plan();

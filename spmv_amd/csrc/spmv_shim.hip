@@ -243,7 +243,10 @@ extern "C" int spmv_shim_build(spmv_dev *d, const spmv_plan *plan)
             if (!rc) rc = f64 ? build_vector_tiles<double>(d) : build_vector_tiles<float>(d);
             staged = d->vt_staged;
             groups = d->vt_tiles;
-            if (!rc && plan->autotune && blocked_mode(d, staged, groups) != 1) rc = f64 ? autotune_vector<double>(d) : autotune_vector<float>(d);
+            if (!rc && plan->autotune && blocked_mode(d, staged, groups) != 1) {
+                if (d->vt_wide) rc = f64 ? autotune_rows<double>(d, nullptr) : autotune_rows<float>(d, nullptr); // wide x windows: the rows kernel over uniform blocks
+                else rc = f64 ? autotune_vector<double>(d) : autotune_vector<float>(d);
+            }
             break;
         }
         case SPMV_SCHED_NNZ_SPLIT:
@@ -260,6 +263,7 @@ extern "C" int spmv_shim_build(spmv_dev *d, const spmv_plan *plan)
             if (!rc) rc = f64 ? build_rowblock_tiles<double>(d) : build_rowblock_tiles<float>(d);
             staged = d->vt_staged;
             groups = d->vt_tiles;
+            if (!rc && plan->autotune && blocked_mode(d, staged, groups) != 1) rc = f64 ? autotune_rows<double>(d, d->rb_split) : autotune_rows<float>(d, d->rb_split);
             break;
         case SPMV_SCHED_SELL:
             rc = f64 ? build_sell<double>(d) : build_sell<float>(d);
