@@ -139,7 +139,8 @@ typedef struct spmv_hip_info {
     double inspect_ms;          /* wall time of the inspector inside create */
     const char *schedule_name;
     const char *kernel_name;    /* symbol of the dominant kernel (as rocprofv3 shows it) */
-    int tuned_choice;           /* csr-vector autotune: 0 none, 10/11 tile 4-deep, 5/12 tile 2-deep, 4 pipe; cache_blocked: 100 / 101 =
+    int tuned_choice;           /* csr-vector autotune: 0 none, 10/11 tile 4-deep, 5/12 tile 2-deep, 4 pipe (row-block schedule and csr-vector's wide form: 10 / 5 = the rows
+                                   kernel four / two steps deep); cache_blocked: 100 / 101 =
                                    the smaller / larger groups-per-pipeline-step form (8 / 12; 6 / 8 with blk_waves = 8) */
     float tune_ms[3];           /* measured ms of {tile/4-deep, tile/2-deep, pipe} at create (0 if not tuned; pipe: 0 when 99 % of the tiles stage their x windows -- not timed); cache_blocked: of the
                                    row-block executor's two groups-per-step forms ([2] unused) */

@@ -705,6 +705,7 @@ extern "C" int spmv_shim_info(const spmv_dev *d, spmv_hip_info *o)
     o->alg_bytes = 4ll * ((long long) d->m + 1) + d->nnz * (4 + s) + s * d->n + s * d->m;
     o->inspect_ms = d->inspect_ms;
     o->tuned_choice = d->blk_on ? 100 + d->blk.form : d->vec_choice; // cache_blocked: 100 / 101 = the smaller / larger form of blocked_forms()
+    if (!d->blk_on && d->rows_depth && (d->plan.sched == SPMV_SCHED_ROWBLOCK || (d->plan.sched == SPMV_SCHED_CSR_VECTOR && d->vt_wide))) o->tuned_choice = d->rows_depth == 2 ? VEC_TILE_D2 : VEC_TILE_D4; // the rows kernel's depth, in the tile forms' codes
     for (int k = 0; k < 3; ++k) o->tune_ms[k] = d->blk_on ? d->blk.tune_ms[k] : d->tune_ms[k];
     o->schedule_name = kSchedNames[d->plan.sched];
     o->kernel_name = kKernelNames[d->plan.sched];
