@@ -38,7 +38,7 @@ constexpr size_t kVecXTileBytes = 48 * 1024; // LDS budget of one row tile's x s
 template <typename T> static int build_long_rows(spmv_dev *d, int thr);
 template <typename T>
 static int build_csr5(spmv_dev *d, Csr5Plan &P, int m, long long nnz, const int *rowptr, const int *colidx, const T *val, int empty_rows,
-                      double mean_row_len, const int *out_rows, bool natural = false);
+                      double mean_row_len, const int *out_rows, bool natural = false, int sigma_override = 0);
 template <typename T> static int autotune_vector(spmv_dev *d);
 template <typename T> static int autotune_rows(spmv_dev *d, const int *split);
 template <typename T> static int autotune_blocked(spmv_dev *d);
@@ -474,9 +474,10 @@ static int build_csr5_sigma(spmv_dev *d, Csr5Plan &P, const int *rp, int m2, con
 // allowed then) names the y row of each CSR row -- used for the long-row sub-matrix.
 template <typename T>
 static int build_csr5(spmv_dev *d, Csr5Plan &P, int m, long long nnz, const int *rowptr, const int *colidx, const T *val, int empty_rows,
-                      double mean_row_len, const int *out_rows, bool natural)
+                      double mean_row_len, const int *out_rows, bool natural, int sigma_override)
 {
-    int sigma = d->plan.csr5_sigma;
+    const size_t alloc_mark = d->sched_allocs.size();
+    int sigma = sigma_override ? sigma_override : d->plan.csr5_sigma;
     // sigma = 16 whatever the row length (the reference's CPU heuristic shrinks sigma for short rows; here larger
     // tiles amortise the per-tile descriptor / tile_ptr / carry work: 5-entry rows ran 0.48 / 0.34 / 0.28 ms at
     // sigma 4 / 8 / 16); smaller tiles only when there would be too few of them to fill the chip
@@ -518,11 +519,21 @@ static int build_csr5(spmv_dev *d, Csr5Plan &P, int m, long long nnz, const int 
         P.empty_list = elist;
     }
     P.m2 = m2;
+    int rc;
     switch (sigma) {
-    case 4: return build_csr5_sigma<T, 4>(d, P, rp, m2, colidx, val);
-    case 8: return build_csr5_sigma<T, 8>(d, P, rp, m2, colidx, val);
-    default: return build_csr5_sigma<T, 16>(d, P, rp, m2, colidx, val);
+    case 4: rc = build_csr5_sigma<T, 4>(d, P, rp, m2, colidx, val); break;
+    case 8: rc = build_csr5_sigma<T, 8>(d, P, rp, m2, colidx, val); break;
+    default: rc = build_csr5_sigma<T, 16>(d, P, rp, m2, colidx, val); break;
     }
+    // Natural-layout tiles of 512 entries (the automatic size between 2^19 and 2^22 non-zeros) of which no group stages its x windows, finished by forward completion:
+    // 256-entry tiles run the launch in one round of twice as many, lighter workgroups (webbase-style R-MAT stand-in 26.1 -> 25.0 us; with the carry fix-up launch
+    // the sizes measured equal).  The inspector at this size is a fraction of a millisecond: build again.
+    if (!rc && natural && !sigma_override && d->plan.csr5_sigma == 0 && sigma == 8 && P.staged == 0 && P.forward) {
+        quiesce(d);
+        while (d->sched_allocs.size() > alloc_mark) sched_free(d, d->sched_allocs.back().first);
+        return build_csr5<T>(d, P, m, nnz, rowptr, colidx, val, empty_rows, mean_row_len, out_rows, natural, 4);
+    }
+    return rc;
 }
 
 // Row blocks x column slabs (kernels/blocked.hpp): the inspector's three kernels.  values_only re-permutes new values into the
